@@ -1,0 +1,261 @@
+"""ctypes loader for the CPU oracle (oracle/dann_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (diskann_amd/) must never import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libdann_oracle.so")
+
+F32, F16, U8, I8 = 0, 1, 2, 3
+COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
+IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
+
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dann_oracle.cpp")
+    hdr = os.path.join(_HERE, "dann_oracle.h")
+    stale = (not os.path.exists(_LIB)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB) for p in (src, hdr) if os.path.exists(p)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "all"])
+    return _LIB
+
+
+class OrcIndex(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("metric", C.c_int32),
+        ("dim", C.c_uint32),
+        ("capacity", C.c_uint32),
+        ("nstart", C.c_uint32),
+        ("max_degree", C.c_uint32),
+        ("row_stride", C.c_uint64),
+        ("rows", C.c_void_p),
+        ("adj", C.c_void_p),
+    ]
+
+
+class OrcBuildConfig(C.Structure):
+    _fields_ = [
+        ("pruned_degree", C.c_uint32),
+        ("max_degree", C.c_uint32),
+        ("l_build", C.c_uint32),
+        ("alpha", C.c_float),
+        ("max_occlusion_size", C.c_uint32),
+        ("max_backedges", C.c_uint32),
+        ("intra_batch_candidates", C.c_uint32),
+        ("saturate_after_prune", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB)
+    vp, u32, i32, f32, u64, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_uint64, C.c_size_t
+    P = C.POINTER
+    L.orc_f16_to_f32.restype = f32
+    L.orc_f16_to_f32.argtypes = [C.c_uint16]
+    L.orc_f32_to_f16.restype = C.c_uint16
+    L.orc_f32_to_f16.argtypes = [f32]
+    for name in ("orc_distance", "orc_query_distance", "orc_distance_scalar_ref", "orc_query_distance_fast"):
+        fn = getattr(L, name)
+        fn.restype = f32
+        fn.argtypes = [i32, i32, vp, vp, sz]
+    L.orc_search.restype = i32
+    L.orc_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp]
+    L.orc_search_batch.restype = i32
+    L.orc_search_batch.argtypes = [P(OrcIndex), vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, i32, vp]
+    L.orc_expand_beam.restype = i32
+    L.orc_expand_beam.argtypes = [P(OrcIndex), vp, vp, u32, vp, vp]
+    L.orc_prune_pool.restype = i32
+    L.orc_prune_pool.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp, vp, u32, i32, vp, vp]
+    L.orc_insert.restype = i32
+    L.orc_insert.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp]
+    L.orc_multi_insert.restype = i32
+    L.orc_multi_insert.argtypes = [P(OrcIndex), P(OrcBuildConfig), vp, u32, vp]
+    L.orc_medoid_f32.restype = C.c_int64
+    L.orc_medoid_f32.argtypes = [vp, u64, u32, vp]
+    L.orc_pq_build_lut.restype = None
+    L.orc_pq_build_lut.argtypes = [i32, vp, vp, vp, u32, u32, vp, vp]
+    L.orc_pq_lookup.restype = f32
+    L.orc_pq_lookup.argtypes = [vp, vp, u32]
+    L.orc_sq8_compress.restype = None
+    L.orc_sq8_compress.argtypes = [vp, u32, vp, f32, vp, vp]
+    L.orc_sq8_distance.restype = f32
+    L.orc_sq8_distance.argtypes = [i32, vp, f32, vp, f32, u32, f32, f32]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def layer_bytes(dtype, dim):
+    return int(dim) * np.dtype(NP_DTYPE[dtype]).itemsize
+
+
+def inmem2_stride(dtype, dim):
+    """diskann-inmem row stride: round_up(bytes + 1 tag byte, 32) (store.rs:198-211)."""
+    b = layer_bytes(dtype, dim) + 1
+    return (b + 31) // 32 * 32
+
+
+class Index:
+    """Host-side arrays in the diskann-inmem layout + the oracle's algorithms over them."""
+
+    def __init__(self, dtype, metric, dim, capacity, max_degree, start_rows, row_stride=None):
+        self.dtype, self.metric, self.dim = dtype, metric, int(dim)
+        self.capacity, self.max_degree = int(capacity), int(max_degree)
+        start_rows = np.ascontiguousarray(start_rows, dtype=NP_DTYPE[dtype]).reshape(-1, self.dim)
+        self.nstart = start_rows.shape[0]
+        self.row_bytes = layer_bytes(dtype, dim)
+        self.row_stride = int(row_stride) if row_stride else self.row_bytes
+        n = self.capacity + self.nstart
+        self.rows = np.zeros((n, self.row_stride), dtype=np.uint8)
+        self.adj = np.zeros((n, self.max_degree + 1), dtype=np.uint32)
+        for i in range(self.nstart):
+            self.set_row(self.capacity + i, start_rows[i])
+        self._c = OrcIndex(dtype, metric, self.dim, self.capacity, self.nstart, self.max_degree,
+                           self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data)
+
+    # -- storage ------------------------------------------------------------
+    def set_row(self, slot, vec):
+        vec = np.ascontiguousarray(vec, dtype=NP_DTYPE[self.dtype]).reshape(-1)
+        assert vec.size == self.dim
+        self.rows[slot, : self.row_bytes] = vec.view(np.uint8)
+
+    def set_rows(self, first, mat):
+        mat = np.ascontiguousarray(mat, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        self.rows[first: first + mat.shape[0], : self.row_bytes] = mat.view(np.uint8).reshape(mat.shape[0], -1)
+
+    def row(self, slot):
+        return self.rows[slot, : self.row_bytes].view(NP_DTYPE[self.dtype])
+
+    def set_neighbors(self, slot, ids):
+        ids = np.asarray(ids, dtype=np.uint32)
+        assert ids.size <= self.max_degree
+        self.adj[slot, 0] = ids.size
+        self.adj[slot, 1: 1 + ids.size] = ids
+
+    def neighbors(self, slot):
+        n = min(int(self.adj[slot, 0]), self.max_degree)
+        return self.adj[slot, 1: 1 + n].copy()
+
+    # -- algorithms -----------------------------------------------------------
+    def search(self, query, l_value, beam_width=1, k=10, record=False):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        ids = np.empty(k, np.uint32)
+        dists = np.empty(k, np.float32)
+        stats = np.zeros(3, np.uint32)
+        if record:
+            cap = 64 * (l_value + self.nstart) + 1024
+            rid = np.empty(cap, np.uint32)
+            rd = np.empty(cap, np.float32)
+            rn = np.zeros(1, np.uint32)
+            n = lib().orc_search(C.byref(self._c), _p(q), l_value, beam_width, k, _p(ids), _p(dists), _p(stats),
+                                 _p(rid), _p(rd), cap, _p(rn))
+            assert rn[0] <= cap
+            return n, ids, dists, stats, rid[: rn[0]].copy(), rd[: rn[0]].copy()
+        n = lib().orc_search(C.byref(self._c), _p(q), l_value, beam_width, k, _p(ids), _p(dists), _p(stats),
+                             None, None, 0, None)
+        if n < 0:
+            raise RuntimeError(f"orc_search failed: {n}")
+        return n, ids, dists, stats
+
+    def search_batch(self, queries, l_value, beam_width=1, k=10, threads=1, fast=False, timing=False):
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        stats = np.zeros((nq, 3), np.uint32)
+        ns = np.zeros(nq, np.uint64) if timing else None
+        rc = lib().orc_search_batch(C.byref(self._c), _p(q), nq, l_value, beam_width, k, _p(ids), _p(dists),
+                                    _p(counts), _p(stats), threads, int(fast), _p(ns))
+        if rc < 0:
+            raise RuntimeError(f"orc_search_batch failed: {rc}")
+        return (ids, dists, counts, stats, ns) if timing else (ids, dists, counts, stats)
+
+    def expand_beam(self, query, ids):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        oi = np.empty(ids.size, np.uint32)
+        od = np.empty(ids.size, np.float32)
+        n = lib().orc_expand_beam(C.byref(self._c), _p(q), _p(ids), ids.size, _p(oi), _p(od))
+        if n < 0:
+            raise RuntimeError(f"orc_expand_beam failed: {n}")
+        return oi[:n], od[:n]
+
+    def prune_pool(self, cfg, location, pool_ids, pool_dists, force_saturate=False):
+        pid = np.ascontiguousarray(pool_ids, dtype=np.uint32).copy()
+        pd = np.ascontiguousarray(pool_dists, dtype=np.float32).copy()
+        out = np.empty(max(cfg.pruned_degree, 1), np.uint32)
+        evals = np.zeros(1, np.uint64)
+        n = lib().orc_prune_pool(C.byref(self._c), C.byref(cfg), location, _p(pid), _p(pd), pid.size,
+                                 int(force_saturate), _p(out), _p(evals))
+        if n < 0:
+            raise RuntimeError(f"orc_prune_pool failed: {n}")
+        return out[:n].copy(), int(evals[0])
+
+    def insert(self, cfg, slot, counters=None):
+        rc = lib().orc_insert(C.byref(self._c), C.byref(cfg), slot, _p(counters))
+        if rc < 0:
+            raise RuntimeError(f"orc_insert failed: {rc}")
+        return rc
+
+    def multi_insert(self, cfg, slots, counters=None):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        rc = lib().orc_multi_insert(C.byref(self._c), C.byref(cfg), _p(s), s.size, _p(counters))
+        if rc < 0:
+            raise RuntimeError(f"orc_multi_insert failed: {rc}")
+        return rc
+
+
+def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_size=750, max_backedges=None,
+                 intra_batch_candidates=IBC_ALL, saturate_after_prune=False):
+    """graph::config::Builder defaults (diskann/src/graph/config/defaults.rs:14-41)."""
+    return OrcBuildConfig(pruned_degree, max_degree, l_build, alpha, max_occlusion_size,
+                          pruned_degree if max_backedges is None else max_backedges,
+                          intra_batch_candidates, int(saturate_after_prune))
+
+
+def distance(dtype, metric, x, y):
+    x = np.ascontiguousarray(x, dtype=NP_DTYPE[dtype])
+    y = np.ascontiguousarray(y, dtype=NP_DTYPE[dtype])
+    return float(lib().orc_distance(dtype, metric, _p(x), _p(y), x.size))
+
+
+def query_distance(dtype, metric, q, row, fast=False):
+    q = np.ascontiguousarray(q, dtype=NP_DTYPE[dtype])
+    row = np.ascontiguousarray(row, dtype=NP_DTYPE[dtype])
+    fn = lib().orc_query_distance_fast if fast else lib().orc_query_distance
+    return float(fn(dtype, metric, _p(q), _p(row), q.size))
+
+
+def distance_scalar_ref(dtype, metric, x, y):
+    x = np.ascontiguousarray(x, dtype=NP_DTYPE[dtype])
+    y = np.ascontiguousarray(y, dtype=NP_DTYPE[dtype])
+    return float(lib().orc_distance_scalar_ref(dtype, metric, _p(x), _p(y), x.size))
+
+
+def medoid_f32(data):
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    mean = np.empty(data.shape[1], np.float32)
+    r = lib().orc_medoid_f32(_p(data), data.shape[0], data.shape[1], _p(mean))
+    return int(r), mean

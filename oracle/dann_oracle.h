@@ -1,0 +1,134 @@
+/*
+ * oracle/dann_oracle.h -- C interface of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a CPU restatement of the reference
+ * (microsoft/DiskANN, Rust workspace v0.56) algorithm for the hot path named in
+ * BASELINE.json.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load it -- and only as the checker / the timed CPU
+ * baseline, never as part of the shipped product path (diskann_amd/).
+ *
+ * Parity pins: grid_search golden JSONs (18 cases), f16 conversion table, the
+ * in-source provider smoke expectations, PQ/SQ known-answer tests -- see
+ * tests/golden/ and tests/test_oracle_*.py.  The reference itself (Rust) cannot
+ * be compiled in this image (no cargo/rustc), so there is no oracle/_ref.
+ *
+ * Enum values equal include/dann.h (and the reference's `#[repr(C)] Metric`,
+ * diskann-vector/src/distance/metric.rs:8-20).
+ */
+#ifndef DANN_ORACLE_H
+#define DANN_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_U8 = 2, ORC_I8 = 3 };
+enum { ORC_COSINE = 0, ORC_INNER_PRODUCT = 1, ORC_L2 = 2, ORC_COSINE_NORMALIZED = 3 };
+enum { ORC_IBC_NONE = 0, ORC_IBC_ALL = 0xFFFFFFFFu }; /* else Max(n) */
+
+/* An index over caller-owned arrays, laid out as diskann-inmem lays them out:
+ * rows:  (capacity + nstart) rows of `row_stride` bytes (store.rs:198-241), the
+ *        frozen start points occupy slots [capacity, capacity+nstart)
+ *        (store.rs:259-262);
+ * adj:   (capacity + nstart) rows of (max_degree+1) u32: [len, ids...]
+ *        (neighbors.rs:60-101). */
+typedef struct {
+    int32_t dtype;
+    int32_t metric;
+    uint32_t dim;
+    uint32_t capacity;
+    uint32_t nstart;
+    uint32_t max_degree;
+    uint64_t row_stride;
+    uint8_t* rows;
+    uint32_t* adj;
+} orc_index;
+
+/* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs) */
+typedef struct {
+    uint32_t pruned_degree;
+    uint32_t max_degree;      /* "max_degree_with_slack" */
+    uint32_t l_build;
+    float alpha;
+    uint32_t max_occlusion_size;
+    uint32_t max_backedges;
+    uint32_t intra_batch_candidates; /* ORC_IBC_NONE, n, or ORC_IBC_ALL */
+    uint32_t saturate_after_prune;
+} orc_build_config;
+
+/* ---- numerics -------------------------------------------------------- */
+/* f16 bit pattern -> f32 (pinned by diskann-wide/test_data/float16_conversion.txt) */
+float orc_f16_to_f32(uint16_t h);
+uint16_t orc_f32_to_f16(float f);
+
+/* layers::Distance::evaluate (T x T, prune path), V3 association.
+ * diskann-inmem/src/layers/full.rs:224-242 -> distance_provider.rs -> simd.rs */
+float orc_distance(int32_t dtype, int32_t metric, const void* x, const void* y, size_t dim);
+/* layers::QueryDistance::evaluate (query x row, search path; f16 rows use the
+ * f32 x f16 kernels with the query widened once). full.rs:317-336,351-504 */
+float orc_query_distance(int32_t dtype, int32_t metric, const void* query, const void* row, size_t dim);
+/* scalar reference (diskann-vector/src/distance/reference.rs) for tolerance tests */
+float orc_distance_scalar_ref(int32_t dtype, int32_t metric, const void* x, const void* y, size_t dim);
+/* AVX2 intrinsics twin of orc_query_distance (bitwise identical; used for the timed
+ * CPU baseline).  Falls back to the emulation for combinations without a twin. */
+float orc_query_distance_fast(int32_t dtype, int32_t metric, const void* query, const void* row, size_t dim);
+
+/* ---- search ---------------------------------------------------------- */
+/* DiskANNIndex::search(Knn{l,beam}) through the inmem2 accessor:
+ * index.rs:1933-2000, knn_search.rs:155-193, provider.rs:408-480,899-950, queue.rs.
+ * stats = {cmps, hops, result_count(reference quirk: k-1 when the buffer fills)}.
+ * out_ids are slot ids (< capacity); unwritten entries are 0xFFFFFFFF / +inf.
+ * rec_* (optional) receives the VisitedSearchRecord (record.rs:86-93).
+ * Returns number of results written (>=0) or <0 on error. */
+int32_t orc_search(const orc_index* ix, const void* query, uint32_t l_value, uint32_t beam_width,
+                   uint32_t k, uint32_t* out_ids, float* out_dists, uint32_t* stats,
+                   uint32_t* rec_ids, float* rec_dists, uint32_t rec_cap, uint32_t* rec_n);
+
+/* nq independent queries over `threads` host threads, static block partition
+ * (diskann-benchmark-core/src/search/api.rs:399-436). per_query_ns optional. */
+int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, uint32_t l_value,
+                         uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists,
+                         uint32_t* out_counts, uint32_t* stats, uint32_t threads, int32_t fast,
+                         uint64_t* per_query_ns);
+
+/* ExpandBeam::expand_beam (provider.rs:620-690) for a pre-filtered id list. */
+int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
+                        uint32_t* out_ids, float* out_dists);
+
+/* ---- build ----------------------------------------------------------- */
+/* prune::robust_prune over a sorted pool (internal/prune.rs:106-259) + occlude_list
+ * (index.rs:2565-2650).  pool_* is sorted here with the oracle's tie rule
+ * (distance, then original position).  Returns the number of neighbours. */
+int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_t location,
+                       uint32_t* pool_ids, float* pool_dists, uint32_t pool_n, int32_t force_saturate,
+                       uint32_t* out_neighbors, uint64_t* pair_evals);
+/* DiskANNIndex::insert for a row already stored at `slot` (index.rs:226-341). */
+int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters);
+/* DiskANNIndex::multi_insert for rows already stored at slots[0..n)
+ * (index.rs:815-1030, max_minibatch_par = 1). */
+int32_t orc_multi_insert(orc_index* ix, const orc_build_config* cfg, const uint32_t* slots, uint32_t n,
+                         uint64_t* counters);
+/* medoid rule (diskann-utils/src/sampling/medoid.rs:15-48), f32 rows. Returns row index. */
+int64_t orc_medoid_f32(const float* data, uint64_t nrows, uint32_t dim, float* out_mean);
+
+/* ---- quantised variants ---------------------------------------------- */
+/* PQ: FixedChunkPQTable::populate_chunk_distances_impl + pq_dist_lookup_single
+ * (diskann-providers/src/model/pq/fixed_chunk_pq_table.rs:152-192,82-100). */
+void orc_pq_build_lut(int32_t metric, const float* pivots /*256 x dim*/, const float* centroid /*dim or NULL*/,
+                      const uint32_t* chunk_offsets /*nchunks+1*/, uint32_t nchunks, uint32_t dim,
+                      const float* query, float* lut /*nchunks x 256*/);
+float orc_pq_lookup(const float* lut, const uint8_t* code, uint32_t nchunks);
+/* SQ-8: ScalarQuantizer::compress + compensated distances
+ * (diskann-quantization/src/scalar/quantizer.rs:189-236,407-430, vectors.rs:171-338). */
+void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,
+                      float* compensation);
+float orc_sq8_distance(int32_t metric, const uint8_t* x, float cx, const uint8_t* y, float cy,
+                       uint32_t dim, float scale, float shift_norm_sq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""Distance numerics of the oracle: the contracts the reference's own kernel tests state
+(diskann-vector/src/distance/implementations.rs:514-594,719-759;
+ diskann-inmem/src/layers/full.rs:573-575)."""
+import numpy as np
+import pytest
+
+import oracle
+
+METRICS = [oracle.L2, oracle.INNER_PRODUCT, oracle.COSINE, oracle.COSINE_NORMALIZED]
+
+
+def _rand(rng, dtype, dim):
+    if dtype == oracle.U8:
+        return rng.integers(0, 256, dim, dtype=np.uint8)
+    if dtype == oracle.I8:
+        return rng.integers(-128, 128, dim, dtype=np.int8)
+    return rng.uniform(-1, 1, dim).astype(oracle.NP_DTYPE[dtype])
+
+
+@pytest.mark.parametrize("dtype", [oracle.F32, oracle.F16])
+def test_float_kernels_vs_scalar_reference(dtype):
+    rng = np.random.default_rng(0x12345)
+    for dim in list(range(0, 70)) + [100, 127, 128, 129, 160, 255, 256, 384, 768]:
+        for metric in METRICS:
+            x, y = _rand(rng, dtype, dim), _rand(rng, dtype, dim)
+            got = oracle.distance(dtype, metric, x, y)
+            want = oracle.distance_scalar_ref(dtype, metric, x, y)
+            assert abs(got - want) <= 1e-4 + 1e-4 * abs(want), (dtype, metric, dim)
+            q = oracle.query_distance(dtype, metric, x, y)
+            assert abs(q - got) <= 1e-3 + 1e-4 * abs(got)  # full.rs:573-575
+
+
+@pytest.mark.parametrize("dtype", [oracle.U8, oracle.I8])
+def test_integer_kernels_exact(dtype):
+    rng = np.random.default_rng(1)
+    for dim in list(range(0, 70)) + [100, 128, 160]:
+        x, y = _rand(rng, dtype, dim), _rand(rng, dtype, dim)
+        xi, yi = x.astype(np.int64), y.astype(np.int64)
+        assert oracle.distance(dtype, oracle.L2, x, y) == float(np.float32(((xi - yi) ** 2).sum()))
+        assert oracle.distance(dtype, oracle.INNER_PRODUCT, x, y) == float(np.float32(-(xi * yi).sum()))
+        # CosineNormalized == Cosine for integers (distance_provider.rs:274-297)
+        assert oracle.distance(dtype, oracle.COSINE_NORMALIZED, x, y) == oracle.distance(dtype, oracle.COSINE, x, y)
+        assert oracle.query_distance(dtype, oracle.L2, x, y) == oracle.distance(dtype, oracle.L2, x, y)
+
+
+def test_avx2_twin_is_bit_identical():
+    rng = np.random.default_rng(2)
+    for dtype in (oracle.F32, oracle.F16):
+        for dim in list(range(0, 80)) + [100, 128, 384, 768, 771]:
+            for metric in (oracle.L2, oracle.INNER_PRODUCT, oracle.COSINE_NORMALIZED):
+                q, r = _rand(rng, dtype, dim), _rand(rng, dtype, dim)
+                a = np.float32(oracle.query_distance(dtype, metric, q, r))
+                b = np.float32(oracle.query_distance(dtype, metric, q, r, fast=True))
+                assert a.view(np.uint32) == b.view(np.uint32), (dtype, dim, metric)
+
+
+def test_l2_association_order_f32():
+    """Appendix A rule 14 spelled out in numpy float32 for dim=128."""
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(128).astype(np.float32), rng.standard_normal(128).astype(np.float32)
+    acc = np.zeros(32, np.float32)
+    for t in range(4):
+        c = (x[32 * t: 32 * t + 32] - y[32 * t: 32 * t + 32]).astype(np.float32)
+        # fused multiply-add: exact product in float64, single rounding
+        acc = (c.astype(np.float64) * c.astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+    s = acc.reshape(4, 8)
+    v = (s[0] + s[1]) + (s[2] + s[3])
+    want = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))
+    got = np.float32(oracle.distance(oracle.F32, oracle.L2, x, y))
+    assert got.view(np.uint32) == np.float32(want).view(np.uint32)
+
+
+def test_cosine_edge_cases():
+    z = np.zeros(16, np.float32)
+    o = np.ones(16, np.float32)
+    assert oracle.distance(oracle.F32, oracle.COSINE, z, o) == 1.0  # zero norm -> similarity 0
+    assert oracle.distance(oracle.F32, oracle.COSINE, o, o) == 0.0
+    assert oracle.distance(oracle.F32, oracle.COSINE, o, -o) == 2.0
+
+
+def test_medoid_rule():
+    rng = np.random.default_rng(4)
+    data = rng.standard_normal((500, 32)).astype(np.float32)
+    r, mean = oracle.medoid_f32(data)
+    m = (data.astype(np.float64).sum(0) / 500).astype(np.float32)
+    assert np.array_equal(mean, m)
+    d = np.array([oracle.distance(oracle.F32, oracle.L2, m, row) for row in data], np.float32)
+    assert r == int(np.argmin(d))
+
+
+def test_pq_lookup_kat():
+    """fixed_chunk_pq_table.rs:1081-1093 pq_dist_lookup_test: out = LUT[0*256+1] + LUT[1*256+3]."""
+    lut = np.arange(512, dtype=np.float32)
+    code = np.array([1, 3], np.uint8)
+    got = oracle.lib().orc_pq_lookup(lut.ctypes.data, code.ctypes.data, 2)
+    assert got == float(lut[1] + lut[256 + 3])
+
+
+def test_sq8_formulas():
+    rng = np.random.default_rng(5)
+    dim = 64
+    shift = rng.uniform(-1, 0, dim).astype(np.float32)
+    scale = np.float32(2.5)
+    xs = rng.uniform(-1, 1, (2, dim)).astype(np.float32)
+    codes = np.zeros((2, dim), np.uint8)
+    comp = np.zeros(2, np.float32)
+    L = oracle.lib()
+    for i in range(2):
+        c = np.zeros(1, np.float32)
+        L.orc_sq8_compress(xs[i].ctypes.data, dim, shift.ctypes.data, scale, codes[i].ctypes.data, c.ctypes.data)
+        comp[i] = c[0]
+        want = np.round(np.clip((xs[i] - shift) * np.float32(255.0 / scale), 0, 255))
+        assert np.abs(codes[i].astype(np.float32) - want).max() <= 1  # float32 vs float64 rounding at .5
+    recon = codes.astype(np.float32) * (scale / 255) + shift
+    l2 = L.orc_sq8_distance(oracle.L2, codes[0].ctypes.data, comp[0], codes[1].ctypes.data, comp[1], dim, scale,
+                            float((shift * shift).sum()))
+    assert abs(l2 - float(((recon[0] - recon[1]) ** 2).sum())) <= 1e-3 * max(1.0, abs(l2))
+    ip = L.orc_sq8_distance(oracle.INNER_PRODUCT, codes[0].ctypes.data, comp[0], codes[1].ctypes.data, comp[1], dim,
+                            scale, float((shift * shift).sum()))
+    assert abs(-ip - float((recon[0] * recon[1]).sum())) <= 1e-3 * max(1.0, abs(ip))
