@@ -1,0 +1,107 @@
+"""ctypes binding of include/dann.h (libdann_hip.so).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load,
+importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdann_hip.so")
+
+F32, F16, U8, I8 = 0, 1, 2, 3
+COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
+OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
+
+
+class Config(C.Structure):
+    """dann_config == provider::Config + Full::new (diskann-inmem/src/provider.rs:160-217)."""
+    _fields_ = [("dtype", C.c_int32), ("metric", C.c_int32), ("dim", C.c_uint32), ("capacity", C.c_uint32),
+                ("max_degree", C.c_uint32), ("num_start_points", C.c_uint32), ("row_stride", C.c_uint32),
+                ("device", C.c_int32)]
+
+
+class BuildConfig(C.Structure):
+    """dann_build_config == graph::config::Builder (diskann/src/graph/config/mod.rs:261-338)."""
+    _fields_ = [("pruned_degree", C.c_uint32), ("max_degree", C.c_uint32), ("l_build", C.c_uint32),
+                ("alpha", C.c_float), ("max_occlusion_size", C.c_uint32), ("max_backedges", C.c_uint32),
+                ("intra_batch_candidates", C.c_uint32), ("saturate_after_prune", C.c_uint32)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32)]
+
+
+# every symbol include/dann.h declares: name -> (restype, argtypes)
+_vp, _u32, _i32, _u64, _f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64, C.c_float
+_P = C.POINTER
+SYMBOLS = {
+    "dann_layer_bytes": (_i32, [_i32, _u32]),
+    "dann_inmem2_row_stride": (_i32, [_i32, _u32]),
+    "dann_index_create": (_i32, [_P(Config), _vp, _u64, _P(_vp)]),
+    "dann_index_destroy": (_i32, [_vp]),
+    "dann_index_max_degree": (_i32, [_vp]),
+    "dann_index_get_config": (_i32, [_vp, _P(Config)]),
+    "dann_set_element": (_i32, [_vp, _u32, _vp, _u64]),
+    "dann_set_elements": (_i32, [_vp, _u32, _u32, _vp, _u64]),
+    "dann_get_element": (_i32, [_vp, _u32, _vp, _u64]),
+    "dann_upload_store": (_i32, [_vp, _vp, _u64, _u32]),
+    "dann_get_neighbors": (_i32, [_vp, _u32, _vp, _u32, _P(_u32)]),
+    "dann_set_neighbors": (_i32, [_vp, _u32, _vp, _u32]),
+    "dann_append_neighbors": (_i32, [_vp, _u32, _vp, _u32]),
+    "dann_set_neighbors_bulk": (_i32, [_vp, _vp, _u32, _vp]),
+    "dann_upload_graph": (_i32, [_vp, _vp, _u64]),
+    "dann_download_graph": (_i32, [_vp, _vp, _u64]),
+    "dann_distance": (_i32, [_vp, _vp, _u64, _vp, _u64, _P(_f32)]),
+    "dann_distance_pairs": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "dann_query_create": (_i32, [_vp, _vp, _u64, _P(_vp)]),
+    "dann_query_destroy": (_i32, [_vp]),
+    "dann_query_distance": (_i32, [_vp, _vp, _u64, _P(_f32)]),
+    "dann_expand_beam": (_i32, [_vp, _vp, _u32, _vp, _vp, _P(_u32)]),
+    "dann_expand_beam_batch": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "dann_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "dann_search_batch_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),
+    "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
+    "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
+    "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
+    "dann_last_error": (_i32, [C.c_char_p, _u64]),
+    "dann_kernel_time": (_i32, [_vp, _i32, _P(C.c_double), _P(_u64)]),
+    "dann_kernel_time_reset": (_i32, [_vp]),
+    "dann_set_visited_bits": (_i32, [_vp, _u32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdann_hip.so (raises if it is absent: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m diskann_amd.build` "
+                "(or __graft_entry__.build()).  diskann_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class DannError(RuntimeError):
+    """ANNError analogue: carries the DANN_E* status and the library's message."""
+
+    def __init__(self, status, where):
+        buf = C.create_string_buffer(512)
+        lib().dann_last_error(buf, 512)
+        self.status = status
+        super().__init__(f"{where} failed with status {status}: {buf.value.decode(errors='replace')}")
+
+
+def check(status, where):
+    if status < 0:
+        raise DannError(status, where)
+    return status

@@ -1,0 +1,650 @@
+// api.hip -- the C ABI of include/dann.h: index lifetime, HBM layout, host<->device
+// staging and kernel dispatch.  No CPU fallback exists anywhere in this library: every
+// distance, search and prune result comes from a HIP kernel, and a missing/failed device
+// surfaces as DANN_EHIP.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dann_device.h"
+#include "dann_internal.h"
+
+namespace dann {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int32_t hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return DANN_EHIP;
+}
+
+static uint32_t elem_size(int32_t dtype) { return dtype == DT_F32 ? 4u : dtype == DT_F16 ? 2u : 1u; }
+static bool valid_dtype(int32_t d) { return d >= 0 && d <= 3; }
+static bool valid_metric(int32_t m) { return m >= 0 && m <= 3; }
+
+// temporary device buffer with RAII
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T>
+    T* as() {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// time one launch on the index stream with HIP events (the stream the kernel runs on)
+template <class F>
+static int32_t timed(dann_index* idx, int which, F&& f) {
+    DANN_HIP(hipEventRecord(idx->ev0, idx->stream));
+    int32_t rc = f();
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipEventRecord(idx->ev1, idx->stream));
+    DANN_HIP(hipEventSynchronize(idx->ev1));
+    float ms = 0.f;
+    DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+    idx->clocks[which].total_ms += ms;
+    idx->clocks[which].launches += 1;
+    return DANN_OK;
+}
+
+static uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam) {
+    if (idx->visited_bits) return idx->visited_bits;
+    // expected visited ids ~ hops * degree, hops ~ L; keep the table under 75 % full with
+    // slack 1.5x (the reference sizes its hash set as 1.1 * R * 1.3 * L, scratch.rs:186-197)
+    uint64_t want = (uint64_t)(1.5 * (double)(l_value + idx->cfg.num_start_points + beam) * idx->cfg.max_degree) + 64;
+    uint32_t bits = 10;
+    while ((1ull << bits) * 3 / 4 < want && bits < 15) ++bits;
+    return bits;
+}
+
+}  // namespace dann
+
+using namespace dann;
+
+dann::IndexView dann_index::view() const {
+    IndexView v;
+    v.rows = d_rows;
+    v.adj = d_adj;
+    v.row_stride = cfg.row_stride;
+    v.adj_stride = cfg.max_degree + 1;
+    v.dim = cfg.dim;
+    v.capacity = cfg.capacity;
+    v.nslots = nslots;
+    v.max_degree = cfg.max_degree;
+    v.nstart = cfg.num_start_points;
+    v.dtype = cfg.dtype;
+    v.metric = cfg.metric;
+    return v;
+}
+
+extern "C" {
+
+int32_t dann_last_error(char* buf, uint64_t len) {
+    size_t n = strlen(g_err);
+    if (buf && len) {
+        size_t c = n < len - 1 ? n : len - 1;
+        memcpy(buf, g_err, c);
+        buf[c] = 0;
+    }
+    return (int32_t)n;
+}
+
+int32_t dann_layer_bytes(int32_t dtype, uint32_t dim) {
+    if (!valid_dtype(dtype)) {
+        set_error("bad dtype %d", dtype);
+        return DANN_EINVAL;
+    }
+    return (int32_t)(dim * elem_size(dtype));
+}
+
+int32_t dann_inmem2_row_stride(int32_t dtype, uint32_t dim) {
+    int32_t b = dann_layer_bytes(dtype, dim);
+    if (b < 0) return b;
+    return (b + 1 + 31) / 32 * 32;
+}
+
+int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64_t start_len, dann_index** out) {
+    if (!cfg || !out) {
+        set_error("null argument");
+        return DANN_EINVAL;
+    }
+    *out = nullptr;
+    if (!valid_dtype(cfg->dtype) || !valid_metric(cfg->metric) || cfg->dim == 0 || cfg->max_degree == 0) {
+        set_error("invalid config (dtype %d metric %d dim %u max_degree %u)", cfg->dtype, cfg->metric, cfg->dim,
+                  cfg->max_degree);
+        return DANN_EINVAL;
+    }
+    const uint32_t lb = cfg->dim * elem_size(cfg->dtype);
+    if ((uint64_t)cfg->capacity + cfg->num_start_points >= 0x7FFFFFFFull) {
+        set_error("capacity + start points must be below 2^31 - 1");
+        return DANN_EINVAL;
+    }
+    if (start_len != (uint64_t)lb * cfg->num_start_points || (cfg->num_start_points && !start_rows)) {
+        set_error("start rows: expected %llu bytes, got %llu", (unsigned long long)lb * cfg->num_start_points,
+                  (unsigned long long)start_len);
+        return DANN_ELENGTH;
+    }
+    dann_index* idx = new (std::nothrow) dann_index();
+    if (!idx) return DANN_ENOMEM;
+    idx->cfg = *cfg;
+    idx->layer_bytes = lb;
+    if (idx->cfg.row_stride == 0) idx->cfg.row_stride = (lb + 15u) & ~15u;
+    if (idx->cfg.row_stride < lb || (idx->cfg.row_stride & 15u)) {
+        set_error("row_stride %u must be >= %u and a multiple of 16", idx->cfg.row_stride, lb);
+        delete idx;
+        return DANN_EINVAL;
+    }
+    idx->nslots = cfg->capacity + cfg->num_start_points;
+    int dev = cfg->device;
+    if (dev < 0) {
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) {
+            delete idx;
+            return hip_fail(e, "hipGetDevice");
+        }
+    }
+    idx->device = dev;
+    idx->cfg.device = dev;
+    DeviceGuard guard(dev);
+    auto fail = [&](hipError_t e, const char* what) {
+        int32_t rc = hip_fail(e, what);
+        dann_index_destroy(idx);
+        return rc;
+    };
+    if (!guard.ok) return fail(hipErrorInvalidDevice, "hipSetDevice");
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&idx->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&idx->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+    const size_t rows_bytes = (size_t)idx->nslots * idx->cfg.row_stride + 256;
+    const size_t adj_bytes = (size_t)idx->nslots * (cfg->max_degree + 1) * 4;
+    if ((e = hipMalloc((void**)&idx->d_rows, rows_bytes)) != hipSuccess) return fail(e, "hipMalloc(rows)");
+    if ((e = hipMalloc((void**)&idx->d_adj, adj_bytes)) != hipSuccess) return fail(e, "hipMalloc(adjacency)");
+    if ((e = hipMemsetAsync(idx->d_rows, 0, rows_bytes, idx->stream)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemsetAsync(idx->d_adj, 0, adj_bytes, idx->stream)) != hipSuccess) return fail(e, "hipMemset");
+    if (cfg->num_start_points) {
+        e = hipMemcpy2DAsync(idx->d_rows + (size_t)cfg->capacity * idx->cfg.row_stride, idx->cfg.row_stride, start_rows,
+                             lb, lb, cfg->num_start_points, hipMemcpyHostToDevice, idx->stream);
+        if (e != hipSuccess) return fail(e, "hipMemcpy2D(start rows)");
+    }
+    if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    *out = idx;
+    return DANN_OK;
+}
+
+int32_t dann_index_destroy(dann_index* idx) {
+    if (!idx) return DANN_OK;
+    DeviceGuard guard(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    if (idx->d_rows) (void)hipFree(idx->d_rows);
+    if (idx->d_adj) (void)hipFree(idx->d_adj);
+    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+    return DANN_OK;
+}
+
+int32_t dann_index_max_degree(const dann_index* idx) { return idx ? (int32_t)idx->cfg.max_degree : DANN_EINVAL; }
+
+int32_t dann_index_get_config(const dann_index* idx, dann_config* out) {
+    if (!idx || !out) return DANN_EINVAL;
+    *out = idx->cfg;
+    return DANN_OK;
+}
+
+#define CHECK_IDX(idx)              \
+    if (!(idx)) {                   \
+        set_error("null index");    \
+        return DANN_EINVAL;         \
+    }                               \
+    DeviceGuard _guard((idx)->device)
+
+int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) {
+    CHECK_IDX(idx);
+    if (n == 0) return DANN_OK;
+    if (!rows) return DANN_EINVAL;
+    if (len != (uint64_t)n * idx->layer_bytes) {
+        set_error("raw byte slice of length %llu does not match expected length %llu", (unsigned long long)len,
+                  (unsigned long long)n * idx->layer_bytes);
+        return DANN_ELENGTH;
+    }
+    if ((uint64_t)first_slot + n > idx->cfg.capacity) {
+        set_error("slot range [%u, %llu) exceeds capacity %u", first_slot, (unsigned long long)first_slot + n,
+                  idx->cfg.capacity);
+        return DANN_EBOUNDS;
+    }
+    DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride, idx->cfg.row_stride, rows,
+                              idx->layer_bytes, idx->layer_bytes, n, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len) {
+    return dann_set_elements(idx, slot, 1, bytes, len);
+}
+
+int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len) {
+    CHECK_IDX(idx);
+    if (!bytes) return DANN_EINVAL;
+    if (len != idx->layer_bytes) {
+        set_error("expected slice of length %u - instead got %llu", idx->layer_bytes, (unsigned long long)len);
+        return DANN_ELENGTH;
+    }
+    if (slot >= idx->nslots) return DANN_EBOUNDS;
+    DANN_HIP(hipMemcpyAsync(bytes, idx->d_rows + (size_t)slot * idx->cfg.row_stride, len, hipMemcpyDeviceToHost,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows) {
+    CHECK_IDX(idx);
+    if (!base) return DANN_EINVAL;
+    if (nrows > idx->nslots) return DANN_EBOUNDS;
+    if (stride < idx->layer_bytes) return DANN_ELENGTH;
+    DANN_HIP(hipMemcpy2DAsync(idx->d_rows, idx->cfg.row_stride, base, stride, idx->layer_bytes, nrows,
+                              hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+// ---- adjacency ---------------------------------------------------------------------------
+int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len) {
+    CHECK_IDX(idx);
+    if (!out_len) return DANN_EINVAL;
+    if (slot >= idx->nslots) {
+        set_error("adjacency list %u is out of bounds (%u entries)", slot, idx->nslots);
+        return DANN_EBOUNDS;
+    }
+    std::vector<uint32_t> row(idx->cfg.max_degree + 1);
+    DANN_HIP(hipMemcpyAsync(row.data(), idx->d_adj + (size_t)slot * row.size(), row.size() * 4, hipMemcpyDeviceToHost,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    uint32_t len = std::min(row[0], idx->cfg.max_degree);
+    *out_len = len;
+    if (len > cap || (len && !out)) return DANN_ETOOLONG;
+    if (len) memcpy(out, row.data() + 1, (size_t)len * 4);
+    return DANN_OK;
+}
+
+int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) {
+    CHECK_IDX(idx);
+    if (slot >= idx->nslots) return DANN_EBOUNDS;
+    if (n > idx->cfg.max_degree) {
+        set_error("adjacency list of length %u exceeds max degree %u", n, idx->cfg.max_degree);
+        return DANN_ETOOLONG;
+    }
+    if (n && !ids) return DANN_EINVAL;
+    std::vector<uint32_t> row(n + 1);
+    row[0] = n;
+    if (n) memcpy(row.data() + 1, ids, (size_t)n * 4);
+    DANN_HIP(hipMemcpyAsync(idx->d_adj + (size_t)slot * (idx->cfg.max_degree + 1), row.data(), row.size() * 4,
+                            hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) {
+    CHECK_IDX(idx);
+    if (slot >= idx->nslots) return DANN_EBOUNDS;
+    std::vector<uint32_t> cur(idx->cfg.max_degree);
+    uint32_t len = 0;
+    int32_t rc = dann_get_neighbors(idx, slot, cur.data(), idx->cfg.max_degree, &len);
+    if (rc != DANN_OK) return rc;
+    uint32_t slack = idx->cfg.max_degree - len;  // clamp, provider.rs:804-816
+    uint32_t take = std::min(n, slack);
+    for (uint32_t i = 0; i < take; ++i) cur[len + i] = ids[i];
+    return dann_set_neighbors(idx, slot, cur.data(), len + take);
+}
+
+int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t n, const uint32_t* lists) {
+    CHECK_IDX(idx);
+    if (n == 0) return DANN_OK;
+    if (!slots || !lists) return DANN_EINVAL;
+    const uint32_t w = idx->cfg.max_degree + 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (slots[i] >= idx->nslots) return DANN_EBOUNDS;
+        if (lists[(size_t)i * w] > idx->cfg.max_degree) return DANN_ETOOLONG;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        DANN_HIP(hipMemcpyAsync(idx->d_adj + (size_t)slots[i] * w, lists + (size_t)i * w, (size_t)w * 4,
+                                hipMemcpyHostToDevice, idx->stream));
+    }
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) {
+    CHECK_IDX(idx);
+    if (!adj) return DANN_EINVAL;
+    if (nrows > idx->nslots) return DANN_EBOUNDS;
+    DANN_HIP(hipMemcpyAsync(idx->d_adj, adj, (size_t)nrows * (idx->cfg.max_degree + 1) * 4, hipMemcpyHostToDevice,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows) {
+    CHECK_IDX(idx);
+    if (!adj) return DANN_EINVAL;
+    if (nrows > idx->nslots) return DANN_EBOUNDS;
+    DANN_HIP(hipMemcpyAsync(adj, idx->d_adj, (size_t)nrows * (idx->cfg.max_degree + 1) * 4, hipMemcpyDeviceToHost,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+// ---- distances ---------------------------------------------------------------------------
+int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const void* y, uint64_t ylen, float* out) {
+    CHECK_IDX(idx);
+    if (!x || !y || !out) return DANN_EINVAL;
+    if (xlen != idx->layer_bytes || ylen != idx->layer_bytes) {
+        set_error("expected slices of length %u - instead got %llu and %llu", idx->layer_bytes,
+                  (unsigned long long)xlen, (unsigned long long)ylen);
+        return DANN_ELENGTH;
+    }
+    const size_t stride = (idx->layer_bytes + 15u) & ~15u;
+    DevBuf buf;
+    DANN_HIP(buf.alloc(2 * stride + 16));
+    uint8_t* d = buf.as<uint8_t>();
+    DANN_HIP(hipMemcpyAsync(d, x, xlen, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(d + stride, y, ylen, hipMemcpyHostToDevice, idx->stream));
+    float* d_out = reinterpret_cast<float*>(d + 2 * stride);
+    int32_t rc = launch_distance_raw(idx->cfg.dtype, idx->cfg.metric, idx->cfg.dim, d, d + stride, stride, 1, d_out,
+                                     idx->stream);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out, d_out, 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint32_t* b, uint32_t n, float* out) {
+    CHECK_IDX(idx);
+    if (n == 0) return DANN_OK;
+    if (!a || !b || !out) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (a[i] >= idx->nslots || b[i] >= idx->nslots) return DANN_EBOUNDS;
+    DevBuf buf;
+    DANN_HIP(buf.alloc((size_t)n * 12));
+    uint32_t* da = buf.as<uint32_t>();
+    uint32_t* db = da + n;
+    float* dout = reinterpret_cast<float*>(db + n);
+    DANN_HIP(hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(db, b, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = launch_distance_pairs(idx->view(), da, db, n, dout, idx->stream);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len, dann_query** out) {
+    CHECK_IDX(idx);
+    if (!query || !out) return DANN_EINVAL;
+    *out = nullptr;
+    if (len != idx->layer_bytes) {  // Full::check_dim (full.rs:86-99)
+        set_error("query of %llu bytes does not match the layer's %u bytes", (unsigned long long)len, idx->layer_bytes);
+        return DANN_ELENGTH;
+    }
+    dann_query* q = new (std::nothrow) dann_query();
+    if (!q) return DANN_ENOMEM;
+    q->idx = idx;
+    hipError_t e = hipMalloc(&q->d_query, (len + 15) & ~15ull);
+    if (e != hipSuccess) {
+        delete q;
+        return hip_fail(e, "hipMalloc(query)");
+    }
+    e = hipMemcpyAsync(q->d_query, query, len, hipMemcpyHostToDevice, idx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(q->d_query);
+        delete q;
+        return hip_fail(e, "hipMemcpy(query)");
+    }
+    *out = q;
+    return DANN_OK;
+}
+
+int32_t dann_query_destroy(dann_query* q) {
+    if (!q) return DANN_OK;
+    DeviceGuard guard(q->idx->device);
+    if (q->d_query) (void)hipFree(q->d_query);
+    delete q;
+    return DANN_OK;
+}
+
+// shared by dann_query_distance / dann_expand_beam: search-path kernel over a temporary row
+// set or stored rows
+static int32_t expand_on_device(const dann_index* idx, const IndexView& view, const void* d_query, const uint32_t* ids,
+                                uint32_t n, float* out) {
+    DevBuf buf;
+    DANN_HIP(buf.alloc((size_t)n * 8 + 16));
+    uint64_t* d_off = buf.as<uint64_t>();
+    uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_off + 2);
+    float* d_out = reinterpret_cast<float*>(d_ids + n);
+    uint64_t off[2] = {0, n};
+    DANN_HIP(hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = launch_expand_beam(view, d_query, 1, d_ids, d_off, n, d_out, idx->stream);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, float* out) {
+    if (!q || !row || !out) return DANN_EINVAL;
+    const dann_index* idx = q->idx;
+    DeviceGuard guard(idx->device);
+    if (len != idx->layer_bytes) {
+        set_error("expected slice of length %u - instead got %llu", idx->layer_bytes, (unsigned long long)len);
+        return DANN_ELENGTH;
+    }
+    DevBuf rowbuf;
+    DANN_HIP(rowbuf.alloc((len + 15) & ~15ull));
+    DANN_HIP(hipMemcpyAsync(rowbuf.p, row, len, hipMemcpyHostToDevice, idx->stream));
+    IndexView v = idx->view();
+    v.rows = rowbuf.as<uint8_t>();
+    v.nslots = 1;
+    uint32_t zero = 0;
+    return expand_on_device(idx, v, q->d_query, &zero, 1, out);
+}
+
+int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, uint32_t* out_ids, float* out_dists,
+                         uint32_t* out_n) {
+    if (!q || !out_n) return DANN_EINVAL;
+    const dann_index* idx = q->idx;
+    DeviceGuard guard(idx->device);
+    *out_n = 0;
+    if (n == 0) return DANN_OK;
+    if (!ids || !out_ids || !out_dists) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (ids[i] >= idx->nslots) return DANN_EBOUNDS;
+    int32_t rc = expand_on_device(idx, idx->view(), q->d_query, ids, n, out_dists);
+    if (rc != DANN_OK) return rc;
+    memcpy(out_ids, ids, (size_t)n * 4);  // every slot of the snapshot is readable (no tags)
+    *out_n = n;
+    return DANN_OK;
+}
+
+int32_t dann_expand_beam_batch(const dann_index* cidx, const void* queries, uint32_t nq, const uint32_t* ids,
+                               const uint64_t* offsets, float* out_dists) {
+    dann_index* idx = const_cast<dann_index*>(cidx);
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !ids || !offsets || !out_dists) return DANN_EINVAL;
+    const uint64_t total = offsets[nq];
+    uint64_t max_len = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (offsets[i + 1] < offsets[i]) return DANN_EINVAL;
+        max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+    }
+    for (uint64_t i = 0; i < total; ++i)
+        if (ids[i] >= idx->nslots) return DANN_EBOUNDS;
+    if (total == 0) return DANN_OK;
+    DevBuf bq, bo, bi, bd;
+    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    DANN_HIP(bo.alloc((size_t)(nq + 1) * 8));
+    DANN_HIP(bi.alloc(total * 4));
+    DANN_HIP(bd.alloc(total * 4));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bo.p, offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bi.p, ids, total * 4, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = timed(idx, 1, [&] {
+        return launch_expand_beam(idx->view(), bq.p, nq, bi.as<uint32_t>(), bo.as<uint64_t>(), max_len, bd.as<float>(),
+                                  idx->stream);
+    });
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, total * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+// ---- search --------------------------------------------------------------------------------
+static int32_t search_device(dann_index* idx, const void* d_queries, const uint32_t* d_qslots, uint32_t nq,
+                             uint32_t l_value, uint32_t beam, uint32_t k, uint32_t* d_ids, float* d_dists,
+                             dann_search_stats* d_stats, uint32_t* d_rec_ids, float* d_rec_d, uint32_t rec_stride,
+                             uint32_t* d_rec_n) {
+    SearchArgs a;
+    a.ix = idx->view();
+    a.queries = d_queries;
+    a.qslots = d_qslots;
+    a.nq = nq;
+    a.l_value = l_value;
+    a.beam_width = beam;
+    a.k = k;
+    a.ht_bits = auto_visited_bits(idx, l_value, beam);
+    a.out_ids = d_ids;
+    a.out_dists = d_dists;
+    a.stats = d_stats;
+    a.rec_ids = d_rec_ids;
+    a.rec_dists = d_rec_d;
+    a.rec_stride = rec_stride;
+    a.rec_n = d_rec_n;
+    return timed(idx, 0, [&] { return launch_search(a, idx->stream); });
+}
+
+int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
+                                 uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
+                                 dann_search_stats* d_out_stats) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
+    return search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
+                         nullptr, nullptr, 0, nullptr);
+}
+
+int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
+                          uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
+    DevBuf bq, bi, bd, bs;
+    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    DANN_HIP(bi.alloc((size_t)nq * k * 4));
+    DANN_HIP(bd.alloc((size_t)nq * k * 4));
+    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = search_device(idx, bq.p, nullptr, nq, l_value, beam_width, k, bi.as<uint32_t>(), bd.as<float>(),
+                               bs.as<dann_search_stats>(), nullptr, nullptr, 0, nullptr);
+    if (rc != DANN_OK) return rc;
+    std::vector<dann_search_stats> stats(nq);
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (stats[i].status) {
+            set_error("query %u: per-query scratch exhausted (visited table 2^%u entries); raise it with "
+                      "dann_set_visited_bits",
+                      i, auto_visited_bits(idx, l_value, beam_width));
+            return DANN_EOVERFLOW;
+        }
+    }
+    return DANN_OK;
+}
+
+int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,
+                                 uint32_t* rec_ids, float* rec_dists, uint32_t rec_stride, uint32_t* rec_n,
+                                 dann_search_stats* out_stats) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!slots || !rec_ids || !rec_dists || !rec_n || rec_stride == 0) return DANN_EINVAL;
+    for (uint32_t i = 0; i < nq; ++i)
+        if (slots[i] >= idx->nslots) return DANN_EBOUNDS;
+    DevBuf bsl, bri, brd, brn, bs;
+    DANN_HIP(bsl.alloc((size_t)nq * 4));
+    DANN_HIP(bri.alloc((size_t)nq * rec_stride * 4));
+    DANN_HIP(brd.alloc((size_t)nq * rec_stride * 4));
+    DANN_HIP(brn.alloc((size_t)nq * 4));
+    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
+    DANN_HIP(hipMemcpyAsync(bsl.p, slots, (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = search_device(idx, nullptr, bsl.as<uint32_t>(), nq, l_value, 1, 0, nullptr, nullptr,
+                               bs.as<dann_search_stats>(), bri.as<uint32_t>(), brd.as<float>(), rec_stride,
+                               brn.as<uint32_t>());
+    if (rc != DANN_OK) return rc;
+    std::vector<dann_search_stats> stats(nq);
+    DANN_HIP(hipMemcpyAsync(rec_ids, bri.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(rec_dists, brd.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(rec_n, brn.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
+                            idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+    for (uint32_t i = 0; i < nq; ++i)
+        if (stats[i].status) {
+            set_error("query %u: visited table or record buffer exhausted", i);
+            return DANN_EOVERFLOW;
+        }
+    return DANN_OK;
+}
+
+// ---- diagnostics -----------------------------------------------------------------------------
+int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) {
+    if (!idx || which < 0 || which > 3) return DANN_EINVAL;
+    if (total_ms) *total_ms = idx->clocks[which].total_ms;
+    if (launches) *launches = idx->clocks[which].launches;
+    return DANN_OK;
+}
+
+int32_t dann_kernel_time_reset(dann_index* idx) {
+    if (!idx) return DANN_EINVAL;
+    for (auto& c : idx->clocks) c = KernelClock();
+    return DANN_OK;
+}
+
+int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) {
+    if (!idx || (bits != 0 && (bits < 6 || bits > 15))) return DANN_EINVAL;
+    idx->visited_bits = bits;
+    return DANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// dann_device.h -- CDNA4 (gfx950) device primitives for the DiskANN hot path.
+//
+// The distance functions reproduce, bit for bit, the association order of the
+// reference's x86-64-v3 kernels (diskann-vector/src/distance/simd.rs:321-483 main-loop
+// strategies, :686-747 simd_op, diskann-wide/src/arch/x86_64/v3/f32x8_.rs:185-212
+// sum_tree), because the returned neighbour ids must equal the CPU path's at fixed L
+// and near-ties in the L-queue are decided by the last ulp.
+//
+// Mapping onto a 64-wide wavefront.  The CPU keeps NACC accumulators of 8 f32 lanes; element
+// e of a vector is accumulated (one FMA per visit, increasing e) into "chain"
+// c = e mod (8*NACC).  A chain is a strictly sequential FMA sequence, so a whole chain must
+// live in one GPU lane.  We give every candidate row a group of G = 2*NACC adjacent lanes;
+// lane v of the group owns chains 4v..4v+3, i.e. per "trip" of 8*NACC elements it loads the
+// 4 consecutive elements [trip + 4v, trip + 4v + 4) -- one 16-byte load for f32 rows,
+// one 8-byte load for f16 rows -- so a group reads 128 (64) contiguous bytes per
+// instruction and a wavefront reads 64/G rows at once.  The accumulator combine
+// `(s0+s1)+(s2+s3)` and the 8-lane horizontal tree are three DPP adds plus three in-lane
+// adds.  The result is valid in lane v == 0 of each group.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dann {
+
+enum : int { DT_F32 = 0, DT_F16 = 1, DT_U8 = 2, DT_I8 = 3 };
+enum : int { M_COSINE = 0, M_IP = 1, M_L2 = 2, M_COSN = 3 };
+enum : int { OP_L2 = 0, OP_IP = 1, OP_COS = 2 };
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kVisitedBit = 0x80000000u;
+
+// DPP controls (cdna4 ISA: quad_perm = 0x00-0xFF, row_shl:n = 0x100+n)
+constexpr int DPP_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_SHL4 = 0x104;  // lane i <- lane i+4 (within a row of 16)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- element loads: 4 consecutive elements as f32 -----------------------------------
+struct F4 {
+    float x, y, z, w;
+};
+__device__ __forceinline__ F4 load4(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    return {t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ F4 load4(const __half* p) {
+    // exact widening (v_cvt_f32_f16), as `half` -> f32 on the CPU
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    __half2 a = __builtin_bit_cast(__half2, t.x), b = __builtin_bit_cast(__half2, t.y);
+    float2 fa = __half22float2(a), fb = __half22float2(b);
+    return {fa.x, fa.y, fb.x, fb.y};
+}
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const __half* p) { return __half2float(*p); }
+
+// FullCosineAccumulator::sum (simd.rs:2329-2362)
+__device__ __forceinline__ float cosine_finish(float normx, float normy, float prod) {
+    float denominator = __fsqrt_rn(normx) * __fsqrt_rn(normy);
+    if (normx < 1.17549435e-38f || normy < 1.17549435e-38f) return 0.0f;
+    float v = __fdiv_rn(prod, denominator);
+    float m = (v != v) ? 1.0f : (v < 1.0f ? v : 1.0f);
+    return m > -1.0f ? m : -1.0f;
+}
+
+// PostOp (diskann-vector/src/distance/implementations.rs:215-401)
+template <int OP, bool NORMALIZED>
+__device__ __forceinline__ float post_op(float raw) {
+    if (OP == OP_L2) return raw;
+    if (OP == OP_IP) return NORMALIZED ? 1.0f - raw : -raw;
+    return 1.0f - raw;
+}
+
+// One FMA step of a schema (simd.rs L2 :817-845, IP :1588-1616, cosine :2296-2305)
+template <int OP>
+struct FAcc {
+    float s[4], nx[4], ny[4];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = nx[i] = ny[i] = 0.0f;
+    }
+    __device__ __forceinline__ void step(const F4& x, const F4& y) {
+        const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (OP == OP_L2) {
+                float c = xs[i] - ys[i];
+                s[i] = __builtin_fmaf(c, c, s[i]);
+            } else if (OP == OP_IP) {
+                s[i] = __builtin_fmaf(xs[i], ys[i], s[i]);
+            } else {
+                nx[i] = __builtin_fmaf(xs[i], xs[i], nx[i]);
+                ny[i] = __builtin_fmaf(ys[i], ys[i], ny[i]);
+                s[i] = __builtin_fmaf(xs[i], ys[i], s[i]);
+            }
+        }
+    }
+};
+
+// accumulator combine across the group + partial block + horizontal tree for one f32x8
+// logical vector held as 4 floats in each of G lanes.  Returns the sum (valid in lane v==0).
+template <int NACC, class PartialFn>
+__device__ __forceinline__ float finish_vec(float (&a)[4], PartialFn&& partial) {
+    // (s0+s1) [+ (s2+s3)]: lane v holds accumulator v/2, vector lanes 4*(v&1)+i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = a[i] + dpp_f<DPP_XOR2>(a[i]);
+    if (NACC == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = a[i] + dpp_f<DPP_SHL4>(a[i]);
+    }
+    partial(a);
+    // sum_tree: ((x0+x4)+(x2+x6)) + ((x1+x5)+(x3+x7)); lane even holds x0..3, odd x4..7
+    float q0 = a[0] + dpp_f<DPP_XOR1>(a[0]);
+    float q1 = a[1] + dpp_f<DPP_XOR1>(a[1]);
+    float q2 = a[2] + dpp_f<DPP_XOR1>(a[2]);
+    float q3 = a[3] + dpp_f<DPP_XOR1>(a[3]);
+    return (q0 + q2) + (q1 + q3);
+}
+
+// Distance between `q` (QT elements, any address space) and `row` (RT elements), both of
+// length `dim`, computed by a group of G = 2*NACC lanes; `v` = lane index inside the group.
+// DIM > 0 fixes the length at compile time (fully unrolled, all loads issued up front).
+template <int NACC, int OP, int DIM, typename QT, typename RT>
+__device__ __forceinline__ float group_distance_raw(const QT* __restrict__ q, const RT* __restrict__ row, int dim,
+                                                    int v) {
+    constexpr int G = 2 * NACC, TRIP = 4 * G;
+    if (DIM > 0) dim = DIM;
+    const int full_end = dim & ~7;
+    FAcc<OP> acc;
+    acc.init();
+    if constexpr (DIM > 0) {
+        constexpr int NT = (DIM / 8 * 8 + TRIP - 1) / TRIP;
+        F4 ys[NT], xs[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int e = t * TRIP + 4 * v;
+            if (e < full_end) ys[t] = load4(row + e);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int e = t * TRIP + 4 * v;
+            if (e < full_end) xs[t] = load4(q + e);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int e = t * TRIP + 4 * v;
+            if (e < full_end) acc.step(xs[t], ys[t]);
+        }
+    } else {
+        for (int e = 4 * v; e < full_end; e += TRIP) {
+            F4 y = load4(row + e);
+            F4 x = load4(q + e);
+            acc.step(x, y);
+        }
+    }
+    const int rem = dim & 7;
+    // partial block: zero-padded masked load accumulated into the *combined* vector
+    // (simd.rs:735-745, SIMDSchema::epilogue :545-563)
+    auto partial = [&](float(&a)[4], int which) {
+        if (rem == 0) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int l = 4 * (v & 1) + i;
+            float x = 0.0f, y = 0.0f;
+            if (l < rem) {
+                x = load1(q + full_end + l);
+                y = load1(row + full_end + l);
+            }
+            if (OP == OP_L2) {
+                float c = x - y;
+                a[i] = __builtin_fmaf(c, c, a[i]);
+            } else if (which == 0) {
+                a[i] = __builtin_fmaf(x, y, a[i]);
+            } else if (which == 1) {
+                a[i] = __builtin_fmaf(x, x, a[i]);
+            } else {
+                a[i] = __builtin_fmaf(y, y, a[i]);
+            }
+        }
+    };
+    float s = finish_vec<NACC>(acc.s, [&](float(&a)[4]) { partial(a, 0); });
+    if (OP == OP_COS) {
+        float nx = finish_vec<NACC>(acc.nx, [&](float(&a)[4]) { partial(a, 1); });
+        float ny = finish_vec<NACC>(acc.ny, [&](float(&a)[4]) { partial(a, 2); });
+        return cosine_finish(nx, ny, s);
+    }
+    return s;
+}
+
+
+// Fixed-length variant with the query slice of this lane preloaded in registers
+// (DIM % (8*NACC) == 0, so there is neither an epilogue block nor a partial block).
+// `U` rows are processed together: all U*NT row loads are issued before the first FMA so
+// one lane keeps U*NT 16-byte requests in flight.
+template <int NACC, int OP, int DIM, int U, typename RT>
+__device__ __forceinline__ void group_distance_pre(const F4 (&xs)[DIM / (8 * NACC)], const RT* const (&rows)[U],
+                                                   const bool (&active)[U], int v, float (&out)[U]) {
+    constexpr int G = 2 * NACC, TRIP = 4 * G, NT = DIM / TRIP;
+    F4 ys[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (active[u]) ys[u][t] = load4(rows[u] + t * TRIP + 4 * v);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        FAcc<OP> acc;
+        acc.init();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc.step(xs[t], ys[u][t]);
+        float s = finish_vec<NACC>(acc.s, [](float(&)[4]) {});
+        if (OP == OP_COS) {
+            float nx = finish_vec<NACC>(acc.nx, [](float(&)[4]) {});
+            float ny = finish_vec<NACC>(acc.ny, [](float(&)[4]) {});
+            s = cosine_finish(nx, ny, s);
+        }
+        out[u] = s;
+    }
+}
+
+// ---- integer rows (u8 / i8): exact i32 accumulation, any order is bit-identical
+// (simd.rs:1192-1225, 1947-1979, 2109-2143, 2790-2827, 2996-3033).  Group of 8 lanes,
+// 16 bytes per lane per step, v_dot4 accumulate.  Valid in lane v == 0.
+template <bool SIGNED>
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
+    if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+    return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
+}
+template <bool SIGNED>
+__device__ __forceinline__ int elem(const uint8_t* p) {
+    return SIGNED ? (int)(int8_t)*p : (int)*p;
+}
+__device__ __forceinline__ int group8_sum(int x) {
+    x += dpp_i<DPP_XOR1>(x);
+    x += dpp_i<DPP_XOR2>(x);
+    x += dpp_i<DPP_SHL4>(x);
+    return x;
+}
+template <int OP, bool SIGNED>
+__device__ __forceinline__ float group_distance_int(const uint8_t* __restrict__ q, const uint8_t* __restrict__ row,
+                                                    int dim, int v) {
+    int xx = 0, yy = 0, xy = 0;
+    const int vec_end = dim & ~15;
+    for (int e = 16 * v; e < vec_end; e += 128) {
+        uint4 x = *reinterpret_cast<const uint4*>(q + e);
+        uint4 y = *reinterpret_cast<const uint4*>(row + e);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xy = dot4<SIGNED>(xs[i], ys[i], xy);
+            if (OP != OP_IP) {
+                xx = dot4<SIGNED>(xs[i], xs[i], xx);
+                yy = dot4<SIGNED>(ys[i], ys[i], yy);
+            }
+        }
+    }
+    for (int e = vec_end + v; e < dim; e += 8) {
+        int a = elem<SIGNED>(q + e), b = elem<SIGNED>(row + e);
+        xy += a * b;
+        xx += a * a;
+        yy += b * b;
+    }
+    xy = group8_sum(xy);
+    if (OP == OP_IP) return (float)xy;
+    xx = group8_sum(xx);
+    yy = group8_sum(yy);
+    if (OP == OP_L2) return (float)(int)((uint32_t)xx + (uint32_t)yy - 2u * (uint32_t)xy);
+    return cosine_finish((float)xx, (float)yy, (float)xy);
+}
+
+// ---- dtype dispatch ------------------------------------------------------------------
+// Query-side staging type and group width for the *search* path
+// (Full<T>::query_distance, diskann-inmem/src/layers/full.rs:351-504):
+//   f32 rows: f32 query, L2/IP Strategy4x1 (NACC 4), cosine Strategy2x4 (NACC 2)
+//   f16 rows: query widened to f32 once, L2/IP Strategy4x2 (== NACC 4), cosine NACC 2
+//   u8/i8  : integer query, exact
+// and for the *pair* path (DistanceProvider::distance_comparer, V3):
+//   f16 x f16: L2/IP/cosine all Strategy2x4 (NACC 2)  (simd.rs:989,1752,2591)
+template <int DT, int OP, bool PAIR>
+struct Scheme {
+    static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8);
+    static constexpr int NACC = (OP == OP_COS) ? 2 : ((DT == DT_F16 && PAIR) ? 2 : 4);
+    static constexpr int G = kInt ? 8 : 2 * NACC;
+};
+
+template <int DT>
+struct RowType {
+    using type = float;
+};
+template <>
+struct RowType<DT_F16> {
+    using type = __half;
+};
+template <>
+struct RowType<DT_U8> {
+    using type = uint8_t;
+};
+template <>
+struct RowType<DT_I8> {
+    using type = uint8_t;
+};
+
+// `q` is the staged query: f32 for float rows, raw bytes for integer rows.
+template <int DT, int OP, bool PAIR, int DIM, typename QT>
+__device__ __forceinline__ float group_distance(const QT* q, const uint8_t* row, int dim, int v) {
+    if constexpr (DT == DT_U8 || DT == DT_I8) {
+        return group_distance_int<OP, DT == DT_I8>(reinterpret_cast<const uint8_t*>(q), row, dim, v);
+    } else {
+        using RT = typename RowType<DT>::type;
+        return group_distance_raw<Scheme<DT, OP, PAIR>::NACC, OP, DIM>(q, reinterpret_cast<const RT*>(row), dim, v);
+    }
+}
+
+// metric -> (OP, NORMALIZED); integers treat CosineNormalized as Cosine
+// (distance_provider.rs:274-297, full.rs:470,499)
+__host__ __device__ inline int metric_op(int dtype, int metric) {
+    if (metric == M_L2) return OP_L2;
+    if (metric == M_IP) return OP_IP;
+    if (metric == M_COSINE) return OP_COS;
+    return (dtype == DT_U8 || dtype == DT_I8) ? OP_COS : OP_IP;  // CosineNormalized
+}
+
+}  // namespace dann

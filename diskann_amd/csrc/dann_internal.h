@@ -1,0 +1,89 @@
+// dann_internal.h -- host-side structures shared by the translation units of libdann_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/dann.h"
+
+namespace dann {
+
+void set_error(const char* fmt, ...);
+int32_t hip_fail(hipError_t e, const char* what);
+
+#define DANN_HIP(call)                                        \
+    do {                                                      \
+        hipError_t _e = (call);                               \
+        if (_e != hipSuccess) return ::dann::hip_fail(_e, #call); \
+    } while (0)
+
+struct KernelClock {
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+// Device view of the index, passed by value to kernels.
+struct IndexView {
+    const uint8_t* rows;   // (capacity + nstart) rows, row_stride bytes apart
+    uint32_t* adj;         // (capacity + nstart) x (max_degree + 1) u32: [len, ids...]
+    uint64_t row_stride;
+    uint32_t adj_stride;   // max_degree + 1
+    uint32_t dim;
+    uint32_t capacity;
+    uint32_t nslots;       // capacity + nstart
+    uint32_t max_degree;
+    uint32_t nstart;
+    int32_t dtype;
+    int32_t metric;
+};
+
+struct SearchArgs {
+    IndexView ix;
+    const void* queries;     // nq rows of layer bytes, or nullptr when `qslots` is used
+    const uint32_t* qslots;  // insert-time search: query i = stored row qslots[i]
+    uint32_t nq;
+    uint32_t l_value;
+    uint32_t beam_width;
+    uint32_t k;
+    uint32_t ht_bits;
+    uint32_t* out_ids;       // nq x k (may be null in record mode)
+    float* out_dists;
+    dann_search_stats* stats;
+    uint32_t* rec_ids;       // nq x rec_stride (record mode) or null
+    float* rec_dists;
+    uint32_t rec_stride;
+    uint32_t* rec_n;
+};
+
+int32_t launch_search(const SearchArgs& a, hipStream_t stream);
+size_t search_lds_bytes(const SearchArgs& a);
+
+int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
+                           const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);
+int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
+                              hipStream_t stream);
+// raw rows x[i] vs y[i] (pair kernel numerics), n pairs of `bytes` each
+int32_t launch_distance_raw(int32_t dtype, int32_t metric, uint32_t dim, const void* d_x, const void* d_y,
+                            uint64_t stride, uint32_t n, float* d_out, hipStream_t stream);
+
+}  // namespace dann
+
+struct dann_index {
+    dann_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t* d_rows = nullptr;
+    uint32_t* d_adj = nullptr;
+    uint32_t layer_bytes = 0;
+    uint32_t nslots = 0;
+    uint32_t visited_bits = 0;
+    dann::KernelClock clocks[4];
+    dann::IndexView view() const;
+};
+
+struct dann_query {
+    const dann_index* idx;
+    void* d_query = nullptr;
+};

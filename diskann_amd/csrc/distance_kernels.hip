@@ -1,0 +1,206 @@
+// distance_kernels.hip -- stand-alone batched distance kernels (the parity seam and the
+// gather-distance roofline kernel).
+//
+//   expand_beam_kernel   == ExpandBeam::expand_beam for a batch of (query, id list) pairs
+//                           diskann-inmem/src/provider.rs:492-497, 620-690
+//   pair_kernel          == layers::Distance::evaluate between stored rows (RobustPrune's
+//                           primitive) diskann-inmem/src/layers/full.rs:224-242,
+//                           diskann/src/graph/internal/prune.rs:212-215
+#include "dann_device.h"
+#include "dann_internal.h"
+
+namespace dann {
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kChunk = 512;  // candidate ids per workgroup
+
+template <int DT, int OP, bool NORM, int DIM>
+__global__ __launch_bounds__(kWave) void expand_beam_kernel(IndexView ix, const void* queries, const uint32_t* ids,
+                                                            const uint64_t* offsets, float* out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using S = Scheme<DT, OP, false>;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    constexpr bool kInt = S::kInt;
+    using QT = typename std::conditional<kInt, uint8_t, float>::type;
+    using RT = typename RowType<DT>::type;
+    const uint32_t lane = threadIdx.x, qi = blockIdx.x;
+    const uint64_t lo = offsets[qi] + (uint64_t)blockIdx.y * kChunk;
+    const uint64_t hi_all = offsets[qi + 1];
+    if (lo >= hi_all) return;
+    const uint64_t hi = lo + kChunk < hi_all ? lo + kChunk : hi_all;
+    const uint32_t esz = (DT == DT_F32) ? 4u : (DT == DT_F16 ? 2u : 1u);
+    QT* qs = reinterpret_cast<QT*>(smem);
+    const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(queries) + (uint64_t)qi * ix.dim * esz;
+    if constexpr (kInt) {
+        for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
+    } else {
+        const RT* src = reinterpret_cast<const RT*>(qsrc);
+        for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
+    }
+    __syncthreads();
+    const int g = lane / G, v = lane % G;
+    if constexpr (DIM > 0 && !kInt) {
+        constexpr int NTQ = DIM / (4 * G), U = 4;
+        F4 xq[NTQ];
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) xq[t] = load4(reinterpret_cast<const float*>(qs) + t * 4 * G + 4 * v);
+        for (uint64_t c0 = lo; c0 < hi; c0 += GROUPS * U) {
+            const RT* rows[U];
+            bool act[U];
+            float o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t c = c0 + u * GROUPS + g;
+                act[u] = c < hi;
+                uint32_t id = act[u] ? ids[c] : 0u;
+                rows[u] = reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride);
+            }
+            group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, o);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t c = c0 + u * GROUPS + g;
+                if (act[u] && v == 0) out[c] = post_op<OP, NORM>(o[u]);
+            }
+        }
+    } else {
+        for (uint64_t c0 = lo; c0 < hi; c0 += GROUPS) {
+            uint64_t c = c0 + g;
+            if (c < hi) {
+                const uint8_t* row = ix.rows + (uint64_t)ids[c] * ix.row_stride;
+                float d = group_distance<DT, OP, false, 0>(qs, row, (int)ix.dim, v);
+                if (v == 0) out[c] = post_op<OP, NORM>(d);
+            }
+        }
+    }
+}
+
+// pair i: rows xa[i], yb[i] given as byte pointers base + id*stride (stored rows) or
+// base + i*stride (raw rows).
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(256) void pair_kernel(const uint8_t* xbase, const uint8_t* ybase, uint64_t xstride,
+                                                   uint64_t ystride, const uint32_t* a, const uint32_t* b, uint32_t n,
+                                                   uint32_t dim, float* out) {
+    using S = Scheme<DT, OP, true>;
+    constexpr int G = S::G;
+    using RT = typename RowType<DT>::type;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = tid / G;
+    const int v = tid % G;
+    if (p >= n) return;  // whole groups exit together (G divides 64)
+    const uint8_t* x = xbase + (uint64_t)(a ? a[p] : p) * xstride;
+    const uint8_t* y = ybase + (uint64_t)(b ? b[p] : p) * ystride;
+    float d;
+    if constexpr (S::kInt) {
+        d = group_distance_int<OP, DT == DT_I8>(x, y, (int)dim, v);
+    } else {
+        d = group_distance_raw<S::NACC, OP, 0>(reinterpret_cast<const RT*>(x), reinterpret_cast<const RT*>(y), (int)dim,
+                                               v);
+    }
+    if (v == 0) out[p] = post_op<OP, NORM>(d);
+}
+
+template <int DT, int OP, bool NORM>
+int32_t launch_pairs_t(const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys, const uint32_t* a,
+                       const uint32_t* b, uint32_t n, uint32_t dim, float* out, hipStream_t stream) {
+    constexpr int G = Scheme<DT, OP, true>::G;
+    const uint64_t threads = (uint64_t)n * G;
+    const uint32_t blocks = (uint32_t)((threads + 255) / 256);
+    hipLaunchKernelGGL((pair_kernel<DT, OP, NORM>), dim3(blocks), dim3(256), 0, stream, xb, yb, xs, ys, a, b, n, dim,
+                       out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pair_kernel launch");
+    return DANN_OK;
+}
+
+template <int DT>
+int32_t launch_pairs_dt(int32_t metric, const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys,
+                        const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, float* out,
+                        hipStream_t stream) {
+    const int op = metric_op(DT, metric);
+    const bool norm = metric == M_COSN && op == OP_IP;
+    if (op == OP_L2) return launch_pairs_t<DT, OP_L2, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+    if (op == OP_IP) {
+        if (norm) return launch_pairs_t<DT, OP_IP, true>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+        return launch_pairs_t<DT, OP_IP, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+    }
+    return launch_pairs_t<DT, OP_COS, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+}
+
+int32_t launch_pairs_any(int32_t dtype, int32_t metric, const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys,
+                         const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, float* out,
+                         hipStream_t stream) {
+    if (n == 0) return DANN_OK;
+    switch (dtype) {
+        case DT_F32: return launch_pairs_dt<DT_F32>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
+        case DT_F16: return launch_pairs_dt<DT_F16>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
+        case DT_U8: return launch_pairs_dt<DT_U8>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
+        case DT_I8: return launch_pairs_dt<DT_I8>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
+    }
+    set_error("bad dtype %d", dtype);
+    return DANN_EINVAL;
+}
+
+template <int DT, int OP, bool NORM, int DIM>
+int32_t launch_eb_t(const IndexView& ix, const void* q, uint32_t nq, uint32_t chunks, const uint32_t* ids,
+                    const uint64_t* offsets, float* out, hipStream_t stream) {
+    const bool is_int = DT == DT_U8 || DT == DT_I8;
+    size_t lds = ((is_int ? ix.dim : ix.dim * 4u) + 15u) & ~15u;
+    hipLaunchKernelGGL((expand_beam_kernel<DT, OP, NORM, DIM>), dim3(nq, chunks), dim3(kWave), lds, stream, ix, q, ids,
+                       offsets, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "expand_beam_kernel launch");
+    return DANN_OK;
+}
+
+template <int DT>
+int32_t launch_eb_dt(const IndexView& ix, const void* q, uint32_t nq, uint32_t chunks, const uint32_t* ids,
+                     const uint64_t* offsets, float* out, hipStream_t stream) {
+    const int op = metric_op(ix.dtype, ix.metric);
+    const bool norm = ix.metric == M_COSN && op == OP_IP;
+    if (op == OP_L2) {
+        if (DT == DT_F32 && ix.dim == 128)
+            return launch_eb_t<DT, OP_L2, false, (DT == DT_F32 ? 128 : 0)>(ix, q, nq, chunks, ids, offsets, out, stream);
+        return launch_eb_t<DT, OP_L2, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+    }
+    if (op == OP_IP) {
+        if (norm) return launch_eb_t<DT, OP_IP, true, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+        return launch_eb_t<DT, OP_IP, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+    }
+    return launch_eb_t<DT, OP_COS, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+}
+
+}  // namespace
+
+// `d_offsets[nq+1]` on device; `max_len` = longest list (host-known) sizes the grid.
+int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
+                           const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream) {
+    if (nq == 0 || max_len == 0) return DANN_OK;
+    const uint32_t chunks = (uint32_t)((max_len + kChunk - 1) / kChunk);
+    if (chunks > 65535u) {
+        set_error("id list too long for one launch (%llu ids)", (unsigned long long)max_len);
+        return DANN_EUNSUPPORTED;
+    }
+    switch (ix.dtype) {
+        case DT_F32: return launch_eb_dt<DT_F32>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
+        case DT_F16: return launch_eb_dt<DT_F16>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
+        case DT_U8: return launch_eb_dt<DT_U8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
+        case DT_I8: return launch_eb_dt<DT_I8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
+    }
+    set_error("bad dtype %d", ix.dtype);
+    return DANN_EINVAL;
+}
+
+int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
+                              hipStream_t stream) {
+    return launch_pairs_any(ix.dtype, ix.metric, ix.rows, ix.rows, ix.row_stride, ix.row_stride, d_a, d_b, n, ix.dim,
+                            d_out, stream);
+}
+
+int32_t launch_distance_raw(int32_t dtype, int32_t metric, uint32_t dim, const void* d_x, const void* d_y,
+                            uint64_t stride, uint32_t n, float* d_out, hipStream_t stream) {
+    return launch_pairs_any(dtype, metric, reinterpret_cast<const uint8_t*>(d_x), reinterpret_cast<const uint8_t*>(d_y),
+                            stride, stride, nullptr, nullptr, n, dim, d_out, stream);
+}
+
+}  // namespace dann

@@ -1,0 +1,435 @@
+// search_kernels.hip -- batched Vamana beam search, one wavefront per query.
+//
+// Replaces, for a batch of independent queries, the reference call chain
+//   DiskANNIndex::search_internal          diskann/src/graph/index.rs:1933-2000
+//     NeighborPriorityQueue                diskann/src/neighbor/queue.rs:130-318
+//     SearchAccessor::expand_beam          diskann-inmem/src/provider.rs:436-480
+//       Neighbors::get                     diskann-inmem/src/neighbors.rs:124-163
+//       NotInMut (visited set)             diskann/src/graph/glue.rs:524-561
+//       expand_beam_inner + QueryDistance  diskann-inmem/src/provider.rs:620-690, layers/full.rs:317-336
+//   Translate::post_process                diskann-inmem/src/provider.rs:899-950
+// with results identical to the CPU path (ids, distances, cmps, hops).
+//
+// Design (MI355X): the whole beam loop of one query runs inside one 64-lane wavefront
+// (workgroup = 1 wave, so the only barriers are wave-local).  Per hop:
+//   1. pop the W closest unexpanded queue entries (ballot + readlane; the sorted L-queue
+//      lives in registers, entry p in lane p%64 slot p/64);
+//   2. read their adjacency rows (one coalesced 4*(R+1)-byte read each), test-and-insert
+//      every neighbour id into an exact open-addressing visited table in LDS
+//      (ds_cmpst), compact the survivors in adjacency order (ballot + mbcnt);
+//   3. gather: G lanes per surviving candidate row, 16-byte loads, 64/G rows per
+//      wave-instruction, U rows in flight per lane group -- random 512-byte rows are
+//      read as whole 128-byte lines; FMA chains in the reference's association order;
+//   4. merge the (id, dist) batch into the queue by rank: the sequential
+//      `insert` calls of index.rs:1986-1988 keep the best `capacity` elements under the
+//      total order (distance asc, insertion time desc) -- queue.rs:142-170: lower-bound
+//      insertion puts a new element *before* equal-distance ones, a full queue drops its
+//      last element, and an element worse than the last is rejected -- so inserting a
+//      batch one by one equals taking the top-`capacity` of old ∪ new under that order.
+//      Ranks are computed with wave-uniform readlane broadcasts, the permutation goes
+//      through an LDS staging buffer.
+// HBM traffic per query = cmps * row bytes + hops * adjacency row; everything else stays
+// in registers/LDS.
+#include "dann_device.h"
+#include "dann_internal.h"
+
+namespace dann {
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxBeam = 16;
+
+struct SearchLds {
+    uint32_t ht_off, cand_id_off, cand_d_off, stage_id_off, stage_d_off, beam_off, q_off, total;
+};
+
+__host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
+
+__host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_bits, uint32_t cmax, uint32_t qcap,
+                                                       uint32_t qbytes) {
+    SearchLds l;
+    uint32_t off = 0;
+    l.q_off = off;
+    off += round16(qbytes);
+    l.ht_off = off;
+    off += (1u << ht_bits) * 4u;
+    l.cand_id_off = off;
+    off += round16(cmax * 4u);
+    l.cand_d_off = off;
+    off += round16(cmax * 4u);
+    l.stage_id_off = off;
+    off += round16(qcap * 4u);
+    l.stage_d_off = off;
+    off += round16(qcap * 4u);
+    l.beam_off = off;
+    off += round16(kMaxBeam * 4u);
+    l.total = off;
+    return l;
+}
+
+// exact visited set: open addressing, linear probing, ds_cmpst.  Returns true if `id`
+// was not present (and is now).  == hashbrown::HashSet::insert (glue.rs:542-549).
+__device__ __forceinline__ bool ht_insert(uint32_t* ht, uint32_t mask, uint32_t shift, uint32_t id) {
+    uint32_t h = (id * 2654435761u) >> shift;
+    for (;;) {
+        uint32_t old = atomicCAS(&ht[h], kEmpty, id);
+        if (old == kEmpty) return true;
+        if (old == id) return false;
+        h = (h + 1) & mask;
+    }
+}
+
+template <int DT, int OP, bool NORM, int QS, int DIM>
+__global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using S = Scheme<DT, OP, false>;
+    constexpr int G = S::G;
+    constexpr int GROUPS = kWave / G;
+    constexpr bool kInt = S::kInt;
+    using QT = typename std::conditional<kInt, uint8_t, float>::type;
+    using RT = typename RowType<DT>::type;
+
+    const IndexView& ix = a.ix;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t R = ix.max_degree;
+    const uint32_t W = a.beam_width;
+    const uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207)
+    const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
+                                                                              : ((ix.nstart + 63u) & ~63u);
+    const uint32_t esz = (DT == DT_F32) ? 4u : (DT == DT_F16 ? 2u : 1u);
+    const uint32_t qbytes = kInt ? ix.dim : ix.dim * 4u;
+    const SearchLds L = search_lds_layout(a.ht_bits, cmax, QS * kWave, qbytes);
+    QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
+    uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
+    uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
+    float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
+    uint32_t* stage_id = reinterpret_cast<uint32_t*>(smem + L.stage_id_off);
+    float* stage_d = reinterpret_cast<float*>(smem + L.stage_d_off);
+    uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
+
+    // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
+    {
+        const uint8_t* qsrc = a.qslots ? ix.rows + (uint64_t)a.qslots[qi] * ix.row_stride
+                                       : reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.dim * esz;
+        if constexpr (kInt) {
+            for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
+        } else {
+            const RT* src = reinterpret_cast<const RT*>(qsrc);
+            for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
+        }
+    }
+    const uint32_t ht_size = 1u << a.ht_bits, ht_mask = ht_size - 1u, ht_shift = 32u - a.ht_bits;
+    for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
+    __syncthreads();
+
+    const int g = lane / G, v = lane % G;
+    // query slice of this lane in registers for the fixed-length float path
+    constexpr int NTQ = (DIM > 0 && !kInt) ? DIM / (4 * G) : 1;
+    F4 xq[NTQ];
+    if constexpr (DIM > 0 && !kInt) {
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) xq[t] = load4(reinterpret_cast<const float*>(qs) + t * 4 * G + 4 * v);
+    }
+
+    // ---- queue state: entry p at lane p % 64, slot p / 64 ------------------------------
+    uint32_t qid[QS];
+    float qd[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        qid[s] = kEmpty;
+        qd[s] = 0.0f;
+    }
+    uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
+
+    // distance of every candidate in cand_id[0..nc) -> cand_d
+    auto gather = [&](uint32_t nc) {
+        if constexpr (DIM > 0 && !kInt) {
+            constexpr int U = 2;
+            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
+                const RT* rows[U];
+                bool act[U];
+                float out[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    act[u] = c < nc;
+                    uint32_t id = act[u] ? cand_id[c] : 0u;
+                    rows[u] = reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride);
+                }
+                group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, out);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);
+                }
+            }
+        } else {
+            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS) {
+                uint32_t c = c0 + g;
+                bool act = c < nc;
+                uint32_t id = act ? cand_id[c] : 0u;
+                const uint8_t* row = ix.rows + (uint64_t)id * ix.row_stride;
+                float d = 0.0f;
+                if (act) d = group_distance<DT, OP, false, 0>(qs, row, (int)ix.dim, v);
+                if (act && v == 0) cand_d[c] = post_op<OP, NORM>(d);
+            }
+        }
+    };
+
+    // merge cand[m0 .. m0+n) (n <= 64) into the queue
+    auto merge = [&](uint32_t m0, uint32_t n) {
+        const bool has = lane < n;
+        const float nd = has ? cand_d[m0 + lane] : 0.0f;
+        const uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
+        const bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
+        const uint64_t vmask = ballot64(nvalid);
+        uint32_t shift[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) shift[s] = 0;
+        uint32_t pos_new = 0;
+        for (uint32_t jj = 0; jj < n; ++jj) {
+            if (!((vmask >> jj) & 1ull)) continue;
+            const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), jj));
+            uint32_t old_less = 0;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const bool ov = (uint32_t)(s * kWave) + lane < size;
+                shift[s] += (ov && dj <= qd[s]) ? 1u : 0u;
+                old_less += (uint32_t)__popcll(ballot64(ov && qd[s] < dj));
+            }
+            const bool before = (dj < nd) || (dj == nd && jj > lane);
+            pos_new += (before ? 1u : 0u) + (lane == jj ? old_less : 0u);
+        }
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint32_t p = (uint32_t)(s * kWave) + lane;
+            if (p < size) {
+                const uint32_t np = p + shift[s];
+                if (np < qcap) {
+                    stage_id[np] = qid[s];
+                    stage_d[np] = qd[s];
+                }
+            }
+        }
+        if (nvalid && pos_new < qcap) {
+            stage_id[pos_new] = nid;
+            stage_d[pos_new] = nd;
+        }
+        const uint32_t total = size + (uint32_t)__popcll(vmask);
+        size = total < qcap ? total : qcap;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint32_t p = (uint32_t)(s * kWave) + lane;
+            if (p < size) {
+                qid[s] = stage_id[p];
+                qd[s] = stage_d[p];
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958) ---
+    {
+        const uint32_t ns = ix.nstart;
+        for (uint32_t i = lane; i < ns; i += kWave) {
+            cand_id[i] = ix.capacity + i;
+            ht_insert(ht, ht_mask, ht_shift, ix.capacity + i);
+        }
+        ht_count = ns;
+        __syncthreads();
+        gather(ns);
+        __syncthreads();
+        cmps = ns;
+        for (uint32_t m0 = 0; m0 < ns; m0 += kWave) merge(m0, (ns - m0) < (uint32_t)kWave ? (ns - m0) : (uint32_t)kWave);
+    }
+
+    // ---- beam loop ----------------------------------------------------------------------
+    for (;;) {
+        // pop up to W closest unexpanded entries (queue.rs:297-313)
+        uint32_t nb = 0;
+        for (uint32_t w = 0; w < W; ++w) {
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                if (found) continue;
+                const bool cand = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
+                const uint64_t m = ballot64(cand);
+                if (m) {
+                    const int l = __builtin_ctzll(m);
+                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l);
+                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l));
+                    if ((int)lane == l) qid[s] |= kVisitedBit;
+                    if (lane == 0) {
+                        beam[nb] = id;
+                        if (a.rec_ids) {  // VisitedSearchRecord::record (search/record.rs:86-93)
+                            if (nrec < a.rec_stride) {
+                                a.rec_ids[(uint64_t)qi * a.rec_stride + nrec] = id;
+                                a.rec_dists[(uint64_t)qi * a.rec_stride + nrec] = d;
+                            }
+                        }
+                    }
+                    if (a.rec_ids) {
+                        if (nrec >= a.rec_stride) status = (uint32_t)(-DANN_EOVERFLOW);
+                        ++nrec;
+                    }
+                    ++nb;
+                    found = true;
+                }
+            }
+            if (!found) break;
+        }
+        if (nb == 0 || status) break;
+        hops += nb;
+        __syncthreads();
+
+        // expand: adjacency rows in pop order, ids in stored order, visited filter
+        // (provider.rs:448-454)
+        uint32_t nc = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t node = beam[b];
+            const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
+            uint32_t len = arow[0];
+            len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
+            if (ht_count + len > ht_size - (ht_size >> 2)) {
+                status = (uint32_t)(-DANN_EOVERFLOW);
+                break;
+            }
+            for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
+                const uint32_t j = j0 + lane;
+                const bool inb = j < len;
+                const uint32_t id = inb ? arow[1 + j] : kEmpty;
+                const bool isnew = inb && id != kEmpty && ht_insert(ht, ht_mask, ht_shift, id);
+                const bool keep = isnew && id < ix.nslots;
+                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                if (keep) cand_id[nc + mbcnt(km)] = id;
+                nc += (uint32_t)__popcll(km);
+                ht_count += (uint32_t)__popcll(nm);
+            }
+        }
+        if (status) break;
+        __syncthreads();
+        gather(nc);
+        __syncthreads();
+        cmps += nc;
+        for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
+    }
+
+    // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
+    uint32_t written = 0;
+    if (a.out_ids) {
+        uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+        float* od = a.out_dists + (uint64_t)qi * a.k;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint32_t p = (uint32_t)(s * kWave) + lane;
+            const uint32_t id = qid[s] & ~kVisitedBit;
+            const bool res = p < size && id < ix.capacity;
+            const uint64_t m = ballot64(res);
+            const uint32_t r = written + mbcnt(m);
+            if (res && r < a.k) {
+                oi[r] = id;
+                od[r] = qd[s];
+            }
+            written += (uint32_t)__popcll(m);
+        }
+        written = written < a.k ? written : a.k;
+        for (uint32_t r = written + lane; r < a.k; r += kWave) {
+            oi[r] = kEmpty;
+            od[r] = __builtin_inff();
+        }
+    }
+    if (lane == 0) {
+        if (a.stats) {
+            dann_search_stats st;
+            st.cmps = cmps;
+            st.hops = hops;
+            st.result_count = written;
+            st.status = status;
+            a.stats[qi] = st;
+        }
+        if (a.rec_n) a.rec_n[qi] = nrec;
+    }
+}
+
+template <int DT, int OP, bool NORM, int QS, int DIM>
+int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream) {
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(kWave), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
+    return DANN_OK;
+}
+
+template <int DT, int OP, bool NORM, int DIM>
+int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
+    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM>(a, lds, stream);
+    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM>(a, lds, stream);
+    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM>(a, lds, stream);
+    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM>(a, lds, stream);
+    set_error("search list size L + start points = %u exceeds the supported maximum of 512", qcap);
+    return DANN_EUNSUPPORTED;
+}
+
+template <int DT>
+int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
+    const int op = metric_op(a.ix.dtype, a.ix.metric);
+    const bool norm = (a.ix.metric == M_COSN) && op == OP_IP;
+    if (op == OP_L2) {
+        if (DT == DT_F32 && a.ix.dim == 128) return launch_qs<DT, OP_L2, false, (DT == DT_F32 ? 128 : 0)>(a, qcap, lds, stream);
+        return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream);
+    }
+    if (op == OP_IP) {
+        if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream);
+        return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream);
+    }
+    return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
+}
+
+uint32_t cmax_of(const SearchArgs& a) {
+    uint32_t c1 = (a.beam_width * a.ix.max_degree + 63u) & ~63u, c2 = (a.ix.nstart + 63u) & ~63u;
+    return c1 > c2 ? c1 : c2;
+}
+uint32_t qs_of(uint32_t qcap) { return qcap <= 64 ? 1 : qcap <= 128 ? 2 : qcap <= 256 ? 4 : 8; }
+
+}  // namespace
+
+size_t search_lds_bytes(const SearchArgs& a) {
+    const bool is_int = a.ix.dtype == DT_U8 || a.ix.dtype == DT_I8;
+    const uint32_t qcap = a.l_value + a.ix.nstart;
+    return search_lds_layout(a.ht_bits, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.dim : a.ix.dim * 4u).total;
+}
+
+int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
+    if (a.nq == 0) return DANN_OK;
+    if (a.l_value == 0 || a.beam_width == 0) {
+        set_error("l_value and beam_width must be non-zero (KnnSearchError, knn_search.rs:27-33)");
+        return DANN_EINVAL;
+    }
+    if (a.beam_width > (uint32_t)kMaxBeam) {
+        set_error("beam_width %u exceeds the supported maximum of %d", a.beam_width, kMaxBeam);
+        return DANN_EUNSUPPORTED;
+    }
+    const uint32_t qcap = a.l_value + a.ix.nstart;
+    const size_t lds = search_lds_bytes(a);
+    if (lds > 160 * 1024) {
+        set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited bits %u)", lds, a.ht_bits);
+        return DANN_EOVERFLOW;
+    }
+    switch (a.ix.dtype) {
+        case DT_F32: return launch_dt<DT_F32>(a, qcap, lds, stream);
+        case DT_F16: return launch_dt<DT_F16>(a, qcap, lds, stream);
+        case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream);
+        case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream);
+    }
+    set_error("bad dtype %d", a.ix.dtype);
+    return DANN_EINVAL;
+}
+
+}  // namespace dann

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's provider/index surface for the hot path.
+
+Names follow the reference: `Provider` (diskann_inmem::Provider), `Config`
+(provider::Config), `Knn` (graph::search::Knn), `Index.search` (DiskANNIndex::search),
+`set_element`, `get_neighbors` / `set_neighbors` / `append_vector`
+(NeighborAccessor(Mut)), `expand_beam` (ExpandBeam), `distance` (layers::Distance).
+All compute happens in libdann_hip.so (HIP kernels); this module only marshals numpy
+buffers through the C ABI of include/dann.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16, U8, I8, COSINE, INNER_PRODUCT, L2,
+                   COSINE_NORMALIZED, IBC_ALL, IBC_NONE)
+
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8}
+STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32)])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Knn:
+    """graph::search::Knn (diskann/src/graph/search/knn_search.rs:65-118)."""
+
+    def __init__(self, l_value, beam_width=None):
+        if l_value == 0:
+            raise ValueError("l_value cannot be zero")
+        if beam_width == 0:
+            raise ValueError("beam width cannot be zero")
+        self.l_value = int(l_value)
+        self.beam_width = 1 if beam_width is None else int(beam_width)
+
+
+def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_size=750, max_backedges=None,
+                 intra_batch_candidates=IBC_ALL, saturate_after_prune=False):
+    """graph::config::Builder with the reference defaults (config/defaults.rs:14-41)."""
+    return BuildConfig(pruned_degree, max_degree, l_build, alpha, max_occlusion_size,
+                       pruned_degree if max_backedges is None else max_backedges, intra_batch_candidates,
+                       int(saturate_after_prune))
+
+
+class Provider:
+    """diskann_inmem::Provider<Full<T>, u32> + DiskANNIndex, resident in one GPU's HBM."""
+
+    def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, row_stride=0, device=-1):
+        self.dtype, self.metric, self.dim = dtype, metric, int(dim)
+        self.capacity, self.max_degree = int(capacity), int(max_degree)
+        sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.dim)
+        self.num_start_points = sp.shape[0]
+        cfg = Config(dtype, metric, self.dim, self.capacity, self.max_degree, self.num_start_points, row_stride,
+                     device)
+        h = C.c_void_p()
+        check(_ffi.lib().dann_index_create(C.byref(cfg), _p(sp), sp.nbytes, C.byref(h)), "dann_index_create")
+        self._h = h
+        got = Config()
+        check(_ffi.lib().dann_index_get_config(self._h, C.byref(got)), "dann_index_get_config")
+        self.row_stride, self.device = got.row_stride, got.device
+        self.layer_bytes = _ffi.lib().dann_layer_bytes(dtype, self.dim)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().dann_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- SetElement ---------------------------------------------------------
+    def set_element(self, slot, vector):
+        v = np.ascontiguousarray(vector, dtype=NP_DTYPE[self.dtype])
+        check(_ffi.lib().dann_set_element(self._h, slot, _p(v), v.nbytes), "dann_set_element")
+
+    def set_elements(self, first_slot, rows):
+        r = np.ascontiguousarray(rows, dtype=NP_DTYPE[self.dtype])
+        n = r.shape[0] if r.ndim == 2 else r.size // self.dim
+        check(_ffi.lib().dann_set_elements(self._h, first_slot, n, _p(r), r.nbytes), "dann_set_elements")
+
+    def get_element(self, slot):
+        out = np.empty(self.dim, NP_DTYPE[self.dtype])
+        check(_ffi.lib().dann_get_element(self._h, slot, _p(out), out.nbytes), "dann_get_element")
+        return out
+
+    def upload_store(self, raw_rows):
+        raw = np.ascontiguousarray(raw_rows, dtype=np.uint8)
+        check(_ffi.lib().dann_upload_store(self._h, _p(raw), raw.shape[1], raw.shape[0]), "dann_upload_store")
+
+    # -- NeighborAccessor(Mut) ------------------------------------------------
+    def get_neighbors(self, slot):
+        out = np.empty(self.max_degree, np.uint32)
+        n = C.c_uint32()
+        check(_ffi.lib().dann_get_neighbors(self._h, slot, _p(out), self.max_degree, C.byref(n)), "dann_get_neighbors")
+        return out[: n.value].copy()
+
+    def set_neighbors(self, slot, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        check(_ffi.lib().dann_set_neighbors(self._h, slot, _p(a), a.size), "dann_set_neighbors")
+
+    def append_vector(self, slot, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        check(_ffi.lib().dann_append_neighbors(self._h, slot, _p(a), a.size), "dann_append_neighbors")
+
+    def upload_graph(self, adj):
+        a = np.ascontiguousarray(adj, dtype=np.uint32)
+        assert a.shape[1] == self.max_degree + 1
+        check(_ffi.lib().dann_upload_graph(self._h, _p(a), a.shape[0]), "dann_upload_graph")
+
+    def download_graph(self):
+        a = np.empty((self.capacity + self.num_start_points, self.max_degree + 1), np.uint32)
+        check(_ffi.lib().dann_download_graph(self._h, _p(a), a.shape[0]), "dann_download_graph")
+        return a
+
+    # -- layers::Distance / QueryDistance / ExpandBeam ------------------------
+    def distance(self, x, y):
+        x = np.ascontiguousarray(x, dtype=NP_DTYPE[self.dtype])
+        y = np.ascontiguousarray(y, dtype=NP_DTYPE[self.dtype])
+        out = C.c_float()
+        check(_ffi.lib().dann_distance(self._h, _p(x), x.nbytes, _p(y), y.nbytes, C.byref(out)), "dann_distance")
+        return out.value
+
+    def distance_pairs(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        out = np.empty(a.size, np.float32)
+        check(_ffi.lib().dann_distance_pairs(self._h, _p(a), _p(b), a.size, _p(out)), "dann_distance_pairs")
+        return out
+
+    def query_distance(self, query, row):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        r = np.ascontiguousarray(row, dtype=NP_DTYPE[self.dtype])
+        h = C.c_void_p()
+        check(_ffi.lib().dann_query_create(self._h, _p(q), q.nbytes, C.byref(h)), "dann_query_create")
+        try:
+            out = C.c_float()
+            check(_ffi.lib().dann_query_distance(h, _p(r), r.nbytes, C.byref(out)), "dann_query_distance")
+            return out.value
+        finally:
+            _ffi.lib().dann_query_destroy(h)
+
+    def expand_beam(self, query, ids):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        h = C.c_void_p()
+        check(_ffi.lib().dann_query_create(self._h, _p(q), q.nbytes, C.byref(h)), "dann_query_create")
+        try:
+            oi = np.empty(ids.size, np.uint32)
+            od = np.empty(ids.size, np.float32)
+            n = C.c_uint32()
+            check(_ffi.lib().dann_expand_beam(h, _p(ids), ids.size, _p(oi), _p(od), C.byref(n)), "dann_expand_beam")
+            return oi[: n.value], od[: n.value]
+        finally:
+            _ffi.lib().dann_query_destroy(h)
+
+    def expand_beam_batch(self, queries, ids, offsets):
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.empty(ids.size, np.float32)
+        check(_ffi.lib().dann_expand_beam_batch(self._h, _p(q), q.shape[0], _p(ids), _p(off), _p(out)),
+              "dann_expand_beam_batch")
+        return out
+
+    # -- DiskANNIndex::search -------------------------------------------------
+    def search(self, params, queries, k=10):
+        """nq independent Knn searches; returns (ids[nq,k], dists[nq,k], stats[nq])."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        stats = np.zeros(nq, STATS_DTYPE)
+        check(_ffi.lib().dann_search_batch(self._h, _p(q), nq, params.l_value, params.beam_width, k, _p(ids),
+                                           _p(dists), _p(stats)), "dann_search_batch")
+        return ids, dists, stats
+
+    def search_record(self, slots, l_value, rec_stride=None):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        rec_stride = rec_stride or 4 * (l_value + self.num_start_points) + 64
+        rid = np.empty((s.size, rec_stride), np.uint32)
+        rd = np.empty((s.size, rec_stride), np.float32)
+        rn = np.zeros(s.size, np.uint32)
+        stats = np.zeros(s.size, STATS_DTYPE)
+        check(_ffi.lib().dann_search_record_batch(self._h, _p(s), s.size, l_value, _p(rid), _p(rd), rec_stride,
+                                                  _p(rn), _p(stats)), "dann_search_record_batch")
+        return rid, rd, rn, stats
+
+    # -- build -------------------------------------------------------------------
+    def insert_batch(self, cfg, slots):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        check(_ffi.lib().dann_insert_batch(self._h, C.byref(cfg), _p(s), s.size), "dann_insert_batch")
+
+    def build(self, cfg, first, n, growth=0.02, max_batch=16384):
+        return check(_ffi.lib().dann_build(self._h, C.byref(cfg), first, n, growth, max_batch), "dann_build")
+
+    def prune_batch(self, cfg, locs, pool_ids, pool_dists, offsets, force_saturate=False):
+        locs = np.ascontiguousarray(locs, dtype=np.uint32)
+        pid = np.ascontiguousarray(pool_ids, dtype=np.uint32)
+        pd = np.ascontiguousarray(pool_dists, dtype=np.float32)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.zeros((locs.size, cfg.pruned_degree + 1), np.uint32)
+        check(_ffi.lib().dann_prune_batch(self._h, C.byref(cfg), _p(locs), locs.size, _p(pid), _p(pd), _p(off),
+                                          int(force_saturate), _p(out)), "dann_prune_batch")
+        return out
+
+    # -- diagnostics ---------------------------------------------------------------
+    def kernel_time(self, which=0):
+        ms, n = C.c_double(), C.c_uint64()
+        check(_ffi.lib().dann_kernel_time(self._h, which, C.byref(ms), C.byref(n)), "dann_kernel_time")
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        check(_ffi.lib().dann_kernel_time_reset(self._h), "dann_kernel_time_reset")
+
+    def set_visited_bits(self, bits):
+        check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")

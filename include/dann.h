@@ -1,0 +1,186 @@
+/*
+ * dann.h -- C ABI of the MI355X-native DiskANN hot path (libdann_hip.so).
+ *
+ * This is the drop-in boundary: the batched distance-evaluation path inside Vamana beam
+ * search and RobustPrune index build, behind the surface of the reference's
+ * `diskann-inmem` provider.  Each entry point names the reference interface it
+ * replaces (paths relative to the microsoft/DiskANN Rust workspace, v0.56).  The
+ * reference-side binding a maintainer would add (Rust `extern "C"` block + adapter) is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions (those of the reference's only C surface, diskann-garnet/src/lib.rs:261-372,
+ * 682-756): opaque handles, caller-owned buffers passed as pointer + length, `int32_t`
+ * status (>= 0 ok, < 0 one of DANN_E*), no exceptions or aborts cross the boundary,
+ * a thread-local message is available from dann_last_error().  Entry points are
+ * thread-safe for distinct handles; search entry points may be called concurrently on
+ * a shared index as long as no mutation is in flight (the GPU index is an immutable
+ * snapshot between mutations; the reference's EBR/tag machinery stays on the host).
+ *
+ * All "host" pointers are plain host memory; `_device` variants take HIP device
+ * pointers that live on the index's device.
+ */
+#ifndef DANN_H
+#define DANN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element type of the stored rows: layers::Full<T>, diskann-inmem/src/layers/full.rs:351-504 */
+typedef enum { DANN_F32 = 0, DANN_F16 = 1, DANN_U8 = 2, DANN_I8 = 3 } dann_dtype;
+
+/* == `#[repr(C)] enum Metric`, diskann-vector/src/distance/metric.rs:8-20 */
+typedef enum {
+    DANN_COSINE = 0,
+    DANN_INNER_PRODUCT = 1,
+    DANN_L2 = 2,
+    DANN_COSINE_NORMALIZED = 3
+} dann_metric;
+
+enum {
+    DANN_OK = 0,
+    DANN_EINVAL = -1,    /* null pointer / zero L / zero beam width / bad enum         */
+    DANN_ELENGTH = -2,   /* byte length does not match the layer (full.rs:228-241)    */
+    DANN_EBOUNDS = -3,   /* slot id out of bounds (neighbors.rs:OutOfBounds)          */
+    DANN_ETOOLONG = -4,  /* adjacency list longer than max_degree (neighbors.rs:TooLong) */
+    DANN_EHIP = -5,      /* a HIP runtime call failed; see dann_last_error()          */
+    DANN_ENOMEM = -6,
+    DANN_EOVERFLOW = -7, /* per-query scratch (visited table / record) exhausted      */
+    DANN_EUNSUPPORTED = -8
+} /* dann_status */;
+
+typedef struct dann_index dann_index; /* == diskann_inmem::Provider<Full<T>, _> + DiskANNIndex */
+typedef struct dann_query dann_query; /* == layers::QueryDistance / ExpandBeam object   */
+
+/* provider::Config + Full::new (diskann-inmem/src/provider.rs:160-217, 96-131) */
+typedef struct {
+    int32_t dtype;             /* dann_dtype  */
+    int32_t metric;            /* dann_metric */
+    uint32_t dim;
+    uint32_t capacity;         /* dynamic slots [0, capacity)                              */
+    uint32_t max_degree;       /* adjacency capacity per slot                              */
+    uint32_t num_start_points; /* frozen slots [capacity, capacity+n) (store.rs:259-262)   */
+    uint32_t row_stride;       /* bytes between rows; 0 = packed (dim*sizeof(T) rounded up
+                                  to 16).  dann_inmem2_row_stride() gives the reference's
+                                  own stride so a Store buffer can be uploaded verbatim    */
+    int32_t device;            /* HIP device ordinal, -1 = current                         */
+} dann_config;
+
+/* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs:14-41) */
+typedef struct {
+    uint32_t pruned_degree;
+    uint32_t max_degree;             /* "max_degree_with_slack"; <= dann_config.max_degree  */
+    uint32_t l_build;
+    float alpha;                     /* default 1.2                                         */
+    uint32_t max_occlusion_size;     /* default 750                                         */
+    uint32_t max_backedges;          /* single-insert only; default pruned_degree           */
+    uint32_t intra_batch_candidates; /* 0 = None, n = Max(n), 0xFFFFFFFF = All              */
+    uint32_t saturate_after_prune;   /* default 0                                           */
+} dann_build_config;
+
+/* per-query search statistics: SearchStats (diskann/src/graph/index.rs:90-102) */
+typedef struct {
+    uint32_t cmps;
+    uint32_t hops;
+    uint32_t result_count; /* entries written (the reference's Translate post-processor reports
+                              k-1 when the buffer fills, provider.rs:933-944; we report k)   */
+    uint32_t status;       /* 0 ok, else DANN_E* negated (per-query overflow reporting)      */
+} dann_search_stats;
+
+/* ---- layer / lifetime ---------------------------------------------------------- */
+/* Layer::bytes (layers/mod.rs:37-42): dim * sizeof(T), or DANN_EINVAL */
+int32_t dann_layer_bytes(int32_t dtype, uint32_t dim);
+/* Store row stride of the reference: round_up(bytes + 1 tag byte, 32) (store.rs:198-211) */
+int32_t dann_inmem2_row_stride(int32_t dtype, uint32_t dim);
+/* Provider::new + DiskANNIndex::new (provider.rs:96-131).  start_rows: num_start_points
+ * rows of dann_layer_bytes() each. */
+int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64_t start_len,
+                          dann_index** out);
+int32_t dann_index_destroy(dann_index* idx);
+int32_t dann_index_max_degree(const dann_index* idx);   /* Provider::max_degree */
+int32_t dann_index_get_config(const dann_index* idx, dann_config* out);
+
+/* ---- vectors: Set::set / SetElement::set_element (full.rs:110-130, provider.rs:334-373) */
+int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len);
+int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len);
+int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len);
+/* upload a whole diskann-inmem Store buffer verbatim (rows at `stride`, tag bytes ignored) */
+int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows);
+
+/* ---- adjacency: NeighborAccessor(Mut) (provider.rs:768-823, neighbors.rs:124-224) -- */
+int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len);
+int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n);
+/* append with the reference's clamp-on-overflow (provider.rs:804-816) */
+int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n);
+/* set_neighbors_bulk: lists[i] = [len, ids...] rows of (max_degree+1) u32 */
+int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t n, const uint32_t* lists);
+/* whole Neighbors buffer, (capacity+num_start_points) x (max_degree+1) u32 (neighbors.rs:60-101) */
+int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows);
+int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows);
+
+/* ---- distances (parity seam) ----------------------------------------------------- */
+/* layers::Distance::evaluate (full.rs:224-242): two raw rows, T x T kernel */
+int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const void* y, uint64_t ylen,
+                      float* out);
+/* the same between stored rows, n pairs in one launch (RobustPrune's primitive, prune.rs:212-215) */
+int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint32_t* b, uint32_t n, float* out);
+/* Search::query_distance + QueryDistance::evaluate (full.rs:165-171, 317-336) */
+int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len, dann_query** out);
+int32_t dann_query_destroy(dann_query* q);
+int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, float* out);
+/* ExpandBeam::expand_beam (provider.rs:492-497, 620-690): pre-filtered ids -> (id, dist) */
+int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, uint32_t* out_ids,
+                         float* out_dists, uint32_t* out_n);
+/* batched form: nq queries, ragged id lists (offsets has nq+1 entries); out_dists is
+ * aligned with `ids` */
+int32_t dann_expand_beam_batch(const dann_index* idx, const void* queries, uint32_t nq, const uint32_t* ids,
+                               const uint64_t* offsets, float* out_dists);
+
+/* ---- search: DiskANNIndex::search(Knn{l_value, beam_width}) for nq independent queries
+ * (index.rs:1933-2000,2029-2065; knn_search.rs:155-193; provider.rs:408-480,899-950).
+ * out_ids/out_dists: nq x k (unwritten entries 0xFFFFFFFF / +inf); ids are slot ids. ---- */
+int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value,
+                          uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists,
+                          dann_search_stats* out_stats);
+/* device-resident form: every pointer is a device pointer on the index's device; the
+ * launch is enqueued on the index stream and the call returns after it completes. */
+int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
+                                 uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
+                                 dann_search_stats* d_out_stats);
+/* insert-time search: also returns the VisitedSearchRecord (record.rs:86-93) per query:
+ * rec_ids/rec_dists: nq x rec_stride, rec_n: nq */
+int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,
+                                 uint32_t* rec_ids, float* rec_dists, uint32_t rec_stride, uint32_t* rec_n,
+                                 dann_search_stats* out_stats);
+
+/* ---- build ------------------------------------------------------------------------ */
+/* occlude_list / robust_prune over caller pools (index.rs:2565-2650, prune.rs:106-259):
+ * pool i = pool_ids/pool_dists[offsets[i] .. offsets[i+1]) for location locs[i];
+ * out_adj: n rows of (pruned_degree+1) u32 [len, ids...] */
+int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* locs, uint32_t n,
+                         const uint32_t* pool_ids, const float* pool_dists, const uint64_t* offsets,
+                         int32_t force_saturate, uint32_t* out_adj);
+/* DiskANNIndex::multi_insert (index.rs:815-1030) for rows already stored at `slots` */
+int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n);
+/* insert every slot in [first, first+n) in id order with a geometric batch schedule
+ * (batch = clamp(ceil(inserted * growth), 1, max_batch)); returns the number of batches */
+int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
+                   uint32_t max_batch);
+
+/* ---- diagnostics ------------------------------------------------------------------- */
+/* thread-local message of the last failing call on this thread; returns its length */
+int32_t dann_last_error(char* buf, uint64_t len);
+/* HIP-event time (ms) and launch count of the named kernel since the last reset.
+ * which: 0 = beam search, 1 = gather distance, 2 = prune, 3 = back-edge */
+int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches);
+int32_t dann_kernel_time_reset(dann_index* idx);
+/* tuning knob: log2 of the per-query visited-table entries (0 = auto from L and degree) */
+int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANN_H */

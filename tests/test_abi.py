@@ -1,0 +1,47 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol
+that include/dann.h declares; size helpers follow the reference's layout rules."""
+import os
+import re
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol():
+    import diskann_amd as da
+    from diskann_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "dann.h")).read()
+    declared = set(re.findall(r"\b(dann_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = da.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libdann_hip.so does not export {name}"
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+
+
+def test_layout_helpers():
+    import diskann_amd as da
+    L = da.lib()
+    # Layer::bytes and the Store stride round_up(bytes + 1, 32) (store.rs:198-211)
+    assert L.dann_layer_bytes(da.F32, 128) == 512 and L.dann_inmem2_row_stride(da.F32, 128) == 544
+    assert L.dann_layer_bytes(da.U8, 128) == 128 and L.dann_inmem2_row_stride(da.U8, 128) == 160
+    assert L.dann_layer_bytes(da.F16, 100) == 200 and L.dann_inmem2_row_stride(da.F16, 100) == 224
+    assert L.dann_layer_bytes(7, 4) == da._ffi.EINVAL
+
+
+def test_knn_parameter_validation():
+    import diskann_amd as da
+    with pytest.raises(ValueError):
+        da.Knn(0)
+    with pytest.raises(ValueError):
+        da.Knn(10, 0)
+    assert da.Knn(10).beam_width == 1
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "diskann_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "dann_oracle" not in text, f

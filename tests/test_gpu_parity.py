@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from gridutil import grid_data, grid_neighbors, grid_start_point
+from helpers import bits, make_pair, rand_vectors, random_graph
+
+pytestmark = pytest.mark.gpu
+
+da = pytest.importorskip("diskann_amd")
+
+DTYPES = [oracle.F32, oracle.F16, oracle.U8, oracle.I8]
+METRICS = [oracle.L2, oracle.INNER_PRODUCT, oracle.COSINE, oracle.COSINE_NORMALIZED]
+
+
+def _prov(dtype, metric, dim, n=4):
+    return da.Provider(dtype, metric, dim, n, 4, np.zeros((1, dim), oracle.NP_DTYPE[dtype]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_distance_kernels_bit_exact(dtype):
+    """layers::Distance (pair) and QueryDistance numerics for every metric; dims cover
+    empty main loops, epilogue blocks and partial blocks (full.rs:510-703)."""
+    rng = np.random.default_rng(11)
+    dims = [1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40, 63, 64, 65, 100, 127, 128, 129, 160, 256, 384, 771]
+    for metric in METRICS:
+        for dim in dims:
+            p = _prov(dtype, metric, dim)
+            x = rand_vectors(rng, dtype, 1, dim)[0]
+            y = rand_vectors(rng, dtype, 1, dim)[0]
+            got = np.float32(p.distance(x, y))
+            want = np.float32(oracle.distance(dtype, metric, x, y))
+            assert got.view(np.uint32) == want.view(np.uint32), (dtype, metric, dim, got, want)
+            gq = np.float32(p.query_distance(x, y))
+            wq = np.float32(oracle.query_distance(dtype, metric, x, y))
+            assert gq.view(np.uint32) == wq.view(np.uint32), (dtype, metric, dim, gq, wq)
+            p.close()
+
+
+def test_distance_length_errors():
+    """wrong lengths are errors, not panics (full.rs:228-241, 327-335)."""
+    p = _prov(oracle.F32, oracle.L2, 16)
+    with pytest.raises(da.DannError) as e:
+        p.distance(np.zeros(16, np.float32), np.zeros(15, np.float32))
+    assert e.value.status == da._ffi.ELENGTH
+    with pytest.raises(da.DannError):
+        p.query_distance(np.zeros(17, np.float32), np.zeros(16, np.float32))
+    with pytest.raises(da.DannError) as e:
+        p.set_neighbors(0, np.arange(5))
+    assert e.value.status == da._ffi.ETOOLONG
+    with pytest.raises(da.DannError) as e:
+        p.set_neighbors(99, [1])
+    assert e.value.status == da._ffi.EBOUNDS
+
+
+def test_denormals_and_specials():
+    p = _prov(oracle.F32, oracle.L2, 8)
+    x = np.full(8, 1e-30, np.float32)
+    y = np.zeros(8, np.float32)
+    for a, b in ((x, y), (np.full(8, 1e-22, np.float32), y), (np.full(8, 3e38, np.float32), -np.full(8, 3e38, np.float32))):
+        got = np.float32(p.distance(a, b))
+        want = np.float32(oracle.distance(oracle.F32, oracle.L2, a, b))
+        assert got.view(np.uint32) == want.view(np.uint32)
+
+
+@pytest.mark.parametrize("dtype,metric,dim", [(oracle.F32, oracle.L2, 128), (oracle.F32, oracle.L2, 100),
+                                               (oracle.F16, oracle.L2, 128), (oracle.F32, oracle.COSINE, 96),
+                                               (oracle.U8, oracle.L2, 128), (oracle.I8, oracle.INNER_PRODUCT, 100),
+                                               (oracle.F16, oracle.INNER_PRODUCT, 70)])
+def test_expand_beam_and_pairs(dtype, metric, dim):
+    rng = np.random.default_rng(5)
+    n, R = 3000, 16
+    data = rand_vectors(rng, dtype, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:1], R)
+    q = rand_vectors(rng, dtype, 1, dim)[0]
+    ids = rng.choice(n, 333, replace=False).astype(np.uint32)
+    oi, od = oix.expand_beam(q, ids)
+    gi, gd = gix.expand_beam(q, ids)
+    assert np.array_equal(oi, gi) and np.array_equal(bits(od), bits(gd))
+    # batched ragged form, including an empty list
+    qs = rand_vectors(rng, dtype, 4, dim)
+    lens = [0, 17, 600, 1]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    allids = rng.integers(0, n, int(off[-1])).astype(np.uint32)
+    got = gix.expand_beam_batch(qs, allids, off)
+    for i in range(4):
+        _, want = oix.expand_beam(qs[i], allids[off[i]:off[i + 1]])
+        assert np.array_equal(bits(want), bits(got[off[i]:off[i + 1]]))
+    a = rng.integers(0, n, 500).astype(np.uint32)
+    b = rng.integers(0, n, 500).astype(np.uint32)
+    gp = gix.distance_pairs(a, b)
+    wp = np.array([oracle.distance(dtype, metric, data[i], data[j]) for i, j in zip(a, b)], np.float32)
+    assert np.array_equal(bits(gp), bits(wp))
+
+
+def test_grid_search_golden_on_gpu(golden_dir):
+    """The reference's 18 grid_search golden cases through dann_search_batch."""
+    cases = json.load(open(os.path.join(golden_dir, "grid_search.json")))
+    for case in cases:
+        dims, size = case["grid_dims"], case["grid_size"]
+        data = grid_data(dims, size)
+        n = data.shape[0]
+        R = 2 * dims
+        adj = np.zeros((n + 1, R + 1), np.uint32)
+        for i, nb in enumerate(grid_neighbors(dims, size)):
+            adj[i, 0] = len(nb)
+            adj[i, 1:1 + len(nb)] = nb
+        adj[n, 0], adj[n, 1] = 1, n - 1
+        p = da.Provider(da.F32, da.L2, dims, n, R, grid_start_point(dims, size))
+        p.set_elements(0, data)
+        p.upload_graph(adj)
+        ids, dists, stats = p.search(da.Knn(case["l_value"], case["beam_width"]), np.array(case["query"], np.float32),
+                                     case["k"])
+        want = case["results"]
+        assert [int(i) for i in ids[0][:len(want)]] == [w[0] for w in want], case
+        assert [float(d) for d in dists[0][:len(want)]] == [w[1] for w in want], case
+        assert int(stats["cmps"][0]) == case["comparisons"] and int(stats["hops"][0]) == case["hops"]
+        assert int(stats["result_count"][0]) == case["num_results"]
+
+
+SEARCH_CASES = [
+    (oracle.F32, oracle.L2, 128, 32, 0),
+    (oracle.F32, oracle.L2, 128, 32, 544),      # diskann-inmem stride, uploaded verbatim
+    (oracle.F32, oracle.L2, 100, 24, 0),
+    (oracle.F32, oracle.INNER_PRODUCT, 64, 16, 0),
+    (oracle.F32, oracle.COSINE, 48, 16, 0),
+    (oracle.F16, oracle.L2, 128, 32, 0),
+    (oracle.F16, oracle.COSINE_NORMALIZED, 72, 20, 0),
+    (oracle.U8, oracle.L2, 128, 32, 0),
+    (oracle.I8, oracle.COSINE, 100, 16, 0),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,dim,R,stride", SEARCH_CASES)
+def test_search_parity_random_graph(dtype, metric, dim, R, stride):
+    """ids, distances, cmps and hops equal the oracle's for every query, several L and
+    beam widths, on a random graph (tie-heavy for integer rows)."""
+    rng = np.random.default_rng(1234 + dim)
+    n, nq = 5000, 48
+    data = rand_vectors(rng, dtype, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:1], R, row_stride=stride)
+    queries = rand_vectors(rng, dtype, nq, dim)
+    for L, W, k in ((1, 1, 1), (10, 1, 10), (64, 1, 10), (64, 4, 10), (100, 2, 100), (200, 1, 10), (300, 3, 50)):
+        oi, od, oc, ost = oix.search_batch(queries, L, W, k)
+        gi, gd, gst = gix.search(da.Knn(L, W), queries, k)
+        assert np.array_equal(oi, gi), (L, W)
+        assert np.array_equal(bits(od), bits(gd)), (L, W)
+        assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"]), (L, W)
+        assert np.array_equal(oc, gst["result_count"])
+
+
+def test_search_multiple_start_points_and_short_lists():
+    rng = np.random.default_rng(77)
+    n, dim, R = 2000, 32, 8
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R, nstart=3, min_len=0)
+    starts = rand_vectors(rng, oracle.F32, 3, dim)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, starts, R)
+    queries = rand_vectors(rng, oracle.F32, 32, dim)
+    for L, W in ((5, 1), (40, 2)):
+        oi, od, oc, ost = oix.search_batch(queries, L, W, 10)
+        gi, gd, gst = gix.search(da.Knn(L, W), queries, 10)
+        assert np.array_equal(oi, gi) and np.array_equal(bits(od), bits(gd))
+        assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"])
+
+
+def test_search_record_matches_oracle():
+    """VisitedSearchRecord of the insert-time search (beam 1, query = stored row)."""
+    rng = np.random.default_rng(3)
+    n, dim, R = 3000, 64, 16
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    slots = rng.choice(n, 40, replace=False).astype(np.uint32)
+    rid, rd, rn, st = gix.search_record(slots, 50)
+    for i, s in enumerate(slots):
+        _, _, _, ost, orid, ord_ = oix.search(data[s], 50, 1, 10, record=True)
+        assert rn[i] == orid.size
+        assert np.array_equal(rid[i, :rn[i]], orid) and np.array_equal(bits(rd[i, :rn[i]]), bits(ord_))
+        assert st["cmps"][i] == ost[0] and st["hops"][i] == ost[1]
+
+
+def test_visited_overflow_is_reported():
+    rng = np.random.default_rng(9)
+    n, dim, R = 4000, 16, 32
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    _, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    gix.set_visited_bits(6)
+    with pytest.raises(da.DannError) as e:
+        gix.search(da.Knn(64), data[:4], 10)
+    assert e.value.status == da._ffi.EOVERFLOW
+    gix.set_visited_bits(0)
+    gix.search(da.Knn(64), data[:4], 10)
