@@ -72,9 +72,11 @@ __device__ __forceinline__ float load1(const __half* p) { return __half2float(*p
 
 // FullCosineAccumulator::sum (simd.rs:2329-2362)
 __device__ __forceinline__ float cosine_finish(float normx, float normy, float prod) {
-    float denominator = __fsqrt_rn(normx) * __fsqrt_rn(normy);
+    // NB: __fsqrt_rn is NOT correctly rounded on ROCm 7.2 (15 % of inputs off by 1 ulp on gfx950);
+    // __builtin_sqrtf and operator/ are (measured exhaustively in scratch probes).
+    float denominator = __builtin_sqrtf(normx) * __builtin_sqrtf(normy);
     if (normx < 1.17549435e-38f || normy < 1.17549435e-38f) return 0.0f;
-    float v = __fdiv_rn(prod, denominator);
+    float v = prod / denominator;
     float m = (v != v) ? 1.0f : (v < 1.0f ? v : 1.0f);
     return m > -1.0f ? m : -1.0f;
 }
