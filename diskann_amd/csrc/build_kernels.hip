@@ -1,18 +1,926 @@
-// build_kernels.hip -- placeholder until the RobustPrune / multi_insert kernels land.
+// build_kernels.hip -- RobustPrune and batched Vamana insert on the GPU.
+//
+// Replaces, for a batch of new points, the reference call chain
+//   DiskANNIndex::multi_insert                 diskann/src/graph/index.rs:815-1030
+//     search_and_prune (beam 1, L = l_build)   index.rs:349-434  (search: search_kernels.hip)
+//     robust_prune_with                        index.rs:2476-2532
+//       SortedNeighbors::new                   graph/internal/sorted_neighbors.rs:26-44
+//       occlude_list                           index.rs:2565-2650
+//       prune::robust_prune                    graph/internal/prune.rs:106-259
+//       PruneKind::update_occlude_factor       graph/config/mod.rs:80-103
+//     aggregate_backedges                      index.rs:123-143
+//     multi_insert_bootstrap_leaf              index.rs:597-645
+//     set_neighbors_bulk                       index.rs:948-962
+//     add_edge_and_prune / robust_prune_list   index.rs:2264-2341, 2397-2454
+// with the adjacency lists it produces identical to the CPU restatement (oracle tie rule:
+// equal pool distances keep their original pool order).
+//
+// One wavefront owns one point.  The candidate pool is sorted in LDS (bitonic, 64-bit
+// keys = order-preserving distance bits : pool position); the alpha sweep runs with
+// wave-uniform control flow and evaluates the "candidate vs already selected" distances it
+// needs 64/G pairs at a time with the same G-lane bit-exact distance groups as the search
+// path, consuming them in the reference's sequential order (so `last_checked`, and with it
+// the inner-product "Occluding" rule that depends on *when* a pair is evaluated, are
+// reproduced exactly; surplus speculative distances are discarded).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "dann_device.h"
 #include "dann_internal.h"
+
+namespace dann {
+namespace {
+
+constexpr int kWave = 64;
+constexpr uint32_t kMaxPool = 4096;
+
+struct PruneCfg {
+    uint32_t pruned_degree, max_degree, max_occlusion;
+    float alpha;
+    uint32_t saturate_after_prune;
+};
+
+struct PoolLds {
+    uint32_t keys_off, pid_off, pd_off, sid_off, sd_off, occ_off, last_off, sel_off, total;
+};
+
+__host__ __device__ inline PoolLds pool_lds_layout(uint32_t pcap, uint32_t degree) {
+    PoolLds l;
+    uint32_t off = 0;
+    l.keys_off = off;
+    off += pcap * 8u;
+    l.pid_off = off;
+    off += pcap * 4u;
+    l.pd_off = off;
+    off += pcap * 4u;
+    l.sid_off = off;
+    off += pcap * 4u;
+    l.sd_off = off;
+    off += pcap * 4u;
+    l.occ_off = off;
+    off += pcap * 4u;
+    l.last_off = off;
+    off += ((pcap * 2u) + 15u) & ~15u;
+    l.sel_off = off;
+    off += ((degree + 1u) * 4u + 15u) & ~15u;
+    l.total = off;
+    return l;
+}
+
+__device__ __forceinline__ uint64_t sort_key(float d, uint32_t pos) {
+    uint32_t u = __builtin_bit_cast(uint32_t, d + 0.0f);  // -0.0 -> +0.0: `<` treats them as equal
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | pos;
+}
+
+// PruneKind::update_occlude_factor (config/mod.rs:80-103)
+template <int OP>
+__device__ __forceinline__ float update_occlude(float d_ik, float d_jk, float cur, float alpha, bool occluding) {
+    if (!occluding) {
+        if (d_jk == 0.0f) return 3.402823466e+38f;
+        float r = d_ik / d_jk;
+        if (r != r) return cur;  // f32::max ignores NaN
+        if (cur != cur) return r;
+        return cur > r ? cur : r;
+    }
+    if (d_jk < alpha * d_ik) return alpha + 0.01f;
+    return cur;
+}
+
+// Sort pid/pd[0..P) (already in LDS) by (distance, position), truncate to max_occlusion,
+// run occlude_list for `location` and write [len, ids...] to `out`.
+template <int DT, int OP, bool NORM>
+__device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t P,
+                                  uint32_t pcap, uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out) {
+    using S = Scheme<DT, OP, true>;
+    using RT = typename RowType<DT>::type;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    const uint32_t lane = threadIdx.x;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem + L.keys_off);
+    const uint32_t* pid = reinterpret_cast<const uint32_t*>(smem + L.pid_off);
+    const float* pd = reinterpret_cast<const float*>(smem + L.pd_off);
+    uint32_t* sid = reinterpret_cast<uint32_t*>(smem + L.sid_off);
+    float* sd = reinterpret_cast<float*>(smem + L.sd_off);
+    float* occ = reinterpret_cast<float*>(smem + L.occ_off);
+    uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
+
+    // ---- SortedNeighbors::new -------------------------------------------------------
+    for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= pcap; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+                const uint32_t p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
+    for (uint32_t i = lane; i < N; i += kWave) {
+        const uint32_t pos = (uint32_t)keys[i];
+        sid[i] = pid[pos];
+        sd[i] = pd[pos];
+        occ[i] = 0.0f;
+        last[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- prune::robust_prune ----------------------------------------------------------
+    const uint32_t degree = cfg.pruned_degree;
+    const bool occluding = (ix.metric == M_IP);  // PruneKind::from_metric (config/mod.rs:69-75)
+    const float alpha = cfg.alpha;
+    const float inc = alpha < 1.2f ? alpha : 1.2f;
+    float cur_alpha = 1.0f;
+    uint32_t found = 0;
+    const int g = lane / G, v = lane % G;
+    if (N > 0) {
+        while (found < degree) {
+            for (uint32_t i = 0; i < N && found < degree; ++i) {
+                float o = occ[i];
+                uint32_t l = last[i];
+                if (o > cur_alpha) continue;
+                const uint32_t idi = sid[i];
+                if (idi == location || idi >= ix.nslots) {  // excluded / not retrievable
+                    if (lane == 0) occ[i] = 3.402823466e+38f;
+                    continue;
+                }
+                const RT* xi = reinterpret_cast<const RT*>(ix.rows + (uint64_t)idi * ix.row_stride);
+                const float di = sd[i];
+                bool rejected = false;
+                while (l != found && !rejected) {
+                    const uint32_t cnt = (found - l) < (uint32_t)GROUPS ? (found - l) : (uint32_t)GROUPS;
+                    // speculative distances for selected entries l .. l+cnt (one group each)
+                    float d = 0.0f;
+                    {
+                        const bool have = (uint32_t)g < cnt;
+                        const uint32_t rp = have ? sel[l + g] : 0u;
+                        if (have && rp < i) {
+                            const uint8_t* y = ix.rows + (uint64_t)sid[rp] * ix.row_stride;
+                            d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(xi, y, (int)ix.dim, v));
+                        }
+                    }
+                    // consume in order (prune.rs:196-232)
+                    for (uint32_t gg = 0; gg < cnt; ++gg) {
+                        const uint32_t rp = sel[l + gg];
+                        if (rp >= i) continue;
+                        const float dg =
+                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), gg * G));
+                        o = update_occlude<OP>(di, dg, o, cur_alpha, occluding);
+                        if (o > cur_alpha) {
+                            l = l + gg + 1;
+                            rejected = true;
+                            break;
+                        }
+                    }
+                    if (!rejected) l += cnt;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    last[i] = (uint16_t)l;
+                    if (o > cur_alpha) {
+                        occ[i] = o;
+                    } else {
+                        occ[i] = 3.402823466e+38f;
+                        sel[found] = i;
+                    }
+                }
+                if (!(o > cur_alpha)) ++found;
+                __syncthreads();
+            }
+            if (cur_alpha == alpha) break;
+            const float next = cur_alpha * inc;
+            cur_alpha = next < alpha ? next : alpha;
+        }
+    }
+    // ---- neighbours + optional saturation (index.rs:2626-2649) ---------------------------
+    __syncthreads();
+    uint32_t nout = found;
+    if (force_saturate || (cfg.saturate_after_prune && alpha > 1.0f)) {
+        // sequential in pool order; AdjacencyList::push filters duplicates
+        for (uint32_t i = 0; i < N && nout < degree; ++i) {
+            const uint32_t id = sid[i];
+            if (id == location) continue;
+            bool dup = false;
+            for (uint32_t n = lane; n < nout; n += kWave) dup |= (sid[sel[n]] == id);
+            if (ballot64(dup)) continue;
+            if (lane == 0) sel[nout] = i;
+            ++nout;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
+    if (lane == 0) out[0] = nout;
+}
+
+// ---- kernel A: prune caller-provided pools (phase 2 of multi_insert, dann_prune_batch) -----
+struct PoolArgs {
+    IndexView ix;
+    PruneCfg cfg;
+    const uint32_t* locs;      // n locations
+    const uint32_t* pool_ids;  // pools
+    const float* pool_d;
+    const uint64_t* offsets;   // n+1 (ragged) or null
+    uint32_t stride;           // when offsets == null: pool i at i*stride, count counts[i]
+    const uint32_t* counts;
+    uint32_t cand;             // intra-batch candidates per item (0 = none); batch = locs[0..n)
+    uint32_t n;
+    uint32_t pcap;
+    int32_t force_saturate;
+    uint32_t* out;             // n x out_stride
+    uint32_t out_stride;
+    uint32_t* err;             // set to 1 on pool overflow
+};
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void pool_prune_kernel(PoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using S = Scheme<DT, OP, true>;
+    using RT = typename RowType<DT>::type;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    const uint32_t lane = threadIdx.x, item = blockIdx.x;
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
+    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
+    const uint32_t loc = a.locs[item];
+    uint64_t lo;
+    uint32_t cnt;
+    if (a.offsets) {
+        lo = a.offsets[item];
+        cnt = (uint32_t)(a.offsets[item + 1] - lo);
+    } else {
+        lo = (uint64_t)item * a.stride;
+        cnt = a.counts[item];
+    }
+    // extras = around(ids, position, cand) (utils/async_tools.rs:51-131)
+    uint32_t nex = 0;
+    if (a.cand != 0 && a.n > 1) nex = a.cand < a.n - 1 ? a.cand : a.n - 1;
+    uint32_t* out = a.out + (uint64_t)item * a.out_stride;
+    if (cnt + nex > a.pcap) {
+        if (lane == 0) {
+            *a.err = 1;
+            out[0] = 0;
+        }
+        return;
+    }
+    for (uint32_t i = lane; i < cnt; i += kWave) {
+        pid[i] = a.pool_ids[lo + i];
+        pd[i] = a.pool_d[lo + i];
+    }
+    if (nex) {
+        const uint32_t half = (nex + 1) / 2;
+        const uint32_t start = item >= half ? item - half : a.n - (half - item);
+        const RT* x = reinterpret_cast<const RT*>(a.ix.rows + (uint64_t)loc * a.ix.row_stride);
+        const int g = lane / G, v = lane % G;
+        for (uint32_t r0 = 0; r0 < nex; r0 += GROUPS) {
+            const uint32_t r = r0 + g;
+            if (r < nex) {
+                // r-th yielded position: walk from `start`, skipping `item`
+                uint32_t p = start + r;
+                // positions wrap; the skipped element shifts everything after it by one
+                const uint32_t dist_to_item = item >= start ? item - start : item + a.n - start;
+                if (r >= dist_to_item) p += 1;
+                p %= a.n;
+                const uint32_t id = a.locs[p];
+                const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
+                float d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)a.ix.dim, v));
+                if (v == 0) {
+                    pid[cnt + r] = id;
+                    pd[cnt + r] = d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, loc, cnt + nex, a.pcap, smem, L, a.force_saturate != 0, out);
+}
+
+// ---- kernel B: robust_prune_list over explicit candidate lists ---------------------------
+// (bootstrap: list = own edges ∪ other batch members; index.rs:597-645)
+struct ListArgs {
+    IndexView ix;
+    PruneCfg cfg;
+    const uint32_t* locs;
+    const uint32_t* pending;  // n x pend_stride: [len, ids...] current edges of each item
+    uint32_t pend_stride;
+    uint32_t n;
+    uint32_t pcap;
+    uint32_t* out;
+    uint32_t out_stride;
+    uint32_t* err;
+};
+
+template <int DT, int OP, bool NORM>
+__device__ void fill_list_distances(const IndexView& ix, uint32_t loc, uint32_t* pid, float* pd, uint32_t cnt) {
+    using S = Scheme<DT, OP, true>;
+    using RT = typename RowType<DT>::type;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    const uint32_t lane = threadIdx.x;
+    const int g = lane / G, v = lane % G;
+    const RT* x = reinterpret_cast<const RT*>(ix.rows + (uint64_t)loc * ix.row_stride);
+    for (uint32_t r0 = 0; r0 < cnt; r0 += GROUPS) {
+        const uint32_t r = r0 + g;
+        if (r < cnt) {
+            const uint8_t* y = ix.rows + (uint64_t)pid[r] * ix.row_stride;
+            float d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)ix.dim, v));
+            if (v == 0) pd[r] = d;
+        }
+    }
+}
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void bootstrap_kernel(ListArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x, item = blockIdx.x;
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
+    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
+    const uint32_t loc = a.locs[item];
+    const uint32_t* mine = a.pending + (uint64_t)item * a.pend_stride;
+    const uint32_t ne = mine[0];
+    uint32_t* out = a.out + (uint64_t)item * a.out_stride;
+    if (ne + a.n > a.pcap) {
+        if (lane == 0) {
+            *a.err = 1;
+            out[0] = 0;
+        }
+        return;
+    }
+    // AdjacencyList::from_iter_untrusted(edges ++ other sources): first occurrence wins.
+    // Own edges are unique and never contain `loc`; a batch member already present in the
+    // edges is skipped.
+    for (uint32_t i = lane; i < ne; i += kWave) pid[i] = mine[1 + i];
+    __syncthreads();
+    uint32_t cnt = ne;
+    for (uint32_t p0 = 0; p0 < a.n; p0 += kWave) {
+        const uint32_t p = p0 + lane;
+        uint32_t id = kEmpty;
+        bool take = false;
+        if (p < a.n && p != item) {
+            id = a.locs[p];
+            take = true;
+            for (uint32_t e = 0; e < ne; ++e) take &= (pid[e] != id);
+        }
+        const uint64_t m = ballot64(take);
+        if (take) pid[cnt + mbcnt(m)] = id;
+        cnt += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    fill_list_distances<DT, OP, NORM>(a.ix, loc, pid, pd, cnt);
+    __syncthreads();
+    prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, loc, cnt, a.pcap, smem, L, true, out);
+}
+
+// ---- kernel C: back-edges, one wave per distinct target (add_edge_and_prune) ----------------
+struct BackArgs {
+    IndexView ix;
+    PruneCfg cfg;
+    const uint64_t* keys;      // sorted (target << 32 | source), `nkeys` valid entries first
+    const uint32_t* seg_start; // nseg segment start indices (arbitrary order)
+    const uint32_t* seg_len;   // length of the segment starting at index i (indexed by start)
+    uint32_t nseg;
+    uint32_t nkeys;
+    uint32_t pcap;
+    uint32_t* err;
+    uint32_t* counters;        // [0] appends, [1] prunes
+};
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void backedge_kernel(BackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x, seg = blockIdx.x;
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
+    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
+    const uint32_t start = a.seg_start[seg];
+    const uint32_t src = (uint32_t)(a.keys[start] >> 32);
+    // adjacency of `src` (Neighbors::get)
+    uint32_t* arow = a.ix.adj + (uint64_t)src * a.ix.adj_stride;
+    uint32_t len = arow[0];
+    len = len < a.ix.max_degree ? len : a.ix.max_degree;
+    for (uint32_t i = lane; i < len; i += kWave) pid[i] = arow[1 + i];
+    __syncthreads();
+    // extend_from_slice(sorted targets): unique append
+    uint32_t cnt = len;
+    bool overflow = false;
+    const uint32_t end = start + a.seg_len[start];
+    for (uint32_t k0 = start; k0 < end; k0 += kWave) {
+        const uint32_t k = k0 + lane;
+        const bool mine = k < end;
+        const uint32_t id = mine ? (uint32_t)a.keys[k] : kEmpty;
+        bool take = mine;
+        if (mine)
+            for (uint32_t e = 0; e < len; ++e) take &= (pid[e] != id);
+        const uint64_t tm = ballot64(take);
+        const uint32_t ntake = (uint32_t)__popcll(tm);
+        if (cnt + ntake > a.pcap) {
+            overflow = true;
+            break;
+        }
+        if (take) pid[cnt + mbcnt(tm)] = id;
+        cnt += ntake;
+    }
+    if (overflow) {
+        if (lane == 0) *a.err = 1;
+        return;
+    }
+    const uint32_t added = cnt - len;
+    if (added == 0) return;
+    __syncthreads();
+    if (cnt <= a.cfg.max_degree) {
+        // append_vector with the provider-capacity clamp (provider.rs:795-822)
+        const uint32_t slack = a.ix.max_degree - len;
+        const uint32_t take = added < slack ? added : slack;
+        for (uint32_t i = lane; i < take; i += kWave) arow[1 + len + i] = pid[len + i];
+        __syncthreads();
+        if (lane == 0) {
+            arow[0] = len + take;
+            if (a.counters) atomicAdd(&a.counters[0], 1u);
+        }
+        return;
+    }
+    fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
+    __syncthreads();
+    // the list lives in LDS, so the result can go straight into the adjacency row (nobody
+    // else reads this row during the back-edge phase)
+    prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
+    if (lane == 0 && a.counters) atomicAdd(&a.counters[1], 1u);
+}
+
+// ---- small utility kernels -------------------------------------------------------------------
+__global__ void make_keys_kernel(const uint32_t* locs, const uint32_t* pending, uint32_t pend_stride, uint32_t n,
+                                 uint32_t degree, uint64_t* keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * degree) return;
+    const uint32_t item = t / degree, e = t % degree;
+    const uint32_t* row = pending + (uint64_t)item * pend_stride;
+    keys[t] = e < row[0] ? (((uint64_t)row[1 + e] << 32) | locs[item]) : ~0ull;
+}
+
+__global__ void segment_kernel(const uint64_t* keys, uint32_t total, uint32_t* seg_start, uint32_t* meta) {
+    // meta[0] = #segments, meta[1] = #valid keys (invalid keys sort to the end)
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t k = keys[t];
+    if (k == ~0ull) return;
+    if (t + 1 == total || keys[t + 1] == ~0ull) meta[1] = t + 1;
+    if (t == 0 || (uint32_t)(keys[t - 1] >> 32) != (uint32_t)(k >> 32)) seg_start[atomicAdd(&meta[0], 1u)] = t;
+}
+
+__global__ void seglen_kernel(const uint64_t* keys, const uint32_t* seg_start, uint32_t* seg_len, uint32_t* meta) {
+    // meta[2] = max segment length
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= meta[0]) return;
+    const uint32_t st = seg_start[s];
+    const uint32_t tgt = (uint32_t)(keys[st] >> 32);
+    uint32_t e = st + 1;
+    while (e < meta[1] && (uint32_t)(keys[e] >> 32) == tgt) ++e;
+    seg_len[st] = e - st;
+    atomicMax(&meta[2], e - st);
+}
+
+__global__ void set_bulk_kernel(IndexView ix, const uint32_t* locs, const uint32_t* pending, uint32_t pend_stride,
+                                uint32_t n) {
+    const uint32_t item = blockIdx.x;
+    if (item >= n) return;
+    const uint32_t* row = pending + (uint64_t)item * pend_stride;
+    uint32_t* arow = ix.adj + (uint64_t)locs[item] * ix.adj_stride;
+    const uint32_t len = row[0];
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) arow[1 + i] = row[1 + i];
+    if (threadIdx.x == 0) arow[0] = len;
+}
+
+// ---- dispatch helpers ------------------------------------------------------------------------
+template <template <int, int, bool> class Launcher, class Args>
+int32_t dispatch(const IndexView& ix, const Args& a, uint32_t grid, size_t lds, hipStream_t stream) {
+    const int op = metric_op(ix.dtype, ix.metric);
+    const bool norm = ix.metric == M_COSN && op == OP_IP;
+#define DANN_CASE(DT)                                                                          \
+    case DT:                                                                                   \
+        if (op == OP_L2) return Launcher<DT, OP_L2, false>::run(a, grid, lds, stream);         \
+        if (op == OP_IP)                                                                       \
+            return norm ? Launcher<DT, OP_IP, true>::run(a, grid, lds, stream)                 \
+                        : Launcher<DT, OP_IP, false>::run(a, grid, lds, stream);               \
+        return Launcher<DT, OP_COS, false>::run(a, grid, lds, stream);
+    switch (ix.dtype) {
+        DANN_CASE(DT_F32)
+        DANN_CASE(DT_F16)
+        DANN_CASE(DT_U8)
+        DANN_CASE(DT_I8)
+    }
+#undef DANN_CASE
+    set_error("bad dtype %d", ix.dtype);
+    return DANN_EINVAL;
+}
+
+#define DANN_LAUNCHER(NAME, KERNEL, ARGS)                                                          \
+    template <int DT, int OP, bool NORM>                                                           \
+    struct NAME {                                                                                  \
+        static int32_t run(const ARGS& a, uint32_t grid, size_t lds, hipStream_t stream) {         \
+            auto kern = KERNEL<DT, OP, NORM>;                                                      \
+            if (lds > 64 * 1024) {                                                                 \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");                    \
+            }                                                                                      \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave), lds, stream, a);                     \
+            hipError_t e = hipGetLastError();                                                      \
+            if (e != hipSuccess) return hip_fail(e, #KERNEL " launch");                            \
+            return DANN_OK;                                                                        \
+        }                                                                                          \
+    };
+DANN_LAUNCHER(PoolLauncher, pool_prune_kernel, PoolArgs)
+DANN_LAUNCHER(BootLauncher, bootstrap_kernel, ListArgs)
+DANN_LAUNCHER(BackLauncher, backedge_kernel, BackArgs)
+
+uint32_t next_pow2(uint32_t x) {
+    uint32_t p = 64;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+PruneCfg to_prune_cfg(const dann_build_config& c) {
+    PruneCfg p;
+    p.pruned_degree = c.pruned_degree;
+    p.max_degree = c.max_degree;
+    p.max_occlusion = c.max_occlusion_size ? c.max_occlusion_size : 750;
+    p.alpha = c.alpha;
+    p.saturate_after_prune = c.saturate_after_prune;
+    return p;
+}
+
+int32_t validate_cfg(const dann_index* idx, const dann_build_config* cfg) {
+    if (!cfg) return DANN_EINVAL;
+    if (cfg->pruned_degree == 0 || cfg->l_build == 0 || cfg->max_degree < cfg->pruned_degree ||
+        cfg->max_degree > idx->cfg.max_degree || !(cfg->alpha >= 1.0f)) {
+        set_error("invalid build config (pruned_degree %u, max_degree %u (provider %u), l_build %u, alpha %g)",
+                  cfg->pruned_degree, cfg->max_degree, idx->cfg.max_degree, cfg->l_build, (double)cfg->alpha);
+        return DANN_EINVAL;
+    }
+    if (cfg->max_occlusion_size > kMaxPool) {
+        set_error("max_occlusion_size %u exceeds the supported %u", cfg->max_occlusion_size, kMaxPool);
+        return DANN_EUNSUPPORTED;
+    }
+    return DANN_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        return hipMalloc(&p, n ? n : 1);
+    }
+    template <class T>
+    T* as() {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// persistent per-index scratch for batched inserts
+struct BuildScratch {
+    uint32_t batch_cap = 0, rec_stride = 0, pend_stride = 0, degree = 0;
+    DevBuf slots, rec_ids, rec_d, rec_n, stats, pending, pending2, keys_in, keys_out, seg_start, seg_len, meta, sort_tmp;
+    size_t sort_tmp_bytes = 0;
+};
+
+int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uint32_t degree) {
+    if (batch <= s.batch_cap && rec_stride == s.rec_stride && degree == s.degree) return DANN_OK;
+    const uint32_t cap = std::max<uint32_t>(batch, 1024);
+    s.batch_cap = cap;
+    s.rec_stride = rec_stride;
+    s.degree = degree;
+    s.pend_stride = degree + 1;
+    const size_t nkeys = (size_t)cap * degree;
+    DANN_HIP(s.slots.alloc((size_t)cap * 4));
+    DANN_HIP(s.rec_ids.alloc((size_t)cap * rec_stride * 4));
+    DANN_HIP(s.rec_d.alloc((size_t)cap * rec_stride * 4));
+    DANN_HIP(s.rec_n.alloc((size_t)cap * 4));
+    DANN_HIP(s.stats.alloc((size_t)cap * sizeof(dann_search_stats)));
+    DANN_HIP(s.pending.alloc((size_t)cap * s.pend_stride * 4));
+    DANN_HIP(s.pending2.alloc((size_t)cap * s.pend_stride * 4));
+    DANN_HIP(s.keys_in.alloc(nkeys * 8));
+    DANN_HIP(s.keys_out.alloc(nkeys * 8));
+    DANN_HIP(s.seg_start.alloc(nkeys * 4));
+    DANN_HIP(s.seg_len.alloc(nkeys * 4));
+    DANN_HIP(s.meta.alloc(64));
+    size_t tmp = 0;
+    DANN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, s.keys_in.as<uint64_t>(), s.keys_out.as<uint64_t>(),
+                                               (int)nkeys, 0, 64, nullptr));
+    s.sort_tmp_bytes = tmp;
+    DANN_HIP(s.sort_tmp.alloc(tmp));
+    return DANN_OK;
+}
+
+}  // namespace
+
+static int32_t visited_bits_for(const dann_index* idx, uint32_t l_value) {
+    if (idx->visited_bits) return (int32_t)idx->visited_bits;
+    uint64_t want = (uint64_t)(1.5 * (double)(l_value + idx->cfg.num_start_points + 1) * idx->cfg.max_degree) + 64;
+    uint32_t bits = 10;
+    while ((1ull << bits) * 3 / 4 < want && bits < 15) ++bits;
+    return (int32_t)bits;
+}
+
+// one multi_insert batch, everything on the index stream
+static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
+                                   const uint32_t* d_slots, uint32_t n) {
+    const IndexView ix = idx->view();
+    const PruneCfg pc = to_prune_cfg(cfg);
+    hipStream_t st = idx->stream;
+    const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
+    const uint32_t nex = (cand != 0 && n > 1) ? std::min(cand, n - 1) : 0;
+
+    // ---- candidate generation: search with record ---------------------------------------------
+    SearchArgs sa;
+    sa.ix = ix;
+    sa.queries = nullptr;
+    sa.qslots = d_slots;
+    sa.nq = n;
+    sa.l_value = cfg.l_build;
+    sa.beam_width = 1;
+    sa.k = 0;
+    sa.ht_bits = (uint32_t)visited_bits_for(idx, cfg.l_build);
+    sa.out_ids = nullptr;
+    sa.out_dists = nullptr;
+    sa.stats = s.stats.as<dann_search_stats>();
+    sa.rec_ids = s.rec_ids.as<uint32_t>();
+    sa.rec_dists = s.rec_d.as<float>();
+    sa.rec_stride = s.rec_stride;
+    sa.rec_n = s.rec_n.as<uint32_t>();
+    DANN_HIP(hipMemsetAsync(s.meta.p, 0, 64, st));
+    int32_t rc = launch_search(sa, st);
+    if (rc != DANN_OK) return rc;
+
+    // ---- prune (robust_prune_with) ---------------------------------------------------------------
+    uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes
+    {
+        PoolArgs pa;
+        pa.ix = ix;
+        pa.cfg = pc;
+        pa.locs = d_slots;
+        pa.pool_ids = s.rec_ids.as<uint32_t>();
+        pa.pool_d = s.rec_d.as<float>();
+        pa.offsets = nullptr;
+        pa.stride = s.rec_stride;
+        pa.counts = s.rec_n.as<uint32_t>();
+        pa.cand = cand;
+        pa.n = n;
+        pa.pcap = next_pow2(s.rec_stride + nex);
+        pa.force_saturate = 0;
+        pa.out = s.pending.as<uint32_t>();
+        pa.out_stride = s.pend_stride;
+        pa.err = meta + 3;
+        if (pa.pcap > kMaxPool) {
+            set_error("candidate pool bound %u exceeds %u: lower l_build or intra_batch_candidates", pa.pcap, kMaxPool);
+            return DANN_EUNSUPPORTED;
+        }
+        const size_t lds = pool_lds_layout(pa.pcap, pc.pruned_degree).total;
+        rc = dispatch<PoolLauncher>(ix, pa, n, lds, st);
+        if (rc != DANN_OK) return rc;
+    }
+
+    // ---- aggregate back-edges: sort (target, source) keys ---------------------------------------
+    uint32_t* pending = s.pending.as<uint32_t>();
+    auto aggregate = [&](uint32_t* h_meta) -> int32_t {
+        const uint32_t total = n * s.degree;
+        DANN_HIP(hipMemsetAsync(meta, 0, 12, st));
+        hipLaunchKernelGGL(make_keys_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slots, pending,
+                           s.pend_stride, n, s.degree, s.keys_in.as<uint64_t>());
+        size_t tmp = s.sort_tmp_bytes;
+        DANN_HIP(hipcub::DeviceRadixSort::SortKeys(s.sort_tmp.p, tmp, s.keys_in.as<uint64_t>(),
+                                                   s.keys_out.as<uint64_t>(), (int)total, 0, 64, st));
+        hipLaunchKernelGGL(segment_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s.keys_out.as<uint64_t>(),
+                           total, s.seg_start.as<uint32_t>(), meta);
+        hipLaunchKernelGGL(seglen_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s.keys_out.as<uint64_t>(),
+                           s.seg_start.as<uint32_t>(), s.seg_len.as<uint32_t>(), meta);
+        DANN_HIP(hipMemcpyAsync(h_meta, meta, 16, hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipStreamSynchronize(st));
+        return DANN_OK;
+    };
+    uint32_t h_meta[4] = {0, 0, 0, 0};
+    rc = aggregate(h_meta);
+    if (rc != DANN_OK) return rc;
+    if (h_meta[3]) {
+        set_error("candidate pool overflow in prune (pool cap %u)", next_pow2(s.rec_stride + nex));
+        return DANN_EOVERFLOW;
+    }
+    {   // search status (visited table / record overflow)
+        std::vector<dann_search_stats> hs(n);
+        DANN_HIP(hipMemcpyAsync(hs.data(), s.stats.p, (size_t)n * sizeof(dann_search_stats), hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < n; ++i)
+            if (hs[i].status) {
+                set_error("insert search %u: visited table or record buffer exhausted", i);
+                return DANN_EOVERFLOW;
+            }
+    }
+
+    // ---- bootstrap (index.rs:926-938) -----------------------------------------------------------------
+    const uint32_t resolved = std::max<uint32_t>(cand, 1);
+    if (resolved < n && (h_meta[0] + 7) / 8 <= n) {
+        ListArgs la;
+        la.ix = ix;
+        la.cfg = pc;
+        la.locs = d_slots;
+        la.pending = pending;
+        la.pend_stride = s.pend_stride;
+        la.n = n;
+        la.pcap = next_pow2(pc.pruned_degree + n);
+        la.out = s.pending2.as<uint32_t>();
+        la.out_stride = s.pend_stride;
+        la.err = meta + 3;
+        if (la.pcap > kMaxPool) {
+            set_error("bootstrap of a %u-point batch into a nearly empty graph is not supported (cap %u); "
+                      "use a geometric batch schedule (dann_build)", n, kMaxPool);
+            return DANN_EUNSUPPORTED;
+        }
+        const size_t lds = pool_lds_layout(la.pcap, pc.pruned_degree).total;
+        rc = dispatch<BootLauncher>(ix, la, n, lds, st);
+        if (rc != DANN_OK) return rc;
+        pending = s.pending2.as<uint32_t>();
+        rc = aggregate(h_meta);
+        if (rc != DANN_OK) return rc;
+    }
+
+    // ---- graph update -------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(set_bulk_kernel, dim3(n), dim3(64), 0, st, ix, d_slots, pending, s.pend_stride, n);
+    if (h_meta[0]) {
+        BackArgs ba;
+        ba.ix = ix;
+        ba.cfg = pc;
+        ba.keys = s.keys_out.as<uint64_t>();
+        ba.seg_start = s.seg_start.as<uint32_t>();
+        ba.seg_len = s.seg_len.as<uint32_t>();
+        ba.nseg = h_meta[0];
+        ba.nkeys = h_meta[1];
+        ba.pcap = next_pow2(ix.max_degree + h_meta[2]);
+        ba.err = meta + 3;
+        ba.counters = meta + 4;
+        if (ba.pcap > kMaxPool) {
+            set_error("a node received %u back-edges in one batch (cap %u): lower max_batch", h_meta[2], kMaxPool);
+            return DANN_EOVERFLOW;
+        }
+        const size_t lds = pool_lds_layout(ba.pcap, pc.pruned_degree).total;
+        rc = dispatch<BackLauncher>(ix, ba, ba.nseg, lds, st);
+        if (rc != DANN_OK) return rc;
+    }
+    DANN_HIP(hipStreamSynchronize(st));
+    return DANN_OK;
+}
+
+}  // namespace dann
+
 using namespace dann;
+
+static BuildScratch& scratch_of(dann_index* idx) {
+    // one scratch per index, owned by a side table keyed on the handle (freed with the process;
+    // indices are long-lived)
+    static thread_local std::vector<std::pair<dann_index*, BuildScratch*>> table;
+    for (auto& kv : table)
+        if (kv.first == idx) return *kv.second;
+    table.emplace_back(idx, new BuildScratch());
+    return *table.back().second;
+}
+
 extern "C" {
-int32_t dann_prune_batch(dann_index*, const dann_build_config*, const uint32_t*, uint32_t, const uint32_t*,
-                         const float*, const uint64_t*, int32_t, uint32_t*) {
-    set_error("dann_prune_batch: not built yet");
-    return DANN_EUNSUPPORTED;
+
+int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) {
+    if (!idx) return DANN_EINVAL;
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (n == 0) return DANN_OK;
+    if (!slots) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] >= idx->cfg.capacity) {
+            set_error("slot %u out of bounds (capacity %u)", slots[i], idx->cfg.capacity);
+            return DANN_EBOUNDS;
+        }
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), n);
 }
-int32_t dann_insert_batch(dann_index*, const dann_build_config*, const uint32_t*, uint32_t) {
-    set_error("dann_insert_batch: not built yet");
-    return DANN_EUNSUPPORTED;
+
+int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
+                   uint32_t max_batch) {
+    if (!idx) return DANN_EINVAL;
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if ((uint64_t)first + n > idx->cfg.capacity) return DANN_EBOUNDS;
+    if (!(growth > 0.0f) || max_batch == 0) return DANN_EINVAL;
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, std::min(max_batch, n ? n : 1u), rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    std::vector<uint32_t> ids;
+    uint32_t done = 0;
+    int32_t batches = 0;
+    while (done < n) {
+        // geometric schedule: batch = clamp(ceil(inserted * growth), 1, max_batch)
+        uint32_t b = (uint32_t)std::ceil((double)(first + done) * (double)growth);
+        b = std::max<uint32_t>(1, std::min(b, max_batch));
+        b = std::min(b, n - done);
+        ids.resize(b);
+        for (uint32_t i = 0; i < b; ++i) ids[i] = first + done + i;
+        DANN_HIP(hipMemcpyAsync(s.slots.p, ids.data(), (size_t)b * 4, hipMemcpyHostToDevice, idx->stream));
+        DANN_HIP(hipStreamSynchronize(idx->stream));
+        rc = insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), b);
+        if (rc != DANN_OK) return rc;
+        done += b;
+        ++batches;
+    }
+    return batches;
 }
-int32_t dann_build(dann_index*, const dann_build_config*, uint32_t, uint32_t, float, uint32_t) {
-    set_error("dann_build: not built yet");
-    return DANN_EUNSUPPORTED;
+
+int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* locs, uint32_t n,
+                         const uint32_t* pool_ids, const float* pool_dists, const uint64_t* offsets,
+                         int32_t force_saturate, uint32_t* out_adj) {
+    if (!idx) return DANN_EINVAL;
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (n == 0) return DANN_OK;
+    if (!locs || !pool_ids || !pool_dists || !offsets || !out_adj) return DANN_EINVAL;
+    const uint64_t total = offsets[n];
+    uint64_t maxlen = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return DANN_EINVAL;
+        maxlen = std::max(maxlen, offsets[i + 1] - offsets[i]);
+    }
+    for (uint64_t i = 0; i < total; ++i)
+        if (pool_ids[i] >= idx->nslots) return DANN_EBOUNDS;
+    if (maxlen > kMaxPool) {
+        set_error("pool of %llu candidates exceeds the supported %u", (unsigned long long)maxlen, kMaxPool);
+        return DANN_EUNSUPPORTED;
+    }
+    const uint32_t ostride = cfg->pruned_degree + 1;
+    DevBuf dl, di, dd, doff, dout, derr;
+    DANN_HIP(dl.alloc((size_t)n * 4));
+    DANN_HIP(di.alloc(total * 4));
+    DANN_HIP(dd.alloc(total * 4));
+    DANN_HIP(doff.alloc((size_t)(n + 1) * 8));
+    DANN_HIP(dout.alloc((size_t)n * ostride * 4));
+    DANN_HIP(derr.alloc(4));
+    hipStream_t st = idx->stream;
+    DANN_HIP(hipMemcpyAsync(dl.p, locs, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    DANN_HIP(hipMemcpyAsync(di.p, pool_ids, total * 4, hipMemcpyHostToDevice, st));
+    DANN_HIP(hipMemcpyAsync(dd.p, pool_dists, total * 4, hipMemcpyHostToDevice, st));
+    DANN_HIP(hipMemcpyAsync(doff.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    DANN_HIP(hipMemsetAsync(derr.p, 0, 4, st));
+    PoolArgs pa;
+    pa.ix = idx->view();
+    pa.cfg = to_prune_cfg(*cfg);
+    pa.locs = dl.as<uint32_t>();
+    pa.pool_ids = di.as<uint32_t>();
+    pa.pool_d = dd.as<float>();
+    pa.offsets = doff.as<uint64_t>();
+    pa.stride = 0;
+    pa.counts = nullptr;
+    pa.cand = 0;
+    pa.n = n;
+    pa.pcap = next_pow2((uint32_t)maxlen);
+    pa.force_saturate = force_saturate;
+    pa.out = dout.as<uint32_t>();
+    pa.out_stride = ostride;
+    pa.err = derr.as<uint32_t>();
+    const size_t lds = pool_lds_layout(pa.pcap, pa.cfg.pruned_degree).total;
+    rc = dispatch<PoolLauncher>(pa.ix, pa, n, lds, st);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out_adj, dout.p, (size_t)n * ostride * 4, hipMemcpyDeviceToHost, st));
+    DANN_HIP(hipStreamSynchronize(st));
+    return DANN_OK;
 }
-}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""GPU build path (RobustPrune, multi_insert) against the CPU oracle: identical adjacency."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import bits, make_pair, rand_vectors, random_graph
+
+pytestmark = pytest.mark.gpu
+da = pytest.importorskip("diskann_amd")
+
+
+def _cfgs(pruned, maxdeg, l_build, **kw):
+    return oracle.build_config(pruned, maxdeg, l_build, **kw), da.build_config(pruned, maxdeg, l_build, **kw)
+
+
+@pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.F16, oracle.L2),
+                                          (oracle.F32, oracle.INNER_PRODUCT), (oracle.U8, oracle.L2),
+                                          (oracle.F32, oracle.COSINE)])
+def test_prune_batch_matches_oracle(dtype, metric):
+    rng = np.random.default_rng(21)
+    n, dim, R = 1500, 40, 12
+    data = rand_vectors(rng, dtype, n, dim)
+    adj = random_graph(rng, n, 16)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:1], 16)
+    ocfg, gcfg = _cfgs(R, 16, 50)
+    locs = rng.choice(n, 24, replace=False).astype(np.uint32)
+    pools, dists, off = [], [], [0]
+    for i, loc in enumerate(locs):
+        m = [0, 1, 5, 70, 200, 333][i % 6]
+        ids = rng.choice(n, m, replace=False).astype(np.uint32)
+        if m > 3:
+            ids[2] = loc  # the point itself is masked out (index.rs:2607-2613)
+        d = np.array([oracle.distance(dtype, metric, data[loc], data[j]) for j in ids], np.float32)
+        pools.append(ids)
+        dists.append(d)
+        off.append(off[-1] + m)
+    pid = np.concatenate(pools) if pools else np.zeros(0, np.uint32)
+    pdd = np.concatenate(dists) if dists else np.zeros(0, np.float32)
+    for sat in (False, True):
+        got = gix.prune_batch(gcfg, locs, pid, pdd, np.array(off, np.uint64), force_saturate=sat)
+        for i, loc in enumerate(locs):
+            want, _ = oix.prune_pool(ocfg, int(loc), pools[i], dists[i], force_saturate=sat)
+            assert got[i, 0] == want.size, (i, sat)
+            assert np.array_equal(got[i, 1:1 + want.size], want), (i, sat)
+
+
+BUILD_CASES = [
+    (oracle.F32, oracle.L2, 32, oracle.IBC_NONE),
+    (oracle.F32, oracle.L2, 32, 4),
+    (oracle.F32, oracle.L2, 32, oracle.IBC_ALL),
+    (oracle.F16, oracle.L2, 24, oracle.IBC_NONE),
+    (oracle.F32, oracle.INNER_PRODUCT, 16, oracle.IBC_NONE),
+    (oracle.U8, oracle.L2, 16, 4),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,dim,ibc", BUILD_CASES)
+def test_insert_batch_matches_oracle_multi_insert(dtype, metric, dim, ibc):
+    """Same batches through dann_insert_batch and the oracle's multi_insert: the whole
+    adjacency buffer must be identical after every batch (bootstrap included)."""
+    rng = np.random.default_rng(100 + dim)
+    n, R, maxdeg, lb = 700, 8, 10, 24
+    data = rand_vectors(rng, dtype, n, dim)
+    start = data.mean(axis=0, keepdims=True).astype(oracle.NP_DTYPE[dtype])
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(dtype, metric, data, adj, start, maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=ibc)
+    sizes = [1, 1, 2, 3, 5, 8, 16, 30, 64, 120, 450]
+    s = 0
+    for b in sizes:
+        e = min(s + b, n)
+        slots = np.arange(s, e, dtype=np.uint32)
+        oix.multi_insert(ocfg, slots)
+        gix.insert_batch(gcfg, slots)
+        got = gix.download_graph()
+        lens = oix.adj[:, 0]
+        assert np.array_equal(got[:, 0], lens), (b, np.nonzero(got[:, 0] != lens)[0][:5])
+        mask = np.arange(maxdeg)[None, :] < lens[:, None]
+        assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask]), b
+        s = e
+    assert s == n
+
+
+def test_dann_build_schedule_and_recall():
+    rng = np.random.default_rng(8)
+    n, dim, R, maxdeg, lb = 3000, 32, 16, 20, 40
+    # clustered data so that recall is meaningful
+    centers = rng.standard_normal((20, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 20, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    mid, _ = oracle.medoid_f32(data)
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[mid:mid + 1], maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    growth, max_batch = 0.05, 256
+    nb = gix.build(gcfg, 0, n, growth, max_batch)
+    done, batches = 0, 0
+    while done < n:
+        b = max(1, min(int(math.ceil(done * np.float64(np.float32(growth)))), max_batch, n - done))
+        oix.multi_insert(ocfg, np.arange(done, done + b, dtype=np.uint32))
+        done += b
+        batches += 1
+    assert nb == batches
+    got = gix.download_graph()
+    lens = oix.adj[:, 0]
+    assert np.array_equal(got[:, 0], lens)
+    mask = np.arange(maxdeg)[None, :] < lens[:, None]
+    assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask])
+    # recall of the GPU-built graph
+    q = (centers[rng.integers(0, 20, 200)] + 0.3 * rng.standard_normal((200, dim))).astype(np.float32)
+    d2 = ((q[:, None, :] - data[None, :, :]) ** 2).sum(-1)
+    gt = np.argsort(d2, axis=1)[:, :10]
+    ids, _, _ = gix.search(da.Knn(64), q, 10)
+    recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(200)])
+    assert recall > 0.9, recall
