@@ -203,6 +203,7 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
+    if (idx->d_fail) (void)hipFree(idx->d_fail);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -547,7 +548,8 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.rec_dists = d_rec_d;
     a.rec_stride = rec_stride;
     a.rec_n = d_rec_n;
-    return timed(idx, 0, [&] { return launch_search(a, idx->stream); });
+    a.qmap = nullptr;
+    return timed(idx, 0, [&] { return search_with_retry(idx, a); });
 }
 
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,

@@ -675,8 +675,9 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
     sa.rec_dists = s.rec_d.as<float>();
     sa.rec_stride = s.rec_stride;
     sa.rec_n = s.rec_n.as<uint32_t>();
+    sa.qmap = nullptr;
     DANN_HIP(hipMemsetAsync(s.meta.p, 0, 64, st));
-    int32_t rc = launch_search(sa, st);
+    int32_t rc = search_with_retry(idx, sa);
     if (rc != DANN_OK) return rc;
 
     // ---- prune (robust_prune_with) ---------------------------------------------------------------

@@ -7,6 +7,8 @@
 
 #include "../../include/dann.h"
 
+struct dann_index;
+
 namespace dann {
 
 void set_error(const char* fmt, ...);
@@ -54,9 +56,12 @@ struct SearchArgs {
     float* rec_dists;
     uint32_t rec_stride;
     uint32_t* rec_n;
+    const uint32_t* qmap;    // optional: process queries qmap[0..nq) (retry of overflowed queries)
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream);
+// launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
+int32_t search_with_retry(dann_index* idx, SearchArgs a);
 size_t search_lds_bytes(const SearchArgs& a);
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
@@ -79,6 +84,8 @@ struct dann_index {
     uint32_t layer_bytes = 0;
     uint32_t nslots = 0;
     uint32_t visited_bits = 0;
+    uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
+    size_t fail_cap = 0;
     dann::KernelClock clocks[4];
     dann::IndexView view() const;
 };

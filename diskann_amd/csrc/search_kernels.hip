@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     const IndexView& ix = a.ix;
     const uint32_t lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
+    const uint32_t qi = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;
     const uint32_t R = ix.max_degree;
     const uint32_t W = a.beam_width;
     const uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207)
@@ -398,6 +398,15 @@ uint32_t cmax_of(const SearchArgs& a) {
 }
 uint32_t qs_of(uint32_t qcap) { return qcap <= 64 ? 1 : qcap <= 128 ? 2 : qcap <= 256 ? 4 : 8; }
 
+// collect the indices of queries whose status is non-zero
+__global__ void collect_failed_kernel(const dann_search_stats* stats, const uint32_t* qmap, uint32_t n, uint32_t* count,
+                                      uint32_t* list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t q = qmap ? qmap[t] : t;
+    if (stats[q].status) list[atomicAdd(count, 1u)] = q;
+}
+
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
@@ -430,6 +439,39 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
     }
     set_error("bad dtype %d", a.ix.dtype);
     return DANN_EINVAL;
+}
+
+int32_t search_with_retry(dann_index* idx, SearchArgs a) {
+    hipStream_t st = idx->stream;
+    int32_t rc = launch_search(a, st);
+    if (rc != DANN_OK || a.nq == 0 || !a.stats) return rc;
+    if (idx->fail_cap < a.nq) {
+        if (idx->d_fail) (void)hipFree(idx->d_fail);
+        idx->d_fail = nullptr;
+        idx->fail_cap = 0;
+        DANN_HIP(hipMalloc((void**)&idx->d_fail, (2 * (size_t)a.nq + 4) * 4));
+        idx->fail_cap = a.nq;
+    }
+    uint32_t* count = idx->d_fail;
+    uint32_t* lists[2] = {idx->d_fail + 4, idx->d_fail + 4 + idx->fail_cap};
+    uint32_t n = a.nq;
+    const uint32_t* qmap = a.qmap;
+    for (int round = 0;; ++round) {
+        DANN_HIP(hipMemsetAsync(count, 0, 4, st));
+        hipLaunchKernelGGL(collect_failed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.stats, qmap, n, count,
+                           lists[round & 1]);
+        uint32_t h = 0;
+        DANN_HIP(hipMemcpyAsync(&h, count, 4, hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipStreamSynchronize(st));
+        if (h == 0) return DANN_OK;
+        if (a.ht_bits >= 15) return DANN_OK;  // callers see the per-query status
+        a.ht_bits += 1;
+        a.qmap = qmap = lists[round & 1];
+        a.nq = n = h;
+        if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
+        rc = launch_search(a, st);
+        if (rc != DANN_OK) return rc;
+    }
 }
 
 }  // namespace dann
