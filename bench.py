@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--nq", type=int, default=100_000, help="queries per step per GPU (one launch)")
     ap.add_argument("--dist", default="sift_like", choices=["sift_like", "uniform"])
     ap.add_argument("--max-degree", type=int, default=32)
     ap.add_argument("--pruned-degree", type=int, default=28)
@@ -176,7 +176,7 @@ def main():
         return recall_at_k(ids, gt, k), st
 
     # ---- choose L: first L of the sweep with recall@10 >= target (reference protocol) --------
-    sweep = [10, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 400, 500]
+    sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256, 320, 400, 500]
     W = args.beam_width
     chosen, rec, st = None, 0.0, None
     if args.L:
@@ -266,6 +266,28 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": avg_kernel_ms,
             },
+        }
+        # the other BASELINE.json configurations, measured on the same index (not the headline):
+        # configs[1] single-query beam search at L=64, configs[2] 1024 concurrent queries
+        def timed_small(nq_small, L_small, reps):
+            lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), nq_small, L_small, W, k,
+                                         C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dists.data_ptr()),
+                                         C.c_void_p(d_stats.data_ptr()))
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            for r in range(reps):
+                qptr = queries.data_ptr() + (r % 64) * nq_small * args.dim * 4
+                lib.dann_search_batch_device(prov._h, C.c_void_p(qptr), nq_small, L_small, W, k,
+                                             C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dists.data_ptr()),
+                                             C.c_void_p(d_stats.data_ptr()))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_0) / reps
+        lat = timed_small(1, 64, 200)
+        t1024 = timed_small(1024, chosen, 50)
+        out["other_configs"] = {
+            "single_query_L64_latency_us": lat * 1e6,
+            "single_query_L64_qps": 1.0 / lat,
+            "concurrent_1024_qps_at_L": 1024 / t1024,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k, d_ids)

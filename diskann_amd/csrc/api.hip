@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -46,14 +48,14 @@ struct DevBuf {
 };
 
 struct DeviceGuard {
-    int prev = -1;
+    int prev = -1, cur = -1;
     bool ok = true;
-    explicit DeviceGuard(int dev) {
+    explicit DeviceGuard(int dev) : cur(dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
+        if (prev >= 0 && prev != cur) (void)hipSetDevice(prev);  // hipSetDevice costs ~0.5 ms on ROCm 7.2
     }
 };
 
@@ -72,12 +74,14 @@ static int32_t timed(dann_index* idx, int which, F&& f) {
     return DANN_OK;
 }
 
-static uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam) {
+uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam) {
     if (idx->visited_bits) return idx->visited_bits;
-    // expected visited ids ~ hops * degree, hops ~ L; keep the table under 75 % full with
-    // slack 1.5x (the reference sizes its hash set as 1.1 * R * 1.3 * L, scratch.rs:186-197)
-    uint64_t want = (uint64_t)(1.5 * (double)(l_value + idx->cfg.num_start_points + beam) * idx->cfg.max_degree) + 64;
-    uint32_t bits = 10;
+    // Visited ids ~ cmps.  Measured on Vamana graphs cmps stays well below hops * degree
+    // (about half the neighbours of an expanded node were seen before), so size the table
+    // for 0.75 * (L + starts + beam) * degree ids at <= 75 % load and rely on the retry path
+    // (search_with_retry) for the tail; LDS per query is what bounds occupancy.
+    uint64_t want = (uint64_t)(0.75 * (double)(l_value + idx->cfg.num_start_points + beam) * idx->cfg.max_degree) + 64;
+    uint32_t bits = 9;
     while ((1ull << bits) * 3 / 4 < want && bits < 15) ++bits;
     return bits;
 }
@@ -183,6 +187,7 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
     if ((e = hipEventCreate(&idx->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
     const size_t rows_bytes = (size_t)idx->nslots * idx->cfg.row_stride + 256;
     const size_t adj_bytes = (size_t)idx->nslots * (cfg->max_degree + 1) * 4;
+    if ((e = hipHostMalloc((void**)&idx->h_flag, 64, hipHostMallocMapped)) != hipSuccess) return fail(e, "hipHostMalloc");
     if ((e = hipMalloc((void**)&idx->d_rows, rows_bytes)) != hipSuccess) return fail(e, "hipMalloc(rows)");
     if ((e = hipMalloc((void**)&idx->d_adj, adj_bytes)) != hipSuccess) return fail(e, "hipMalloc(adjacency)");
     if ((e = hipMemsetAsync(idx->d_rows, 0, rows_bytes, idx->stream)) != hipSuccess) return fail(e, "hipMemset");
@@ -204,6 +209,8 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_fail) (void)hipFree(idx->d_fail);
+    if (idx->h_flag) (void)hipHostFree(idx->h_flag);
+    if (idx->d_spill) (void)hipFree(idx->d_spill);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -549,17 +556,41 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.rec_stride = rec_stride;
     a.rec_n = d_rec_n;
     a.qmap = nullptr;
-    return timed(idx, 0, [&] { return search_with_retry(idx, a); });
+    a.fail_flag = nullptr;
+    a.spill = nullptr;
+    a.spill_next = nullptr;
+    a.spill_slices = a.spill_bits = 0;
+    timespec ta, tb;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
+    int32_t rc = search_with_retry(idx, a);
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (getenv("DANN_DEBUG_TIMING")) fprintf(stderr, "[dann api] search_with_retry %.1f us\n", (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3);
+    return rc;
 }
 
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
                                  dann_search_stats* d_out_stats) {
-    CHECK_IDX(idx);
-    if (nq == 0) return DANN_OK;
-    if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
-    return search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
-                         nullptr, nullptr, 0, nullptr);
+    static const bool dbg = getenv("DANN_DEBUG_TIMING") != nullptr;
+    timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int32_t rc;
+    {
+        CHECK_IDX(idx);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (nq == 0) return DANN_OK;
+        if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
+        rc = search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
+                           nullptr, nullptr, 0, nullptr);
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+    }
+    if (dbg) {
+        timespec t3;
+        clock_gettime(CLOCK_MONOTONIC, &t3);
+        auto us = [](timespec a, timespec b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+        fprintf(stderr, "[dann api] guard %.1f search %.1f unguard %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return rc;
 }
 
 int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,

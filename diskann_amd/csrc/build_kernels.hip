@@ -594,13 +594,13 @@ struct DevBuf {
 };
 
 struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
+    int prev = -1, cur = -1;
+    explicit DeviceGuard(int dev) : cur(dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) (void)hipSetDevice(dev);
     }
     ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
+        if (prev >= 0 && prev != cur) (void)hipSetDevice(prev);  // hipSetDevice costs ~0.5 ms on ROCm 7.2
     }
 };
 
@@ -642,11 +642,7 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
 }  // namespace
 
 static int32_t visited_bits_for(const dann_index* idx, uint32_t l_value) {
-    if (idx->visited_bits) return (int32_t)idx->visited_bits;
-    uint64_t want = (uint64_t)(1.5 * (double)(l_value + idx->cfg.num_start_points + 1) * idx->cfg.max_degree) + 64;
-    uint32_t bits = 10;
-    while ((1ull << bits) * 3 / 4 < want && bits < 15) ++bits;
-    return (int32_t)bits;
+    return (int32_t)auto_visited_bits(idx, l_value, 1);
 }
 
 // one multi_insert batch, everything on the index stream
@@ -676,6 +672,10 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
     sa.rec_stride = s.rec_stride;
     sa.rec_n = s.rec_n.as<uint32_t>();
     sa.qmap = nullptr;
+    sa.fail_flag = nullptr;
+    sa.spill = nullptr;
+    sa.spill_next = nullptr;
+    sa.spill_slices = sa.spill_bits = 0;
     DANN_HIP(hipMemsetAsync(s.meta.p, 0, 64, st));
     int32_t rc = search_with_retry(idx, sa);
     if (rc != DANN_OK) return rc;

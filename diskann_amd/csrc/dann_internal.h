@@ -56,13 +56,19 @@ struct SearchArgs {
     float* rec_dists;
     uint32_t rec_stride;
     uint32_t* rec_n;
+    uint32_t* spill;         // pool of global-memory visited tables (all kEmpty between launches)
+    uint32_t* spill_next;    // pool allocation counter (zeroed before each launch)
+    uint32_t spill_slices;
+    uint32_t spill_bits;     // log2 entries per slice
+    uint32_t* fail_flag;     // set non-zero by any query that exhausts its scratch
     const uint32_t* qmap;    // optional: process queries qmap[0..nq) (retry of overflowed queries)
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream);
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
-int32_t search_with_retry(dann_index* idx, SearchArgs a);
+int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);
+uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam);
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
                            const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);
@@ -86,6 +92,9 @@ struct dann_index {
     uint32_t visited_bits = 0;
     uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
     size_t fail_cap = 0;
+    uint32_t* d_spill = nullptr;   // spill pool + counter (last word)
+    uint32_t spill_slices = 0, spill_bits = 0;
+    uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
     dann::KernelClock clocks[4];
     dann::IndexView view() const;
 };

@@ -32,15 +32,29 @@
 // in registers/LDS.
 #include "dann_device.h"
 #include "dann_internal.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace dann {
 namespace {
 
 constexpr int kWave = 64;
 constexpr int kMaxBeam = 16;
+constexpr int kGatherRows = 4;
+
+// optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
+#ifdef DANN_PHASE_CYCLES
+__device__ unsigned long long g_phase_cycles[8];
+#define PH_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PH_ADD(idx, t0, t1) ph_acc[idx] += (t1) - (t0)
+#else
+#define PH_T(var)
+#define PH_ADD(idx, t0, t1)
+#endif  // rows in flight per lane group in the fixed-length gather
 
 struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, stage_id_off, stage_d_off, beam_off, q_off, total;
+    uint32_t ht_off, cand_id_off, cand_d_off, stage_id_off, stage_d_off, snew_off, beam_off, q_off, total;
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -57,22 +71,36 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_bits, uint32_
     off += round16(cmax * 4u);
     l.cand_d_off = off;
     off += round16(cmax * 4u);
-    l.stage_id_off = off;
-    off += round16(qcap * 4u);
+    l.stage_id_off = off;  // two buffers of qcap entries each (current / next queue image)
+    off += round16(2u * qcap * 4u);
     l.stage_d_off = off;
-    off += round16(qcap * 4u);
+    off += round16(2u * qcap * 4u);
+    l.snew_off = off;      // the surviving new distances of one merge, sorted
+    off += 64u * 4u;
     l.beam_off = off;
     off += round16(kMaxBeam * 4u);
     l.total = off;
     return l;
 }
 
-// exact visited set: open addressing, linear probing, ds_cmpst.  Returns true if `id`
-// was not present (and is now).  == hashbrown::HashSet::insert (glue.rs:542-549).
-__device__ __forceinline__ bool ht_insert(uint32_t* ht, uint32_t mask, uint32_t shift, uint32_t id) {
+// exact visited set: open addressing, linear probing, ds_cmpst.  == hashbrown::HashSet::insert
+// (glue.rs:542-549).  Two levels: the LDS table takes ids until it is 75 % full ("open");
+// after that it is frozen (lookups only) and new ids go to a spill table in global memory
+// claimed from a small pool -- rare, slower, still exact.
+enum : int { kPresent = 0, kInserted = 1, kAbsent = 2 };
+__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t mask, uint32_t shift, uint32_t id, bool open) {
     uint32_t h = (id * 2654435761u) >> shift;
     for (;;) {
-        uint32_t old = atomicCAS(&ht[h], kEmpty, id);
+        uint32_t old = open ? atomicCAS(&ht[h], kEmpty, id) : ht[h];
+        if (old == kEmpty) return open ? kInserted : kAbsent;
+        if (old == id) return kPresent;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32_t shift, uint32_t id) {
+    uint32_t h = (id * 2246822519u) >> shift;
+    for (;;) {
+        uint32_t old = atomicCAS(&gt[h], kEmpty, id);
         if (old == kEmpty) return true;
         if (old == id) return false;
         h = (h + 1) & mask;
@@ -106,6 +134,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
     uint32_t* stage_id = reinterpret_cast<uint32_t*>(smem + L.stage_id_off);
     float* stage_d = reinterpret_cast<float*>(smem + L.stage_d_off);
+    float* snew = reinterpret_cast<float*>(smem + L.snew_off);
+    constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
+    uint32_t cur = 0;                       // which half of stage_* mirrors the queue
     uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
 
     // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
@@ -141,11 +172,19 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         qd[s] = 0.0f;
     }
     uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
+    uint32_t pf_node = kEmpty, pf_len = 0, pf_val = kEmpty;
+    bool lds_open = true;
+#ifdef DANN_PHASE_CYCLES
+    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    uint32_t* spill = nullptr;
+    uint32_t spill_count = 0;
+    const uint32_t spill_size = 1u << a.spill_bits, spill_mask = spill_size - 1u, spill_shift = 32u - a.spill_bits;
 
     // distance of every candidate in cand_id[0..nc) -> cand_d
     auto gather = [&](uint32_t nc) {
         if constexpr (DIM > 0 && !kInt) {
-            constexpr int U = 2;
+            constexpr int U = kGatherRows;
             for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
                 const RT* rows[U];
                 bool act[U];
@@ -177,57 +216,92 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
     };
 
-    // merge cand[m0 .. m0+n) (n <= 64) into the queue
+    // merge cand[m0 .. m0+n) (n <= 64) into the queue.
+    // Exactness: the sequential inserts keep the best `qcap` elements under the total order
+    // (distance asc, insertion time desc), so (1) when the queue is full a candidate worse
+    // than its last element can be dropped up front (queue.rs:142-146), (2) a surviving
+    // candidate j lands at  #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)},
+    // (3) an old element e moves up by #{surviving j: d_j <= d_e}.
     auto merge = [&](uint32_t m0, uint32_t n) {
-        const bool has = lane < n;
-        const float nd = has ? cand_d[m0 + lane] : 0.0f;
-        const uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
-        const bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
-        const uint64_t vmask = ballot64(nvalid);
+        const float* oldd = stage_d + cur * QCAPP;
+        bool has = lane < n;
+        float nd = has ? cand_d[m0 + lane] : 0.0f;
+        uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
+        bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
+        if (size == qcap && qcap > 0) nvalid = nvalid && !(oldd[size - 1] < nd);
+        const uint64_t km = ballot64(nvalid);
+        const uint32_t nv = (uint32_t)__popcll(km);
+        if (nv == 0) return;
+        if (nv != n) {  // compact the survivors, emission order preserved
+            const uint32_t cj = mbcnt(km);
+            __syncthreads();
+            if (nvalid) {
+                cand_d[m0 + cj] = nd;
+                cand_id[m0 + cj] = nid;
+            }
+            __syncthreads();
+            has = lane < nv;
+            nd = has ? cand_d[m0 + lane] : 0.0f;
+            nid = has ? cand_id[m0 + lane] : kEmpty;
+        }
+        // rank among the survivors
+        uint32_t before = 0;
+        for (uint32_t jj = 0; jj < nv; ++jj) {
+            const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), jj));
+            before += ((dj < nd) | ((dj == nd) & (jj > lane))) ? 1u : 0u;
+        }
+        if (has) snew[before] = nd;
+        __syncthreads();
+        // old elements: shift = #{new <= d_e}  (upper bound in snew[0..nv))
         uint32_t shift[QS];
 #pragma unroll
-        for (int s = 0; s < QS; ++s) shift[s] = 0;
-        uint32_t pos_new = 0;
-        for (uint32_t jj = 0; jj < n; ++jj) {
-            if (!((vmask >> jj) & 1ull)) continue;
-            const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), jj));
-            uint32_t old_less = 0;
+        for (int s = 0; s < QS; ++s) {
+            uint32_t lo = 0;
 #pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const bool ov = (uint32_t)(s * kWave) + lane < size;
-                shift[s] += (ov && dj <= qd[s]) ? 1u : 0u;
-                old_less += (uint32_t)__popcll(ballot64(ov && qd[s] < dj));
+            for (uint32_t step = 64; step > 0; step >>= 1) {
+                const uint32_t t = lo + step;
+                if (t <= nv && snew[t - 1] <= qd[s]) lo = t;
             }
-            const bool before = (dj < nd) || (dj == nd && jj > lane);
-            pos_new += (before ? 1u : 0u) + (lane == jj ? old_less : 0u);
+            shift[s] = lo;
         }
+        // new elements: #{old < d_j}  (lower bound in the queue image)
+        uint32_t lb = 0;
+#pragma unroll
+        for (uint32_t step = QCAPP; step > 0; step >>= 1) {
+            const uint32_t t = lb + step;
+            if (t <= size && oldd[t - 1] < nd) lb = t;
+        }
+        const uint32_t pos_new = before + lb;
+        // scatter into the other half
+        uint32_t* nxt_id = stage_id + (cur ^ 1u) * QCAPP;
+        float* nxt_d = stage_d + (cur ^ 1u) * QCAPP;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
             if (p < size) {
                 const uint32_t np = p + shift[s];
                 if (np < qcap) {
-                    stage_id[np] = qid[s];
-                    stage_d[np] = qd[s];
+                    nxt_id[np] = qid[s];
+                    nxt_d[np] = qd[s];
                 }
             }
         }
-        if (nvalid && pos_new < qcap) {
-            stage_id[pos_new] = nid;
-            stage_d[pos_new] = nd;
+        if (has && pos_new < qcap) {
+            nxt_id[pos_new] = nid;
+            nxt_d[pos_new] = nd;
         }
-        const uint32_t total = size + (uint32_t)__popcll(vmask);
+        const uint32_t total = size + nv;
         size = total < qcap ? total : qcap;
+        cur ^= 1u;
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
             if (p < size) {
-                qid[s] = stage_id[p];
-                qd[s] = stage_d[p];
+                qid[s] = nxt_id[p];
+                qd[s] = nxt_d[p];
             }
         }
-        __syncthreads();
     };
 
     // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958) ---
@@ -235,7 +309,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         const uint32_t ns = ix.nstart;
         for (uint32_t i = lane; i < ns; i += kWave) {
             cand_id[i] = ix.capacity + i;
-            ht_insert(ht, ht_mask, ht_shift, ix.capacity + i);
+            ht_visit(ht, ht_mask, ht_shift, ix.capacity + i, true);
         }
         ht_count = ns;
         __syncthreads();
@@ -247,6 +321,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     // ---- beam loop ----------------------------------------------------------------------
     for (;;) {
+        PH_T(ph0);
         // pop up to W closest unexpanded entries (queue.rs:297-313)
         uint32_t nb = 0;
         for (uint32_t w = 0; w < W; ++w) {
@@ -283,6 +358,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         if (nb == 0 || status) break;
         hops += nb;
         __syncthreads();
+        PH_T(ph1);
+        PH_ADD(0, ph0, ph1);
 
         // expand: adjacency rows in pop order, ids in stored order, visited filter
         // (provider.rs:448-454)
@@ -290,32 +367,84 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t node = beam[b];
             const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
-            uint32_t len = arow[0];
+            const bool hit = (node == pf_node);
+#ifdef DANN_PHASE_CYCLES
+            ph_acc[hit ? 5 : 6] += 1;
+#endif
+            uint32_t len = hit ? pf_len : arow[0];
             len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            if (ht_count + len > ht_size - (ht_size >> 2)) {
+            if (lds_open && ht_count + len > ht_size - (ht_size >> 2)) {
+                // freeze the LDS table, claim a spill table
+                lds_open = false;
+                uint32_t slice = kEmpty;
+                if (a.spill) {
+                    if (lane == 0) slice = atomicAdd(a.spill_next, 1u);
+                    slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
+                }
+                if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
+            }
+            if (!lds_open && (!spill || spill_count + len > spill_size - (spill_size >> 2))) {
                 status = (uint32_t)(-DANN_EOVERFLOW);
                 break;
             }
             for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
                 const uint32_t j = j0 + lane;
                 const bool inb = j < len;
-                const uint32_t id = inb ? arow[1 + j] : kEmpty;
-                const bool isnew = inb && id != kEmpty && ht_insert(ht, ht_mask, ht_shift, id);
+                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
+                bool isnew = false;
+                if (inb && id != kEmpty) {
+                    const int r = ht_visit(ht, ht_mask, ht_shift, id, lds_open);
+                    isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
+                }
                 const bool keep = isnew && id < ix.nslots;
                 const uint64_t nm = ballot64(isnew), km = ballot64(keep);
                 if (keep) cand_id[nc + mbcnt(km)] = id;
                 nc += (uint32_t)__popcll(km);
-                ht_count += (uint32_t)__popcll(nm);
+                if (lds_open) ht_count += (uint32_t)__popcll(nm);
+                else spill_count += (uint32_t)__popcll(nm);
             }
         }
         if (status) break;
         __syncthreads();
+        PH_T(ph2);
+        PH_ADD(1, ph1, ph2);
+        // speculative adjacency prefetch: while the candidate rows are in flight, fetch the
+        // adjacency row of the best unexpanded entry of the *current* queue; if no new
+        // candidate beats it, the next hop starts without a dependent HBM round trip.
+        pf_node = kEmpty;
+        if (W == 1 && R <= (uint32_t)kWave) {
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                if (pf_node != kEmpty) continue;
+                const bool cnd = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
+                const uint64_t m = ballot64(cnd);
+                if (m) pf_node = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], __builtin_ctzll(m));
+            }
+            if (pf_node != kEmpty) {
+                const uint32_t* prow = ix.adj + (uint64_t)pf_node * ix.adj_stride;
+                pf_len = prow[0];
+                pf_val = lane < R ? prow[1 + lane] : kEmpty;
+            }
+        }
         gather(nc);
         __syncthreads();
+        PH_T(ph3);
+        PH_ADD(2, ph2, ph3);
         cmps += nc;
         for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
+        PH_T(ph4);
+        PH_ADD(3, ph3, ph4);
+        PH_ADD(4, ph0, ph4);
     }
 
+#ifdef DANN_PHASE_CYCLES
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph_acc[i]);
+#endif
+    if (spill) {  // hand the spill table back clean
+        __syncthreads();
+        for (uint32_t i = lane; i < spill_size; i += kWave) spill[i] = kEmpty;
+    }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
     uint32_t written = 0;
     if (a.out_ids) {
@@ -349,6 +478,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             st.status = status;
             a.stats[qi] = st;
         }
+        if (status && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.rec_n) a.rec_n[qi] = nrec;
     }
 }
@@ -441,11 +571,22 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
     return DANN_EINVAL;
 }
 
+#ifdef DANN_PHASE_CYCLES
+extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 64);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 64);
+    }
+    return 0;
+}
+#endif
+
 int32_t search_with_retry(dann_index* idx, SearchArgs a) {
+    auto tE = std::chrono::steady_clock::now();
     hipStream_t st = idx->stream;
-    int32_t rc = launch_search(a, st);
-    if (rc != DANN_OK || a.nq == 0 || !a.stats) return rc;
-    if (idx->fail_cap < a.nq) {
+    if (a.nq == 0) return DANN_OK;
+    if (idx->fail_cap < a.nq || !idx->d_fail) {
         if (idx->d_fail) (void)hipFree(idx->d_fail);
         idx->d_fail = nullptr;
         idx->fail_cap = 0;
@@ -454,6 +595,51 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     }
     uint32_t* count = idx->d_fail;
     uint32_t* lists[2] = {idx->d_fail + 4, idx->d_fail + 4 + idx->fail_cap};
+    // failure flag in pinned host memory: written over the fabric only by a query that
+    // overflows (rare), read by the host after the stream sync -- no memset / D2H copy
+    auto tA = std::chrono::steady_clock::now();
+    if (!idx->d_spill) {  // 256 spill tables of 2^14 ids (16 MiB), cleaned by their users
+        const uint32_t slices = 256, sbits = 14;
+        const size_t words = ((size_t)slices << sbits) + 16;
+        DANN_HIP(hipMalloc((void**)&idx->d_spill, words * 4));
+        DANN_HIP(hipMemsetAsync(idx->d_spill, 0xFF, words * 4, st));
+        idx->spill_slices = slices;
+        idx->spill_bits = sbits;
+    }
+    a.spill = idx->d_spill;
+    a.spill_slices = idx->spill_slices;
+    a.spill_bits = idx->spill_bits;
+    a.spill_next = idx->d_spill + ((size_t)idx->spill_slices << idx->spill_bits);
+    DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
+    volatile uint32_t* hflag = idx->h_flag;
+    *hflag = 0;
+    auto tB = std::chrono::steady_clock::now();
+    a.fail_flag = idx->h_flag;
+    // HIP events bracket exactly the beam-search launch, on the stream it runs on
+    static const bool dbg = getenv("DANN_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    auto t0 = now();
+    DANN_HIP(hipEventRecord(idx->ev0, st));
+    auto t1 = now();
+    int32_t rc = launch_search(a, st);
+    if (rc != DANN_OK) return rc;
+    auto t2 = now();
+    DANN_HIP(hipEventRecord(idx->ev1, st));
+    auto t3 = now();
+    DANN_HIP(hipEventSynchronize(idx->ev1));
+    auto t4 = now();
+    float ms = 0.f;
+    DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+    auto t5 = now();
+    if (dbg) fprintf(stderr, "[dann] rec0 %.1f launch %.1f rec1 %.1f sync %.1f elapsed %.1f us, kernel %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5), ms * 1e3);
+    idx->clocks[0].total_ms += ms;
+    idx->clocks[0].launches += 1;
+    const uint32_t h_flag = *hflag;
+    auto t6 = now();
+    if (dbg) fprintf(stderr, "[dann] entry->tA %.1f flag write %.1f tB->t0 %.1f flag read %.1f us\n", us(tE, tA), us(tA, tB), us(tB, t0), us(t5, t6));
+    if (!h_flag || !a.stats) return DANN_OK;
+    // rare path: re-run the overflowed queries with a visited table twice as large
     uint32_t n = a.nq;
     const uint32_t* qmap = a.qmap;
     for (int round = 0;; ++round) {
@@ -469,6 +655,7 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         a.qmap = qmap = lists[round & 1];
         a.nq = n = h;
         if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
+        DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
         rc = launch_search(a, st);
         if (rc != DANN_OK) return rc;
     }
