@@ -173,6 +173,7 @@ def main():
         if st[:, 3].any():
             raise RuntimeError(f"per-query scratch overflow at L={L}")
         ids = d_ids.cpu().numpy().view(np.uint32)
+        evaluate.last_ids = ids
         return recall_at_k(ids, gt, k), st
 
     # ---- choose L: first L of the sweep with recall@10 >= target (reference protocol) --------
@@ -290,14 +291,15 @@ def main():
             "concurrent_1024_qps_at_L": 1024 / t1024,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k, d_ids)
+            out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k,
+                                                evaluate.last_ids)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, d_ids):
+def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
     """The CPU restatement of the reference path (oracle, AVX2 kernels) on the same graph
     bytes, same queries, all host cores, static block partition of the queries
     (diskann-benchmark-core/src/search/api.rs:399-436)."""
@@ -317,7 +319,7 @@ def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, d_ids):
         ids, _, _, _ = oix.search_batch(qs, L, W, k, threads=cores, fast=True)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    same = bool(np.array_equal(ids, d_ids.cpu().numpy().view(np.uint32)[:nqc]))
+    same = bool(np.array_equal(ids, gpu_ids[:nqc]))
     return {
         "value": nqc / best,
         "unit": "queries/s",

@@ -74,16 +74,20 @@ static int32_t timed(dann_index* idx, int which, F&& f) {
     return DANN_OK;
 }
 
-uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam) {
-    if (idx->visited_bits) return idx->visited_bits;
-    // Visited ids ~ cmps.  Measured on Vamana graphs cmps stays well below hops * degree
-    // (about half the neighbours of an expanded node were seen before), so size the table
-    // for 0.75 * (L + starts + beam) * degree ids at <= 75 % load and rely on the retry path
-    // (search_with_retry) for the tail; LDS per query is what bounds occupancy.
-    uint64_t want = (uint64_t)(0.75 * (double)(l_value + idx->cfg.num_start_points + beam) * idx->cfg.max_degree) + 64;
-    uint32_t bits = 9;
-    while ((1ull << bits) * 3 / 4 < want && bits < 15) ++bits;
-    return bits;
+uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t beam) {
+    if (idx->visited_bits) return 1u << idx->visited_bits;
+    // Visited ids == cmps.  Measured on Vamana graphs (R = 32): cmps ~= R * (0.55 L + 12), i.e.
+    // well below hops * degree because about half the neighbours of an expanded node were seen
+    // before.  Size the LDS table for 1.25x that at <= 75 % load; rarer, larger queries continue
+    // in a global-memory spill table (search_kernels.hip), so this only trades occupancy
+    // (LDS per query) against the spill rate -- never correctness.
+    const double est = (double)idx->cfg.max_degree * (0.55 * (double)(l_value + beam) + 12.0) +
+                       (double)idx->cfg.num_start_points;
+    uint64_t entries = (uint64_t)(1.25 * est / 0.75) + 63;
+    entries = entries / 64 * 64;
+    if (entries < 256) entries = 256;
+    if (entries > 32768) entries = 32768;
+    return (uint32_t)entries;
 }
 
 }  // namespace dann
@@ -547,7 +551,7 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.l_value = l_value;
     a.beam_width = beam;
     a.k = k;
-    a.ht_bits = auto_visited_bits(idx, l_value, beam);
+    a.ht_entries = auto_visited_entries(idx, l_value, beam);
     a.out_ids = d_ids;
     a.out_dists = d_dists;
     a.stats = d_stats;
@@ -560,37 +564,17 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.spill = nullptr;
     a.spill_next = nullptr;
     a.spill_slices = a.spill_bits = 0;
-    timespec ta, tb;
-    clock_gettime(CLOCK_MONOTONIC, &ta);
-    int32_t rc = search_with_retry(idx, a);
-    clock_gettime(CLOCK_MONOTONIC, &tb);
-    if (getenv("DANN_DEBUG_TIMING")) fprintf(stderr, "[dann api] search_with_retry %.1f us\n", (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3);
-    return rc;
+    return search_with_retry(idx, a);
 }
 
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
                                  dann_search_stats* d_out_stats) {
-    static const bool dbg = getenv("DANN_DEBUG_TIMING") != nullptr;
-    timespec t0, t1, t2;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    int32_t rc;
-    {
-        CHECK_IDX(idx);
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        if (nq == 0) return DANN_OK;
-        if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
-        rc = search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
-                           nullptr, nullptr, 0, nullptr);
-        clock_gettime(CLOCK_MONOTONIC, &t2);
-    }
-    if (dbg) {
-        timespec t3;
-        clock_gettime(CLOCK_MONOTONIC, &t3);
-        auto us = [](timespec a, timespec b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
-        fprintf(stderr, "[dann api] guard %.1f search %.1f unguard %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3));
-    }
-    return rc;
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
+    return search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
+                         nullptr, nullptr, 0, nullptr);
 }
 
 int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
@@ -616,9 +600,9 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i) {
         if (stats[i].status) {
-            set_error("query %u: per-query scratch exhausted (visited table 2^%u entries); raise it with "
+            set_error("query %u: per-query scratch exhausted (visited table %u entries); raise it with "
                       "dann_set_visited_bits",
-                      i, auto_visited_bits(idx, l_value, beam_width));
+                      i, auto_visited_entries(idx, l_value, beam_width));
             return DANN_EOVERFLOW;
         }
     }

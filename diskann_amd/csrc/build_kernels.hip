@@ -641,10 +641,6 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
 
 }  // namespace
 
-static int32_t visited_bits_for(const dann_index* idx, uint32_t l_value) {
-    return (int32_t)auto_visited_bits(idx, l_value, 1);
-}
-
 // one multi_insert batch, everything on the index stream
 static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
                                    const uint32_t* d_slots, uint32_t n) {
@@ -663,7 +659,7 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
     sa.l_value = cfg.l_build;
     sa.beam_width = 1;
     sa.k = 0;
-    sa.ht_bits = (uint32_t)visited_bits_for(idx, cfg.l_build);
+    sa.ht_entries = auto_visited_entries(idx, cfg.l_build, 1);
     sa.out_ids = nullptr;
     sa.out_dists = nullptr;
     sa.stats = s.stats.as<dann_search_stats>();

@@ -48,7 +48,7 @@ struct SearchArgs {
     uint32_t l_value;
     uint32_t beam_width;
     uint32_t k;
-    uint32_t ht_bits;
+    uint32_t ht_entries;     // per-query LDS visited-table entries (multiple of 64)
     uint32_t* out_ids;       // nq x k (may be null in record mode)
     float* out_dists;
     dann_search_stats* stats;
@@ -68,7 +68,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream);
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);
-uint32_t auto_visited_bits(const dann_index* idx, uint32_t l_value, uint32_t beam);
+uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t beam);
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
                            const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);

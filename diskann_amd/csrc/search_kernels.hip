@@ -32,9 +32,6 @@
 // in registers/LDS.
 #include "dann_device.h"
 #include "dann_internal.h"
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
 
 namespace dann {
 namespace {
@@ -59,14 +56,14 @@ struct SearchLds {
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
-__host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_bits, uint32_t cmax, uint32_t qcap,
+__host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
                                                        uint32_t qbytes) {
     SearchLds l;
     uint32_t off = 0;
     l.q_off = off;
     off += round16(qbytes);
     l.ht_off = off;
-    off += (1u << ht_bits) * 4u;
+    off += ht_entries * 4u;  // any multiple of 64
     l.cand_id_off = off;
     off += round16(cmax * 4u);
     l.cand_d_off = off;
@@ -88,13 +85,14 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_bits, uint32_
 // after that it is frozen (lookups only) and new ids go to a spill table in global memory
 // claimed from a small pool -- rare, slower, still exact.
 enum : int { kPresent = 0, kInserted = 1, kAbsent = 2 };
-__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t mask, uint32_t shift, uint32_t id, bool open) {
-    uint32_t h = (id * 2654435761u) >> shift;
+__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t size, uint32_t id, bool open) {
+    // table size is any multiple of 64: slot = mulhi(hash, size)
+    uint32_t h = __umulhi(id * 2654435761u, size);
     for (;;) {
         uint32_t old = open ? atomicCAS(&ht[h], kEmpty, id) : ht[h];
         if (old == kEmpty) return open ? kInserted : kAbsent;
         if (old == id) return kPresent;
-        h = (h + 1) & mask;
+        h = (h + 1 == size) ? 0u : h + 1;
     }
 }
 __device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32_t shift, uint32_t id) {
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                                                                               : ((ix.nstart + 63u) & ~63u);
     const uint32_t esz = (DT == DT_F32) ? 4u : (DT == DT_F16 ? 2u : 1u);
     const uint32_t qbytes = kInt ? ix.dim : ix.dim * 4u;
-    const SearchLds L = search_lds_layout(a.ht_bits, cmax, QS * kWave, qbytes);
+    const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
         }
     }
-    const uint32_t ht_size = 1u << a.ht_bits, ht_mask = ht_size - 1u, ht_shift = 32u - a.ht_bits;
+    const uint32_t ht_size = a.ht_entries;
     for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
     __syncthreads();
 
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         const uint32_t ns = ix.nstart;
         for (uint32_t i = lane; i < ns; i += kWave) {
             cand_id[i] = ix.capacity + i;
-            ht_visit(ht, ht_mask, ht_shift, ix.capacity + i, true);
+            ht_visit(ht, ht_size, ix.capacity + i, true);
         }
         ht_count = ns;
         __syncthreads();
@@ -393,7 +391,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
                 if (inb && id != kEmpty) {
-                    const int r = ht_visit(ht, ht_mask, ht_shift, id, lds_open);
+                    const int r = ht_visit(ht, ht_size, id, lds_open);
                     isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
                 }
                 const bool keep = isnew && id < ix.nslots;
@@ -542,7 +540,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 size_t search_lds_bytes(const SearchArgs& a) {
     const bool is_int = a.ix.dtype == DT_U8 || a.ix.dtype == DT_I8;
     const uint32_t qcap = a.l_value + a.ix.nstart;
-    return search_lds_layout(a.ht_bits, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.dim : a.ix.dim * 4u).total;
+    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.dim : a.ix.dim * 4u).total;
 }
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
@@ -558,7 +556,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
     const uint32_t qcap = a.l_value + a.ix.nstart;
     const size_t lds = search_lds_bytes(a);
     if (lds > 160 * 1024) {
-        set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited bits %u)", lds, a.ht_bits);
+        set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited table %u entries)", lds, a.ht_entries);
         return DANN_EOVERFLOW;
     }
     switch (a.ix.dtype) {
@@ -583,7 +581,6 @@ extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) {
 #endif
 
 int32_t search_with_retry(dann_index* idx, SearchArgs a) {
-    auto tE = std::chrono::steady_clock::now();
     hipStream_t st = idx->stream;
     if (a.nq == 0) return DANN_OK;
     if (idx->fail_cap < a.nq || !idx->d_fail) {
@@ -597,7 +594,6 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     uint32_t* lists[2] = {idx->d_fail + 4, idx->d_fail + 4 + idx->fail_cap};
     // failure flag in pinned host memory: written over the fabric only by a query that
     // overflows (rare), read by the host after the stream sync -- no memset / D2H copy
-    auto tA = std::chrono::steady_clock::now();
     if (!idx->d_spill) {  // 256 spill tables of 2^14 ids (16 MiB), cleaned by their users
         const uint32_t slices = 256, sbits = 14;
         const size_t words = ((size_t)slices << sbits) + 16;
@@ -613,33 +609,24 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;
-    auto tB = std::chrono::steady_clock::now();
     a.fail_flag = idx->h_flag;
-    // HIP events bracket exactly the beam-search launch, on the stream it runs on
-    static const bool dbg = getenv("DANN_DEBUG_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    auto t0 = now();
-    DANN_HIP(hipEventRecord(idx->ev0, st));
-    auto t1 = now();
-    int32_t rc = launch_search(a, st);
+    // HIP events bracket exactly the beam-search launches, on the stream they run on
+    auto timed_launch = [&](const SearchArgs& args) -> int32_t {
+        DANN_HIP(hipEventRecord(idx->ev0, st));
+        int32_t r = launch_search(args, st);
+        if (r != DANN_OK) return r;
+        DANN_HIP(hipEventRecord(idx->ev1, st));
+        DANN_HIP(hipEventSynchronize(idx->ev1));
+        float ms = 0.f;
+        DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+        idx->clocks[0].total_ms += ms;
+        return DANN_OK;
+    };
+    int32_t rc = timed_launch(a);
     if (rc != DANN_OK) return rc;
-    auto t2 = now();
-    DANN_HIP(hipEventRecord(idx->ev1, st));
-    auto t3 = now();
-    DANN_HIP(hipEventSynchronize(idx->ev1));
-    auto t4 = now();
-    float ms = 0.f;
-    DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
-    auto t5 = now();
-    if (dbg) fprintf(stderr, "[dann] rec0 %.1f launch %.1f rec1 %.1f sync %.1f elapsed %.1f us, kernel %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5), ms * 1e3);
-    idx->clocks[0].total_ms += ms;
-    idx->clocks[0].launches += 1;
-    const uint32_t h_flag = *hflag;
-    auto t6 = now();
-    if (dbg) fprintf(stderr, "[dann] entry->tA %.1f flag write %.1f tB->t0 %.1f flag read %.1f us\n", us(tE, tA), us(tA, tB), us(tB, t0), us(t5, t6));
-    if (!h_flag || !a.stats) return DANN_OK;
-    // rare path: re-run the overflowed queries with a visited table twice as large
+    idx->clocks[0].launches += 1;  // one logical search = one "launch" (+ rare retry launches, time included)
+    if (!*hflag || !a.stats) return DANN_OK;
+    // rare path: queries that exhausted LDS table + spill pool are re-run with a larger LDS table
     uint32_t n = a.nq;
     const uint32_t* qmap = a.qmap;
     for (int round = 0;; ++round) {
@@ -650,13 +637,14 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         DANN_HIP(hipMemcpyAsync(&h, count, 4, hipMemcpyDeviceToHost, st));
         DANN_HIP(hipStreamSynchronize(st));
         if (h == 0) return DANN_OK;
-        if (a.ht_bits >= 15) return DANN_OK;  // callers see the per-query status
-        a.ht_bits += 1;
+        if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status
+        a.ht_entries *= 2;
         a.qmap = qmap = lists[round & 1];
         a.nq = n = h;
         if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
         DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
-        rc = launch_search(a, st);
+        *hflag = 0;
+        rc = timed_launch(a);
         if (rc != DANN_OK) return rc;
     }
 }
