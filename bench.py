@@ -290,6 +290,16 @@ def main():
             "single_query_L64_qps": 1.0 / lat,
             "concurrent_1024_qps_at_L": 1024 / t1024,
         }
+        # HBM traffic per launch from the committed PMC pass (rocprofv3 cannot run inside bench.py);
+        # only reported when the profiled workload is this workload.
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            wl = pm["workload"]
+            if (wl["nq"], wl["L"], wl["beam_width"], wl["n"], wl["dim"]) == (args.nq, chosen, W, args.n, args.dim):
+                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch_corrected"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+        except (OSError, KeyError, ValueError):
+            pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k,
                                                 evaluate.last_ids)
