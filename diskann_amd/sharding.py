@@ -1,0 +1,56 @@
+"""Query-stream sharding across the GPUs of one node (replicated index, no data-path collective).
+
+`partition` is the reference's task partition (diskann/src/utils/async_tools.rs:289-365,
+used by diskann-benchmark-core/src/search/api.rs:410 to split the query set over tasks):
+ranges are contiguous, disjoint, cover 0..nitems, and differ in length by at most one.
+`search_sharded` runs one rank's slice through any search callable and assembles the full
+result on every rank with all_gather (control plane only: k ids + k distances per query).
+"""
+import numpy as np
+
+
+def partition(nitems, ntasks, task):
+    if ntasks <= 0:
+        raise ValueError("ntasks must be positive")
+    if task >= ntasks or task < 0:
+        raise ValueError(f"task id {task} must be less than the number of tasks {ntasks}")
+    k, m = divmod(nitems, ntasks)
+    if task >= m:
+        start = m * (k + 1) + (task - m) * k
+        return start, start + k
+    start = task * (k + 1)
+    return start, start + k + 1
+
+
+def search_sharded(search_fn, queries, k, rank=0, world=1, group=None):
+    """search_fn(queries_slice) -> (ids[nq_local, k] uint32, dists[nq_local, k] float32).
+
+    Returns (ids[nq, k], dists[nq, k]) identical on every rank and identical to a single-rank
+    run (queries are independent)."""
+    queries = np.asarray(queries)
+    nq = queries.shape[0]
+    lo, hi = partition(nq, world, rank)
+    ids, dists = search_fn(queries[lo:hi])
+    ids = np.ascontiguousarray(ids, dtype=np.uint32).reshape(hi - lo, k)
+    dists = np.ascontiguousarray(dists, dtype=np.float32).reshape(hi - lo, k)
+    if world == 1:
+        return ids, dists
+    import torch
+    import torch.distributed as dist
+    # pad every shard to the longest one (lengths differ by at most 1)
+    longest = partition(nq, world, 0)[1] - partition(nq, world, 0)[0]
+    pad_i = torch.zeros((longest, k), dtype=torch.int64)
+    pad_d = torch.zeros((longest, k), dtype=torch.float32)
+    pad_i[: hi - lo] = torch.from_numpy(ids.astype(np.int64))
+    pad_d[: hi - lo] = torch.from_numpy(dists)
+    all_i = [torch.zeros_like(pad_i) for _ in range(world)]
+    all_d = [torch.zeros_like(pad_d) for _ in range(world)]
+    dist.all_gather(all_i, pad_i, group=group)
+    dist.all_gather(all_d, pad_d, group=group)
+    out_i = np.empty((nq, k), np.uint32)
+    out_d = np.empty((nq, k), np.float32)
+    for r in range(world):
+        a, b = partition(nq, world, r)
+        out_i[a:b] = all_i[r][: b - a].numpy().astype(np.uint32)
+        out_d[a:b] = all_d[r][: b - a].numpy()
+    return out_i, out_d

@@ -818,7 +818,15 @@ int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, 
     std::vector<int32_t> status(threads, 0);
     auto work = [&](uint32_t t) {
         /* PartitionIter: contiguous ranges (search/api.rs:410-419) */
-        uint64_t lo = (uint64_t)nq * t / threads, hi = (uint64_t)nq * (t + 1) / threads;
+        /* partition_impl, diskann/src/utils/async_tools.rs:351-365 */
+        uint64_t kk = nq / threads, mm = nq - kk * threads, lo, hi;
+        if (t >= mm) {
+            lo = mm * (kk + 1) + (t - mm) * kk;
+            hi = lo + kk;
+        } else {
+            lo = (uint64_t)t * (kk + 1);
+            hi = lo + kk + 1;
+        }
         for (uint64_t q = lo; q < hi; ++q) {
             auto t0 = std::chrono::steady_clock::now();
             int32_t r = search_one(ix, (const uint8_t*)queries + q * qbytes, l_value, beam_width, k,
