@@ -300,7 +300,7 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/pmc_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
         except (OSError, KeyError, ValueError):
             pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k,
                                                 evaluate.last_ids)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdann_hip.so")
 
-F32, F16, U8, I8 = 0, 1, 2, 3
+F32, F16, U8, I8, SQ8 = 0, 1, 2, 3, 4
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
@@ -19,7 +19,7 @@ class Config(C.Structure):
     """dann_config == provider::Config + Full::new (diskann-inmem/src/provider.rs:160-217)."""
     _fields_ = [("dtype", C.c_int32), ("metric", C.c_int32), ("dim", C.c_uint32), ("capacity", C.c_uint32),
                 ("max_degree", C.c_uint32), ("num_start_points", C.c_uint32), ("row_stride", C.c_uint32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("sq_scale", C.c_float), ("sq_shift_norm_sq", C.c_float)]
 
 
 class BuildConfig(C.Structure):
@@ -66,6 +66,9 @@ SYMBOLS = {
     "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
+    "dann_sq8_compress": (_i32, [_i32, _vp, _u32, _u32, _vp, _f32, _vp]),
+    "dann_pq_build_lut": (_i32, [_i32, _i32, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),
+    "dann_pq_scan": (_i32, [_i32, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "dann_last_error": (_i32, [C.c_char_p, _u64]),
     "dann_kernel_time": (_i32, [_vp, _i32, _P(C.c_double), _P(_u64)]),
     "dann_kernel_time_reset": (_i32, [_vp]),

@@ -31,7 +31,8 @@ int32_t hip_fail(hipError_t e, const char* what) {
 }
 
 static uint32_t elem_size(int32_t dtype) { return dtype == DT_F32 ? 4u : dtype == DT_F16 ? 2u : 1u; }
-static bool valid_dtype(int32_t d) { return d >= 0 && d <= 3; }
+static uint32_t layer_bytes_of(int32_t dtype, uint32_t dim) { return dim * elem_size(dtype) + (dtype == DT_SQ8 ? 4u : 0u); }
+static bool valid_dtype(int32_t d) { return d >= 0 && d <= 4; }
 static bool valid_metric(int32_t m) { return m >= 0 && m <= 3; }
 
 // temporary device buffer with RAII
@@ -107,6 +108,14 @@ dann::IndexView dann_index::view() const {
     v.nstart = cfg.num_start_points;
     v.dtype = cfg.dtype;
     v.metric = cfg.metric;
+    v.layer_bytes = layer_bytes;
+    {   // (1/255)^2 * scale^2 in f32, in the reference's order (vectors.rs:236-241, quantizer.rs:316-320)
+        const float ibs = 1.0f / 255.0f;
+        const float bit_scale = ibs * ibs;
+        const float scale_sq = cfg.sq_scale * cfg.sq_scale;
+        v.sq_k = bit_scale * scale_sq;
+        v.sq_shift_norm_sq = cfg.sq_shift_norm_sq;
+    }
     return v;
 }
 
@@ -127,7 +136,7 @@ int32_t dann_layer_bytes(int32_t dtype, uint32_t dim) {
         set_error("bad dtype %d", dtype);
         return DANN_EINVAL;
     }
-    return (int32_t)(dim * elem_size(dtype));
+    return (int32_t)layer_bytes_of(dtype, dim);
 }
 
 int32_t dann_inmem2_row_stride(int32_t dtype, uint32_t dim) {
@@ -147,7 +156,19 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
                   cfg->max_degree);
         return DANN_EINVAL;
     }
-    const uint32_t lb = cfg->dim * elem_size(cfg->dtype);
+    const uint32_t lb = layer_bytes_of(cfg->dtype, cfg->dim);
+    {
+        int op;
+        bool norm;
+        if (!resolve_metric(cfg->dtype, cfg->metric, &op, &norm)) {
+            set_error("metric %d is not defined for dtype %d", cfg->metric, cfg->dtype);
+            return DANN_EUNSUPPORTED;
+        }
+        if (cfg->dtype == DT_SQ8 && !(cfg->sq_scale > 0.0f)) {
+            set_error("DANN_SQ8 needs sq_scale > 0");
+            return DANN_EINVAL;
+        }
+    }
     if ((uint64_t)cfg->capacity + cfg->num_start_points >= 0x7FFFFFFFull) {
         set_error("capacity + start points must be below 2^31 - 1");
         return DANN_EINVAL;
@@ -388,8 +409,7 @@ int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const
     DANN_HIP(hipMemcpyAsync(d, x, xlen, hipMemcpyHostToDevice, idx->stream));
     DANN_HIP(hipMemcpyAsync(d + stride, y, ylen, hipMemcpyHostToDevice, idx->stream));
     float* d_out = reinterpret_cast<float*>(d + 2 * stride);
-    int32_t rc = launch_distance_raw(idx->cfg.dtype, idx->cfg.metric, idx->cfg.dim, d, d + stride, stride, 1, d_out,
-                                     idx->stream);
+    int32_t rc = launch_distance_raw(idx->view(), d, d + stride, stride, 1, d_out, idx->stream);
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(out, d_out, 4, hipMemcpyDeviceToHost, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));

@@ -166,7 +166,9 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
                         const uint32_t rp = have ? sel[l + g] : 0u;
                         if (have && rp < i) {
                             const uint8_t* y = ix.rows + (uint64_t)sid[rp] * ix.row_stride;
-                            d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(xi, y, (int)ix.dim, v));
+                            d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(xi, y, (int)ix.dim, v),
+                                                              reinterpret_cast<const uint8_t*>(xi), y, ix.dim,
+                                                              SqParams{ix.sq_k, ix.sq_shift_norm_sq});
                         }
                     }
                     // consume in order (prune.rs:196-232)
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(kWave) void pool_prune_kernel(PoolArgs a) {
                 p %= a.n;
                 const uint32_t id = a.locs[p];
                 const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
-                float d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)a.ix.dim, v));
+                float d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)a.ix.dim, v),
+                                                        reinterpret_cast<const uint8_t*>(x), y, a.ix.dim,
+                                                        SqParams{a.ix.sq_k, a.ix.sq_shift_norm_sq});
                 if (v == 0) {
                     pid[cnt + r] = id;
                     pd[cnt + r] = d;
@@ -332,7 +336,9 @@ __device__ void fill_list_distances(const IndexView& ix, uint32_t loc, uint32_t*
         const uint32_t r = r0 + g;
         if (r < cnt) {
             const uint8_t* y = ix.rows + (uint64_t)pid[r] * ix.row_stride;
-            float d = post_op<OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)ix.dim, v));
+            float d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)ix.dim, v),
+                                                    reinterpret_cast<const uint8_t*>(x), y, ix.dim,
+                                                    SqParams{ix.sq_k, ix.sq_shift_norm_sq});
             if (v == 0) pd[r] = d;
         }
     }
@@ -503,20 +509,34 @@ __global__ void set_bulk_kernel(IndexView ix, const uint32_t* locs, const uint32
 // ---- dispatch helpers ------------------------------------------------------------------------
 template <template <int, int, bool> class Launcher, class Args>
 int32_t dispatch(const IndexView& ix, const Args& a, uint32_t grid, size_t lds, hipStream_t stream) {
-    const int op = metric_op(ix.dtype, ix.metric);
-    const bool norm = ix.metric == M_COSN && op == OP_IP;
-#define DANN_CASE(DT)                                                                          \
-    case DT:                                                                                   \
-        if (op == OP_L2) return Launcher<DT, OP_L2, false>::run(a, grid, lds, stream);         \
-        if (op == OP_IP)                                                                       \
-            return norm ? Launcher<DT, OP_IP, true>::run(a, grid, lds, stream)                 \
-                        : Launcher<DT, OP_IP, false>::run(a, grid, lds, stream);               \
-        return Launcher<DT, OP_COS, false>::run(a, grid, lds, stream);
+    int op;
+    bool norm;
+    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm)) {
+        set_error("metric %d is not defined for dtype %d", ix.metric, ix.dtype);
+        return DANN_EUNSUPPORTED;
+    }
+#define DANN_CASE(DT)                                                                                  \
+    case DT:                                                                                           \
+        if (op == OP_L2) {                                                                             \
+            if constexpr (DT == DT_SQ8) {                                                              \
+                if (norm) return Launcher<DT, OP_L2, true>::run(a, grid, lds, stream);                 \
+            }                                                                                          \
+            return Launcher<DT, OP_L2, false>::run(a, grid, lds, stream);                              \
+        }                                                                                              \
+        if (op == OP_IP) {                                                                             \
+            if constexpr (DT == DT_F32 || DT == DT_F16) {                                              \
+                if (norm) return Launcher<DT, OP_IP, true>::run(a, grid, lds, stream);                 \
+            }                                                                                          \
+            return Launcher<DT, OP_IP, false>::run(a, grid, lds, stream);                              \
+        }                                                                                              \
+        if constexpr (DT != DT_SQ8) return Launcher<DT, OP_COS, false>::run(a, grid, lds, stream);     \
+        return DANN_EUNSUPPORTED;
     switch (ix.dtype) {
         DANN_CASE(DT_F32)
         DANN_CASE(DT_F16)
         DANN_CASE(DT_U8)
         DANN_CASE(DT_I8)
+        DANN_CASE(DT_SQ8)
     }
 #undef DANN_CASE
     set_error("bad dtype %d", ix.dtype);

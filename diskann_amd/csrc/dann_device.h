@@ -23,7 +23,7 @@
 
 namespace dann {
 
-enum : int { DT_F32 = 0, DT_F16 = 1, DT_U8 = 2, DT_I8 = 3 };
+enum : int { DT_F32 = 0, DT_F16 = 1, DT_U8 = 2, DT_I8 = 3, DT_SQ8 = 4 };
 enum : int { M_COSINE = 0, M_IP = 1, M_L2 = 2, M_COSN = 3 };
 enum : int { OP_L2 = 0, OP_IP = 1, OP_COS = 2 };
 
@@ -298,7 +298,7 @@ __device__ __forceinline__ float group_distance_int(const uint8_t* __restrict__ 
 //   f16 x f16: L2/IP/cosine all Strategy2x4 (NACC 2)  (simd.rs:989,1752,2591)
 template <int DT, int OP, bool PAIR>
 struct Scheme {
-    static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8);
+    static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8);
     static constexpr int NACC = (OP == OP_COS) ? 2 : ((DT == DT_F16 && PAIR) ? 2 : 4);
     static constexpr int G = kInt ? 8 : 2 * NACC;
 };
@@ -319,11 +319,15 @@ template <>
 struct RowType<DT_I8> {
     using type = uint8_t;
 };
+template <>
+struct RowType<DT_SQ8> {
+    using type = uint8_t;
+};
 
 // `q` is the staged query: f32 for float rows, raw bytes for integer rows.
 template <int DT, int OP, bool PAIR, int DIM, typename QT>
 __device__ __forceinline__ float group_distance(const QT* q, const uint8_t* row, int dim, int v) {
-    if constexpr (DT == DT_U8 || DT == DT_I8) {
+    if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {
         return group_distance_int<OP, DT == DT_I8>(reinterpret_cast<const uint8_t*>(q), row, dim, v);
     } else {
         using RT = typename RowType<DT>::type;
@@ -331,13 +335,55 @@ __device__ __forceinline__ float group_distance(const QT* q, const uint8_t* row,
     }
 }
 
-// metric -> (OP, NORMALIZED); integers treat CosineNormalized as Cosine
-// (distance_provider.rs:274-297, full.rs:470,499)
-__host__ __device__ inline int metric_op(int dtype, int metric) {
-    if (metric == M_L2) return OP_L2;
-    if (metric == M_IP) return OP_IP;
-    if (metric == M_COSINE) return OP_COS;
-    return (dtype == DT_U8 || dtype == DT_I8) ? OP_COS : OP_IP;  // CosineNormalized
+// scalar-quantiser parameters of an SQ-8 index
+struct SqParams {
+    float k;              // (1/255)^2 * scale^2, evaluated in f32 in the reference's order
+    float shift_norm_sq;  // ||shift||^2
+};
+
+__device__ __forceinline__ float load_f32_unaligned(const uint8_t* p) {
+    uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    return __builtin_bit_cast(float, u);
+}
+
+// raw kernel result -> SimilarityScore.  Full-precision rows: PostOp; SQ-8 rows: the compensated
+// epilogues of diskann-quantization/src/scalar/vectors.rs:216-245 (L2), :306-370 (IP),
+// :403-465 (CosineNormalized); `x`, `y` are the two rows (code bytes + trailing f32 compensation).
+template <int DT, int OP, bool NORM>
+__device__ __forceinline__ float finish_distance(float raw, const uint8_t* x, const uint8_t* y, uint32_t dim,
+                                                 const SqParams& sq) {
+    if constexpr (DT != DT_SQ8) {
+        return post_op<OP, NORM>(raw);
+    } else if constexpr (OP == OP_L2) {
+        const float l2 = sq.k * raw;
+        if (!NORM) return l2;
+        const float sim = 1.0f - l2 / 2.0f;
+        return 1.0f - sim;
+    } else {
+        const float cx = load_f32_unaligned(x + dim), cy = load_f32_unaligned(y + dim);
+        const float r = __builtin_fmaf(sq.k, raw, sq.shift_norm_sq) + (cy + cx);
+        return -r;
+    }
+}
+
+// (dtype, metric) -> (OP, NORMALIZED).  Integers treat CosineNormalized as Cosine
+// (distance_provider.rs:274-297, full.rs:470,499); SQ-8 CosineNormalized is L2-based.
+// Returns false for unsupported combinations (SQ-8 has no plain Cosine).
+__host__ __device__ inline bool resolve_metric(int dtype, int metric, int* op, bool* norm) {
+    *norm = false;
+    if (dtype == DT_SQ8) {
+        if (metric == M_L2) { *op = OP_L2; return true; }
+        if (metric == M_IP) { *op = OP_IP; return true; }
+        if (metric == M_COSN) { *op = OP_L2; *norm = true; return true; }
+        return false;
+    }
+    if (metric == M_L2) { *op = OP_L2; return true; }
+    if (metric == M_IP) { *op = OP_IP; return true; }
+    if (metric == M_COSINE) { *op = OP_COS; return true; }
+    if (dtype == DT_U8 || dtype == DT_I8) { *op = OP_COS; return true; }
+    *op = OP_IP;
+    *norm = true;  // CosineNormalized on float rows = 1 - <x, y>
+    return true;
 }
 
 }  // namespace dann

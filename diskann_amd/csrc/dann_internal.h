@@ -38,6 +38,9 @@ struct IndexView {
     uint32_t nstart;
     int32_t dtype;
     int32_t metric;
+    uint32_t layer_bytes;  // bytes of one row's payload (dim * sizeof(T); SQ-8: dim + 4)
+    float sq_k;            // SQ-8: (1/255)^2 * scale^2
+    float sq_shift_norm_sq;
 };
 
 struct SearchArgs {
@@ -75,8 +78,8 @@ int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t 
 int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
                               hipStream_t stream);
 // raw rows x[i] vs y[i] (pair kernel numerics), n pairs of `bytes` each
-int32_t launch_distance_raw(int32_t dtype, int32_t metric, uint32_t dim, const void* d_x, const void* d_y,
-                            uint64_t stride, uint32_t n, float* d_out, hipStream_t stream);
+int32_t launch_distance_raw(const IndexView& ix, const void* d_x, const void* d_y, uint64_t stride, uint32_t n,
+                            float* d_out, hipStream_t stream);
 
 }  // namespace dann
 

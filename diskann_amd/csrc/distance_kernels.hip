@@ -29,11 +29,11 @@ __global__ __launch_bounds__(kWave) void expand_beam_kernel(IndexView ix, const 
     const uint64_t hi_all = offsets[qi + 1];
     if (lo >= hi_all) return;
     const uint64_t hi = lo + kChunk < hi_all ? lo + kChunk : hi_all;
-    const uint32_t esz = (DT == DT_F32) ? 4u : (DT == DT_F16 ? 2u : 1u);
     QT* qs = reinterpret_cast<QT*>(smem);
-    const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(queries) + (uint64_t)qi * ix.dim * esz;
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(queries) + (uint64_t)qi * ix.layer_bytes;
     if constexpr (kInt) {
-        for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
+        for (uint32_t i = lane; i < ix.layer_bytes; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
     } else {
         const RT* src = reinterpret_cast<const RT*>(qsrc);
         for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kWave) void expand_beam_kernel(IndexView ix, const 
             if (c < hi) {
                 const uint8_t* row = ix.rows + (uint64_t)ids[c] * ix.row_stride;
                 float d = group_distance<DT, OP, false, 0>(qs, row, (int)ix.dim, v);
-                if (v == 0) out[c] = post_op<OP, NORM>(d);
+                if (v == 0) out[c] = finish_distance<DT, OP, NORM>(d, reinterpret_cast<const uint8_t*>(qs), row, ix.dim, sqp);
             }
         }
     }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kWave) void expand_beam_kernel(IndexView ix, const 
 template <int DT, int OP, bool NORM>
 __global__ __launch_bounds__(256) void pair_kernel(const uint8_t* xbase, const uint8_t* ybase, uint64_t xstride,
                                                    uint64_t ystride, const uint32_t* a, const uint32_t* b, uint32_t n,
-                                                   uint32_t dim, float* out) {
+                                                   uint32_t dim, SqParams sqp, float* out) {
     using S = Scheme<DT, OP, true>;
     constexpr int G = S::G;
     using RT = typename RowType<DT>::type;
@@ -97,17 +97,17 @@ __global__ __launch_bounds__(256) void pair_kernel(const uint8_t* xbase, const u
         d = group_distance_raw<S::NACC, OP, 0>(reinterpret_cast<const RT*>(x), reinterpret_cast<const RT*>(y), (int)dim,
                                                v);
     }
-    if (v == 0) out[p] = post_op<OP, NORM>(d);
+    if (v == 0) out[p] = finish_distance<DT, OP, NORM>(d, x, y, dim, sqp);
 }
 
 template <int DT, int OP, bool NORM>
 int32_t launch_pairs_t(const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys, const uint32_t* a,
-                       const uint32_t* b, uint32_t n, uint32_t dim, float* out, hipStream_t stream) {
+                       const uint32_t* b, uint32_t n, uint32_t dim, SqParams sqp, float* out, hipStream_t stream) {
     constexpr int G = Scheme<DT, OP, true>::G;
     const uint64_t threads = (uint64_t)n * G;
     const uint32_t blocks = (uint32_t)((threads + 255) / 256);
     hipLaunchKernelGGL((pair_kernel<DT, OP, NORM>), dim3(blocks), dim3(256), 0, stream, xb, yb, xs, ys, a, b, n, dim,
-                       out);
+                       sqp, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pair_kernel launch");
     return DANN_OK;
@@ -115,27 +115,40 @@ int32_t launch_pairs_t(const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64
 
 template <int DT>
 int32_t launch_pairs_dt(int32_t metric, const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys,
-                        const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, float* out,
+                        const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, SqParams sqp, float* out,
                         hipStream_t stream) {
-    const int op = metric_op(DT, metric);
-    const bool norm = metric == M_COSN && op == OP_IP;
-    if (op == OP_L2) return launch_pairs_t<DT, OP_L2, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
-    if (op == OP_IP) {
-        if (norm) return launch_pairs_t<DT, OP_IP, true>(xb, yb, xs, ys, a, b, n, dim, out, stream);
-        return launch_pairs_t<DT, OP_IP, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+    int op;
+    bool norm;
+    if (!resolve_metric(DT, metric, &op, &norm)) {
+        set_error("metric %d is not defined for dtype %d", metric, DT);
+        return DANN_EUNSUPPORTED;
     }
-    return launch_pairs_t<DT, OP_COS, false>(xb, yb, xs, ys, a, b, n, dim, out, stream);
+    if (op == OP_L2) {
+        if constexpr (DT == DT_SQ8) {
+            if (norm) return launch_pairs_t<DT, OP_L2, true>(xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        }
+        return launch_pairs_t<DT, OP_L2, false>(xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+    }
+    if (op == OP_IP) {
+        if constexpr (DT == DT_F32 || DT == DT_F16) {
+            if (norm) return launch_pairs_t<DT, OP_IP, true>(xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        }
+        return launch_pairs_t<DT, OP_IP, false>(xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+    }
+    if constexpr (DT != DT_SQ8) return launch_pairs_t<DT, OP_COS, false>(xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+    return DANN_EUNSUPPORTED;
 }
 
 int32_t launch_pairs_any(int32_t dtype, int32_t metric, const uint8_t* xb, const uint8_t* yb, uint64_t xs, uint64_t ys,
-                         const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, float* out,
+                         const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t dim, SqParams sqp, float* out,
                          hipStream_t stream) {
     if (n == 0) return DANN_OK;
     switch (dtype) {
-        case DT_F32: return launch_pairs_dt<DT_F32>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
-        case DT_F16: return launch_pairs_dt<DT_F16>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
-        case DT_U8: return launch_pairs_dt<DT_U8>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
-        case DT_I8: return launch_pairs_dt<DT_I8>(metric, xb, yb, xs, ys, a, b, n, dim, out, stream);
+        case DT_F32: return launch_pairs_dt<DT_F32>(metric, xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        case DT_F16: return launch_pairs_dt<DT_F16>(metric, xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        case DT_U8: return launch_pairs_dt<DT_U8>(metric, xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        case DT_I8: return launch_pairs_dt<DT_I8>(metric, xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
+        case DT_SQ8: return launch_pairs_dt<DT_SQ8>(metric, xb, yb, xs, ys, a, b, n, dim, sqp, out, stream);
     }
     set_error("bad dtype %d", dtype);
     return DANN_EINVAL;
@@ -144,8 +157,8 @@ int32_t launch_pairs_any(int32_t dtype, int32_t metric, const uint8_t* xb, const
 template <int DT, int OP, bool NORM, int DIM>
 int32_t launch_eb_t(const IndexView& ix, const void* q, uint32_t nq, uint32_t chunks, const uint32_t* ids,
                     const uint64_t* offsets, float* out, hipStream_t stream) {
-    const bool is_int = DT == DT_U8 || DT == DT_I8;
-    size_t lds = ((is_int ? ix.dim : ix.dim * 4u) + 15u) & ~15u;
+    const bool is_int = DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8;
+    size_t lds = ((is_int ? ix.layer_bytes : ix.dim * 4u) + 15u) & ~15u;
     hipLaunchKernelGGL((expand_beam_kernel<DT, OP, NORM, DIM>), dim3(nq, chunks), dim3(kWave), lds, stream, ix, q, ids,
                        offsets, out);
     hipError_t e = hipGetLastError();
@@ -156,18 +169,29 @@ int32_t launch_eb_t(const IndexView& ix, const void* q, uint32_t nq, uint32_t ch
 template <int DT>
 int32_t launch_eb_dt(const IndexView& ix, const void* q, uint32_t nq, uint32_t chunks, const uint32_t* ids,
                      const uint64_t* offsets, float* out, hipStream_t stream) {
-    const int op = metric_op(ix.dtype, ix.metric);
-    const bool norm = ix.metric == M_COSN && op == OP_IP;
+    int op;
+    bool norm;
+    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm)) {
+        set_error("metric %d is not defined for dtype %d", ix.metric, ix.dtype);
+        return DANN_EUNSUPPORTED;
+    }
     if (op == OP_L2) {
-        if (DT == DT_F32 && ix.dim == 128)
-            return launch_eb_t<DT, OP_L2, false, (DT == DT_F32 ? 128 : 0)>(ix, q, nq, chunks, ids, offsets, out, stream);
+        if constexpr (DT == DT_F32) {
+            if (ix.dim == 128) return launch_eb_t<DT, OP_L2, false, 128>(ix, q, nq, chunks, ids, offsets, out, stream);
+        }
+        if constexpr (DT == DT_SQ8) {
+            if (norm) return launch_eb_t<DT, OP_L2, true, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+        }
         return launch_eb_t<DT, OP_L2, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
     }
     if (op == OP_IP) {
-        if (norm) return launch_eb_t<DT, OP_IP, true, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+        if constexpr (DT == DT_F32 || DT == DT_F16) {
+            if (norm) return launch_eb_t<DT, OP_IP, true, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+        }
         return launch_eb_t<DT, OP_IP, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
     }
-    return launch_eb_t<DT, OP_COS, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+    if constexpr (DT != DT_SQ8) return launch_eb_t<DT, OP_COS, false, 0>(ix, q, nq, chunks, ids, offsets, out, stream);
+    return DANN_EUNSUPPORTED;
 }
 
 }  // namespace
@@ -186,6 +210,7 @@ int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t 
         case DT_F16: return launch_eb_dt<DT_F16>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
         case DT_U8: return launch_eb_dt<DT_U8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
         case DT_I8: return launch_eb_dt<DT_I8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
+        case DT_SQ8: return launch_eb_dt<DT_SQ8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
     }
     set_error("bad dtype %d", ix.dtype);
     return DANN_EINVAL;
@@ -194,13 +219,14 @@ int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t 
 int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
                               hipStream_t stream) {
     return launch_pairs_any(ix.dtype, ix.metric, ix.rows, ix.rows, ix.row_stride, ix.row_stride, d_a, d_b, n, ix.dim,
-                            d_out, stream);
+                            SqParams{ix.sq_k, ix.sq_shift_norm_sq}, d_out, stream);
 }
 
-int32_t launch_distance_raw(int32_t dtype, int32_t metric, uint32_t dim, const void* d_x, const void* d_y,
-                            uint64_t stride, uint32_t n, float* d_out, hipStream_t stream) {
-    return launch_pairs_any(dtype, metric, reinterpret_cast<const uint8_t*>(d_x), reinterpret_cast<const uint8_t*>(d_y),
-                            stride, stride, nullptr, nullptr, n, dim, d_out, stream);
+int32_t launch_distance_raw(const IndexView& ix, const void* d_x, const void* d_y, uint64_t stride, uint32_t n,
+                            float* d_out, hipStream_t stream) {
+    return launch_pairs_any(ix.dtype, ix.metric, reinterpret_cast<const uint8_t*>(d_x),
+                            reinterpret_cast<const uint8_t*>(d_y), stride, stride, nullptr, nullptr, n, ix.dim,
+                            SqParams{ix.sq_k, ix.sq_shift_norm_sq}, d_out, stream);
 }
 
 }  // namespace dann

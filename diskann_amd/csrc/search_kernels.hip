@@ -123,8 +123,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     const uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207)
     const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
                                                                               : ((ix.nstart + 63u) & ~63u);
-    const uint32_t esz = (DT == DT_F32) ? 4u : (DT == DT_F16 ? 2u : 1u);
-    const uint32_t qbytes = kInt ? ix.dim : ix.dim * 4u;
+    const uint32_t qbytes = kInt ? ix.layer_bytes : ix.dim * 4u;
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
     {
         const uint8_t* qsrc = a.qslots ? ix.rows + (uint64_t)a.qslots[qi] * ix.row_stride
-                                       : reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.dim * esz;
+                                       : reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
         if constexpr (kInt) {
-            for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
+            for (uint32_t i = lane; i < ix.layer_bytes; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
         } else {
             const RT* src = reinterpret_cast<const RT*>(qsrc);
             for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     uint32_t c = c0 + u * GROUPS + g;
-                    if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);
+                    if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
                 }
             }
         } else {
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 const uint8_t* row = ix.rows + (uint64_t)id * ix.row_stride;
                 float d = 0.0f;
                 if (act) d = group_distance<DT, OP, false, 0>(qs, row, (int)ix.dim, v);
-                if (act && v == 0) cand_d[c] = post_op<OP, NORM>(d);
+                if (act && v == 0)
+                    cand_d[c] = finish_distance<DT, OP, NORM>(d, reinterpret_cast<const uint8_t*>(qs), row, ix.dim, sqp);
             }
         }
     };
@@ -507,17 +508,29 @@ int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
 
 template <int DT>
 int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
-    const int op = metric_op(a.ix.dtype, a.ix.metric);
-    const bool norm = (a.ix.metric == M_COSN) && op == OP_IP;
+    int op;
+    bool norm;
+    if (!resolve_metric(a.ix.dtype, a.ix.metric, &op, &norm)) {
+        set_error("metric %d is not defined for dtype %d", a.ix.metric, a.ix.dtype);
+        return DANN_EUNSUPPORTED;
+    }
     if (op == OP_L2) {
-        if (DT == DT_F32 && a.ix.dim == 128) return launch_qs<DT, OP_L2, false, (DT == DT_F32 ? 128 : 0)>(a, qcap, lds, stream);
+        if constexpr (DT == DT_F32) {
+            if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream);
+        }
+        if constexpr (DT == DT_SQ8) {
+            if (norm) return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream);
+        }
         return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream);
     }
     if (op == OP_IP) {
-        if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream);
+        if constexpr (DT == DT_F32 || DT == DT_F16) {
+            if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream);
+        }
         return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream);
     }
-    return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
+    if constexpr (DT != DT_SQ8) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
+    return DANN_EUNSUPPORTED;
 }
 
 uint32_t cmax_of(const SearchArgs& a) {
@@ -538,9 +551,10 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    const bool is_int = a.ix.dtype == DT_U8 || a.ix.dtype == DT_I8;
+    const bool is_int = a.ix.dtype == DT_U8 || a.ix.dtype == DT_I8 || a.ix.dtype == DT_SQ8;
     const uint32_t qcap = a.l_value + a.ix.nstart;
-    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.dim : a.ix.dim * 4u).total;
+    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.layer_bytes : a.ix.dim * 4u)
+        .total;
 }
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
@@ -564,6 +578,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
         case DT_F16: return launch_dt<DT_F16>(a, qcap, lds, stream);
         case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream);
         case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream);
+        case DT_SQ8: return launch_dt<DT_SQ8>(a, qcap, lds, stream);
     }
     set_error("bad dtype %d", a.ix.dtype);
     return DANN_EINVAL;

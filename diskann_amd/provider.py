@@ -12,10 +12,10 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16, U8, I8, COSINE, INNER_PRODUCT, L2,
+from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16, U8, I8, SQ8, COSINE, INNER_PRODUCT, L2,
                    COSINE_NORMALIZED, IBC_ALL, IBC_NONE)
 
-NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8}
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8}
 STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32)])
 
 
@@ -46,13 +46,15 @@ def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_si
 class Provider:
     """diskann_inmem::Provider<Full<T>, u32> + DiskANNIndex, resident in one GPU's HBM."""
 
-    def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, row_stride=0, device=-1):
+    def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, row_stride=0, device=-1,
+                 sq_scale=0.0, sq_shift_norm_sq=0.0):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
-        sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.dim)
+        self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim  # SQ-8 rows carry a trailing f32 compensation
+        sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.row_elems)
         self.num_start_points = sp.shape[0]
         cfg = Config(dtype, metric, self.dim, self.capacity, self.max_degree, self.num_start_points, row_stride,
-                     device)
+                     device, sq_scale, sq_shift_norm_sq)
         h = C.c_void_p()
         check(_ffi.lib().dann_index_create(C.byref(cfg), _p(sp), sp.nbytes, C.byref(h)), "dann_index_create")
         self._h = h
@@ -79,11 +81,11 @@ class Provider:
 
     def set_elements(self, first_slot, rows):
         r = np.ascontiguousarray(rows, dtype=NP_DTYPE[self.dtype])
-        n = r.shape[0] if r.ndim == 2 else r.size // self.dim
+        n = r.shape[0] if r.ndim == 2 else r.size // self.row_elems
         check(_ffi.lib().dann_set_elements(self._h, first_slot, n, _p(r), r.nbytes), "dann_set_elements")
 
     def get_element(self, slot):
-        out = np.empty(self.dim, NP_DTYPE[self.dtype])
+        out = np.empty(self.row_elems, NP_DTYPE[self.dtype])
         check(_ffi.lib().dann_get_element(self._h, slot, _p(out), out.nbytes), "dann_get_element")
         return out
 
@@ -158,7 +160,7 @@ class Provider:
             _ffi.lib().dann_query_destroy(h)
 
     def expand_beam_batch(self, queries, ids, offsets):
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         out = np.empty(ids.size, np.float32)
@@ -169,7 +171,7 @@ class Provider:
     # -- DiskANNIndex::search -------------------------------------------------
     def search(self, params, queries, k=10):
         """nq independent Knn searches; returns (ids[nq,k], dists[nq,k], stats[nq])."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
         nq = q.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dists = np.empty((nq, k), np.float32)
@@ -218,3 +220,35 @@ class Provider:
 
     def set_visited_bits(self, bits):
         check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")
+
+
+def sq8_compress(x, shift, scale, device=-1):
+    """ScalarQuantizer::compress_into (8 bits) on the GPU: rows of dim code bytes + f32 compensation."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = x.reshape(-1, x.shape[-1])
+    shift = np.ascontiguousarray(shift, dtype=np.float32)
+    out = np.empty((x.shape[0], x.shape[1] + 4), np.uint8)
+    check(_ffi.lib().dann_sq8_compress(device, _p(x), x.shape[0], x.shape[1], _p(shift), float(scale), _p(out)),
+          "dann_sq8_compress")
+    return out
+
+
+def pq_build_lut(metric, pivots, chunk_offsets, queries, device=-1):
+    piv = np.ascontiguousarray(pivots, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, piv.shape[1])
+    lut = np.empty((q.shape[0], off.size - 1, 256), np.float32)
+    check(_ffi.lib().dann_pq_build_lut(device, metric, _p(piv), _p(off), off.size - 1, piv.shape[1], _p(q), q.shape[0],
+                                       _p(lut)), "dann_pq_build_lut")
+    return lut
+
+
+def pq_scan(lut, codes, ids, offsets, device=-1):
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.empty(ids.size, np.float32)
+    check(_ffi.lib().dann_pq_scan(device, _p(lut), lut.shape[0], lut.shape[1], _p(codes), codes.shape[0], _p(ids),
+                                  _p(off), _p(out)), "dann_pq_scan")
+    return out

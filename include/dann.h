@@ -30,7 +30,17 @@ extern "C" {
 #endif
 
 /* element type of the stored rows: layers::Full<T>, diskann-inmem/src/layers/full.rs:351-504 */
-typedef enum { DANN_F32 = 0, DANN_F16 = 1, DANN_U8 = 2, DANN_I8 = 3 } dann_dtype;
+typedef enum {
+    DANN_F32 = 0,
+    DANN_F16 = 1,
+    DANN_U8 = 2,
+    DANN_I8 = 3,
+    /* 8-bit scalar-quantised rows: `dim` code bytes followed by the f32 compensation
+     * (CompensatedVector<8>, diskann-quantization/src/scalar/vectors.rs:150-175); distances are
+     * CompensatedSquaredL2 / CompensatedIP / CompensatedCosineNormalized (:171-465).  Queries are
+     * compressed the same way (symmetric, diskann-providers/.../inmem/scalar.rs:261-320). */
+    DANN_SQ8 = 4
+} dann_dtype;
 
 /* == `#[repr(C)] enum Metric`, diskann-vector/src/distance/metric.rs:8-20 */
 typedef enum {
@@ -67,6 +77,8 @@ typedef struct {
                                   to 16).  dann_inmem2_row_stride() gives the reference's
                                   own stride so a Store buffer can be uploaded verbatim    */
     int32_t device;            /* HIP device ordinal, -1 = current                         */
+    float sq_scale;            /* DANN_SQ8 only: ScalarQuantizer::scale()                   */
+    float sq_shift_norm_sq;    /* DANN_SQ8 only: ScalarQuantizer::shift_square_norm()       */
 } dann_config;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs:14-41) */
@@ -169,6 +181,26 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
  * (batch = clamp(ceil(inserted * growth), 1, max_batch)); returns the number of batches */
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
                    uint32_t max_batch);
+
+/* ---- product quantisation: lookup-table build + scan -------------------------------------
+ * FixedChunkPQTable::populate_chunk_distances_impl (L2 / inner product) and pq_dist_lookup_single
+ * (diskann-providers/src/model/pq/fixed_chunk_pq_table.rs:152-192, 82-100), batched:
+ *   pivots: 256 x dim f32 row-major (:105-128), chunk_offsets: nchunks+1 (usize -> u32),
+ *   queries: nq x dim f32 (already centred/rotated by the caller), lut: nq x nchunks x 256 f32.
+ * metric: DANN_L2 or DANN_INNER_PRODUCT.  Host pointers. */
+int32_t dann_pq_build_lut(int32_t device, int32_t metric, const float* pivots, const uint32_t* chunk_offsets,
+                          uint32_t nchunks, uint32_t dim, const float* queries, uint32_t nq, float* lut);
+/* scan: out[q][i] = sum over chunks, in chunk order, of lut[q][c][codes[ids[q][i]][c]];
+ * codes: npoints x nchunks u8; ids: ragged lists (offsets has nq+1 entries), out aligned with ids */
+int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nchunks, const uint8_t* codes,
+                     uint64_t npoints, const uint32_t* ids, const uint64_t* offsets, float* out);
+
+/* ---- scalar quantisation: ScalarQuantizer::compress_into for 8 bits
+ * (diskann-quantization/src/scalar/quantizer.rs:189-236, 395-430): code = round(clamp((x - shift) *
+ * 255/scale, 0, 255)), compensation = scale/255 * sum(code * shift).  x: n x dim f32, shift: dim f32,
+ * out: n rows of dim + 4 bytes.  Host pointers. */
+int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift, float scale,
+                          void* out);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* thread-local message of the last failing call on this thread; returns its length */

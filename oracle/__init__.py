@@ -12,11 +12,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdann_oracle.so")
 
-F32, F16, U8, I8 = 0, 1, 2, 3
+F32, F16, U8, I8, SQ8 = 0, 1, 2, 3, 4
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
 
-NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8}
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8}
 
 
 def build(force=False):
@@ -41,6 +41,8 @@ class OrcIndex(C.Structure):
         ("row_stride", C.c_uint64),
         ("rows", C.c_void_p),
         ("adj", C.c_void_p),
+        ("sq_scale", C.c_float),
+        ("sq_shift_norm_sq", C.c_float),
     ]
 
 
@@ -107,7 +109,7 @@ def _p(a):
 
 
 def layer_bytes(dtype, dim):
-    return int(dim) * np.dtype(NP_DTYPE[dtype]).itemsize
+    return int(dim) * np.dtype(NP_DTYPE[dtype]).itemsize + (4 if dtype == SQ8 else 0)
 
 
 def inmem2_stride(dtype, dim):
@@ -119,10 +121,12 @@ def inmem2_stride(dtype, dim):
 class Index:
     """Host-side arrays in the diskann-inmem layout + the oracle's algorithms over them."""
 
-    def __init__(self, dtype, metric, dim, capacity, max_degree, start_rows, row_stride=None):
+    def __init__(self, dtype, metric, dim, capacity, max_degree, start_rows, row_stride=None, sq_scale=0.0,
+                 sq_shift_norm_sq=0.0):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
-        start_rows = np.ascontiguousarray(start_rows, dtype=NP_DTYPE[dtype]).reshape(-1, self.dim)
+        self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim
+        start_rows = np.ascontiguousarray(start_rows, dtype=NP_DTYPE[dtype]).reshape(-1, self.row_elems)
         self.nstart = start_rows.shape[0]
         self.row_bytes = layer_bytes(dtype, dim)
         self.row_stride = int(row_stride) if row_stride else self.row_bytes
@@ -132,16 +136,16 @@ class Index:
         for i in range(self.nstart):
             self.set_row(self.capacity + i, start_rows[i])
         self._c = OrcIndex(dtype, metric, self.dim, self.capacity, self.nstart, self.max_degree,
-                           self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data)
+                           self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data, sq_scale, sq_shift_norm_sq)
 
     # -- storage ------------------------------------------------------------
     def set_row(self, slot, vec):
         vec = np.ascontiguousarray(vec, dtype=NP_DTYPE[self.dtype]).reshape(-1)
-        assert vec.size == self.dim
+        assert vec.size == self.row_elems
         self.rows[slot, : self.row_bytes] = vec.view(np.uint8)
 
     def set_rows(self, first, mat):
-        mat = np.ascontiguousarray(mat, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        mat = np.ascontiguousarray(mat, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
         self.rows[first: first + mat.shape[0], : self.row_bytes] = mat.view(np.uint8).reshape(mat.shape[0], -1)
 
     def row(self, slot):
@@ -179,7 +183,7 @@ class Index:
         return n, ids, dists, stats
 
     def search_batch(self, queries, l_value, beam_width=1, k=10, threads=1, fast=False, timing=False):
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.dim)
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
         nq = q.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dists = np.empty((nq, k), np.float32)

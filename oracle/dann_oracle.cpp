@@ -378,6 +378,34 @@ inline int eff_metric(int dtype, int metric) {
     return metric;
 }
 inline size_t elem_size(int dtype) { return dtype == ORC_F32 ? 4 : dtype == ORC_F16 ? 2 : 1; }
+inline size_t layer_bytes(int dtype, size_t dim) { return dim * elem_size(dtype) + (dtype == ORC_SQ8 ? 4 : 0); }
+
+/* CompensatedSquaredL2 / CompensatedIP / CompensatedCosineNormalized
+ * (diskann-quantization/src/scalar/vectors.rs:216-245, 306-370, 403-465) on 8-bit codes with the
+ * trailing f32 compensation. */
+float sq8_similarity(int metric, const uint8_t* x, const uint8_t* y, uint32_t dim, float scale, float shift_norm_sq) {
+    const float ibs = 1.0f / 255.0f;
+    const float bit_scale = ibs * ibs;
+    const float scale_sq = scale * scale;
+    float cx, cy;
+    std::memcpy(&cx, x + dim, 4);
+    std::memcpy(&cy, y + dim, 4);
+    if (metric == ORC_INNER_PRODUCT) {
+        uint32_t p = 0;
+        for (uint32_t i = 0; i < dim; ++i) p += (uint32_t)x[i] * (uint32_t)y[i];
+        float r = std::fmaf(bit_scale * scale_sq, (float)p, shift_norm_sq) + (cy + cx);
+        return -r;
+    }
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < dim; ++i) {
+        int32_t c = (int32_t)x[i] - (int32_t)y[i];
+        s += (uint32_t)(c * c);
+    }
+    float l2 = bit_scale * scale_sq * (float)s;
+    if (metric == ORC_L2) return l2;
+    float sim = 1.0f - l2 / 2.0f; /* CosineNormalized */
+    return 1.0f - sim;
+}
 
 /* ======================================================================
  * NeighborPriorityQueue  (diskann/src/neighbor/queue.rs:68-475)
@@ -468,6 +496,7 @@ struct View {
         r[0] = cur + take;
     }
     float pair(uint32_t a, uint32_t b) const {
+        if (ix->dtype == ORC_SQ8) return sq8_similarity(metric, row(a), row(b), ix->dim, ix->sq_scale, ix->sq_shift_norm_sq);
         return post_op(metric, pair_raw(ix->dtype, metric, row(a), row(b), ix->dim));
     }
 };
@@ -485,6 +514,8 @@ struct QueryCtx {
         }
     }
     float eval(uint32_t id) const {
+        if (v.ix->dtype == ORC_SQ8)
+            return sq8_similarity(v.metric, (const uint8_t*)q, v.row(id), v.ix->dim, v.ix->sq_scale, v.ix->sq_shift_norm_sq);
         float raw = fast ? query_raw_fast(v.ix->dtype, v.metric, q32.data(), q, v.row(id), v.ix->dim)
                          : query_raw(v.ix->dtype, v.metric, q32.data(), q, v.row(id), v.ix->dim);
         return post_op(v.metric, raw);
@@ -814,7 +845,7 @@ int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, 
                          uint64_t* per_query_ns) {
     if (!ix || !queries) return -1;
     if (threads == 0) threads = 1;
-    size_t qbytes = (size_t)ix->dim * elem_size(ix->dtype);
+    size_t qbytes = layer_bytes(ix->dtype, ix->dim);
     std::vector<int32_t> status(threads, 0);
     auto work = [&](uint32_t t) {
         /* PartitionIter: contiguous ranges (search/api.rs:410-419) */

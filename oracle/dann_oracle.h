@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-enum { ORC_F32 = 0, ORC_F16 = 1, ORC_U8 = 2, ORC_I8 = 3 };
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_U8 = 2, ORC_I8 = 3, ORC_SQ8 = 4 /* dim code bytes + f32 compensation */ };
 enum { ORC_COSINE = 0, ORC_INNER_PRODUCT = 1, ORC_L2 = 2, ORC_COSINE_NORMALIZED = 3 };
 enum { ORC_IBC_NONE = 0, ORC_IBC_ALL = 0xFFFFFFFFu }; /* else Max(n) */
 
@@ -45,6 +45,8 @@ typedef struct {
     uint64_t row_stride;
     uint8_t* rows;
     uint32_t* adj;
+    float sq_scale;          /* ORC_SQ8: ScalarQuantizer::scale() */
+    float sq_shift_norm_sq;  /* ORC_SQ8: shift_square_norm()      */
 } orc_index;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs) */

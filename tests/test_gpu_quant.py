@@ -1,0 +1,142 @@
+"""Quantised variants on the GPU vs the oracle: SQ-8 (compress, distances, search, build) and
+the PQ lookup-table build + scan."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import bits, random_graph
+
+pytestmark = pytest.mark.gpu
+da = pytest.importorskip("diskann_amd")
+
+
+def _orc_compress(x, shift, scale):
+    L = oracle.lib()
+    out = np.zeros((x.shape[0], x.shape[1] + 4), np.uint8)
+    for i in range(x.shape[0]):
+        c = np.zeros(1, np.float32)
+        L.orc_sq8_compress(x[i].ctypes.data, x.shape[1], shift.ctypes.data, C.c_float(scale),
+                           out[i].ctypes.data, c.ctypes.data)
+        out[i, x.shape[1]:] = c.view(np.uint8)
+    return out
+
+
+def _sq_setup(rng, n, dim):
+    data = rng.normal(0.3, 0.5, (n, dim)).astype(np.float32)
+    # ScalarQuantizer parameters as train.rs would produce them: shift = mean - 2 std, scale = 4 std
+    shift = (data.mean(0) - 2.0 * data.std(0)).astype(np.float32)
+    scale = float(np.float32(4.0 * data.std()))
+    return data, shift, scale
+
+
+def test_sq8_compress_matches_oracle():
+    rng = np.random.default_rng(31)
+    for dim in (7, 64, 128, 100):
+        data, shift, scale = _sq_setup(rng, 300, dim)
+        data[3, 0] = 1e9
+        data[4, 1] = -1e9
+        got = da.sq8_compress(data, shift, scale)
+        want = _orc_compress(data, shift, scale)
+        assert np.array_equal(got, want), dim
+
+
+@pytest.mark.parametrize("metric", [oracle.L2, oracle.INNER_PRODUCT, oracle.COSINE_NORMALIZED])
+def test_sq8_search_and_distances(metric):
+    rng = np.random.default_rng(32 + metric)
+    n, dim, R = 4000, 128, 24
+    data, shift, scale = _sq_setup(rng, n, dim)
+    codes = da.sq8_compress(data, shift, scale)
+    snorm = float(np.float32((shift.astype(np.float32) ** 2).sum(dtype=np.float32)))
+    adj = random_graph(rng, n, R)
+    oix = oracle.Index(oracle.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
+    oix.set_rows(0, codes)
+    oix.adj[:] = adj
+    gix = da.Provider(da.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
+    gix.set_elements(0, codes)
+    gix.upload_graph(adj)
+    queries = da.sq8_compress(rng.normal(0.3, 0.5, (40, dim)).astype(np.float32), shift, scale)
+    ids = rng.choice(n, 200, replace=False).astype(np.uint32)
+    _, od = oix.expand_beam(queries[0], ids)
+    _, gd = gix.expand_beam(queries[0], ids)
+    assert np.array_equal(bits(od), bits(gd))
+    a, b = rng.integers(0, n, 100).astype(np.uint32), rng.integers(0, n, 100).astype(np.uint32)
+    gp = gix.distance_pairs(a, b)
+    L = oracle.lib()
+    for i in range(100):
+        x, y = codes[a[i]], codes[b[i]]
+        want = L.orc_sq8_distance(metric if metric != oracle.COSINE_NORMALIZED else oracle.L2, x.ctypes.data,
+                                  C.c_float(x[dim:].view(np.float32)[0]), y.ctypes.data,
+                                  C.c_float(y[dim:].view(np.float32)[0]), dim, C.c_float(scale), C.c_float(snorm))
+        if metric == oracle.COSINE_NORMALIZED:
+            want = np.float32(1.0) - (np.float32(1.0) - np.float32(want) / np.float32(2.0))
+        assert np.float32(want).view(np.uint32) == gp[i:i + 1].view(np.uint32)[0]
+    for Lv, W in ((20, 1), (64, 2)):
+        oi, od, oc, ost = oix.search_batch(queries, Lv, W, 10)
+        gi, gd, gst = gix.search(da.Knn(Lv, W), queries, 10)
+        assert np.array_equal(oi, gi) and np.array_equal(bits(od), bits(gd))
+        assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"])
+
+
+def test_sq8_cosine_is_rejected():
+    with pytest.raises(da.DannError) as e:
+        da.Provider(da.SQ8, da.COSINE, 16, 10, 4, np.zeros((1, 20), np.uint8), sq_scale=1.0)
+    assert e.value.status == da._ffi.EUNSUPPORTED
+
+
+def test_sq8_build_matches_oracle():
+    rng = np.random.default_rng(35)
+    n, dim, R, maxdeg, lb = 500, 32, 8, 10, 24
+    data, shift, scale = _sq_setup(rng, n, dim)
+    codes = da.sq8_compress(data, shift, scale)
+    snorm = float(np.float32((shift ** 2).sum(dtype=np.float32)))
+    start = da.sq8_compress(data.mean(0, keepdims=True).astype(np.float32), shift, scale)
+    oix = oracle.Index(oracle.SQ8, oracle.L2, dim, n, maxdeg, start, sq_scale=scale, sq_shift_norm_sq=snorm)
+    oix.set_rows(0, codes)
+    gix = da.Provider(da.SQ8, da.L2, dim, n, maxdeg, start, sq_scale=scale, sq_shift_norm_sq=snorm)
+    gix.set_elements(0, codes)
+    ocfg = oracle.build_config(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    gcfg = da.build_config(R, maxdeg, lb, intra_batch_candidates=da.IBC_NONE)
+    s = 0
+    for b in (1, 2, 5, 20, 72, 400):
+        slots = np.arange(s, min(s + b, n), dtype=np.uint32)
+        oix.multi_insert(ocfg, slots)
+        gix.insert_batch(gcfg, slots)
+        s += b
+    got = gix.download_graph()
+    lens = oix.adj[:, 0]
+    assert np.array_equal(got[:, 0], lens)
+    mask = np.arange(maxdeg)[None, :] < lens[:, None]
+    assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask])
+
+
+@pytest.mark.parametrize("metric", [oracle.L2, oracle.INNER_PRODUCT])
+def test_pq_lut_and_scan(metric):
+    rng = np.random.default_rng(40 + metric)
+    dim = 100
+    offsets = np.array([0, 7, 16, 24, 33, 48, 64, 71, 80, 92, 100], np.uint32)  # ragged chunks
+    nchunks = offsets.size - 1
+    pivots = rng.standard_normal((256, dim)).astype(np.float32)
+    queries = rng.standard_normal((5, dim)).astype(np.float32)
+    lut = da.pq_build_lut(metric, pivots, offsets, queries)
+    L = oracle.lib()
+    want = np.zeros((nchunks, 256), np.float32)
+    for q in range(5):
+        L.orc_pq_build_lut(metric, pivots.ctypes.data, None, offsets.ctypes.data, nchunks, dim,
+                           queries[q].ctypes.data, want.ctypes.data)
+        assert np.array_equal(bits(lut[q]), bits(want)), q
+    npts = 3000
+    codes = rng.integers(0, 256, (npts, nchunks), dtype=np.uint8)
+    lens = [0, 5000, 17, 1, 900]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ids = rng.integers(0, npts, int(off[-1])).astype(np.uint32)
+    got = da.pq_scan(lut, codes, ids, off)
+    for q in range(5):
+        for j in range(int(off[q]), int(off[q + 1]), 37):
+            w = L.orc_pq_lookup(lut[q].ctypes.data, codes[ids[j]].ctypes.data, nchunks)
+            assert np.float32(w).view(np.uint32) == got[j:j + 1].view(np.uint32)[0]
+    # known-answer test of the reference (fixed_chunk_pq_table.rs:1081-1093)
+    kat = np.arange(512, dtype=np.float32).reshape(1, 2, 256)
+    out = da.pq_scan(kat, np.array([[1, 3]], np.uint8), np.array([0], np.uint32), np.array([0, 1], np.uint64))
+    assert out[0] == kat[0, 0, 1] + kat[0, 1, 3]
