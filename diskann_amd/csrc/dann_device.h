@@ -70,6 +70,28 @@ __device__ __forceinline__ F4 load4(const __half* p) {
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const __half* p) { return __half2float(*p); }
 
+
+// Raw (unconverted) loads: converting inside a predicated block makes hipcc wait for each load
+// before issuing the next (measured: 16 serialized round trips per f16 gather), so the loaders
+// below only move bits; conversion happens in the compute phase.
+template <typename RT>
+struct Raw4;
+template <>
+struct Raw4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ F4 get() const { return {v.x, v.y, v.z, v.w}; }
+};
+template <>
+struct Raw4<__half> {
+    uint2 v;
+    __device__ __forceinline__ void load(const __half* p) { v = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ F4 get() const {
+        float2 a = __half22float2(__builtin_bit_cast(__half2, v.x)), b = __half22float2(__builtin_bit_cast(__half2, v.y));
+        return {a.x, a.y, b.x, b.y};
+    }
+};
+
 // FullCosineAccumulator::sum (simd.rs:2329-2362)
 __device__ __forceinline__ float cosine_finish(float normx, float normy, float prod) {
     // NB: __fsqrt_rn is NOT correctly rounded on ROCm 7.2 (15 % of inputs off by 1 ulp on gfx950);
@@ -214,12 +236,12 @@ template <int NACC, int OP, int DIM, int U, typename RT>
 __device__ __forceinline__ void group_distance_pre(const F4 (&xs)[DIM / (8 * NACC)], const RT* const (&rows)[U],
                                                    const bool (&active)[U], int v, float (&out)[U]) {
     constexpr int G = 2 * NACC, TRIP = 4 * G, NT = DIM / TRIP;
-    F4 ys[U][NT];
+    Raw4<RT> ys[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (active[u]) ys[u][t] = load4(rows[u] + t * TRIP + 4 * v);
+            if (active[u]) ys[u][t].load(rows[u] + t * TRIP + 4 * v);
         }
     }
 #pragma unroll
@@ -227,7 +249,7 @@ __device__ __forceinline__ void group_distance_pre(const F4 (&xs)[DIM / (8 * NAC
         FAcc<OP> acc;
         acc.init();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc.step(xs[t], ys[u][t]);
+        for (int t = 0; t < NT; ++t) acc.step(xs[t], ys[u][t].get());
         float s = finish_vec<NACC>(acc.s, [](float(&)[4]) {});
         if (OP == OP_COS) {
             float nx = finish_vec<NACC>(acc.nx, [](float(&)[4]) {});
@@ -235,6 +257,207 @@ __device__ __forceinline__ void group_distance_pre(const F4 (&xs)[DIM / (8 * NAC
             s = cosine_finish(nx, ny, s);
         }
         out[u] = s;
+    }
+}
+
+
+// U rows at once with run-time length: per trip the U row loads are issued together, so a lane
+// keeps U (x unroll) requests in flight instead of one.  Same arithmetic as group_distance_raw.
+template <int NACC, int OP, int U, typename QT, typename RT>
+__device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, const RT* const (&rows)[U],
+                                                     const bool (&active)[U], int dim, int v, float (&out)[U]) {
+    constexpr int G = 2 * NACC, TRIP = 4 * G;
+    const int full_end = dim & ~7;
+    FAcc<OP> acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u].init();
+    // T trips of loads are issued before the first FMA: U*T 16-byte requests in flight per lane
+    constexpr int T = 4;
+    for (int e0 = 4 * v; e0 < full_end; e0 += TRIP * T) {
+        Raw4<RT> ys[T][U];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e < full_end && active[u]) ys[t][u].load(rows[u] + e);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+            if (e < full_end) {
+                const F4 x = load4(q + e);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (active[u]) acc[u].step(x, ys[t][u].get());
+            }
+        }
+    }
+    const int rem = dim & 7;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const RT* row = rows[u];
+        const bool act = active[u];
+        auto partial = [&](float(&a)[4], int which) {
+            if (rem == 0 || !act) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int l = 4 * (v & 1) + i;
+                float x = 0.0f, y = 0.0f;
+                if (l < rem) {
+                    x = load1(q + full_end + l);
+                    y = load1(row + full_end + l);
+                }
+                if (OP == OP_L2) {
+                    float c = x - y;
+                    a[i] = __builtin_fmaf(c, c, a[i]);
+                } else if (which == 0) {
+                    a[i] = __builtin_fmaf(x, y, a[i]);
+                } else if (which == 1) {
+                    a[i] = __builtin_fmaf(x, x, a[i]);
+                } else {
+                    a[i] = __builtin_fmaf(y, y, a[i]);
+                }
+            }
+        };
+        float s = finish_vec<NACC>(acc[u].s, [&](float(&a)[4]) { partial(a, 0); });
+        if (OP == OP_COS) {
+            float nx = finish_vec<NACC>(acc[u].nx, [&](float(&a)[4]) { partial(a, 1); });
+            float ny = finish_vec<NACC>(acc[u].ny, [&](float(&a)[4]) { partial(a, 2); });
+            s = cosine_finish(nx, ny, s);
+        }
+        out[u] = s;
+    }
+}
+
+
+// ---- "wide" layout for 2-byte rows: one lane owns a whole 8-lane accumulator --------------------
+// With f16 rows a 4-element slice is only 8 bytes; giving each lane 8 consecutive elements
+// (one 16-byte load) and one CPU accumulator (lane w of a group of NACC lanes == accumulator w)
+// halves the instructions per byte.  Chains stay in-lane, so the association order is unchanged:
+// combine (s0+s1)+(s2+s3) across lanes (two DPP adds), partial block, sum_tree in-lane.
+struct F8v {
+    float e[8];
+};
+__device__ __forceinline__ F8v load8(const float* p) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    return {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ F8v load8(const __half* p) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    F8v r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float2 f = __half22float2(__builtin_bit_cast(__half2, w[i]));
+        r.e[2 * i] = f.x;
+        r.e[2 * i + 1] = f.y;
+    }
+    return r;
+}
+template <typename RT>
+__device__ __forceinline__ F8v cvt8(const uint4& t);
+template <>
+__device__ __forceinline__ F8v cvt8<__half>(const uint4& t) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    F8v r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float2 f = __half22float2(__builtin_bit_cast(__half2, w[i]));
+        r.e[2 * i] = f.x;
+        r.e[2 * i + 1] = f.y;
+    }
+    return r;
+}
+template <int NACC>
+__device__ __forceinline__ float finish_wide(float (&a)[8], const float (&px)[8], const float (&py)[8], int rem,
+                                             int op_kind /*0 L2, 1 xy, 2 xx, 3 yy*/) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = a[i] + dpp_f<DPP_XOR1>(a[i]);
+    if (NACC == 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = a[i] + dpp_f<DPP_XOR2>(a[i]);
+    }
+    if (rem) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = px[i], y = py[i];  // zero beyond `rem`
+            if (op_kind == 0) {
+                const float c = x - y;
+                a[i] = __builtin_fmaf(c, c, a[i]);
+            } else if (op_kind == 1) {
+                a[i] = __builtin_fmaf(x, y, a[i]);
+            } else if (op_kind == 2) {
+                a[i] = __builtin_fmaf(x, x, a[i]);
+            } else {
+                a[i] = __builtin_fmaf(y, y, a[i]);
+            }
+        }
+    }
+    return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+
+template <int NACC, int OP, int U, typename QT, typename RT>
+__device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, const RT* const (&rows)[U],
+                                                    const bool (&active)[U], int dim, int w, float (&out)[U]) {
+    constexpr int TRIP = 8 * NACC;
+    const int full_end = dim & ~7;
+    float s[U][8], nx[U][8], ny[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[u][i] = nx[u][i] = ny[u][i] = 0.0f;
+    constexpr int T = 4;
+    for (int e0 = 8 * w; e0 < full_end; e0 += TRIP * T) {
+        uint4 raw[T][U];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e < full_end && active[u]) raw[t][u] = *reinterpret_cast<const uint4*>(rows[u] + e);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+            if (e >= full_end) continue;
+            const F8v x = load8(q + e);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!active[u]) continue;
+                const F8v y = cvt8<RT>(raw[t][u]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (OP == OP_L2) {
+                        const float c = x.e[i] - y.e[i];
+                        s[u][i] = __builtin_fmaf(c, c, s[u][i]);
+                    } else if (OP == OP_IP) {
+                        s[u][i] = __builtin_fmaf(x.e[i], y.e[i], s[u][i]);
+                    } else {
+                        nx[u][i] = __builtin_fmaf(x.e[i], x.e[i], nx[u][i]);
+                        ny[u][i] = __builtin_fmaf(y.e[i], y.e[i], ny[u][i]);
+                        s[u][i] = __builtin_fmaf(x.e[i], y.e[i], s[u][i]);
+                    }
+                }
+            }
+        }
+    }
+    const int rem = dim & 7;
+    float px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) px[i] = (rem && i < rem) ? load1(q + full_end + i) : 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float py[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) py[i] = (rem && active[u] && i < rem) ? load1(rows[u] + full_end + i) : 0.0f;
+        float r = finish_wide<NACC>(s[u], px, py, rem, OP == OP_L2 ? 0 : 1);
+        if (OP == OP_COS) {
+            float a = finish_wide<NACC>(nx[u], px, py, rem, 2);
+            float b = finish_wide<NACC>(ny[u], px, py, rem, 3);
+            r = cosine_finish(a, b, r);
+        }
+        out[u] = r;
     }
 }
 
@@ -288,6 +511,57 @@ __device__ __forceinline__ float group_distance_int(const uint8_t* __restrict__ 
     return cosine_finish((float)xx, (float)yy, (float)xy);
 }
 
+
+template <int OP, bool SIGNED, int U>
+__device__ __forceinline__ void group_distance_int_multi(const uint8_t* __restrict__ q,
+                                                         const uint8_t* const (&rows)[U], const bool (&active)[U],
+                                                         int dim, int v, float (&out)[U]) {
+    int xx[U], yy[U], xy[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xx[u] = yy[u] = xy[u] = 0;
+    const int vec_end = dim & ~15;
+    for (int e = 16 * v; e < vec_end; e += 128) {
+        uint4 ys[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (active[u]) ys[u] = *reinterpret_cast<const uint4*>(rows[u] + e);
+        const uint4 x = *reinterpret_cast<const uint4*>(q + e);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!active[u]) continue;
+            const uint32_t yw[4] = {ys[u].x, ys[u].y, ys[u].z, ys[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xy[u] = dot4<SIGNED>(xs[i], yw[i], xy[u]);
+                if (OP != OP_IP) {
+                    xx[u] = dot4<SIGNED>(xs[i], xs[i], xx[u]);
+                    yy[u] = dot4<SIGNED>(yw[i], yw[i], yy[u]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (active[u]) {
+            for (int e = vec_end + v; e < dim; e += 8) {
+                int a = elem<SIGNED>(q + e), b = elem<SIGNED>(rows[u] + e);
+                xy[u] += a * b;
+                xx[u] += a * a;
+                yy[u] += b * b;
+            }
+        }
+        int sxy = group8_sum(xy[u]);
+        if (OP == OP_IP) {
+            out[u] = (float)sxy;
+            continue;
+        }
+        int sxx = group8_sum(xx[u]), syy = group8_sum(yy[u]);
+        if (OP == OP_L2) out[u] = (float)(int)((uint32_t)sxx + (uint32_t)syy - 2u * (uint32_t)sxy);
+        else out[u] = cosine_finish((float)sxx, (float)syy, (float)sxy);
+    }
+}
+
 // ---- dtype dispatch ------------------------------------------------------------------
 // Query-side staging type and group width for the *search* path
 // (Full<T>::query_distance, diskann-inmem/src/layers/full.rs:351-504):
@@ -301,6 +575,9 @@ struct Scheme {
     static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8);
     static constexpr int NACC = (OP == OP_COS) ? 2 : ((DT == DT_F16 && PAIR) ? 2 : 4);
     static constexpr int G = kInt ? 8 : 2 * NACC;
+    // search-path gather: 2-byte rows use the wide layout (one lane per accumulator)
+    static constexpr bool kWide = (DT == DT_F16) && !PAIR;
+    static constexpr int GS = kWide ? NACC : G;
 };
 
 template <int DT>
@@ -332,6 +609,24 @@ __device__ __forceinline__ float group_distance(const QT* q, const uint8_t* row,
     } else {
         using RT = typename RowType<DT>::type;
         return group_distance_raw<Scheme<DT, OP, PAIR>::NACC, OP, DIM>(q, reinterpret_cast<const RT*>(row), dim, v);
+    }
+}
+
+
+template <int DT, int OP, bool PAIR, int U, typename QT>
+__device__ __forceinline__ void group_distance_many(const QT* q, const uint8_t* const (&rows)[U],
+                                                    const bool (&active)[U], int dim, int v, float (&out)[U]) {
+    if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {
+        group_distance_int_multi<OP, DT == DT_I8, U>(reinterpret_cast<const uint8_t*>(q), rows, active, dim, v, out);
+    } else {
+        using RT = typename RowType<DT>::type;
+        const RT* typed[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) typed[u] = reinterpret_cast<const RT*>(rows[u]);
+        if constexpr (Scheme<DT, OP, PAIR>::kWide)
+            group_distance_wide<Scheme<DT, OP, PAIR>::NACC, OP, U>(q, typed, active, dim, v, out);
+        else
+            group_distance_multi<Scheme<DT, OP, PAIR>::NACC, OP, U>(q, typed, active, dim, v, out);
     }
 }
 

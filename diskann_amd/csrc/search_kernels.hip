@@ -109,7 +109,7 @@ template <int DT, int OP, bool NORM, int QS, int DIM>
 __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using S = Scheme<DT, OP, false>;
-    constexpr int G = S::G;
+    constexpr int G = (DIM > 0) ? S::G : S::GS;  // fixed-length path: narrow groups, query slice in registers
     constexpr int GROUPS = kWave / G;
     constexpr bool kInt = S::kInt;
     using QT = typename std::conditional<kInt, uint8_t, float>::type;
@@ -202,15 +202,26 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 }
             }
         } else {
-            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS) {
-                uint32_t c = c0 + g;
-                bool act = c < nc;
-                uint32_t id = act ? cand_id[c] : 0u;
-                const uint8_t* row = ix.rows + (uint64_t)id * ix.row_stride;
-                float d = 0.0f;
-                if (act) d = group_distance<DT, OP, false, 0>(qs, row, (int)ix.dim, v);
-                if (act && v == 0)
-                    cand_d[c] = finish_distance<DT, OP, NORM>(d, reinterpret_cast<const uint8_t*>(qs), row, ix.dim, sqp);
+            constexpr int U = S::kWide ? 2 : kGatherRows;
+            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
+                const uint8_t* rows[U];
+                bool act[U];
+                float out[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    act[u] = c < nc;
+                    uint32_t id = act[u] ? cand_id[c] : 0u;
+                    rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
+                }
+                group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, out);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    if (act[u] && v == 0)
+                        cand_d[c] = finish_distance<DT, OP, NORM>(out[u], reinterpret_cast<const uint8_t*>(qs), rows[u],
+                                                                  ix.dim, sqp);
+                }
             }
         }
     };
@@ -515,7 +526,7 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
         return DANN_EUNSUPPORTED;
     }
     if (op == OP_L2) {
-        if constexpr (DT == DT_F32) {
+        if constexpr (DT == DT_F32 || DT == DT_F16) {
             if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream);
         }
         if constexpr (DT == DT_SQ8) {
