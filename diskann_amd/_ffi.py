@@ -66,6 +66,10 @@ SYMBOLS = {
     "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
+    "dann_save_graph": (_i32, [_vp, C.c_char_p]),
+    "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
+    "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),
+    "dann_load_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _P(_u32)]),
     "dann_sq8_compress": (_i32, [_i32, _vp, _u32, _u32, _vp, _f32, _vp]),
     "dann_pq_build_lut": (_i32, [_i32, _i32, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),
     "dann_pq_scan": (_i32, [_i32, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),

@@ -664,6 +664,150 @@ int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_
     return DANN_OK;
 }
 
+// ---- on-disk formats ---------------------------------------------------------------------------
+struct File {
+    FILE* f = nullptr;
+    ~File() {
+        if (f) fclose(f);
+    }
+};
+
+int32_t dann_save_graph(const dann_index* idx, const char* path) {
+    CHECK_IDX(idx);
+    if (!path) return DANN_EINVAL;
+    const uint32_t w = idx->cfg.max_degree + 1;
+    std::vector<uint32_t> adj((size_t)idx->nslots * w);
+    int32_t rc = dann_download_graph(idx, adj.data(), idx->nslots);
+    if (rc != DANN_OK) return rc;
+    File out;
+    out.f = fopen(path, "wb");
+    if (!out.f) {
+        set_error("cannot open %s for writing", path);
+        return DANN_EINVAL;
+    }
+    uint64_t file_size = 24;
+    for (uint32_t i = 0; i < idx->nslots; ++i) file_size += 4ull * (1 + std::min(adj[(size_t)i * w], idx->cfg.max_degree));
+    const uint32_t max_degree = idx->cfg.max_degree, start = idx->cfg.capacity;
+    const uint64_t nstart = idx->cfg.num_start_points;
+    bool ok = fwrite(&file_size, 8, 1, out.f) == 1 && fwrite(&max_degree, 4, 1, out.f) == 1 &&
+              fwrite(&start, 4, 1, out.f) == 1 && fwrite(&nstart, 8, 1, out.f) == 1;
+    for (uint32_t i = 0; ok && i < idx->nslots; ++i) {
+        const uint32_t len = std::min(adj[(size_t)i * w], idx->cfg.max_degree);
+        ok = fwrite(&len, 4, 1, out.f) == 1 && (len == 0 || fwrite(&adj[(size_t)i * w + 1], 4, len, out.f) == len);
+    }
+    if (!ok) {
+        set_error("short write to %s", path);
+        return DANN_EINVAL;
+    }
+    return DANN_OK;
+}
+
+int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, uint64_t* out_num_start,
+                        uint64_t* out_num_points) {
+    CHECK_IDX(idx);
+    if (!path) return DANN_EINVAL;
+    File in;
+    in.f = fopen(path, "rb");
+    if (!in.f) {
+        set_error("cannot open %s", path);
+        return DANN_EINVAL;
+    }
+    uint64_t file_size = 0, nstart = 0;
+    uint32_t max_degree = 0, start = 0;
+    if (fread(&file_size, 8, 1, in.f) != 1 || fread(&max_degree, 4, 1, in.f) != 1 || fread(&start, 4, 1, in.f) != 1 ||
+        fread(&nstart, 8, 1, in.f) != 1) {
+        set_error("%s: truncated header", path);
+        return DANN_ELENGTH;
+    }
+    const uint32_t w = idx->cfg.max_degree + 1;
+    std::vector<uint32_t> adj((size_t)idx->nslots * w, 0u);
+    std::vector<uint32_t> buf;
+    uint64_t pos = 24, npts = 0;
+    while (pos < file_size) {
+        uint32_t len = 0;
+        if (fread(&len, 4, 1, in.f) != 1) {
+            set_error("%s: truncated adjacency list %llu", path, (unsigned long long)npts);
+            return DANN_ELENGTH;
+        }
+        buf.resize(len);
+        if (len && fread(buf.data(), 4, len, in.f) != len) {
+            set_error("%s: truncated adjacency list %llu", path, (unsigned long long)npts);
+            return DANN_ELENGTH;
+        }
+        if (npts < idx->nslots) {
+            if (len > idx->cfg.max_degree) {
+                set_error("%s: node %llu has %u neighbours, index max_degree is %u", path, (unsigned long long)npts, len,
+                          idx->cfg.max_degree);
+                return DANN_ETOOLONG;
+            }
+            adj[(size_t)npts * w] = len;
+            if (len) memcpy(&adj[(size_t)npts * w + 1], buf.data(), (size_t)len * 4);
+        }
+        pos += 4ull * (1 + len);
+        ++npts;
+    }
+    int32_t rc = dann_upload_graph(idx, adj.data(), idx->nslots);
+    if (rc != DANN_OK) return rc;
+    if (out_start) *out_start = start;
+    if (out_num_start) *out_num_start = nstart;
+    if (out_num_points) *out_num_points = npts;
+    return DANN_OK;
+}
+
+int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t first_slot, uint32_t n) {
+    CHECK_IDX(idx);
+    if (!path) return DANN_EINVAL;
+    if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
+    std::vector<uint8_t> rows((size_t)n * idx->layer_bytes);
+    if (n) {
+        DANN_HIP(hipMemcpy2DAsync(rows.data(), idx->layer_bytes, idx->d_rows + (size_t)first_slot * idx->cfg.row_stride,
+                                  idx->cfg.row_stride, idx->layer_bytes, n, hipMemcpyDeviceToHost, idx->stream));
+        DANN_HIP(hipStreamSynchronize(idx->stream));
+    }
+    File out;
+    out.f = fopen(path, "wb");
+    if (!out.f) {
+        set_error("cannot open %s for writing", path);
+        return DANN_EINVAL;
+    }
+    // `.bin`: dim counts elements of the stored type (SQ-8 rows are written as dim + 4 bytes)
+    const uint32_t dim = idx->cfg.dtype == DT_SQ8 ? idx->layer_bytes : idx->cfg.dim;
+    if (fwrite(&n, 4, 1, out.f) != 1 || fwrite(&dim, 4, 1, out.f) != 1 ||
+        (rows.size() && fwrite(rows.data(), 1, rows.size(), out.f) != rows.size())) {
+        set_error("short write to %s", path);
+        return DANN_EINVAL;
+    }
+    return DANN_OK;
+}
+
+int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n) {
+    CHECK_IDX(idx);
+    if (!path) return DANN_EINVAL;
+    File in;
+    in.f = fopen(path, "rb");
+    if (!in.f) {
+        set_error("cannot open %s", path);
+        return DANN_EINVAL;
+    }
+    uint32_t n = 0, dim = 0;
+    if (fread(&n, 4, 1, in.f) != 1 || fread(&dim, 4, 1, in.f) != 1) return DANN_ELENGTH;
+    const uint32_t want_dim = idx->cfg.dtype == DT_SQ8 ? idx->layer_bytes : idx->cfg.dim;
+    if (dim != want_dim) {
+        set_error("data of dimension %u does not match full precision layer's dimension %u", dim, want_dim);
+        return DANN_ELENGTH;
+    }
+    if ((uint64_t)first_slot + n > idx->cfg.capacity) return DANN_EBOUNDS;
+    std::vector<uint8_t> rows((size_t)n * idx->layer_bytes);
+    if (rows.size() && fread(rows.data(), 1, rows.size(), in.f) != rows.size()) {
+        set_error("%s: truncated payload", path);
+        return DANN_ELENGTH;
+    }
+    int32_t rc = dann_set_elements(idx, first_slot, n, rows.data(), rows.size());
+    if (rc != DANN_OK) return rc;
+    if (out_n) *out_n = n;
+    return DANN_OK;
+}
+
 // ---- diagnostics -----------------------------------------------------------------------------
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) {
     if (!idx || which < 0 || which > 3) return DANN_EINVAL;

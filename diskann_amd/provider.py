@@ -209,6 +209,26 @@ class Provider:
                                           int(force_saturate), _p(out)), "dann_prune_batch")
         return out
 
+    # -- the reference's on-disk formats ----------------------------------------------
+    def save_graph(self, path):
+        check(_ffi.lib().dann_save_graph(self._h, str(path).encode()), "dann_save_graph")
+
+    def load_graph(self, path):
+        start, nstart, npts = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        check(_ffi.lib().dann_load_graph(self._h, str(path).encode(), C.byref(start), C.byref(nstart), C.byref(npts)),
+              "dann_load_graph")
+        return start.value, nstart.value, npts.value
+
+    def save_vectors_bin(self, path, first_slot=0, n=None):
+        n = self.capacity - first_slot if n is None else n
+        check(_ffi.lib().dann_save_vectors_bin(self._h, str(path).encode(), first_slot, n), "dann_save_vectors_bin")
+
+    def load_vectors_bin(self, path, first_slot=0):
+        n = C.c_uint32()
+        check(_ffi.lib().dann_load_vectors_bin(self._h, str(path).encode(), first_slot, C.byref(n)),
+              "dann_load_vectors_bin")
+        return n.value
+
     # -- diagnostics ---------------------------------------------------------------
     def kernel_time(self, which=0):
         ms, n = C.c_double(), C.c_uint64()

@@ -195,6 +195,18 @@ int32_t dann_pq_build_lut(int32_t device, int32_t metric, const float* pivots, c
 int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nchunks, const uint8_t* codes,
                      uint64_t npoints, const uint32_t* ids, const uint64_t* offsets, float* out);
 
+/* ---- on-disk formats of the reference (so a GPU-built index loads in the reference and vice versa)
+ * graph: diskann-providers/src/storage/bin.rs:234-380 -- 24-byte header {u64 file_size, u32 max_degree,
+ *        u32 start_point, u64 num_start_points} then per node {u32 len, len x u32}, nodes in slot order
+ *        (dynamic slots, then the frozen start points).
+ * vectors: diskann-utils/src/io.rs:24 `.bin` -- {u32 npts, u32 dim} then row-major payload. */
+int32_t dann_save_graph(const dann_index* idx, const char* path);
+/* loads adjacency for min(file points, index slots) nodes; out_* may be NULL */
+int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, uint64_t* out_num_start,
+                        uint64_t* out_num_points);
+int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t first_slot, uint32_t n);
+int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n);
+
 /* ---- scalar quantisation: ScalarQuantizer::compress_into for 8 bits
  * (diskann-quantization/src/scalar/quantizer.rs:189-236, 395-430): code = round(clamp((x - shift) *
  * 255/scale, 0, 255)), compensation = scale/255 * sum(code * shift).  x: n x dim f32, shift: dim f32,
