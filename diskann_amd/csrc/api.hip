@@ -236,6 +236,7 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->d_fail) (void)hipFree(idx->d_fail);
     if (idx->h_flag) (void)hipHostFree(idx->h_flag);
     if (idx->d_spill) (void)hipFree(idx->d_spill);
+    if (idx->build_scratch && idx->build_scratch_free) idx->build_scratch_free(idx->build_scratch);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -251,11 +252,12 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out) {
     return DANN_OK;
 }
 
-#define CHECK_IDX(idx)              \
-    if (!(idx)) {                   \
-        set_error("null index");    \
-        return DANN_EINVAL;         \
-    }                               \
+#define CHECK_IDX(idx)                                  \
+    if (!(idx)) {                                       \
+        set_error("null index");                        \
+        return DANN_EINVAL;                             \
+    }                                                   \
+    std::lock_guard<std::recursive_mutex> _lock((idx)->mu); \
     DeviceGuard _guard((idx)->device)
 
 int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) {
@@ -344,7 +346,7 @@ int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, 
 }
 
 int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) {
-    CHECK_IDX(idx);
+    if (!idx) return DANN_EINVAL;
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     std::vector<uint32_t> cur(idx->cfg.max_degree);
     uint32_t len = 0;

@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "dann_device.h"
@@ -818,19 +819,18 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
 using namespace dann;
 
 static BuildScratch& scratch_of(dann_index* idx) {
-    // one scratch per index, owned by a side table keyed on the handle (freed with the process;
-    // indices are long-lived)
-    static thread_local std::vector<std::pair<dann_index*, BuildScratch*>> table;
-    for (auto& kv : table)
-        if (kv.first == idx) return *kv.second;
-    table.emplace_back(idx, new BuildScratch());
-    return *table.back().second;
+    if (!idx->build_scratch) {
+        idx->build_scratch = new BuildScratch();
+        idx->build_scratch_free = [](void* p) { delete static_cast<BuildScratch*>(p); };
+    }
+    return *static_cast<BuildScratch*>(idx->build_scratch);
 }
 
 extern "C" {
 
 int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) {
     if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -852,6 +852,7 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
                    uint32_t max_batch) {
     if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -885,6 +886,7 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
                          const uint32_t* pool_ids, const float* pool_dists, const uint64_t* offsets,
                          int32_t force_saturate, uint32_t* out_adj) {
     if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;

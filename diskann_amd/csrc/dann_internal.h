@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/dann.h"
@@ -97,8 +98,13 @@ struct dann_index {
     size_t fail_cap = 0;
     uint32_t* d_spill = nullptr;   // spill pool + counter (last word)
     uint32_t spill_slices = 0, spill_bits = 0;
+    void* build_scratch = nullptr;            // owned by build_kernels.hip
+    void (*build_scratch_free)(void*) = nullptr;
     uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
     dann::KernelClock clocks[4];
+    // one stream, one pair of events and one set of scratch buffers per index: calls that launch
+    // work are serialised per handle (they would serialise on the stream anyway)
+    mutable std::recursive_mutex mu;
     dann::IndexView view() const;
 };
 

@@ -121,3 +121,26 @@ def test_duplicate_vectors_tie_order():
     q = base[rng.integers(0, 40, 32)] + 0.0
     for L, W in ((10, 1), (50, 1), (50, 4), (200, 2)):
         _check(oix, gix, q, L, W, 20)
+
+
+def test_concurrent_searches_on_a_shared_index():
+    """N host threads call search on one handle (the reference runs one tokio task per query block on
+    a shared &DiskANNIndex, search/api.rs:409-425): results must equal the single-threaded ones."""
+    import threading
+    rng = np.random.default_rng(10)
+    n, dim, R = 3000, 16, 12
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    _, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    qs = [rand_vectors(rng, oracle.F32, 50 + 7 * t, dim) for t in range(8)]
+    want = [gix.search(da.Knn(40), q, 10) for q in qs]
+    got = [None] * 8
+
+    def work(t):
+        for _ in range(5):
+            got[t] = gix.search(da.Knn(40), qs[t], 10)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for t in range(8):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(bits(got[t][1]), bits(want[t][1]))
