@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sq8", action="store_true")
+    ap.add_argument("--sharded-build", action="store_true",
+                    help="N>1: build with diskann_amd.sharding.build_sharded (batch partitioned across ranks, RCCL "
+                         "all-gather of the pending adjacency rows) instead of one independent build per rank")
     ap.add_argument("--visited-bits", type=int, default=0)
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
     return ap.parse_args()
@@ -150,7 +153,11 @@ def main():
     prov.set_elements(0, base_h)
     t1 = time.time()
     cfg = da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE)
-    nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
+    if args.sharded_build and world > 1:
+        from diskann_amd.sharding import build_sharded
+        nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world)
+    else:
+        nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
     torch.cuda.synchronize()
     t_build = time.time() - t1
     gt = ground_truth(torch, base, queries, 10)

@@ -65,6 +65,8 @@ SYMBOLS = {
     "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),
     "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
+    "dann_insert_batch_candidates": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _u32, _u32, _vp]),
+    "dann_insert_batch_commit": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp]),
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
     "dann_save_graph": (_i32, [_vp, C.c_char_p]),
     "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
@@ -90,6 +92,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m diskann_amd.build` "
                 "(or __graft_entry__.build()).  diskann_amd has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process cannot
+        # both own the GPU ("No HIP GPUs are available" for whichever initialises second).  If torch
+        # is installed, load it first so that libdann_hip.so binds to the runtime torch uses.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional for the library itself
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -238,6 +238,7 @@ struct PoolArgs {
     const uint32_t* counts;
     uint32_t cand;             // intra-batch candidates per item (0 = none); batch = locs[0..n)
     uint32_t n;
+    uint32_t pos0;             // batch position of work item 0 (a rank may own a slice of the batch)
     uint32_t pcap;
     int32_t force_saturate;
     uint32_t* out;             // n x out_stride
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kWave) void pool_prune_kernel(PoolArgs a) {
     using S = Scheme<DT, OP, true>;
     using RT = typename RowType<DT>::type;
     constexpr int G = S::G, GROUPS = kWave / G;
-    const uint32_t lane = threadIdx.x, item = blockIdx.x;
+    const uint32_t lane = threadIdx.x, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
     const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
     uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
     float* pd = reinterpret_cast<float*>(smem + L.pd_off);
@@ -259,16 +260,16 @@ __global__ __launch_bounds__(kWave) void pool_prune_kernel(PoolArgs a) {
     uint64_t lo;
     uint32_t cnt;
     if (a.offsets) {
-        lo = a.offsets[item];
-        cnt = (uint32_t)(a.offsets[item + 1] - lo);
+        lo = a.offsets[wi];
+        cnt = (uint32_t)(a.offsets[wi + 1] - lo);
     } else {
-        lo = (uint64_t)item * a.stride;
-        cnt = a.counts[item];
+        lo = (uint64_t)wi * a.stride;
+        cnt = a.counts[wi];
     }
     // extras = around(ids, position, cand) (utils/async_tools.rs:51-131)
     uint32_t nex = 0;
     if (a.cand != 0 && a.n > 1) nex = a.cand < a.n - 1 ? a.cand : a.n - 1;
-    uint32_t* out = a.out + (uint64_t)item * a.out_stride;
+    uint32_t* out = a.out + (uint64_t)wi * a.out_stride;
     if (cnt + nex > a.pcap) {
         if (lane == 0) {
             *a.err = 1;
@@ -662,21 +663,25 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
 
 }  // namespace
 
-// one multi_insert batch, everything on the index stream
-static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
-                                   const uint32_t* d_slots, uint32_t n) {
+// ---- one multi_insert batch in two phases, everything on the index stream -------------------------
+// Phase 1 (candidate generation, index.rs:349-434): insert-time search + RobustPrune for the batch
+// positions [lo, hi); writes (hi - lo) rows [len, ids...] of `pend_stride` u32 to d_pending_out.
+// Only reads the graph, so ranks holding identical replicas can each take a slice of the batch.
+static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
+                                const uint32_t* d_slots, uint32_t n, uint32_t lo, uint32_t hi,
+                                uint32_t* d_pending_out) {
     const IndexView ix = idx->view();
     const PruneCfg pc = to_prune_cfg(cfg);
     hipStream_t st = idx->stream;
+    const uint32_t m = hi - lo;
+    if (m == 0) return DANN_OK;
     const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
     const uint32_t nex = (cand != 0 && n > 1) ? std::min(cand, n - 1) : 0;
-
-    // ---- candidate generation: search with record ---------------------------------------------
     SearchArgs sa;
     sa.ix = ix;
     sa.queries = nullptr;
-    sa.qslots = d_slots;
-    sa.nq = n;
+    sa.qslots = d_slots + lo;
+    sa.nq = m;
     sa.l_value = cfg.l_build;
     sa.beam_width = 1;
     sa.k = 0;
@@ -693,43 +698,66 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
     sa.spill = nullptr;
     sa.spill_next = nullptr;
     sa.spill_slices = sa.spill_bits = 0;
-    DANN_HIP(hipMemsetAsync(s.meta.p, 0, 64, st));
+    uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes
+    DANN_HIP(hipMemsetAsync(meta, 0, 64, st));
     int32_t rc = search_with_retry(idx, sa);
     if (rc != DANN_OK) return rc;
-
-    // ---- prune (robust_prune_with) ---------------------------------------------------------------
-    uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes
-    {
-        PoolArgs pa;
-        pa.ix = ix;
-        pa.cfg = pc;
-        pa.locs = d_slots;
-        pa.pool_ids = s.rec_ids.as<uint32_t>();
-        pa.pool_d = s.rec_d.as<float>();
-        pa.offsets = nullptr;
-        pa.stride = s.rec_stride;
-        pa.counts = s.rec_n.as<uint32_t>();
-        pa.cand = cand;
-        pa.n = n;
-        pa.pcap = next_pow2(s.rec_stride + nex);
-        pa.force_saturate = 0;
-        pa.out = s.pending.as<uint32_t>();
-        pa.out_stride = s.pend_stride;
-        pa.err = meta + 3;
-        if (pa.pcap > kMaxPool) {
-            set_error("candidate pool bound %u exceeds %u: lower l_build or intra_batch_candidates", pa.pcap, kMaxPool);
-            return DANN_EUNSUPPORTED;
-        }
-        const size_t lds = pool_lds_layout(pa.pcap, pc.pruned_degree).total;
-        rc = dispatch<PoolLauncher>(ix, pa, n, lds, st);
-        if (rc != DANN_OK) return rc;
+    PoolArgs pa;
+    pa.ix = ix;
+    pa.cfg = pc;
+    pa.locs = d_slots;
+    pa.pool_ids = s.rec_ids.as<uint32_t>();
+    pa.pool_d = s.rec_d.as<float>();
+    pa.offsets = nullptr;
+    pa.stride = s.rec_stride;
+    pa.counts = s.rec_n.as<uint32_t>();
+    pa.cand = cand;
+    pa.n = n;
+    pa.pos0 = lo;
+    pa.pcap = next_pow2(s.rec_stride + nex);
+    pa.force_saturate = 0;
+    pa.out = d_pending_out;
+    pa.out_stride = s.pend_stride;
+    pa.err = meta + 3;
+    if (pa.pcap > kMaxPool) {
+        set_error("candidate pool bound %u exceeds %u: lower l_build or intra_batch_candidates", pa.pcap, kMaxPool);
+        return DANN_EUNSUPPORTED;
     }
+    const size_t lds = pool_lds_layout(pa.pcap, pc.pruned_degree).total;
+    rc = dispatch<PoolLauncher>(ix, pa, m, lds, st);
+    if (rc != DANN_OK) return rc;
+    std::vector<dann_search_stats> hs(m);
+    uint32_t h_err = 0;
+    DANN_HIP(hipMemcpyAsync(hs.data(), s.stats.p, (size_t)m * sizeof(dann_search_stats), hipMemcpyDeviceToHost, st));
+    DANN_HIP(hipMemcpyAsync(&h_err, meta + 3, 4, hipMemcpyDeviceToHost, st));
+    DANN_HIP(hipStreamSynchronize(st));
+    if (h_err) {
+        set_error("candidate pool overflow in prune (pool cap %u)", pa.pcap);
+        return DANN_EOVERFLOW;
+    }
+    for (uint32_t i = 0; i < m; ++i)
+        if (hs[i].status) {
+            set_error("insert search %u: visited table or record buffer exhausted", lo + i);
+            return DANN_EOVERFLOW;
+        }
+    return DANN_OK;
+}
 
-    // ---- aggregate back-edges: sort (target, source) keys ---------------------------------------
-    uint32_t* pending = s.pending.as<uint32_t>();
+// Phase 2 (graph update, index.rs:911-1024): back-edge aggregation, bootstrap when the graph is
+// nearly empty, set_neighbors_bulk, add_edge_and_prune per distinct target.  Deterministic given the
+// pending rows of the *whole* batch, so identical replicas stay identical.
+static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, BuildScratch& s, const uint32_t* d_slots,
+                            uint32_t n, const uint32_t* d_pending) {
+    const IndexView ix = idx->view();
+    const PruneCfg pc = to_prune_cfg(cfg);
+    hipStream_t st = idx->stream;
+    const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
+    uint32_t* meta = s.meta.as<uint32_t>();
+    const uint32_t* pending = d_pending;
+    int32_t rc;
     auto aggregate = [&](uint32_t* h_meta) -> int32_t {
         const uint32_t total = n * s.degree;
-        DANN_HIP(hipMemsetAsync(meta, 0, 12, st));
+        DANN_HIP(hipMemsetAsync(meta, 0, 16, st));
         hipLaunchKernelGGL(make_keys_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slots, pending,
                            s.pend_stride, n, s.degree, s.keys_in.as<uint64_t>());
         size_t tmp = s.sort_tmp_bytes;
@@ -746,20 +774,6 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
     uint32_t h_meta[4] = {0, 0, 0, 0};
     rc = aggregate(h_meta);
     if (rc != DANN_OK) return rc;
-    if (h_meta[3]) {
-        set_error("candidate pool overflow in prune (pool cap %u)", next_pow2(s.rec_stride + nex));
-        return DANN_EOVERFLOW;
-    }
-    {   // search status (visited table / record overflow)
-        std::vector<dann_search_stats> hs(n);
-        DANN_HIP(hipMemcpyAsync(hs.data(), s.stats.p, (size_t)n * sizeof(dann_search_stats), hipMemcpyDeviceToHost, st));
-        DANN_HIP(hipStreamSynchronize(st));
-        for (uint32_t i = 0; i < n; ++i)
-            if (hs[i].status) {
-                set_error("insert search %u: visited table or record buffer exhausted", i);
-                return DANN_EOVERFLOW;
-            }
-    }
 
     // ---- bootstrap (index.rs:926-938) -----------------------------------------------------------------
     const uint32_t resolved = std::max<uint32_t>(cand, 1);
@@ -786,6 +800,10 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
         pending = s.pending2.as<uint32_t>();
         rc = aggregate(h_meta);
         if (rc != DANN_OK) return rc;
+        if (h_meta[3]) {
+            set_error("candidate pool overflow in bootstrap prune");
+            return DANN_EOVERFLOW;
+        }
     }
 
     // ---- graph update -------------------------------------------------------------------------------------
@@ -810,8 +828,21 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
         rc = dispatch<BackLauncher>(ix, ba, ba.nseg, lds, st);
         if (rc != DANN_OK) return rc;
     }
+    uint32_t h_err = 0;
+    DANN_HIP(hipMemcpyAsync(&h_err, meta + 3, 4, hipMemcpyDeviceToHost, st));
     DANN_HIP(hipStreamSynchronize(st));
+    if (h_err) {
+        set_error("back-edge list overflow");
+        return DANN_EOVERFLOW;
+    }
     return DANN_OK;
+}
+
+static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
+                                   const uint32_t* d_slots, uint32_t n) {
+    int32_t rc = batch_candidates(idx, cfg, s, d_slots, n, 0, n, s.pending.as<uint32_t>());
+    if (rc != DANN_OK) return rc;
+    return batch_commit(idx, cfg, s, d_slots, n, s.pending.as<uint32_t>());
 }
 
 }  // namespace dann
@@ -847,6 +878,48 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), n);
+}
+
+// multi-GPU build: phase 1 on a slice of the batch, phase 2 with the all-gathered pending rows.
+// d_pending_* are DEVICE pointers ((pruned_degree + 1) u32 per row) so that they can be the send /
+// receive buffers of an RCCL all-gather.
+int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                     uint32_t lo, uint32_t hi, uint32_t* d_pending_out) {
+    if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (lo > hi || hi > n) return DANN_EINVAL;
+    if (n == 0 || lo == hi) return DANN_OK;
+    if (!slots || !d_pending_out) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] >= idx->cfg.capacity) return DANN_EBOUNDS;
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    return batch_candidates(idx, *cfg, s, s.slots.as<uint32_t>(), n, lo, hi, d_pending_out);
+}
+
+int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                 const uint32_t* d_pending_all) {
+    if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (n == 0) return DANN_OK;
+    if (!slots || !d_pending_all) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] >= idx->cfg.capacity) return DANN_EBOUNDS;
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    return batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all);
 }
 
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
@@ -929,6 +1002,7 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
     pa.counts = nullptr;
     pa.cand = 0;
     pa.n = n;
+    pa.pos0 = 0;
     pa.pcap = next_pow2((uint32_t)maxlen);
     pa.force_saturate = force_saturate;
     pa.out = dout.as<uint32_t>();

@@ -196,6 +196,18 @@ class Provider:
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         check(_ffi.lib().dann_insert_batch(self._h, C.byref(cfg), _p(s), s.size), "dann_insert_batch")
 
+    def insert_batch_candidates(self, cfg, slots, lo, hi, d_pending_out):
+        """phase 1 of a multi-GPU multi_insert: `d_pending_out` is a device pointer (int)."""
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        check(_ffi.lib().dann_insert_batch_candidates(self._h, C.byref(cfg), _p(s), s.size, lo, hi,
+                                                      C.c_void_p(d_pending_out)), "dann_insert_batch_candidates")
+
+    def insert_batch_commit(self, cfg, slots, d_pending_all):
+        """phase 2: `d_pending_all` is a device pointer to the whole batch's pending rows."""
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        check(_ffi.lib().dann_insert_batch_commit(self._h, C.byref(cfg), _p(s), s.size, C.c_void_p(d_pending_all)),
+              "dann_insert_batch_commit")
+
     def build(self, cfg, first, n, growth=0.02, max_batch=16384):
         return check(_ffi.lib().dann_build(self._h, C.byref(cfg), first, n, growth, max_batch), "dann_build")
 

@@ -54,3 +54,50 @@ def search_sharded(search_fn, queries, k, rank=0, world=1, group=None):
         out_i[a:b] = all_i[r][: b - a].numpy().astype(np.uint32)
         out_d[a:b] = all_d[r][: b - a].numpy()
     return out_i, out_d
+
+
+def batch_schedule(first, n, growth, max_batch):
+    """The geometric batch schedule of dann_build: batch = clamp(ceil(inserted * growth), 1, max_batch)."""
+    import math
+    g = float(np.float32(growth))
+    done = 0
+    while done < n:
+        b = int(math.ceil((first + done) * g))
+        b = max(1, min(b, max_batch, n - done))
+        yield first + done, b
+        done += b
+
+
+def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None):
+    """Multi-GPU index build over identical replicas (one `provider` per rank, rows already stored).
+
+    Every batch is one multi_insert (diskann/src/graph/index.rs:815-1030): each rank generates the
+    candidates (insert-time search + RobustPrune) for its `partition` of the batch positions, the
+    pending adjacency rows are all-gathered (RCCL over xGMI when the process group is "nccl": the
+    only exchange step of the build), and every rank applies the same graph update, so the replicas
+    stay byte-identical to a single-GPU dann_build.  Returns the number of batches."""
+    import torch
+    dev = torch.device("cuda", provider.device)
+    width = cfg.pruned_degree + 1
+    batches = 0
+    for start, b in batch_schedule(first, n, growth, max_batch):
+        slots = np.arange(start, start + b, dtype=np.uint32)
+        lo, hi = partition(b, world, rank)
+        longest = partition(b, world, 0)[1]
+        mine = torch.zeros((max(longest, 1), width), dtype=torch.int32, device=dev)
+        provider.insert_batch_candidates(cfg, slots, lo, hi, mine.data_ptr())
+        if world > 1:
+            import torch.distributed as dist
+            gathered = torch.empty((world, max(longest, 1), width), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered, mine, group=group)
+            parts = []
+            for r in range(world):
+                a, z = partition(b, world, r)
+                parts.append(gathered[r, : z - a])
+            pending = torch.cat(parts).contiguous()
+        else:
+            pending = mine[:b].contiguous()
+        torch.cuda.synchronize(dev)
+        provider.insert_batch_commit(cfg, slots, pending.data_ptr())
+        batches += 1
+    return batches

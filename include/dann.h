@@ -177,6 +177,16 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
                          int32_t force_saturate, uint32_t* out_adj);
 /* DiskANNIndex::multi_insert (index.rs:815-1030) for rows already stored at `slots` */
 int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n);
+/* multi-GPU build (replicated index, batch partitioned across ranks): multi_insert split at its
+ * only exchange point.  Phase 1 = candidate generation (search + RobustPrune, index.rs:349-434) for the
+ * batch positions [lo, hi), reading the graph only; phase 2 = graph update (index.rs:911-1024) from the
+ * pending rows of the whole batch.  d_pending_* are DEVICE pointers, rows of (pruned_degree + 1) u32
+ * [len, ids...] in batch order, i.e. directly usable as RCCL all-gather buffers.  Running phase 1 over
+ * [0, n) and then phase 2 equals dann_insert_batch. */
+int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                     uint32_t lo, uint32_t hi, uint32_t* d_pending_out);
+int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                 const uint32_t* d_pending_all);
 /* insert every slot in [first, first+n) in id order with a geometric batch schedule
  * (batch = clamp(ceil(inserted * growth), 1, max_batch)); returns the number of batches */
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,

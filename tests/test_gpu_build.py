@@ -114,3 +114,46 @@ def test_dann_build_schedule_and_recall():
     ids, _, _ = gix.search(da.Knn(64), q, 10)
     recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(200)])
     assert recall > 0.9, recall
+
+
+def test_two_phase_build_equals_single_gpu_build():
+    """Multi-GPU build logic on one GPU: two replicas play rank 0 / rank 1; each generates the candidates
+    of its partition of every batch, the pending rows are concatenated (the all-gather) and both commit.
+    Both replicas must equal a plain dann_build (and therefore the oracle)."""
+    import torch
+    from diskann_amd.sharding import batch_schedule, build_sharded, partition
+    rng = np.random.default_rng(77)
+    n, dim, R, maxdeg, lb = 1500, 24, 8, 10, 24
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    gcfg = da.build_config(R, maxdeg, lb, intra_batch_candidates=4)
+    provs = [da.Provider(da.F32, da.L2, dim, n, maxdeg, start) for _ in range(3)]
+    for p in provs:
+        p.set_elements(0, data)
+    ref, reps = provs[0], provs[1:]
+    growth, max_batch = 0.1, 200
+    nb = ref.build(gcfg, 0, n, growth, max_batch)
+    want = ref.download_graph()
+    w = R + 1
+    batches = 0
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        slots = np.arange(s0, s0 + b, dtype=np.uint32)
+        parts = []
+        for r, p in enumerate(reps):
+            lo, hi = partition(b, 2, r)
+            buf = torch.zeros((max(hi - lo, 1), w), dtype=torch.int32, device="cuda")
+            p.insert_batch_candidates(gcfg, slots, lo, hi, buf.data_ptr())
+            parts.append(buf[: hi - lo])
+        pending = torch.cat(parts).contiguous()
+        torch.cuda.synchronize()
+        for p in reps:
+            p.insert_batch_commit(gcfg, slots, pending.data_ptr())
+        batches += 1
+    assert batches == nb
+    for p in reps:
+        assert np.array_equal(p.download_graph(), want)
+    # and the world-size-1 driver is the same thing
+    solo = da.Provider(da.F32, da.L2, dim, n, maxdeg, start)
+    solo.set_elements(0, data)
+    assert build_sharded(solo, gcfg, 0, n, growth, max_batch) == nb
+    assert np.array_equal(solo.download_graph(), want)
