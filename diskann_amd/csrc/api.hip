@@ -582,6 +582,11 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.rec_stride = rec_stride;
     a.rec_n = d_rec_n;
     a.qmap = nullptr;
+    a.range_ids = nullptr;
+    a.range_d = nullptr;
+    a.range_second = nullptr;
+    a.range_cap = a.range_max = a.range_thresh = a.has_inner = 0;
+    a.radius = a.inner_radius = a.range_slack = 0.0f;
     a.fail_flag = nullptr;
     a.spill = nullptr;
     a.spill_next = nullptr;
@@ -628,6 +633,98 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
             return DANN_EOVERFLOW;
         }
     }
+    return DANN_OK;
+}
+
+int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
+                                uint32_t beam_width, float radius, int32_t has_inner_radius, float inner_radius,
+                                float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
+                                uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
+                                uint32_t* out_second_round) {
+    CHECK_IDX(idx);
+    // RangeSearchError (range_search.rs:30-45, 93-131)
+    if (starting_l == 0 || beam_width == 0) {
+        set_error("l_value and beam width cannot be zero");
+        return DANN_EINVAL;
+    }
+    if (max_returned && max_returned < starting_l) {
+        set_error("max_returned must be greater than or equal to starting_l");
+        return DANN_EINVAL;
+    }
+    if (!(initial_slack >= 0.0f && initial_slack <= 1.0f)) {
+        set_error("initial_search_slack must be between 0 and 1.0");
+        return DANN_EINVAL;
+    }
+    if (!(range_slack >= 1.0f)) {
+        set_error("range_search_slack must be greater than or equal to 1.0");
+        return DANN_EINVAL;
+    }
+    if (has_inner_radius && inner_radius > radius) {
+        set_error("inner_radius must be less than or equal to radius");
+        return DANN_EINVAL;
+    }
+    if (nq == 0) return DANN_OK;
+    if (!queries || !out_ids || !out_dists || out_cap == 0) return DANN_EINVAL;
+    uint64_t cap = max_returned ? max_returned : (uint64_t)4 * out_cap + 1024;
+    cap = std::min<uint64_t>(cap, idx->nslots);
+    cap = std::max<uint64_t>(cap, 1);
+    DevBuf bq, bi, bd, bs, bri, brd, bsec;
+    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    DANN_HIP(bi.alloc((size_t)nq * out_cap * 4));
+    DANN_HIP(bd.alloc((size_t)nq * out_cap * 4));
+    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
+    DANN_HIP(bri.alloc((size_t)nq * cap * 4));
+    DANN_HIP(brd.alloc((size_t)nq * cap * 4));
+    DANN_HIP(bsec.alloc((size_t)nq * 4));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    SearchArgs a;
+    a.ix = idx->view();
+    a.queries = bq.p;
+    a.qslots = nullptr;
+    a.nq = nq;
+    a.l_value = starting_l;
+    a.beam_width = beam_width;
+    a.k = out_cap;
+    a.ht_entries = auto_visited_entries(idx, std::max<uint32_t>(starting_l, 64), beam_width);
+    a.out_ids = bi.as<uint32_t>();
+    a.out_dists = bd.as<float>();
+    a.stats = bs.as<dann_search_stats>();
+    a.rec_ids = nullptr;
+    a.rec_dists = nullptr;
+    a.rec_stride = 0;
+    a.rec_n = nullptr;
+    a.qmap = nullptr;
+    a.range_ids = bri.as<uint32_t>();
+    a.range_d = brd.as<float>();
+    a.range_second = bsec.as<uint32_t>();
+    a.range_cap = (uint32_t)cap;
+    a.range_max = max_returned ? max_returned : 0xFFFFFFFFu;
+    a.range_thresh = (uint32_t)((float)starting_l * initial_slack);
+    a.has_inner = has_inner_radius ? 1u : 0u;
+    a.radius = radius;
+    a.inner_radius = inner_radius;
+    a.range_slack = range_slack;
+    a.fail_flag = nullptr;
+    a.spill = nullptr;
+    a.spill_next = nullptr;
+    a.spill_slices = a.spill_bits = 0;
+    int32_t rc = search_with_retry(idx, a);
+    if (rc != DANN_OK) return rc;
+    std::vector<dann_search_stats> stats(nq);
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
+                            idx->stream));
+    if (out_second_round)
+        DANN_HIP(hipMemcpyAsync(out_second_round, bsec.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+    for (uint32_t i = 0; i < nq; ++i)
+        if (stats[i].status) {
+            set_error("query %u: range result list or visited scratch exhausted (list capacity %llu)", i,
+                      (unsigned long long)cap);
+            return DANN_EOVERFLOW;
+        }
     return DANN_OK;
 }
 

@@ -694,6 +694,11 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     sa.rec_stride = s.rec_stride;
     sa.rec_n = s.rec_n.as<uint32_t>();
     sa.qmap = nullptr;
+    sa.range_ids = nullptr;
+    sa.range_d = nullptr;
+    sa.range_second = nullptr;
+    sa.range_cap = sa.range_max = sa.range_thresh = sa.has_inner = 0;
+    sa.radius = sa.inner_radius = sa.range_slack = 0.0f;
     sa.fail_flag = nullptr;
     sa.spill = nullptr;
     sa.spill_next = nullptr;

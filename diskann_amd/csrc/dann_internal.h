@@ -60,6 +60,15 @@ struct SearchArgs {
     float* rec_dists;
     uint32_t rec_stride;
     uint32_t* rec_n;
+    // graph::search::Range (null range_ids = plain Knn): scratch list of in-range (id, dist) per query
+    uint32_t* range_ids;
+    float* range_d;
+    uint32_t* range_second;  // per query: did the second round run
+    uint32_t range_cap;      // entries per query in range_ids/range_d
+    uint32_t range_max;      // max_returned (0xFFFFFFFF = unlimited)
+    uint32_t range_thresh;   // (starting_l as f32 * initial_slack) as usize
+    uint32_t has_inner;
+    float radius, inner_radius, range_slack;
     uint32_t* spill;         // pool of global-memory visited tables (all kEmpty between launches)
     uint32_t* spill_next;    // pool allocation counter (zeroed before each launch)
     uint32_t spill_slices;

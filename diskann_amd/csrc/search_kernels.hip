@@ -314,6 +314,55 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
     };
 
+    // expand `nb` nodes of beam[]: adjacency rows in pop order, ids in stored order, visited filter
+    // (provider.rs:448-454); survivors go to cand_id[0..nc)
+    auto expand = [&](uint32_t nb) -> uint32_t {
+        uint32_t nc = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t node = beam[b];
+            const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
+            const bool hit = (node == pf_node);
+#ifdef DANN_PHASE_CYCLES
+            ph_acc[hit ? 5 : 6] += 1;
+#endif
+            uint32_t len = hit ? pf_len : arow[0];
+            len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
+            if (lds_open && ht_count + len > ht_size - (ht_size >> 2)) {
+                // freeze the LDS table, claim a spill table (kept once claimed)
+                lds_open = false;
+                if (!spill) {
+                    uint32_t slice = kEmpty;
+                    if (a.spill) {
+                        if (lane == 0) slice = atomicAdd(a.spill_next, 1u);
+                        slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
+                    }
+                    if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
+                }
+            }
+            if (!lds_open && (!spill || spill_count + len > spill_size - (spill_size >> 2))) {
+                status = (uint32_t)(-DANN_EOVERFLOW);
+                break;
+            }
+            for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
+                const uint32_t j = j0 + lane;
+                const bool inb = j < len;
+                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
+                bool isnew = false;
+                if (inb && id != kEmpty) {
+                    const int r = ht_visit(ht, ht_size, id, lds_open);
+                    isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
+                }
+                const bool keep = isnew && id < ix.nslots;
+                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                if (keep) cand_id[nc + mbcnt(km)] = id;
+                nc += (uint32_t)__popcll(km);
+                if (lds_open) ht_count += (uint32_t)__popcll(nm);
+                else spill_count += (uint32_t)__popcll(nm);
+            }
+        }
+        return nc;
+    };
+
     // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958) ---
     {
         const uint32_t ns = ix.nstart;
@@ -371,49 +420,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         PH_T(ph1);
         PH_ADD(0, ph0, ph1);
 
-        // expand: adjacency rows in pop order, ids in stored order, visited filter
-        // (provider.rs:448-454)
-        uint32_t nc = 0;
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t node = beam[b];
-            const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
-            const bool hit = (node == pf_node);
-#ifdef DANN_PHASE_CYCLES
-            ph_acc[hit ? 5 : 6] += 1;
-#endif
-            uint32_t len = hit ? pf_len : arow[0];
-            len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            if (lds_open && ht_count + len > ht_size - (ht_size >> 2)) {
-                // freeze the LDS table, claim a spill table
-                lds_open = false;
-                uint32_t slice = kEmpty;
-                if (a.spill) {
-                    if (lane == 0) slice = atomicAdd(a.spill_next, 1u);
-                    slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
-                }
-                if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
-            }
-            if (!lds_open && (!spill || spill_count + len > spill_size - (spill_size >> 2))) {
-                status = (uint32_t)(-DANN_EOVERFLOW);
-                break;
-            }
-            for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
-                const uint32_t j = j0 + lane;
-                const bool inb = j < len;
-                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
-                bool isnew = false;
-                if (inb && id != kEmpty) {
-                    const int r = ht_visit(ht, ht_size, id, lds_open);
-                    isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
-                }
-                const bool keep = isnew && id < ix.nslots;
-                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                if (keep) cand_id[nc + mbcnt(km)] = id;
-                nc += (uint32_t)__popcll(km);
-                if (lds_open) ht_count += (uint32_t)__popcll(nm);
-                else spill_count += (uint32_t)__popcll(nm);
-            }
-        }
+        const uint32_t nc = expand(nb);
         if (status) break;
         __syncthreads();
         PH_T(ph2);
@@ -447,6 +454,116 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         PH_ADD(4, ph0, ph4);
     }
 
+    // ---- graph::search::Range second phase (range_search.rs:283-316, 424-470) -----------------------
+    uint32_t range_written = 0, range_second = 0;
+    if (a.range_ids && !status) {
+        uint32_t* rids = a.range_ids + (uint64_t)qi * a.range_cap;
+        float* rds = a.range_d + (uint64_t)qi * a.range_cap;
+        const uint32_t max_ret = a.range_max < a.range_cap ? a.range_max : a.range_cap;  // list capacity
+        // in_range = the first starting_l queue entries within the radius (start points included)
+        uint32_t nr = 0;
+        const uint32_t take = size < a.l_value ? size : a.l_value;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint32_t p = (uint32_t)(s * kWave) + lane;
+            const bool in = p < take && qd[s] <= a.radius;
+            const uint64_t m = ballot64(in);
+            const uint32_t r = nr + mbcnt(m);
+            if (in && r < a.range_cap) {
+                rids[r] = qid[s] & ~kVisitedBit;
+                rds[r] = qd[s];
+            }
+            nr += (uint32_t)__popcll(m);
+        }
+        if (nr > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+        const uint32_t init_hops = hops;
+        if (!status && nr >= a.range_thresh && nr < a.range_max) {
+            range_second = 1;
+            // visited := ids of in_range only (range_search.rs:297-301)
+            __syncthreads();
+            for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
+            if (spill)
+                for (uint32_t i = lane; i < spill_size; i += kWave) spill[i] = kEmpty;
+            __threadfence();
+            __syncthreads();
+            lds_open = true;
+            ht_count = 0;
+            spill_count = 0;
+            pf_node = kEmpty;
+            for (uint32_t i0 = 0; i0 < nr && !status; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                const uint32_t cnt = (nr - i0) < (uint32_t)kWave ? (nr - i0) : (uint32_t)kWave;
+                if (lds_open && ht_count + cnt > ht_size - (ht_size >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                else if (i < nr) ht_visit(ht, ht_size, rids[i], true);
+                ht_count += cnt;
+            }
+            __syncthreads();
+            const float rlimit = a.radius * a.range_slack;
+            uint32_t front = 0;
+            while (!status && front < nr && nr < a.range_max) {
+                // next beam: up to W ids from the front of the frontier (== in_range in arrival order)
+                uint32_t nb = nr - front < W ? nr - front : W;
+                __threadfence();
+                if (lane < nb) beam[lane] = rids[front + lane];
+                front += nb;
+                __syncthreads();
+                const uint32_t nc = expand(nb);
+                if (status) break;
+                __syncthreads();
+                gather(nc);
+                __syncthreads();
+                hops += nb;
+                // append survivors in emission order while the list has room
+                for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+                    const uint32_t c = c0 + lane;
+                    const bool in = c < nc && cand_d[c] <= rlimit;
+                    const uint64_t m = ballot64(in);
+                    const uint32_t r = nr + mbcnt(m);
+                    if (in && r < a.range_max) {
+                        if (r < a.range_cap) {
+                            rids[r] = cand_id[c];
+                            rds[r] = cand_d[c];
+                        }
+                    }
+                    uint32_t add = (uint32_t)__popcll(m);
+                    if (nr + add > a.range_max) add = a.range_max - nr;
+                    nr += add;
+                    if (nr > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+                }
+            }
+            hops = init_hops + hops;  // the reference adds the cumulative counter to the initial one (:308-314)
+        }
+        (void)max_ret;
+        // post-process: start points dropped, inner/outer radius filter, output buffer capacity k
+        if (!status && a.out_ids) {
+            __threadfence();
+            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+            float* od = a.out_dists + (uint64_t)qi * a.k;
+            for (uint32_t i0 = 0; i0 < nr; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                uint32_t id = kEmpty;
+                float d = 0.0f;
+                if (i < nr) {
+                    id = rids[i];
+                    d = rds[i];
+                }
+                const bool ok = i < nr && id < ix.capacity && !(a.has_inner && d <= a.inner_radius) && d <= a.radius;
+                const uint64_t m = ballot64(ok);
+                const uint32_t r = range_written + mbcnt(m);
+                if (ok && r < a.k) {
+                    oi[r] = id;
+                    od[r] = d;
+                }
+                range_written += (uint32_t)__popcll(m);
+            }
+            range_written = range_written < a.k ? range_written : a.k;
+            for (uint32_t r = range_written + lane; r < a.k; r += kWave) {
+                oi[r] = kEmpty;
+                od[r] = __builtin_inff();
+            }
+        }
+    }
+
 #ifdef DANN_PHASE_CYCLES
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph_acc[i]);
@@ -456,8 +573,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         for (uint32_t i = lane; i < spill_size; i += kWave) spill[i] = kEmpty;
     }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
-    uint32_t written = 0;
-    if (a.out_ids) {
+    uint32_t written = range_written;
+    if (a.out_ids && !a.range_ids) {
         uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
         float* od = a.out_dists + (uint64_t)qi * a.k;
 #pragma unroll
@@ -490,6 +607,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
         if (status && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.rec_n) a.rec_n[qi] = nrec;
+        if (a.range_second) a.range_second[qi] = range_second;
     }
 }
 

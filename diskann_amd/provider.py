@@ -180,6 +180,22 @@ class Provider:
                                            _p(dists), _p(stats)), "dann_search_batch")
         return ids, dists, stats
 
+    def range_search(self, queries, starting_l, radius, beam_width=1, inner_radius=None, initial_slack=1.0,
+                     range_slack=1.0, max_returned=0, out_cap=None):
+        """graph::search::Range for a batch; returns (ids, dists, stats, second_round)."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        nq = q.shape[0]
+        cap = int(out_cap or max_returned or 1024)
+        ids = np.empty((nq, cap), np.uint32)
+        dists = np.empty((nq, cap), np.float32)
+        stats = np.zeros(nq, STATS_DTYPE)
+        second = np.zeros(nq, np.uint32)
+        check(_ffi.lib().dann_range_search_batch(self._h, _p(q), nq, starting_l, beam_width, radius,
+                                                 int(inner_radius is not None), inner_radius or 0.0, initial_slack,
+                                                 range_slack, max_returned, cap, _p(ids), _p(dists), _p(stats),
+                                                 _p(second)), "dann_range_search_batch")
+        return ids, dists, stats, second
+
     def search_record(self, slots, l_value, rec_stride=None):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         rec_stride = rec_stride or 4 * (l_value + self.num_start_points) + 64

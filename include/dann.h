@@ -162,6 +162,19 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
                                  dann_search_stats* d_out_stats);
+/* graph::search::Range for nq queries (diskann/src/graph/search/range_search.rs:51-470): Knn-style
+ * search with L = starting_l, then -- if at least starting_l * initial_slack of that list lies within
+ * `radius` and fewer than max_returned -- breadth-first expansion of every point within
+ * radius * range_slack.  Results (slot ids, start points dropped, `inner_radius < d <= radius`) go to
+ * out_ids/out_dists (nq x out_cap, unwritten = 0xFFFFFFFF / +inf).  max_returned == 0: unlimited
+ * (the GPU scratch list is then sized 4 * out_cap + 1024 per query; a longer list is DANN_EOVERFLOW).
+ * Stats follow the reference's accounting (cmps of the first phase only, hops = initial + cumulative,
+ * :308-314); out_second_round[q] = range_search_second_round.  Parameter errors == RangeSearchError. */
+int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
+                                uint32_t beam_width, float radius, int32_t has_inner_radius, float inner_radius,
+                                float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
+                                uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
+                                uint32_t* out_second_round);
 /* insert-time search: also returns the VisitedSearchRecord (record.rs:86-93) per query:
  * rec_ids/rec_dists: nq x rec_stride, rec_n: nq */
 int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,

@@ -82,6 +82,8 @@ def lib():
     L.orc_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp]
     L.orc_search_batch.restype = i32
     L.orc_search_batch.argtypes = [P(OrcIndex), vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, i32, vp]
+    L.orc_range_search.restype = i32
+    L.orc_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, u64, vp]
     L.orc_expand_beam.restype = i32
     L.orc_expand_beam.argtypes = [P(OrcIndex), vp, vp, u32, vp, vp]
     L.orc_prune_pool.restype = i32
@@ -195,6 +197,20 @@ class Index:
         if rc < 0:
             raise RuntimeError(f"orc_search_batch failed: {rc}")
         return (ids, dists, counts, stats, ns) if timing else (ids, dists, counts, stats)
+
+    def range_search(self, query, starting_l, radius, beam_width=1, inner_radius=None, initial_slack=1.0,
+                     range_slack=1.0, max_returned=0, out_cap=None):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        cap = out_cap or (max_returned if max_returned else self.capacity + self.nstart)
+        ids = np.empty(cap, np.uint32)
+        dists = np.empty(cap, np.float32)
+        stats = np.zeros(4, np.uint32)
+        n = lib().orc_range_search(C.byref(self._c), _p(q), starting_l, beam_width, radius,
+                                   int(inner_radius is not None), inner_radius or 0.0, initial_slack, range_slack,
+                                   max_returned, _p(ids), _p(dists), cap, _p(stats))
+        if n < 0:
+            raise RuntimeError(f"orc_range_search failed: {n}")
+        return ids[:n].copy(), dists[:n].copy(), stats
 
     def expand_beam(self, query, ids):
         q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])

@@ -885,6 +885,69 @@ int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, 
     return 0;
 }
 
+int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starting_l, uint32_t beam_width,
+                         float radius, int32_t has_inner, float inner_radius, float initial_slack,
+                         float range_slack, uint64_t max_returned, uint32_t* out_ids, float* out_dists,
+                         uint64_t out_cap, uint32_t* stats) {
+    if (!ix || !query || starting_l == 0 || beam_width == 0) return -1;
+    View v(ix);
+    QueryCtx qc(v, query, false);
+    Queue best((size_t)starting_l + ix->nstart);
+    std::unordered_set<uint32_t> visited;
+    SearchOut so;
+    search_internal(qc, best, visited, beam_width, so);
+    const uint32_t init_cmps = so.cmps, init_hops = so.hops;
+    const uint64_t max_ret = max_returned ? max_returned : ~0ull;
+    std::vector<std::pair<uint32_t, float>> in_range;
+    size_t n = std::min(std::min(best.search_l, best.size()), (size_t)starting_l);
+    for (size_t i = 0; i < n; ++i)
+        if (best.dist[i] <= radius) in_range.emplace_back(best.ids[i], best.dist[i]);
+    visited.clear();
+    for (auto& nb : in_range) visited.insert(nb.first);
+    bool second = false;
+    uint32_t hops = init_hops, cum_hops = so.hops;
+    if (in_range.size() >= (size_t)((float)starting_l * initial_slack) && in_range.size() < max_ret) {
+        second = true;
+        size_t front = 0; /* range_frontier == in_range in arrival order */
+        std::vector<uint32_t> beam;
+        std::vector<std::pair<uint32_t, float>> neighbors;
+        while (front < in_range.size() && in_range.size() < max_ret) {
+            beam.clear();
+            while (front < in_range.size() && beam.size() < beam_width) beam.push_back(in_range[front++].first);
+            neighbors.clear();
+            for (uint32_t b : beam) {
+                const uint32_t* adj;
+                uint32_t len = v.get_neighbors(b, &adj);
+                for (uint32_t j = 0; j < len; ++j) {
+                    uint32_t nb = adj[j];
+                    if (visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, qc.eval(nb));
+                }
+            }
+            for (auto& nb : neighbors)
+                if (nb.second <= radius * range_slack && in_range.size() < max_ret) in_range.push_back(nb);
+            cum_hops += (uint32_t)beam.size();
+        }
+        hops = init_hops + cum_hops;
+    }
+    uint64_t written = 0;
+    for (auto& nb : in_range) {
+        if (nb.first >= ix->capacity) continue; /* start points have no external id */
+        if (has_inner && nb.second <= inner_radius) continue;
+        if (!(nb.second <= radius)) continue;
+        if (written >= out_cap) break;
+        out_ids[written] = nb.first;
+        out_dists[written] = nb.second;
+        ++written;
+    }
+    if (stats) {
+        stats[0] = init_cmps;
+        stats[1] = hops;
+        stats[2] = (uint32_t)written;
+        stats[3] = second ? 1u : 0u;
+    }
+    return (int32_t)written;
+}
+
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists) {
     if (!ix || !query) return -1;

@@ -96,6 +96,16 @@ int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, 
                          uint32_t* out_counts, uint32_t* stats, uint32_t threads, int32_t fast,
                          uint64_t* per_query_ns);
 
+/* graph::search::Range (diskann/src/graph/search/range_search.rs:246-470): initial Knn-style search with
+ * L = starting_l, then (if enough of the list is in range) breadth-first expansion of everything within
+ * radius * range_slack.  max_returned == 0 means unlimited; has_inner != 0 enables inner_radius.
+ * stats = {cmps, hops, result_count, range_search_second_round} with the reference's accounting
+ * (cmps of the initial phase only; hops = initial + cumulative, :308-314).  Returns results written. */
+int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starting_l, uint32_t beam_width,
+                         float radius, int32_t has_inner, float inner_radius, float initial_slack,
+                         float range_slack, uint64_t max_returned, uint32_t* out_ids, float* out_dists,
+                         uint64_t out_cap, uint32_t* stats);
+
 /* ExpandBeam::expand_beam (provider.rs:620-690) for a pre-filtered id list. */
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists);

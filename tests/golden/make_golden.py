@@ -53,6 +53,26 @@ def grid_insert():
     print("grid_insert files:", len(out))
 
 
+def range_search():
+    out = []
+    for path in sorted(glob.glob(f"{REF}/diskann/test/generated/graph/test/cases/range_search/*.json")):
+        doc = json.load(open(path))
+        c = doc["payload"]
+        # parameters that are not stored in the baseline come from the test source
+        # (diskann/src/graph/test/cases/range_search.rs:157-470): starting_l is stored; max_returned
+        # only in the two max_results tests (4 and 5)
+        name = os.path.basename(path)[:-5]
+        max_returned = {"max_results_respected_means_no_second_round": 4,
+                        "max_results_respected_and_second_round_triggered": 5}.get(name, 0)
+        out.append({"source": os.path.relpath(path, REF), "name": name, "grid_dims": c["grid_dims"],
+                    "grid_size": c["grid_size"], "query": c["query"], "radius": c["radius"],
+                    "inner_radius": c["inner_radius"], "starting_l": c["starting_l"], "max_returned": max_returned,
+                    "results": c["results"], "comparisons": c["comparisons"], "hops": c["hops"],
+                    "result_count": c["result_count"], "second_round": c["range_search_second_round"]})
+    json.dump(out, open(f"{HERE}/range_search.json", "w"), separators=(",", ":"))
+    print("range_search cases:", len(out))
+
+
 def f16_table():
     bits = np.zeros(65536, np.uint32)
     seen = np.zeros(65536, bool)
@@ -80,4 +100,5 @@ def f16_table():
 if __name__ == "__main__":
     grid_search()
     grid_insert()
+    range_search()
     f16_table()

@@ -84,3 +84,17 @@ def test_provider_smoke_search():
     assert (ext[0], dists[0]) == (1, 0.0)
     assert sorted(ext[1:3]) == [11, 51] and dists[1] == 1.0 and dists[2] == 1.0
     assert (ext[3], dists[3]) == (61, 2.0)
+
+
+def test_range_search_golden(golden_dir):
+    """diskann/test/generated/graph/test/cases/range_search/*.json through the oracle's Range search."""
+    cases = json.load(open(os.path.join(golden_dir, "range_search.json")))
+    assert len(cases) == 5
+    for c in cases:
+        ix = _grid_index(c["grid_dims"], c["grid_size"])
+        ids, dists, stats = ix.range_search(np.array(c["query"], np.float32), c["starting_l"], c["radius"],
+                                            inner_radius=c["inner_radius"], max_returned=c["max_returned"])
+        assert [int(i) for i in ids] == [r[0] for r in c["results"]], c["name"]
+        assert [float(d) for d in dists] == [r[1] for r in c["results"]], c["name"]
+        assert int(stats[0]) == c["comparisons"] and int(stats[1]) == c["hops"], (c["name"], stats)
+        assert int(stats[2]) == c["result_count"] and bool(stats[3]) == c["second_round"], c["name"]
