@@ -64,6 +64,8 @@ SYMBOLS = {
     "dann_search_batch_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "dann_range_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _f32, _i32, _f32, _f32, _f32, _u32, _u32, _vp, _vp,
                                        _vp, _vp]),
+    "dann_rerank_batch": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
+    "dann_rerank_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
     "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),
     "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),

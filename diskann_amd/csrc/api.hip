@@ -728,6 +728,39 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     return DANN_OK;
 }
 
+int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, const uint32_t* d_cand_ids,
+                                 uint32_t cand_stride, uint32_t k, uint32_t* d_out_ids, float* d_out_dists) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!d_queries || !d_cand_ids || !d_out_ids || !d_out_dists || k == 0) return DANN_EINVAL;
+    int32_t rc = timed(idx, 1, [&] {
+        return launch_rerank(idx->view(), d_queries, nq, d_cand_ids, cand_stride, k, d_out_ids, d_out_dists,
+                             idx->stream);
+    });
+    return rc;
+}
+
+int32_t dann_rerank_batch(dann_index* idx, const void* queries, uint32_t nq, const uint32_t* cand_ids,
+                          uint32_t cand_stride, uint32_t k, uint32_t* out_ids, float* out_dists) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !cand_ids || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
+    DevBuf bq, bc, bi, bd;
+    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    DANN_HIP(bc.alloc((size_t)nq * cand_stride * 4));
+    DANN_HIP(bi.alloc((size_t)nq * k * 4));
+    DANN_HIP(bd.alloc((size_t)nq * k * 4));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bc.p, cand_ids, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, idx->stream));
+    int32_t rc = launch_rerank(idx->view(), bq.p, nq, bc.as<uint32_t>(), cand_stride, k, bi.as<uint32_t>(),
+                               bd.as<float>(), idx->stream);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
 int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,
                                  uint32_t* rec_ids, float* rec_dists, uint32_t rec_stride, uint32_t* rec_n,
                                  dann_search_stats* out_stats) {

@@ -85,6 +85,8 @@ uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t 
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
                            const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);
+int32_t launch_rerank(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_cand, uint32_t stride,
+                      uint32_t k, uint32_t* d_out_ids, float* d_out_d, hipStream_t stream);
 int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
                               hipStream_t stream);
 // raw rows x[i] vs y[i] (pair kernel numerics), n pairs of `bytes` each

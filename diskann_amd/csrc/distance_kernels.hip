@@ -75,6 +75,148 @@ __global__ __launch_bounds__(kWave) void expand_beam_kernel(IndexView ix, const 
     }
 }
 
+// Rerank (full_precision.rs:348-397): one wave per query; distances of up to 512 candidates by the
+// search-path groups, bitonic sort of (distance bits, position) keys in LDS, first k written.
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void rerank_kernel(IndexView ix, const void* queries, const uint32_t* cand,
+                                                       uint32_t stride, uint32_t k, uint32_t* out_ids,
+                                                       float* out_d) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using S = Scheme<DT, OP, false>;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    constexpr bool kInt = S::kInt;
+    using QT = typename std::conditional<kInt, uint8_t, float>::type;
+    using RT = typename RowType<DT>::type;
+    const uint32_t lane = threadIdx.x, qi = blockIdx.x;
+    uint32_t pcap = 64;
+    while (pcap < stride) pcap <<= 1;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* cid = reinterpret_cast<uint32_t*>(smem + (size_t)pcap * 8);
+    float* cd = reinterpret_cast<float*>(smem + (size_t)pcap * 12);
+    QT* qs = reinterpret_cast<QT*>(smem + (size_t)pcap * 16);
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(queries) + (uint64_t)qi * ix.layer_bytes;
+    if constexpr (kInt) {
+        for (uint32_t i = lane; i < ix.layer_bytes; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
+    } else {
+        const RT* src = reinterpret_cast<const RT*>(qsrc);
+        for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
+    }
+    // compact valid candidates, order preserved
+    uint32_t n = 0;
+    for (uint32_t i0 = 0; i0 < stride; i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        const uint32_t id = i < stride ? cand[(uint64_t)qi * stride + i] : kEmpty;
+        const bool ok = id != kEmpty && id < ix.nslots;
+        const uint64_t m = ballot64(ok);
+        if (ok) cid[n + mbcnt(m)] = id;
+        n += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    const int g = lane / G, v = lane % G;
+    constexpr int U = 4;
+    for (uint32_t c0 = 0; c0 < n; c0 += GROUPS * U) {
+        const uint8_t* rows[U];
+        bool act[U];
+        float o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = c0 + u * GROUPS + g;
+            act[u] = c < n;
+            rows[u] = ix.rows + (uint64_t)(act[u] ? cid[c] : 0u) * ix.row_stride;
+        }
+        if constexpr (S::kWide) {  // wide groups are a search-kernel layout; here G = S::G lanes per row
+            for (int u = 0; u < U; ++u)
+                o[u] = act[u] ? group_distance<DT, OP, false, 0>(qs, rows[u], (int)ix.dim, v) : 0.0f;
+        } else {
+            group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = c0 + u * GROUPS + g;
+            if (act[u] && v == 0)
+                cd[c] = finish_distance<DT, OP, NORM>(o[u], reinterpret_cast<const uint8_t*>(qs), rows[u], ix.dim, sqp);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < pcap; i += kWave) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            uint32_t u = __builtin_bit_cast(uint32_t, cd[i] + 0.0f);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            key = ((uint64_t)u << 32) | i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= pcap; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+                const uint32_t p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                if ((a > b) == ((i & kk) == 0)) {
+                    keys[i] = b;
+                    keys[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = lane; r < k; r += kWave) {
+        uint32_t id = kEmpty;
+        float d = __builtin_inff();
+        if (r < n) {
+            const uint32_t pos = (uint32_t)keys[r];
+            id = cid[pos];
+            d = cd[pos];
+        }
+        out_ids[(uint64_t)qi * k + r] = id;
+        out_d[(uint64_t)qi * k + r] = d;
+    }
+}
+
+template <int DT, int OP, bool NORM>
+int32_t launch_rerank_t(const IndexView& ix, const void* q, uint32_t nq, const uint32_t* cand, uint32_t stride,
+                        uint32_t k, uint32_t* oi, float* od, hipStream_t stream) {
+    uint32_t pcap = 64;
+    while (pcap < stride) pcap <<= 1;
+    const bool is_int = DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8;
+    const size_t lds = (size_t)pcap * 16 + (((is_int ? ix.layer_bytes : ix.dim * 4u) + 15u) & ~15u);
+    auto kern = rerank_kernel<DT, OP, NORM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+    }
+    hipLaunchKernelGGL(kern, dim3(nq), dim3(kWave), lds, stream, ix, q, cand, stride, k, oi, od);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rerank_kernel launch");
+    return DANN_OK;
+}
+
+template <int DT>
+int32_t launch_rerank_dt(const IndexView& ix, const void* q, uint32_t nq, const uint32_t* cand, uint32_t stride,
+                         uint32_t k, uint32_t* oi, float* od, hipStream_t stream) {
+    int op;
+    bool norm;
+    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm)) return DANN_EUNSUPPORTED;
+    if (op == OP_L2) {
+        if constexpr (DT == DT_SQ8) {
+            if (norm) return launch_rerank_t<DT, OP_L2, true>(ix, q, nq, cand, stride, k, oi, od, stream);
+        }
+        return launch_rerank_t<DT, OP_L2, false>(ix, q, nq, cand, stride, k, oi, od, stream);
+    }
+    if (op == OP_IP) {
+        if constexpr (DT == DT_F32 || DT == DT_F16) {
+            if (norm) return launch_rerank_t<DT, OP_IP, true>(ix, q, nq, cand, stride, k, oi, od, stream);
+        }
+        return launch_rerank_t<DT, OP_IP, false>(ix, q, nq, cand, stride, k, oi, od, stream);
+    }
+    if constexpr (DT != DT_SQ8) return launch_rerank_t<DT, OP_COS, false>(ix, q, nq, cand, stride, k, oi, od, stream);
+    return DANN_EUNSUPPORTED;
+}
+
 // pair i: rows xa[i], yb[i] given as byte pointers base + id*stride (stored rows) or
 // base + i*stride (raw rows).
 template <int DT, int OP, bool NORM>
@@ -213,6 +355,23 @@ int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t 
         case DT_SQ8: return launch_eb_dt<DT_SQ8>(ix, d_queries, nq, chunks, d_ids, d_offsets, d_out, stream);
     }
     set_error("bad dtype %d", ix.dtype);
+    return DANN_EINVAL;
+}
+
+int32_t launch_rerank(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_cand, uint32_t stride,
+                      uint32_t k, uint32_t* d_out_ids, float* d_out_d, hipStream_t stream) {
+    if (nq == 0) return DANN_OK;
+    if (stride == 0 || stride > 4096) {
+        set_error("rerank supports 1..4096 candidates per query (got %u)", stride);
+        return DANN_EUNSUPPORTED;
+    }
+    switch (ix.dtype) {
+        case DT_F32: return launch_rerank_dt<DT_F32>(ix, d_queries, nq, d_cand, stride, k, d_out_ids, d_out_d, stream);
+        case DT_F16: return launch_rerank_dt<DT_F16>(ix, d_queries, nq, d_cand, stride, k, d_out_ids, d_out_d, stream);
+        case DT_U8: return launch_rerank_dt<DT_U8>(ix, d_queries, nq, d_cand, stride, k, d_out_ids, d_out_d, stream);
+        case DT_I8: return launch_rerank_dt<DT_I8>(ix, d_queries, nq, d_cand, stride, k, d_out_ids, d_out_d, stream);
+        case DT_SQ8: return launch_rerank_dt<DT_SQ8>(ix, d_queries, nq, d_cand, stride, k, d_out_ids, d_out_d, stream);
+    }
     return DANN_EINVAL;
 }
 

@@ -196,6 +196,16 @@ class Provider:
                                                  _p(second)), "dann_range_search_batch")
         return ids, dists, stats, second
 
+    def rerank(self, queries, cand_ids, k):
+        """Rerank post-processor: full-precision distances for the candidates of a quantised search."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        c = np.ascontiguousarray(cand_ids, dtype=np.uint32).reshape(q.shape[0], -1)
+        ids = np.empty((q.shape[0], k), np.uint32)
+        d = np.empty((q.shape[0], k), np.float32)
+        check(_ffi.lib().dann_rerank_batch(self._h, _p(q), q.shape[0], _p(c), c.shape[1], k, _p(ids), _p(d)),
+              "dann_rerank_batch")
+        return ids, d
+
     def search_record(self, slots, l_value, rec_stride=None):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         rec_stride = rec_stride or 4 * (l_value + self.num_start_points) + 64

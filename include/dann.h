@@ -175,6 +175,15 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
                                 float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
                                 uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                 uint32_t* out_second_round);
+/* Rerank post-processor (diskann-providers/src/model/graph/provider/async_/inmem/full_precision.rs:348-397):
+ * full-precision distances query x stored row for every candidate id of a quantised search, sorted
+ * ascending (equal distances keep candidate order; the reference's sort is unstable), first k returned.
+ * `idx` is the full-precision index; cand_ids: nq x cand_stride, entries equal to 0xFFFFFFFF are skipped. */
+int32_t dann_rerank_batch(dann_index* idx, const void* queries, uint32_t nq, const uint32_t* cand_ids,
+                          uint32_t cand_stride, uint32_t k, uint32_t* out_ids, float* out_dists);
+/* device-pointer form (queries, cand_ids, outputs on the index's device) */
+int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, const uint32_t* d_cand_ids,
+                                 uint32_t cand_stride, uint32_t k, uint32_t* d_out_ids, float* d_out_dists);
 /* insert-time search: also returns the VisitedSearchRecord (record.rs:86-93) per query:
  * rec_ids/rec_dists: nq x rec_stride, rec_n: nq */
 int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,

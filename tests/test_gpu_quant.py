@@ -140,3 +140,33 @@ def test_pq_lut_and_scan(metric):
     kat = np.arange(512, dtype=np.float32).reshape(1, 2, 256)
     out = da.pq_scan(kat, np.array([[1, 3]], np.uint8), np.array([0], np.uint32), np.array([0, 1], np.uint64))
     assert out[0] == kat[0, 0, 1] + kat[0, 1, 3]
+
+
+@pytest.mark.parametrize("fdtype", [oracle.F32, oracle.F16])
+def test_quantised_search_with_rerank(fdtype):
+    """SQ-8 graph search followed by the Rerank post-processor on the full-precision rows
+    (full_precision.rs:348-397): equals oracle SQ-8 search + oracle full-precision distances,
+    sorted by (distance, candidate order)."""
+    rng = np.random.default_rng(60)
+    n, dim, R, L, k = 3000, 64, 16, 40, 10
+    data, shift, scale = _sq_setup(rng, n, dim)
+    full = data.astype(oracle.NP_DTYPE[fdtype])
+    codes = da.sq8_compress(data, shift, scale)
+    snorm = float(np.float32((shift ** 2).sum(dtype=np.float32)))
+    adj = random_graph(rng, n, R)
+    sq = da.Provider(da.SQ8, da.L2, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
+    sq.set_elements(0, codes)
+    sq.upload_graph(adj)
+    fp = da.Provider(fdtype, da.L2, dim, n, R, full[:1])
+    fp.set_elements(0, full)
+    qf = rng.normal(0.3, 0.5, (30, dim)).astype(np.float32)
+    qc = da.sq8_compress(qf, shift, scale)
+    cand, _, _ = sq.search(da.Knn(L), qc, L)          # every non-start entry of the L-list
+    qfull = qf.astype(oracle.NP_DTYPE[fdtype])
+    ids, d = fp.rerank(qfull, cand, k)
+    for q in range(30):
+        c = [int(x) for x in cand[q] if x != 0xFFFFFFFF]
+        dd = np.array([oracle.query_distance(fdtype, oracle.L2, qfull[q], full[i]) for i in c], np.float32)
+        order = np.argsort(dd, kind="stable")[:k]
+        assert [c[i] for i in order] == [int(x) for x in ids[q, :len(order)]]
+        assert np.array_equal(bits(dd[order]), bits(d[q, :len(order)]))
