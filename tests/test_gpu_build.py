@@ -157,3 +157,29 @@ def test_two_phase_build_equals_single_gpu_build():
     solo.set_elements(0, data)
     assert build_sharded(solo, gcfg, 0, n, growth, max_batch) == nb
     assert np.array_equal(solo.download_graph(), want)
+
+
+def test_build_parity_at_scale():
+    """20 000 points through dann_build (batches up to 2048) vs the oracle's multi_insert with the same
+    schedule: the whole adjacency buffer must be identical."""
+    from diskann_amd.sharding import batch_schedule
+    rng = np.random.default_rng(2024)
+    n, dim, R, maxdeg, lb = 20000, 32, 16, 20, 48
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.4 * rng.standard_normal((n, dim))).astype(np.float32)
+    mid, _ = oracle.medoid_f32(data)
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[mid:mid + 1], maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    growth, max_batch = 0.02, 2048
+    nb = gix.build(gcfg, 0, n, growth, max_batch)
+    k = 0
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+        k += 1
+    assert k == nb
+    got = gix.download_graph()
+    lens = oix.adj[:, 0]
+    assert np.array_equal(got[:, 0], lens)
+    mask = np.arange(maxdeg)[None, :] < lens[:, None]
+    assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask])
