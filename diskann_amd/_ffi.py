@@ -47,6 +47,8 @@ SYMBOLS = {
     "dann_set_elements": (_i32, [_vp, _u32, _u32, _vp, _u64]),
     "dann_get_element": (_i32, [_vp, _u32, _vp, _u64]),
     "dann_upload_store": (_i32, [_vp, _vp, _u64, _u32]),
+    "dann_set_external_ids": (_i32, [_vp, _u32, _u32, _vp]),
+    "dann_to_external": (_i32, [_vp, _vp, _u64, _vp]),
     "dann_get_neighbors": (_i32, [_vp, _u32, _vp, _u32, _P(_u32)]),
     "dann_set_neighbors": (_i32, [_vp, _u32, _vp, _u32]),
     "dann_append_neighbors": (_i32, [_vp, _u32, _vp, _u32]),

@@ -309,6 +309,29 @@ int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, ui
     return DANN_OK;
 }
 
+// ---- external ids ------------------------------------------------------------------------
+int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, const uint64_t* ext_ids) {
+    if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    if (n == 0) return DANN_OK;
+    if (!ext_ids) return DANN_EINVAL;
+    if ((uint64_t)first_slot + n > idx->cfg.capacity) return DANN_EBOUNDS;
+    if (idx->ext_ids.empty()) idx->ext_ids.assign(idx->cfg.capacity, ~0ull);
+    memcpy(idx->ext_ids.data() + first_slot, ext_ids, (size_t)n * 8);
+    return DANN_OK;
+}
+
+int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64_t n, uint64_t* out_ext) {
+    if (!idx || (n && (!slot_ids || !out_ext))) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t s = slot_ids[i];
+        if (s >= idx->cfg.capacity) out_ext[i] = ~0ull;  // start points / padding have no mapping
+        else out_ext[i] = idx->ext_ids.empty() ? (uint64_t)s : idx->ext_ids[s];
+    }
+    return DANN_OK;
+}
+
 // ---- adjacency ---------------------------------------------------------------------------
 int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len) {
     CHECK_IDX(idx);

@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/dann.h"
 
@@ -113,6 +114,7 @@ struct dann_index {
     void (*build_scratch_free)(void*) = nullptr;
     uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
     dann::KernelClock clocks[4];
+    std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
     // one stream, one pair of events and one set of scratch buffers per index: calls that launch
     // work are serialised per handle (they would serialise on the stream anyway)
     mutable std::recursive_mutex mu;

@@ -93,6 +93,17 @@ class Provider:
         raw = np.ascontiguousarray(raw_rows, dtype=np.uint8)
         check(_ffi.lib().dann_upload_store(self._h, _p(raw), raw.shape[1], raw.shape[0]), "dann_upload_store")
 
+    # -- IdMap / Translate ------------------------------------------------------
+    def set_external_ids(self, first_slot, ext_ids):
+        e = np.ascontiguousarray(ext_ids, dtype=np.uint64)
+        check(_ffi.lib().dann_set_external_ids(self._h, first_slot, e.size, _p(e)), "dann_set_external_ids")
+
+    def to_external(self, slot_ids):
+        s = np.ascontiguousarray(slot_ids, dtype=np.uint32)
+        out = np.empty(s.shape, np.uint64)
+        check(_ffi.lib().dann_to_external(self._h, _p(s), s.size, _p(out)), "dann_to_external")
+        return out
+
     # -- NeighborAccessor(Mut) ------------------------------------------------
     def get_neighbors(self, slot):
         out = np.empty(self.max_degree, np.uint32)

@@ -122,6 +122,13 @@ int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint
 /* upload a whole diskann-inmem Store buffer verbatim (rows at `stride`, tag bytes ignored) */
 int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows);
 
+/* ---- external ids: IdMap / Translate post-processing (diskann-inmem/src/ids.rs:18-107, provider.rs:899-950).
+ * Search results are slot ids; these helpers keep the slot -> external id table and translate result
+ * buffers (start points and unmapped slots have no external id: to_external reports them as
+ * 0xFFFFFFFFFFFFFFFF, exactly the entries Translate drops). */
+int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, const uint64_t* ext_ids);
+int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64_t n, uint64_t* out_ext);
+
 /* ---- adjacency: NeighborAccessor(Mut) (provider.rs:768-823, neighbors.rs:124-224) -- */
 int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len);
 int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n);

@@ -183,3 +183,46 @@ def test_build_parity_at_scale():
     assert np.array_equal(got[:, 0], lens)
     mask = np.arange(maxdeg)[None, :] < lens[:, None]
     assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask])
+
+
+def test_provider_smoke_on_gpu():
+    """The reference's in-source provider test (diskann-inmem/src/provider.rs:1080-1256): 5x5 grid,
+    degree 6, pruned degree 4, l_build 10, points inserted one by one with external id 10*i+1; the
+    search from [0,0] returns (1, 0.0), the two distance-1 points, then (61, 2.0)."""
+    from gridutil import grid_data, grid_start_point
+    data = grid_data(2, 5)
+    p = da.Provider(da.F32, da.L2, 2, 25, 6, grid_start_point(2, 5))
+    p.set_elements(0, data)
+    p.set_external_ids(0, [10 * i + 1 for i in range(25)])
+    cfg = da.build_config(4, 6, 10)
+    oix = oracle.Index(oracle.F32, oracle.L2, 2, 25, 6, grid_start_point(2, 5))
+    ocfg = oracle.build_config(4, 6, 10)
+    for i in range(25):                    # DiskANNIndex::insert == multi_insert of one point
+        p.insert_batch(cfg, [i])
+        oix.set_row(i, data[i])
+        oix.insert(ocfg, i)
+        assert np.array_equal(p.download_graph(), oix.adj), i
+    ids, d, st = p.search(da.Knn(10), np.zeros((1, 2), np.float32), 10)
+    ext = p.to_external(ids[0])
+    assert (int(ext[0]), float(d[0, 0])) == (1, 0.0)
+    assert sorted(int(e) for e in ext[1:3]) == [11, 51] and d[0, 1] == 1.0 and d[0, 2] == 1.0
+    assert (int(ext[3]), float(d[0, 3])) == (61, 2.0)
+    assert p.to_external(np.array([25, 0xFFFFFFFF], np.uint32)).tolist() == [2**64 - 1, 2**64 - 1]
+    with pytest.raises(da.DannError):      # wrong-length vector leaves the provider untouched (:1226-1233)
+        p.set_element(3, np.zeros(3, np.float32))
+
+
+def test_single_insert_equals_batch_of_one():
+    rng = np.random.default_rng(91)
+    n, dim, R, maxdeg, lb = 400, 12, 6, 8, 20
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb)
+    for i in range(n):
+        oix.insert(ocfg, i)
+        gix.insert_batch(gcfg, [i])
+    assert np.array_equal(gix.download_graph()[:, 0], oix.adj[:, 0])
+    lens = oix.adj[:, 0]
+    mask = np.arange(maxdeg)[None, :] < lens[:, None]
+    assert np.array_equal(gix.download_graph()[:, 1:][mask], oix.adj[:, 1:][mask])
