@@ -1,9 +1,9 @@
 """diskann_amd: MI355X-native batched distance / beam-search / RobustPrune path behind the
 surface of the reference's diskann-inmem provider (include/dann.h)."""
-from ._ffi import (F32, F16, U8, I8, SQ8, COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED, IBC_ALL, IBC_NONE, BuildConfig,
+from ._ffi import (F32, F16, U8, I8, SQ8, PQ, COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED, IBC_ALL, IBC_NONE, BuildConfig,
                    Config, DannError, SearchStats, lib)
 from .provider import Knn, Provider, build_config, NP_DTYPE, STATS_DTYPE, sq8_compress, pq_build_lut, pq_scan
 
-__all__ = ["F32", "F16", "U8", "I8", "SQ8", "sq8_compress", "pq_build_lut", "pq_scan", "COSINE", "INNER_PRODUCT", "L2", "COSINE_NORMALIZED", "IBC_ALL", "IBC_NONE",
+__all__ = ["F32", "F16", "U8", "I8", "SQ8", "PQ", "sq8_compress", "pq_build_lut", "pq_scan", "COSINE", "INNER_PRODUCT", "L2", "COSINE_NORMALIZED", "IBC_ALL", "IBC_NONE",
            "BuildConfig", "Config", "DannError", "SearchStats", "lib", "Knn", "Provider", "build_config", "NP_DTYPE",
            "STATS_DTYPE"]

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdann_hip.so")
 
-F32, F16, U8, I8, SQ8 = 0, 1, 2, 3, 4
+F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
@@ -19,7 +19,8 @@ class Config(C.Structure):
     """dann_config == provider::Config + Full::new (diskann-inmem/src/provider.rs:160-217)."""
     _fields_ = [("dtype", C.c_int32), ("metric", C.c_int32), ("dim", C.c_uint32), ("capacity", C.c_uint32),
                 ("max_degree", C.c_uint32), ("num_start_points", C.c_uint32), ("row_stride", C.c_uint32),
-                ("device", C.c_int32), ("sq_scale", C.c_float), ("sq_shift_norm_sq", C.c_float)]
+                ("device", C.c_int32), ("sq_scale", C.c_float), ("sq_shift_norm_sq", C.c_float),
+                ("pq_chunks", C.c_uint32)]
 
 
 class BuildConfig(C.Structure):
@@ -78,6 +79,7 @@ SYMBOLS = {
     "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
     "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),
     "dann_load_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _P(_u32)]),
+    "dann_set_pq_table": (_i32, [_vp, _vp, _vp]),
     "dann_sq8_compress": (_i32, [_i32, _vp, _u32, _u32, _vp, _f32, _vp]),
     "dann_pq_build_lut": (_i32, [_i32, _i32, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),
     "dann_pq_scan": (_i32, [_i32, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),

@@ -32,7 +32,7 @@ int32_t hip_fail(hipError_t e, const char* what) {
 
 static uint32_t elem_size(int32_t dtype) { return dtype == DT_F32 ? 4u : dtype == DT_F16 ? 2u : 1u; }
 static uint32_t layer_bytes_of(int32_t dtype, uint32_t dim) { return dim * elem_size(dtype) + (dtype == DT_SQ8 ? 4u : 0u); }
-static bool valid_dtype(int32_t d) { return d >= 0 && d <= 4; }
+static bool valid_dtype(int32_t d) { return d >= 0 && d <= 5; }
 static bool valid_metric(int32_t m) { return m >= 0 && m <= 3; }
 
 // temporary device buffer with RAII
@@ -116,6 +116,9 @@ dann::IndexView dann_index::view() const {
         v.sq_k = bit_scale * scale_sq;
         v.sq_shift_norm_sq = cfg.sq_shift_norm_sq;
     }
+    v.pq_pivots = d_pq_pivots;
+    v.pq_offsets = d_pq_offsets;
+    v.pq_chunks = cfg.pq_chunks;
     return v;
 }
 
@@ -156,7 +159,11 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
                   cfg->max_degree);
         return DANN_EINVAL;
     }
-    const uint32_t lb = layer_bytes_of(cfg->dtype, cfg->dim);
+    if (cfg->dtype == DT_PQ && (cfg->pq_chunks == 0 || cfg->pq_chunks > 128 || cfg->pq_chunks > cfg->dim)) {
+        set_error("DANN_PQ needs 1 <= pq_chunks <= min(dim, 128)");
+        return DANN_EINVAL;
+    }
+    const uint32_t lb = cfg->dtype == DT_PQ ? cfg->pq_chunks : layer_bytes_of(cfg->dtype, cfg->dim);
     {
         int op;
         bool norm;
@@ -236,6 +243,8 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->d_fail) (void)hipFree(idx->d_fail);
     if (idx->h_flag) (void)hipHostFree(idx->h_flag);
     if (idx->d_spill) (void)hipFree(idx->d_spill);
+    if (idx->d_pq_pivots) (void)hipFree(idx->d_pq_pivots);
+    if (idx->d_pq_offsets) (void)hipFree(idx->d_pq_offsets);
     if (idx->build_scratch && idx->build_scratch_free) idx->build_scratch_free(idx->build_scratch);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -305,6 +314,31 @@ int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, ui
     if (stride < idx->layer_bytes) return DANN_ELENGTH;
     DANN_HIP(hipMemcpy2DAsync(idx->d_rows, idx->cfg.row_stride, base, stride, idx->layer_bytes, nrows,
                               hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
+}
+
+int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets) {
+    CHECK_IDX(idx);
+    if (!pivots || !chunk_offsets) return DANN_EINVAL;
+    if (idx->cfg.dtype != DT_PQ) {
+        set_error("dann_set_pq_table: the index is not DANN_PQ");
+        return DANN_EINVAL;
+    }
+    const uint32_t nc = idx->cfg.pq_chunks, dim = idx->cfg.dim;
+    if (chunk_offsets[0] != 0 || chunk_offsets[nc] != dim) {
+        set_error("chunk offsets must start at 0 and end at dim");
+        return DANN_EINVAL;
+    }
+    for (uint32_t c = 0; c < nc; ++c)
+        if (chunk_offsets[c + 1] <= chunk_offsets[c]) {
+            set_error("chunk offsets must be strictly increasing");
+            return DANN_EINVAL;
+        }
+    if (!idx->d_pq_pivots) DANN_HIP(hipMalloc((void**)&idx->d_pq_pivots, (size_t)256 * dim * 4));
+    if (!idx->d_pq_offsets) DANN_HIP(hipMalloc((void**)&idx->d_pq_offsets, (size_t)(nc + 1) * 4));
+    DANN_HIP(hipMemcpyAsync(idx->d_pq_pivots, pivots, (size_t)256 * dim * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(idx->d_pq_offsets, chunk_offsets, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
 }
@@ -584,10 +618,23 @@ int32_t dann_expand_beam_batch(const dann_index* cidx, const void* queries, uint
 }
 
 // ---- search --------------------------------------------------------------------------------
+static int32_t pq_ready(const dann_index* idx) {
+    if (idx->cfg.dtype == DT_PQ && (!idx->d_pq_pivots || !idx->d_pq_offsets)) {
+        set_error("DANN_PQ index has no pivot table: call dann_set_pq_table first");
+        return DANN_EINVAL;
+    }
+    return DANN_OK;
+}
+
 static int32_t search_device(dann_index* idx, const void* d_queries, const uint32_t* d_qslots, uint32_t nq,
                              uint32_t l_value, uint32_t beam, uint32_t k, uint32_t* d_ids, float* d_dists,
                              dann_search_stats* d_stats, uint32_t* d_rec_ids, float* d_rec_d, uint32_t rec_stride,
                              uint32_t* d_rec_n) {
+    if (int32_t prc = pq_ready(idx)) return prc;
+    if (idx->cfg.dtype == DT_PQ && d_qslots) {
+        set_error("insert-time search (query = stored row) is not defined for DANN_PQ");
+        return DANN_EUNSUPPORTED;
+    }
     SearchArgs a;
     a.ix = idx->view();
     a.queries = d_queries;
@@ -633,11 +680,12 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
     DevBuf bq, bi, bd, bs;
-    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
+    DANN_HIP(bq.alloc((size_t)nq * qb + 16));
     DANN_HIP(bi.alloc((size_t)nq * k * 4));
     DANN_HIP(bd.alloc((size_t)nq * k * 4));
     DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->stream));
     int32_t rc = search_device(idx, bq.p, nullptr, nq, l_value, beam_width, k, bi.as<uint32_t>(), bd.as<float>(),
                                bs.as<dann_search_stats>(), nullptr, nullptr, 0, nullptr);
     if (rc != DANN_OK) return rc;
@@ -691,15 +739,17 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     uint64_t cap = max_returned ? max_returned : (uint64_t)4 * out_cap + 1024;
     cap = std::min<uint64_t>(cap, idx->nslots);
     cap = std::max<uint64_t>(cap, 1);
+    if (int32_t prc = pq_ready(idx)) return prc;
+    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
     DevBuf bq, bi, bd, bs, bri, brd, bsec;
-    DANN_HIP(bq.alloc((size_t)nq * idx->layer_bytes + 16));
+    DANN_HIP(bq.alloc((size_t)nq * qb + 16));
     DANN_HIP(bi.alloc((size_t)nq * out_cap * 4));
     DANN_HIP(bd.alloc((size_t)nq * out_cap * 4));
     DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
     DANN_HIP(bri.alloc((size_t)nq * cap * 4));
     DANN_HIP(brd.alloc((size_t)nq * cap * 4));
     DANN_HIP(bsec.alloc((size_t)nq * 4));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->stream));
     SearchArgs a;
     a.ix = idx->view();
     a.queries = bq.p;

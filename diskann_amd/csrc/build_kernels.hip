@@ -583,6 +583,10 @@ PruneCfg to_prune_cfg(const dann_build_config& c) {
 
 int32_t validate_cfg(const dann_index* idx, const dann_build_config* cfg) {
     if (!cfg) return DANN_EINVAL;
+    if (idx->cfg.dtype == DT_PQ) {
+        set_error("index build / prune are not defined on DANN_PQ rows (build on the full-precision index)");
+        return DANN_EUNSUPPORTED;
+    }
     if (cfg->pruned_degree == 0 || cfg->l_build == 0 || cfg->max_degree < cfg->pruned_degree ||
         cfg->max_degree > idx->cfg.max_degree || !(cfg->alpha >= 1.0f)) {
         set_error("invalid build config (pruned_degree %u, max_degree %u (provider %u), l_build %u, alpha %g)",

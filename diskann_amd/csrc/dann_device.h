@@ -23,7 +23,7 @@
 
 namespace dann {
 
-enum : int { DT_F32 = 0, DT_F16 = 1, DT_U8 = 2, DT_I8 = 3, DT_SQ8 = 4 };
+enum : int { DT_F32 = 0, DT_F16 = 1, DT_U8 = 2, DT_I8 = 3, DT_SQ8 = 4, DT_PQ = 5 };
 enum : int { M_COSINE = 0, M_IP = 1, M_L2 = 2, M_COSN = 3 };
 enum : int { OP_L2 = 0, OP_IP = 1, OP_COS = 2 };
 
@@ -572,7 +572,7 @@ __device__ __forceinline__ void group_distance_int_multi(const uint8_t* __restri
 //   f16 x f16: L2/IP/cosine all Strategy2x4 (NACC 2)  (simd.rs:989,1752,2591)
 template <int DT, int OP, bool PAIR>
 struct Scheme {
-    static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8);
+    static constexpr bool kInt = (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8 || DT == DT_PQ);
     static constexpr int NACC = (OP == OP_COS) ? 2 : ((DT == DT_F16 && PAIR) ? 2 : 4);
     static constexpr int G = kInt ? 8 : 2 * NACC;
     // search-path gather: 2-byte rows use the wide layout (one lane per accumulator)
@@ -598,6 +598,10 @@ struct RowType<DT_I8> {
 };
 template <>
 struct RowType<DT_SQ8> {
+    using type = uint8_t;
+};
+template <>
+struct RowType<DT_PQ> {
     using type = uint8_t;
 };
 
@@ -629,6 +633,54 @@ __device__ __forceinline__ void group_distance_many(const QT* q, const uint8_t* 
             group_distance_multi<Scheme<DT, OP, PAIR>::NACC, OP, U>(q, typed, active, dim, v, out);
     }
 }
+
+// simd_op for f32 x f32, Strategy4x1, V3 (simd.rs:321-363, 686-747); IS_L2 ? L2 : IP
+template <bool IS_L2>
+__device__ float simd_op_seq(const float* x, const float* y, uint32_t len) {
+    float acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[a][l] = 0.0f;
+    const uint32_t blocks = len / 8;
+    for (uint32_t g = 0; g < blocks; ++g) {
+        const int a = g & 3;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float xv = x[8 * g + l], yv = y[8 * g + l];
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                if (aa == a) {
+                    if (IS_L2) {
+                        const float c = xv - yv;
+                        acc[aa][l] = __builtin_fmaf(c, c, acc[aa][l]);
+                    } else {
+                        acc[aa][l] = __builtin_fmaf(xv, yv, acc[aa][l]);
+                    }
+                }
+            }
+        }
+    }
+    float s[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+    const uint32_t rem = len & 7u;
+    if (rem) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float xv = (uint32_t)l < rem ? x[8 * blocks + l] : 0.0f;
+            const float yv = (uint32_t)l < rem ? y[8 * blocks + l] : 0.0f;
+            if (IS_L2) {
+                const float c = xv - yv;
+                s[l] = __builtin_fmaf(c, c, s[l]);
+            } else {
+                s[l] = __builtin_fmaf(xv, yv, s[l]);
+            }
+        }
+    }
+    return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
+}
+
 
 // scalar-quantiser parameters of an SQ-8 index
 struct SqParams {
@@ -666,6 +718,11 @@ __device__ __forceinline__ float finish_distance(float raw, const uint8_t* x, co
 // Returns false for unsupported combinations (SQ-8 has no plain Cosine).
 __host__ __device__ inline bool resolve_metric(int dtype, int metric, int* op, bool* norm) {
     *norm = false;
+    if (dtype == DT_PQ) {
+        if (metric == M_L2) { *op = OP_L2; return true; }
+        if (metric == M_IP) { *op = OP_IP; return true; }
+        return false;
+    }
     if (dtype == DT_SQ8) {
         if (metric == M_L2) { *op = OP_L2; return true; }
         if (metric == M_IP) { *op = OP_IP; return true; }

@@ -43,6 +43,10 @@ struct IndexView {
     uint32_t layer_bytes;  // bytes of one row's payload (dim * sizeof(T); SQ-8: dim + 4)
     float sq_k;            // SQ-8: (1/255)^2 * scale^2
     float sq_shift_norm_sq;
+    // PQ rows (DT_PQ): codes of pq_chunks bytes; pivots 256 x dim f32; chunk offsets pq_chunks + 1
+    const float* pq_pivots;
+    const uint32_t* pq_offsets;
+    uint32_t pq_chunks;
 };
 
 struct SearchArgs {
@@ -106,6 +110,8 @@ struct dann_index {
     uint32_t layer_bytes = 0;
     uint32_t nslots = 0;
     uint32_t visited_bits = 0;
+    float* d_pq_pivots = nullptr;
+    uint32_t* d_pq_offsets = nullptr;
     uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
     size_t fail_cap = 0;
     uint32_t* d_spill = nullptr;   // spill pool + counter (last word)

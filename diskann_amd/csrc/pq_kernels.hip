@@ -17,53 +17,6 @@
 namespace dann {
 namespace {
 
-// simd_op for f32 x f32, Strategy4x1, V3 (simd.rs:321-363, 686-747); IS_L2 ? L2 : IP
-template <bool IS_L2>
-__device__ float simd_op_seq(const float* x, const float* y, uint32_t len) {
-    float acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int l = 0; l < 8; ++l) acc[a][l] = 0.0f;
-    const uint32_t blocks = len / 8;
-    for (uint32_t g = 0; g < blocks; ++g) {
-        const int a = g & 3;
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const float xv = x[8 * g + l], yv = y[8 * g + l];
-#pragma unroll
-            for (int aa = 0; aa < 4; ++aa) {
-                if (aa == a) {
-                    if (IS_L2) {
-                        const float c = xv - yv;
-                        acc[aa][l] = __builtin_fmaf(c, c, acc[aa][l]);
-                    } else {
-                        acc[aa][l] = __builtin_fmaf(xv, yv, acc[aa][l]);
-                    }
-                }
-            }
-        }
-    }
-    float s[8];
-#pragma unroll
-    for (int l = 0; l < 8; ++l) s[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
-    const uint32_t rem = len & 7u;
-    if (rem) {
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const float xv = (uint32_t)l < rem ? x[8 * blocks + l] : 0.0f;
-            const float yv = (uint32_t)l < rem ? y[8 * blocks + l] : 0.0f;
-            if (IS_L2) {
-                const float c = xv - yv;
-                s[l] = __builtin_fmaf(c, c, s[l]);
-            } else {
-                s[l] = __builtin_fmaf(xv, yv, s[l]);
-            }
-        }
-    }
-    return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
-}
-
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* pivots, const uint32_t* offsets, uint32_t nchunks,
                                                      uint32_t dim, const float* queries, float* lut) {

@@ -56,6 +56,13 @@ struct SearchLds {
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// bytes of the staged query: f32 vector (float rows), raw bytes (integer rows), lookup table (PQ rows)
+__host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
+    if (ix.dtype == DT_PQ) return ix.pq_chunks * 1024u;
+    if (ix.dtype == DT_U8 || ix.dtype == DT_I8 || ix.dtype == DT_SQ8) return ix.layer_bytes;
+    return ix.dim * 4u;
+}
+
 __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
                                                        uint32_t qbytes) {
     SearchLds l;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     const uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207)
     const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
                                                                               : ((ix.nstart + 63u) & ~63u);
-    const uint32_t qbytes = kInt ? ix.layer_bytes : ix.dim * 4u;
+    const uint32_t qbytes = query_lds_bytes(ix);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
@@ -139,6 +146,19 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
     {
+        if constexpr (DT == DT_PQ) {
+            // populate_chunk_distances_impl (fixed_chunk_pq_table.rs:152-192): the lookup table of this
+            // query, built straight into LDS: entry (chunk, centroid) = metric(query chunk, pivot chunk)
+            const float* q = reinterpret_cast<const float*>(a.queries) + (uint64_t)qi * ix.dim;
+            float* lut = reinterpret_cast<float*>(qs);
+            const uint32_t total = ix.pq_chunks * 256u;
+            for (uint32_t t = lane; t < total; t += kWave) {
+                const uint32_t chunk = t >> 8, centroid = t & 255u;
+                const uint32_t s0 = ix.pq_offsets[chunk], e0 = ix.pq_offsets[chunk + 1];
+                const float raw = simd_op_seq<OP == OP_L2>(q + s0, ix.pq_pivots + (uint64_t)centroid * ix.dim + s0, e0 - s0);
+                lut[t] = (OP == OP_L2) ? raw : -raw;
+            }
+        } else {
         const uint8_t* qsrc = a.qslots ? ix.rows + (uint64_t)a.qslots[qi] * ix.row_stride
                                        : reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
         if constexpr (kInt) {
@@ -146,6 +166,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         } else {
             const RT* src = reinterpret_cast<const RT*>(qsrc);
             for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
+        }
         }
     }
     const uint32_t ht_size = a.ht_entries;
@@ -200,6 +221,24 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     uint32_t c = c0 + u * GROUPS + g;
                     if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
                 }
+            }
+        } else if constexpr (DT == DT_PQ) {
+            // pq_dist_lookup_single (fixed_chunk_pq_table.rs:82-100): one lane per candidate, table entries
+            // added in chunk order in f32; code rows read 16 bytes at a time
+            const float* lut = reinterpret_cast<const float*>(qs);
+            for (uint32_t c = lane; c < nc; c += kWave) {
+                const uint8_t* code = ix.rows + (uint64_t)cand_id[c] * ix.row_stride;
+                float accum = 0.0f;
+                for (uint32_t b0 = 0; b0 < ix.pq_chunks; b0 += 16) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(code + b0);
+                    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t ch = b0 + i;
+                        if (ch < ix.pq_chunks) accum += lut[ch * 256u + ((ws[i >> 2] >> (8 * (i & 3))) & 255u)];
+                    }
+                }
+                cand_d[c] = accum;
             }
         } else {
             constexpr int U = S::kWide ? 2 : kGatherRows;
@@ -658,7 +697,7 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
         }
         return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream);
     }
-    if constexpr (DT != DT_SQ8) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
+    if constexpr (DT != DT_SQ8 && DT != DT_PQ) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
     return DANN_EUNSUPPORTED;
 }
 
@@ -680,10 +719,8 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    const bool is_int = a.ix.dtype == DT_U8 || a.ix.dtype == DT_I8 || a.ix.dtype == DT_SQ8;
     const uint32_t qcap = a.l_value + a.ix.nstart;
-    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, is_int ? a.ix.layer_bytes : a.ix.dim * 4u)
-        .total;
+    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix)).total;
 }
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
@@ -708,6 +745,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
         case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream);
         case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream);
         case DT_SQ8: return launch_dt<DT_SQ8>(a, qcap, lds, stream);
+        case DT_PQ: return launch_dt<DT_PQ>(a, qcap, lds, stream);
     }
     set_error("bad dtype %d", a.ix.dtype);
     return DANN_EINVAL;

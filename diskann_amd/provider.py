@@ -12,10 +12,10 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16, U8, I8, SQ8, COSINE, INNER_PRODUCT, L2,
+from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16, U8, I8, SQ8, PQ, COSINE, INNER_PRODUCT, L2,
                    COSINE_NORMALIZED, IBC_ALL, IBC_NONE)
 
-NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8}
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8, PQ: np.uint8}
 STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32)])
 
 
@@ -47,21 +47,32 @@ class Provider:
     """diskann_inmem::Provider<Full<T>, u32> + DiskANNIndex, resident in one GPU's HBM."""
 
     def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, row_stride=0, device=-1,
-                 sq_scale=0.0, sq_shift_norm_sq=0.0):
+                 sq_scale=0.0, sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
         self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim  # SQ-8 rows carry a trailing f32 compensation
+        self.query_dtype, self.query_elems = NP_DTYPE[dtype], self.row_elems
+        pq_chunks = 0
+        if dtype == PQ:  # rows are PQ codes, queries stay full-precision f32
+            pq_offsets = np.ascontiguousarray(pq_offsets, dtype=np.uint32)
+            pq_chunks = pq_offsets.size - 1
+            self.row_elems = pq_chunks
+            self.query_dtype, self.query_elems = np.float32, self.dim
         sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.row_elems)
         self.num_start_points = sp.shape[0]
         cfg = Config(dtype, metric, self.dim, self.capacity, self.max_degree, self.num_start_points, row_stride,
-                     device, sq_scale, sq_shift_norm_sq)
+                     device, sq_scale, sq_shift_norm_sq, pq_chunks)
         h = C.c_void_p()
         check(_ffi.lib().dann_index_create(C.byref(cfg), _p(sp), sp.nbytes, C.byref(h)), "dann_index_create")
         self._h = h
         got = Config()
         check(_ffi.lib().dann_index_get_config(self._h, C.byref(got)), "dann_index_get_config")
         self.row_stride, self.device = got.row_stride, got.device
-        self.layer_bytes = _ffi.lib().dann_layer_bytes(dtype, self.dim)
+        self.layer_bytes = pq_chunks if dtype == PQ else _ffi.lib().dann_layer_bytes(dtype, self.dim)
+        if dtype == PQ:
+            piv = np.ascontiguousarray(pq_pivots, dtype=np.float32)
+            assert piv.shape == (256, self.dim)
+            check(_ffi.lib().dann_set_pq_table(self._h, _p(piv), _p(pq_offsets)), "dann_set_pq_table")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -182,7 +193,7 @@ class Provider:
     # -- DiskANNIndex::search -------------------------------------------------
     def search(self, params, queries, k=10):
         """nq independent Knn searches; returns (ids[nq,k], dists[nq,k], stats[nq])."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         nq = q.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dists = np.empty((nq, k), np.float32)

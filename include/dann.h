@@ -39,7 +39,12 @@ typedef enum {
      * (CompensatedVector<8>, diskann-quantization/src/scalar/vectors.rs:150-175); distances are
      * CompensatedSquaredL2 / CompensatedIP / CompensatedCosineNormalized (:171-465).  Queries are
      * compressed the same way (symmetric, diskann-providers/.../inmem/scalar.rs:261-320). */
-    DANN_SQ8 = 4
+    DANN_SQ8 = 4,
+    /* product-quantised rows: `pq_chunks` code bytes per row; queries are full-precision f32 vectors,
+     * distances are lookup-table sums (diskann-providers/src/model/pq/fixed_chunk_pq_table.rs:82-192).
+     * The pivot table is attached with dann_set_pq_table(); search / expand_beam only (re-rank the
+     * candidates on a full-precision index with dann_rerank_batch). */
+    DANN_PQ = 5
 } dann_dtype;
 
 /* == `#[repr(C)] enum Metric`, diskann-vector/src/distance/metric.rs:8-20 */
@@ -79,6 +84,7 @@ typedef struct {
     int32_t device;            /* HIP device ordinal, -1 = current                         */
     float sq_scale;            /* DANN_SQ8 only: ScalarQuantizer::scale()                   */
     float sq_shift_norm_sq;    /* DANN_SQ8 only: ScalarQuantizer::shift_square_norm()       */
+    uint32_t pq_chunks;        /* DANN_PQ only: code bytes per row (number of PQ chunks)    */
 } dann_config;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs:14-41) */
@@ -245,6 +251,10 @@ int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, 
                         uint64_t* out_num_points);
 int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t first_slot, uint32_t n);
 int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n);
+
+/* attach the PQ schema of a DANN_PQ index: pivots 256 x dim f32 row-major, chunk_offsets pq_chunks + 1
+ * (FixedChunkPQTable::new, fixed_chunk_pq_table.rs:105-140) */
+int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets);
 
 /* ---- scalar quantisation: ScalarQuantizer::compress_into for 8 bits
  * (diskann-quantization/src/scalar/quantizer.rs:189-236, 395-430): code = round(clamp((x - shift) *

@@ -12,11 +12,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdann_oracle.so")
 
-F32, F16, U8, I8, SQ8 = 0, 1, 2, 3, 4
+F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
 
-NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8}
+NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8, PQ: np.uint8}
 
 
 def build(force=False):
@@ -43,6 +43,9 @@ class OrcIndex(C.Structure):
         ("adj", C.c_void_p),
         ("sq_scale", C.c_float),
         ("sq_shift_norm_sq", C.c_float),
+        ("pq_pivots", C.c_void_p),
+        ("pq_offsets", C.c_void_p),
+        ("pq_chunks", C.c_uint32),
     ]
 
 
@@ -124,13 +127,23 @@ class Index:
     """Host-side arrays in the diskann-inmem layout + the oracle's algorithms over them."""
 
     def __init__(self, dtype, metric, dim, capacity, max_degree, start_rows, row_stride=None, sq_scale=0.0,
-                 sq_shift_norm_sq=0.0):
+                 sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
         self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim
+        self.query_dtype = NP_DTYPE[dtype]
+        self.query_elems = self.row_elems
+        self.pq_pivots = self.pq_offsets = None
+        pq_chunks = 0
+        if dtype == PQ:
+            self.pq_pivots = np.ascontiguousarray(pq_pivots, dtype=np.float32)
+            self.pq_offsets = np.ascontiguousarray(pq_offsets, dtype=np.uint32)
+            pq_chunks = self.pq_offsets.size - 1
+            self.row_elems = pq_chunks
+            self.query_dtype, self.query_elems = np.float32, self.dim
         start_rows = np.ascontiguousarray(start_rows, dtype=NP_DTYPE[dtype]).reshape(-1, self.row_elems)
         self.nstart = start_rows.shape[0]
-        self.row_bytes = layer_bytes(dtype, dim)
+        self.row_bytes = pq_chunks if dtype == PQ else layer_bytes(dtype, dim)
         self.row_stride = int(row_stride) if row_stride else self.row_bytes
         n = self.capacity + self.nstart
         self.rows = np.zeros((n, self.row_stride), dtype=np.uint8)
@@ -138,7 +151,9 @@ class Index:
         for i in range(self.nstart):
             self.set_row(self.capacity + i, start_rows[i])
         self._c = OrcIndex(dtype, metric, self.dim, self.capacity, self.nstart, self.max_degree,
-                           self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data, sq_scale, sq_shift_norm_sq)
+                           self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data, sq_scale, sq_shift_norm_sq,
+                           self.pq_pivots.ctypes.data if dtype == PQ else None,
+                           self.pq_offsets.ctypes.data if dtype == PQ else None, pq_chunks)
 
     # -- storage ------------------------------------------------------------
     def set_row(self, slot, vec):
@@ -185,7 +200,7 @@ class Index:
         return n, ids, dists, stats
 
     def search_batch(self, queries, l_value, beam_width=1, k=10, threads=1, fast=False, timing=False):
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         nq = q.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dists = np.empty((nq, k), np.float32)

@@ -379,6 +379,7 @@ inline int eff_metric(int dtype, int metric) {
 }
 inline size_t elem_size(int dtype) { return dtype == ORC_F32 ? 4 : dtype == ORC_F16 ? 2 : 1; }
 inline size_t layer_bytes(int dtype, size_t dim) { return dim * elem_size(dtype) + (dtype == ORC_SQ8 ? 4 : 0); }
+inline size_t query_bytes(const orc_index* ix) { return ix->dtype == ORC_PQ ? (size_t)ix->dim * 4 : layer_bytes(ix->dtype, ix->dim); }
 
 /* CompensatedSquaredL2 / CompensatedIP / CompensatedCosineNormalized
  * (diskann-quantization/src/scalar/vectors.rs:216-245, 306-370, 403-465) on 8-bit codes with the
@@ -505,6 +506,7 @@ struct QueryCtx {
     const View& v;
     const void* q;
     std::vector<float> q32; /* f16 query widened once, full.rs:421-423 */
+    std::vector<float> lut; /* PQ: populate_chunk_distances_impl, once per query */
     bool fast;
     QueryCtx(const View& view, const void* query, bool fast_) : v(view), q(query), fast(fast_) {
         if (v.ix->dtype == ORC_F16) {
@@ -512,8 +514,14 @@ struct QueryCtx {
             const uint16_t* h = (const uint16_t*)query;
             for (uint32_t i = 0; i < v.ix->dim; ++i) q32[i] = f16_to_f32(h[i]);
         }
+        if (v.ix->dtype == ORC_PQ) {
+            lut.resize((size_t)v.ix->pq_chunks * 256);
+            orc_pq_build_lut(v.metric, v.ix->pq_pivots, nullptr, v.ix->pq_offsets, v.ix->pq_chunks, v.ix->dim,
+                             (const float*)query, lut.data());
+        }
     }
     float eval(uint32_t id) const {
+        if (v.ix->dtype == ORC_PQ) return orc_pq_lookup(lut.data(), v.row(id), v.ix->pq_chunks);
         if (v.ix->dtype == ORC_SQ8)
             return sq8_similarity(v.metric, (const uint8_t*)q, v.row(id), v.ix->dim, v.ix->sq_scale, v.ix->sq_shift_norm_sq);
         float raw = fast ? query_raw_fast(v.ix->dtype, v.metric, q32.data(), q, v.row(id), v.ix->dim)
@@ -845,7 +853,7 @@ int32_t orc_search_batch(const orc_index* ix, const void* queries, uint32_t nq, 
                          uint64_t* per_query_ns) {
     if (!ix || !queries) return -1;
     if (threads == 0) threads = 1;
-    size_t qbytes = layer_bytes(ix->dtype, ix->dim);
+    size_t qbytes = query_bytes(ix);
     std::vector<int32_t> status(threads, 0);
     auto work = [&](uint32_t t) {
         /* PartitionIter: contiguous ranges (search/api.rs:410-419) */

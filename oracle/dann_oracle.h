@@ -25,7 +25,14 @@
 extern "C" {
 #endif
 
-enum { ORC_F32 = 0, ORC_F16 = 1, ORC_U8 = 2, ORC_I8 = 3, ORC_SQ8 = 4 /* dim code bytes + f32 compensation */ };
+enum {
+    ORC_F32 = 0,
+    ORC_F16 = 1,
+    ORC_U8 = 2,
+    ORC_I8 = 3,
+    ORC_SQ8 = 4, /* dim code bytes + f32 compensation */
+    ORC_PQ = 5   /* pq_chunks code bytes; f32 queries; lookup-table distances */
+};
 enum { ORC_COSINE = 0, ORC_INNER_PRODUCT = 1, ORC_L2 = 2, ORC_COSINE_NORMALIZED = 3 };
 enum { ORC_IBC_NONE = 0, ORC_IBC_ALL = 0xFFFFFFFFu }; /* else Max(n) */
 
@@ -47,6 +54,9 @@ typedef struct {
     uint32_t* adj;
     float sq_scale;          /* ORC_SQ8: ScalarQuantizer::scale() */
     float sq_shift_norm_sq;  /* ORC_SQ8: shift_square_norm()      */
+    const float* pq_pivots;      /* ORC_PQ: 256 x dim */
+    const uint32_t* pq_offsets;  /* ORC_PQ: pq_chunks + 1 */
+    uint32_t pq_chunks;
 } orc_index;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs) */

@@ -170,3 +170,38 @@ def test_quantised_search_with_rerank(fdtype):
         order = np.argsort(dd, kind="stable")[:k]
         assert [c[i] for i in order] == [int(x) for x in ids[q, :len(order)]]
         assert np.array_equal(bits(dd[order]), bits(d[q, :len(order)]))
+
+
+@pytest.mark.parametrize("metric,nchunks", [(oracle.L2, 16), (oracle.INNER_PRODUCT, 10), (oracle.L2, 37)])
+def test_pq_beam_search(metric, nchunks):
+    """Beam search over PQ codes (lookup table built per query in LDS, entries added in chunk order)
+    equals the oracle's search with the same table: ids, distances, cmps, hops."""
+    rng = np.random.default_rng(70 + nchunks)
+    n, dim, R = 3000, 100, 16
+    bounds = np.linspace(0, dim, nchunks + 1).round().astype(np.uint32)
+    bounds[0], bounds[-1] = 0, dim
+    pivots = rng.standard_normal((256, dim)).astype(np.float32)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    codes = np.empty((n, nchunks), np.uint8)
+    for c in range(nchunks):
+        s, e = bounds[c], bounds[c + 1]
+        d = ((data[:, None, s:e] - pivots[None, :, s:e]) ** 2).sum(-1)
+        codes[:, c] = d.argmin(1)
+    adj = random_graph(rng, n, R)
+    oix = oracle.Index(oracle.PQ, metric, dim, n, R, codes[:1], pq_pivots=pivots, pq_offsets=bounds)
+    oix.set_rows(0, codes)
+    oix.adj[:] = adj
+    gix = da.Provider(da.PQ, metric, dim, n, R, codes[:1], pq_pivots=pivots, pq_offsets=bounds)
+    gix.set_elements(0, codes)
+    gix.upload_graph(adj)
+    q = rng.standard_normal((32, dim)).astype(np.float32)
+    for L, W in ((10, 1), (48, 1), (48, 3), (150, 2)):
+        oi, od, oc, ost = oix.search_batch(q, L, W, 10)
+        gi, gd, gst = gix.search(da.Knn(L, W), q, 10)
+        assert np.array_equal(oi, gi), (L, W)
+        assert np.array_equal(bits(od), bits(gd)), (L, W)
+        assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"])
+    # the build path is not defined on PQ rows
+    with pytest.raises(da.DannError) as e:
+        gix.insert_batch(da.build_config(4, 8, 10), [0])
+    assert e.value.status in (da._ffi.EUNSUPPORTED, da._ffi.EINVAL)
