@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sq8", action="store_true")
+    ap.add_argument("--no-pq", action="store_true")
+    ap.add_argument("--pq-chunks", type=int, default=16)
     ap.add_argument("--sharded-build", action="store_true",
                     help="N>1: build with diskann_amd.sharding.build_sharded (batch partitioned across ranks, RCCL "
                          "all-gather of the pending adjacency rows) instead of one independent build per rank")
@@ -306,6 +308,12 @@ def main():
                                                           medoid, k, W, chosen, prov)
             except Exception as e:  # never lose the headline line over the secondary config
                 out["other_configs"]["sq8"] = {"error": str(e)[:200]}
+        if not args.no_pq:
+            try:
+                out["other_configs"]["pq"] = pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt,
+                                                        medoid, k, W, prov)
+            except Exception as e:
+                out["other_configs"]["pq"] = {"error": str(e)[:200]}
         # HBM traffic per launch from the committed PMC pass (rocprofv3 cannot run inside bench.py);
         # only reported when the profiled workload is this workload.
         try:
@@ -392,6 +400,68 @@ def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoi
                           "mean_cmps": float(st[:, 0].mean()), "ms_per_100k_queries": dt * 1e3 * 1e5 / args.nq,
                           "algorithmic_bytes_per_query": alg / args.nq}
     return res
+
+
+def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, full_prov):
+    """PQ codes + the f32 index's graph, lookup-table beam search, Rerank on the f32 rows.  Codebook
+    training (k-means per chunk, torch, harness only) is outside the hot path."""
+    nch, dim = args.pq_chunks, args.dim
+    bounds = np.linspace(0, dim, nch + 1).round().astype(np.uint32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    sample = base[torch.randperm(args.n, generator=g, device=dev)[:min(args.n, 131072)]]
+    pivots = torch.zeros((256, dim), device=dev)
+    codes = torch.empty((args.n, nch), dtype=torch.uint8, device=dev)
+    for c in range(nch):
+        s, e = int(bounds[c]), int(bounds[c + 1])
+        x = sample[:, s:e]
+        cent = x[torch.randperm(x.shape[0], generator=g, device=dev)[:256]].clone()
+        for _ in range(10):
+            a = torch.cdist(x, cent).argmin(1)
+            for_sum = torch.zeros_like(cent).index_add_(0, a, x)
+            cnt = torch.bincount(a, minlength=256).clamp(min=1).unsqueeze(1)
+            cent = for_sum / cnt
+        pivots[:, s:e] = cent
+        for lo in range(0, args.n, 262144):
+            codes[lo:lo + 262144, c] = torch.cdist(base[lo:lo + 262144, s:e], cent).argmin(1).to(torch.uint8)
+    codes_h = codes.cpu().numpy()
+    prov = da.Provider(da.PQ, da.L2, dim, args.n, args.max_degree, codes_h[medoid:medoid + 1], device=local,
+                       pq_pivots=pivots.cpu().numpy(), pq_offsets=bounds)
+    prov.set_elements(0, codes_h)
+    prov.upload_graph(full_prov.download_graph())
+    d_st = torch.empty((args.nq, 4), dtype=torch.int32, device=dev)
+    d_out = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
+    d_outd = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
+
+    def run_rr(L):
+        cand = torch.empty((args.nq, L), dtype=torch.int32, device=dev)
+        cd = torch.empty((args.nq, L), dtype=torch.float32, device=dev)
+        _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), args.nq, L, W, L,
+                                                C.c_void_p(cand.data_ptr()), C.c_void_p(cd.data_ptr()),
+                                                C.c_void_p(d_st.data_ptr())), "dann_search_batch_device")
+        _ffi.check(lib.dann_rerank_batch_device(full_prov._h, C.c_void_p(queries.data_ptr()), args.nq,
+                                                C.c_void_p(cand.data_ptr()), L, k, C.c_void_p(d_out.data_ptr()),
+                                                C.c_void_p(d_outd.data_ptr())), "dann_rerank_batch_device")
+    chosen, rec = None, 0.0
+    for L in [16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]:
+        run_rr(L)
+        rec = recall_at_k(d_out.cpu().numpy().view(np.uint32), gt, k)
+        chosen = L
+        if rec >= args.target_recall:
+            break
+    st = d_st.cpu().numpy().view(np.uint32)
+    for _ in range(2):
+        run_rr(chosen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        run_rr(chosen)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    alg = (int(st[:, 0].sum()) * nch + int(st[:, 1].sum()) * (args.max_degree + 1) * 4 + args.nq * chosen * dim * 4)
+    return {"chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
+            "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()),
+            "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)"}
 
 
 def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
