@@ -75,20 +75,10 @@ static int32_t timed(dann_index* idx, int which, F&& f) {
     return DANN_OK;
 }
 
-uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t beam) {
+uint32_t auto_visited_entries(const dann_index* idx, uint32_t, uint32_t) {
+    if (idx->visited_bits >= 64) return std::min<uint32_t>((idx->visited_bits + 63u) / 64u * 64u, 32768u);
     if (idx->visited_bits) return 1u << idx->visited_bits;
-    // Visited ids == cmps.  Measured on Vamana graphs (R = 32): cmps ~= R * (0.55 L + 12), i.e.
-    // well below hops * degree because about half the neighbours of an expanded node were seen
-    // before.  Size the LDS table for 1.25x that at <= 75 % load; rarer, larger queries continue
-    // in a global-memory spill table (search_kernels.hip), so this only trades occupancy
-    // (LDS per query) against the spill rate -- never correctness.
-    const double est = (double)idx->cfg.max_degree * (0.55 * (double)(l_value + beam) + 12.0) +
-                       (double)idx->cfg.num_start_points;
-    uint64_t entries = (uint64_t)(1.25 * est / 0.75) + 63;
-    entries = entries / 64 * 64;
-    if (entries < 256) entries = 256;
-    if (entries > 32768) entries = 32768;
-    return (uint32_t)entries;
+    return 0;  // sized per launch by search_with_retry (search_kernels.hip)
 }
 
 }  // namespace dann
@@ -698,9 +688,8 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i) {
         if (stats[i].status) {
-            set_error("query %u: per-query scratch exhausted (visited table %u entries); raise it with "
-                      "dann_set_visited_bits",
-                      i, auto_visited_entries(idx, l_value, beam_width));
+            set_error("query %u: per-query scratch exhausted (visited table and spill pool); raise the table "
+                      "size with dann_set_visited_bits", i);
             return DANN_EOVERFLOW;
         }
     }
@@ -1015,7 +1004,7 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
 
 // ---- diagnostics -----------------------------------------------------------------------------
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) {
-    if (!idx || which < 0 || which > 3) return DANN_EINVAL;
+    if (!idx || which < 0 || which > 4) return DANN_EINVAL;
     if (total_ms) *total_ms = idx->clocks[which].total_ms;
     if (launches) *launches = idx->clocks[which].launches;
     return DANN_OK;
@@ -1028,7 +1017,8 @@ int32_t dann_kernel_time_reset(dann_index* idx) {
 }
 
 int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) {
-    if (!idx || (bits != 0 && (bits < 6 || bits > 15))) return DANN_EINVAL;
+    // 0 = automatic; 6..15 = log2(entries); >= 64 = explicit entry count (rounded up to a multiple of 64)
+    if (!idx || (bits != 0 && bits < 64 && (bits < 6 || bits > 15)) || bits > 32768) return DANN_EINVAL;
     idx->visited_bits = bits;
     return DANN_OK;
 }

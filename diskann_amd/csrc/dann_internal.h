@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/dann.h"
@@ -86,7 +87,14 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream);
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);
+// explicit table size set with dann_set_visited_bits, or 0 = let search_with_retry size it
 uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t beam);
+// per (L, beam, mode) sizing state of the LDS visited table: cap_ids = 90th percentile of the
+// comparisons per query seen in earlier launches (0 = none yet, use the prior)
+struct VisitedCalib {
+    uint32_t cap_ids = 0;
+    uint64_t calls = 0;
+};
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
                            const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);
@@ -114,12 +122,13 @@ struct dann_index {
     uint32_t* d_pq_offsets = nullptr;
     uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
     size_t fail_cap = 0;
-    uint32_t* d_spill = nullptr;   // spill pool + counter (last word)
+    uint32_t* d_spill = nullptr;   // spill tables | counter (+pad) | busy flags | cmps histogram
+    std::unordered_map<uint64_t, dann::VisitedCalib> calib;
     uint32_t spill_slices = 0, spill_bits = 0;
     void* build_scratch = nullptr;            // owned by build_kernels.hip
     void (*build_scratch_free)(void*) = nullptr;
     uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
-    dann::KernelClock clocks[4];
+    dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries)
     std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
     // one stream, one pair of events and one set of scratch buffers per index: calls that launch
     // work are serialised per handle (they would serialise on the stream anyway)

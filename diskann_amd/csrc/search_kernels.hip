@@ -30,6 +30,9 @@
 //      through an LDS staging buffer.
 // HBM traffic per query = cmps * row bytes + hops * adjacency row; everything else stays
 // in registers/LDS.
+#include <algorithm>
+#include <cmath>
+
 #include "dann_device.h"
 #include "dann_internal.h"
 
@@ -101,6 +104,19 @@ __device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t size, uint32_t id
         if (old == id) return kPresent;
         h = (h + 1 == size) ? 0u : h + 1;
     }
+}
+// Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
+// every probe is an agent-scope atomic, and the table is wiped with write-through (sc1) 16-byte
+// stores drained by s_waitcnt before the busy flag is released -- no release/acquire fences, which
+// cost microseconds each at this occupancy (MI355X_MICROARCH.md, inter-workgroup visibility).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void spill_wipe(uint32_t* table, uint32_t entries, uint32_t lane) {
+    const u32x4 e = {kEmpty, kEmpty, kEmpty, kEmpty};
+    for (uint32_t i = lane * 4u; i < entries; i += kWave * 4u) {
+        uint32_t* p = table + i;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32_t shift, uint32_t id) {
     uint32_t h = (id * 2246822519u) >> shift;
@@ -372,7 +388,18 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 if (!spill) {
                     uint32_t slice = kEmpty;
                     if (a.spill) {
-                        if (lane == 0) slice = atomicAdd(a.spill_next, 1u);
+                        // slices are recycled inside a launch: busy flag per slice, rotating start
+                        if (lane == 0) {
+                            uint32_t* busy = a.spill_next + 16;
+                            uint32_t s = atomicAdd(a.spill_next, 1u) % a.spill_slices;
+                            for (uint32_t t = 0; t < 2u * a.spill_slices; ++t) {
+                                if (atomicCAS(&busy[s], 0u, 1u) == 0u) {
+                                    slice = s;
+                                    break;
+                                }
+                                s = (s + 1 == a.spill_slices) ? 0u : s + 1;
+                            }
+                        }
                         slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
                     }
                     if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
@@ -521,9 +548,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             // visited := ids of in_range only (range_search.rs:297-301)
             __syncthreads();
             for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
-            if (spill)
-                for (uint32_t i = lane; i < spill_size; i += kWave) spill[i] = kEmpty;
-            __threadfence();
+            if (spill) spill_wipe(spill, spill_size, lane);
             __syncthreads();
             lds_open = true;
             ht_count = 0;
@@ -542,7 +567,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             while (!status && front < nr && nr < a.range_max) {
                 // next beam: up to W ids from the front of the frontier (== in_range in arrival order)
                 uint32_t nb = nr - front < W ? nr - front : W;
-                __threadfence();
+                __threadfence_block();  // rids[] written and re-read by this wave only
                 if (lane < nb) beam[lane] = rids[front + lane];
                 front += nb;
                 __syncthreads();
@@ -575,7 +600,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         (void)max_ret;
         // post-process: start points dropped, inner/outer radius filter, output buffer capacity k
         if (!status && a.out_ids) {
-            __threadfence();
+            __threadfence_block();
             uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
             float* od = a.out_dists + (uint64_t)qi * a.k;
             for (uint32_t i0 = 0; i0 < nr; i0 += kWave) {
@@ -609,7 +634,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 #endif
     if (spill) {  // hand the spill table back clean
         __syncthreads();
-        for (uint32_t i = lane; i < spill_size; i += kWave) spill[i] = kEmpty;
+        spill_wipe(spill, spill_size, lane);
+        __syncthreads();
+        if (lane == 0) atomicExch(a.spill_next + 16 + (uint32_t)((spill - a.spill) >> a.spill_bits), 0u);
     }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
     uint32_t written = range_written;
@@ -723,6 +750,44 @@ size_t search_lds_bytes(const SearchArgs& a) {
     return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix)).total;
 }
 
+// ---- sizing of the LDS visited table ---------------------------------------------------------
+// The table trades occupancy (LDS per query) against probe length and the spill rate; results
+// never depend on it.  Measured on MI355X (1M x 128 f32, R = 32, L = 10..250): LDS is allocated in
+// 1280-byte granules (128 per CU), beyond 16 queries per CU extra occupancy buys less than a
+// sparser table, and the best size sits at the top of the occupancy step that holds about the
+// 90th percentile of comparisons per query at 75 % load.
+constexpr uint32_t kLdsGranule = 1280, kLdsGranules = 128, kUsefulWaves = 16, kHistBins = 512;
+
+uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids) {
+    a.ht_entries = 0;
+    const int64_t other = (int64_t)search_lds_bytes(a);
+    uint64_t need = ((uint64_t)((double)cap_ids / 0.75) + 63) / 64 * 64;
+    need = std::min<uint64_t>(std::max<uint64_t>(need, 256), 32768);
+    const uint64_t granules = ((uint64_t)other + need * 4 + kLdsGranule - 1) / kLdsGranule;
+    if (granules > kLdsGranules) return (uint32_t)need;
+    const uint32_t waves = std::min<uint32_t>(kLdsGranules / (uint32_t)granules, kUsefulWaves);
+    const int64_t top = ((int64_t)(kLdsGranules / waves) * kLdsGranule - other) / 4 / 64 * 64;
+    return (uint32_t)std::min<int64_t>(std::max<int64_t>(top, (int64_t)need), 32768);
+}
+
+// prior for a (L, beam) never seen on this index: comparisons per query ~= 4.3 R (L + W)^0.55 on
+// Vamana graphs (about half of an expanded node's neighbours were seen before), 90th pct ~= 1.3x
+uint32_t prior_visited_cap(const SearchArgs& a) {
+    const double l = (double)(a.range_ids ? std::max<uint32_t>(a.l_value, 64) : a.l_value) + a.beam_width;
+    return (uint32_t)(1.3 * 4.3 * (double)a.ix.max_degree * pow(l, 0.55)) + a.ix.nstart;
+}
+
+__global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uint32_t* hist) {
+    __shared__ uint32_t h[kHistBins];
+    for (uint32_t i = threadIdx.x; i < kHistBins; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+        if (!stats[t].status) atomicAdd(&h[min(stats[t].cmps / 64u, kHistBins - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kHistBins; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
 int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
     if (a.nq == 0) return DANN_OK;
     if (a.l_value == 0 || a.beam_width == 0) {
@@ -776,9 +841,10 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     uint32_t* lists[2] = {idx->d_fail + 4, idx->d_fail + 4 + idx->fail_cap};
     // failure flag in pinned host memory: written over the fabric only by a query that
     // overflows (rare), read by the host after the stream sync -- no memset / D2H copy
-    if (!idx->d_spill) {  // 256 spill tables of 2^14 ids (16 MiB), cleaned by their users
-        const uint32_t slices = 256, sbits = 14;
-        const size_t words = ((size_t)slices << sbits) + 16;
+    if (!idx->d_spill) {  // 512 spill tables of 2^14 ids (32 MiB), cleaned and released by their users
+        const uint32_t slices = 512, sbits = 14;
+        // tables | counter (+pad) | busy flags | cmps histogram
+        const size_t words = ((size_t)slices << sbits) + 16 + slices + kHistBins;
         DANN_HIP(hipMalloc((void**)&idx->d_spill, words * 4));
         DANN_HIP(hipMemsetAsync(idx->d_spill, 0xFF, words * 4, st));
         idx->spill_slices = slices;
@@ -788,7 +854,16 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     a.spill_slices = idx->spill_slices;
     a.spill_bits = idx->spill_bits;
     a.spill_next = idx->d_spill + ((size_t)idx->spill_slices << idx->spill_bits);
-    DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
+    DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
+    // automatic table size: calibrated 90th percentile for this (L, beam, mode), else the prior
+    const bool autosize = a.ht_entries == 0;
+    const uint64_t key = ((uint64_t)a.l_value << 32) | ((uint64_t)a.beam_width << 8) | (a.rec_ids ? 1u : 0u) |
+                         (a.range_ids ? 2u : 0u);
+    VisitedCalib* cal = nullptr;
+    if (autosize) {
+        cal = &idx->calib[key];
+        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a));
+    }
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;
     a.fail_flag = idx->h_flag;
@@ -807,6 +882,28 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     int32_t rc = timed_launch(a);
     if (rc != DANN_OK) return rc;
     idx->clocks[0].launches += 1;  // one logical search = one "launch" (+ rare retry launches, time included)
+    // recalibrate on calls 1, 2, 4, 8, ... of this key (a 512-bin histogram of cmps, 2 KiB D2H)
+    if (cal && a.stats && !a.qmap && !a.range_ids && a.nq >= 256) {
+        cal->calls += 1;
+        if ((cal->calls & (cal->calls - 1)) == 0) {
+            uint32_t* d_hist = a.spill_next + 16 + idx->spill_slices;
+            DANN_HIP(hipMemsetAsync(d_hist, 0, kHistBins * 4, st));
+            hipLaunchKernelGGL(cmps_hist_kernel, dim3(std::min<uint32_t>((a.nq + 255) / 256, 256)), dim3(256), 0, st,
+                               a.stats, a.nq, d_hist);
+            uint32_t hist[kHistBins];
+            DANN_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+            DANN_HIP(hipStreamSynchronize(st));
+            uint64_t total = 0, acc = 0;
+            for (uint32_t b = 0; b < kHistBins; ++b) total += hist[b];
+            for (uint32_t b = 0; b < kHistBins && total; ++b) {
+                acc += hist[b];
+                if (acc * 10 >= total * 9) {
+                    cal->cap_ids = (b + 1) * 64;
+                    break;
+                }
+            }
+        }
+    }
     if (!*hflag || !a.stats) return DANN_OK;
     // rare path: queries that exhausted LDS table + spill pool are re-run with a larger LDS table
     uint32_t n = a.nq;
@@ -820,14 +917,17 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         DANN_HIP(hipStreamSynchronize(st));
         if (h == 0) return DANN_OK;
         if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status
-        a.ht_entries *= 2;
+        a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
         a.qmap = qmap = lists[round & 1];
         a.nq = n = h;
         if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
-        DANN_HIP(hipMemsetAsync(a.spill_next, 0, 4, st));
+        DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
         *hflag = 0;
+        const double before = idx->clocks[0].total_ms;
         rc = timed_launch(a);
         if (rc != DANN_OK) return rc;
+        idx->clocks[4].total_ms += idx->clocks[0].total_ms - before;
+        idx->clocks[4].launches += h;
     }
 }
 

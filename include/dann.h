@@ -267,10 +267,12 @@ int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t d
 /* thread-local message of the last failing call on this thread; returns its length */
 int32_t dann_last_error(char* buf, uint64_t len);
 /* HIP-event time (ms) and launch count of the named kernel since the last reset.
- * which: 0 = beam search, 1 = gather distance, 2 = prune, 3 = back-edge */
+ * which: 0 = beam search, 1 = gather distance, 2 = prune, 3 = back-edge,
+ * 4 = beam-search retry launches (their time is also part of 0; `launches` counts re-run queries) */
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches);
 int32_t dann_kernel_time_reset(dann_index* idx);
-/* tuning knob: log2 of the per-query visited-table entries (0 = auto from L and degree) */
+/* tuning knob: per-query LDS visited-table size. 0 = auto from L and degree; 6..15 = log2(entries);
+ * 64..32768 = explicit entry count (rounded up to a multiple of 64). Never affects results. */
 int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
 
 #ifdef __cplusplus

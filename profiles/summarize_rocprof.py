@@ -16,7 +16,7 @@ def trace(db, out, top=25):
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent"])  # top_kernels durations are in us
         for name, calls, total, avg, pct in rows[:top]:
             short = name if len(name) < 160 else name[:157] + "..."
             w.writerow([short, calls, f"{total / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.3f}"])
