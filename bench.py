@@ -305,6 +305,38 @@ def main():
                 "single_query_L64_qps": 1.0 / lat,
                 "concurrent_1024_qps_at_L": 1024 / t1024,
             }
+            # the distance kernel on its own (ExpandBeam::expand_beam batched): 20 000 queries x 256
+            # random row ids -> n_evals x 512 B of gathers; kernel time by HIP events (clock 1)
+            gq, gl = 20000, 256
+            rng = np.random.default_rng(7)
+            gids = rng.integers(0, args.n, gq * gl, dtype=np.uint32)
+            goff = (np.arange(gq + 1, dtype=np.uint64) * gl)
+            qh = queries[:gq].cpu().numpy()
+            prov.expand_beam_batch(qh, gids, goff)
+            prov.kernel_time_reset()
+            for _ in range(3):
+                prov.expand_beam_batch(qh, gids, goff)
+            gms, gn = prov.kernel_time(1)
+            out["other_configs"]["distance_kernel"] = {
+                "kernel": "expand_beam_kernel", "evals_per_launch": gq * gl, "avg_kernel_ms": gms / max(gn, 1),
+                "algorithmic_GBps": gq * gl * row_bytes / (gms / max(gn, 1) * 1e-3) / 1e9,
+                "frac_of_hbm_peak": gq * gl * row_bytes / (gms / max(gn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+            # achievable streaming bandwidth on this box (device-to-device copy, read + write bytes)
+            buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(buf)
+            dst.copy_(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 2 * buf.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del buf, dst
+            out["roofline"]["measured_copy_GBps"] = copy_gbs
+            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         # configs[2], int8 scalar-quantised variant: same data compressed to SQ-8 (128 B + 4 B rows),
         # index built on the GPU over the codes, recall measured against the exact f32 ground truth
         if not args.no_sq8 and not args.no_extras:
