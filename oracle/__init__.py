@@ -85,6 +85,15 @@ def lib():
     L.orc_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp]
     L.orc_search_batch.restype = i32
     L.orc_search_batch.argtypes = [P(OrcIndex), vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, i32, vp]
+    f64 = C.c_double
+    L.orc_adaptive_l.restype = i32
+    L.orc_adaptive_l.argtypes = [u32, u32, u32, f64]
+    L.orc_inline_filter_search.restype = i32
+    L.orc_inline_filter_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, u32, f64, vp, vp, vp]
+    L.orc_multihop_search.restype = i32
+    L.orc_multihop_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, vp, vp, vp]
+    L.orc_filtered_range_search.restype = i32
+    L.orc_filtered_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, vp, u64, vp]
     L.orc_range_search.restype = i32
     L.orc_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, u64, vp]
     L.orc_expand_beam.restype = i32
@@ -225,6 +234,60 @@ class Index:
                                    max_returned, _p(ids), _p(dists), cap, _p(stats))
         if n < 0:
             raise RuntimeError(f"orc_range_search failed: {n}")
+        return ids[:n].copy(), dists[:n].copy(), stats
+
+    def filter_bits(self, match):
+        """bitmap over slots [0, capacity + nstart) from a boolean array / iterable of matching slot ids"""
+        nslots = self.capacity + self.nstart
+        m = np.asarray(match)
+        if m.dtype != np.bool_:
+            b = np.zeros(nslots, bool)
+            b[m.astype(np.int64)] = True
+            m = b
+        assert m.size == nslots
+        return np.packbits(m, bitorder="little").view(np.uint8).tobytes().ljust((nslots + 31) // 32 * 4, b"\0")
+
+    def _bits(self, match):
+        return np.frombuffer(self.filter_bits(match), np.uint32).copy()
+
+    def inline_filter_search(self, query, l_value, k, match, beam_width=1, adaptive=None):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        bits = self._bits(match)
+        ids = np.empty(k, np.uint32)
+        dists = np.empty(k, np.float32)
+        stats = np.zeros(3, np.uint32)
+        samples, scale = adaptive if adaptive else (0, 1.0)
+        n = lib().orc_inline_filter_search(C.byref(self._c), _p(q), l_value, beam_width, k, _p(bits), samples, scale,
+                                           _p(ids), _p(dists), _p(stats))
+        if n < 0:
+            raise RuntimeError(f"orc_inline_filter_search failed: {n}")
+        return n, ids, dists, stats
+
+    def multihop_search(self, query, l_value, k, match, beam_width=1):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        bits = self._bits(match)
+        ids = np.empty(k, np.uint32)
+        dists = np.empty(k, np.float32)
+        stats = np.zeros(3, np.uint32)
+        n = lib().orc_multihop_search(C.byref(self._c), _p(q), l_value, beam_width, k, _p(bits), _p(ids), _p(dists),
+                                      _p(stats))
+        if n < 0:
+            raise RuntimeError(f"orc_multihop_search failed: {n}")
+        return n, ids, dists, stats
+
+    def filtered_range_search(self, query, starting_l, radius, match, beam_width=1, inner_radius=None,
+                              initial_slack=1.0, range_slack=1.0, max_returned=0, out_cap=None):
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        bits = self._bits(match)
+        cap = out_cap or (max_returned if max_returned else self.capacity + self.nstart)
+        ids = np.empty(cap, np.uint32)
+        dists = np.empty(cap, np.float32)
+        stats = np.zeros(4, np.uint32)
+        n = lib().orc_filtered_range_search(C.byref(self._c), _p(q), starting_l, beam_width, radius,
+                                            int(inner_radius is not None), inner_radius or 0.0, initial_slack,
+                                            range_slack, max_returned, _p(bits), _p(ids), _p(dists), cap, _p(stats))
+        if n < 0:
+            raise RuntimeError(f"orc_filtered_range_search failed: {n}")
         return ids[:n].copy(), dists[:n].copy(), stats
 
     def expand_beam(self, query, ids):

@@ -956,6 +956,294 @@ int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starti
     return (int32_t)written;
 }
 
+/* ======================================================================
+ * filtered searches (diskann/src/graph/search/{inline_filter_search,multihop_filter_search,
+ * filtered_range_search}.rs through graph/ext/labeled.rs).  The QueryLabelProvider is a
+ * bitmap over slot ids: is_match(i) = bit i of filter_bits (start points included).
+ * ====================================================================== */
+namespace {
+inline bool is_match(const uint32_t* bits, uint32_t nslots, uint32_t id) {
+    return id < nslots && ((bits[id >> 5] >> (id & 31)) & 1u);
+}
+/* compute_adaptive_l, inline_filter_search.rs:283-301 (f64, truncating casts) */
+size_t compute_adaptive_l(size_t base_l, size_t visited, size_t matched, double max_multiplier) {
+    if (matched == 0 || visited == 0) return (size_t)((double)base_l * max_multiplier);
+    double specificity = (double)matched / (double)visited;
+    double multiplier;
+    if (specificity >= 0.5) multiplier = 1.0;
+    else if (specificity >= 0.1) multiplier = 2.0;
+    else multiplier = std::pow(2.0, -std::log10(specificity));
+    multiplier = std::min(std::max(multiplier, 1.0), max_multiplier);
+    return (size_t)((double)base_l * multiplier);
+}
+struct Matched {
+    uint32_t id;
+    float d;
+};
+/* inline_filter_search_internal, inline_filter_search.rs:166-281.  matched is returned sorted by
+ * distance; ORACLE TIE RULE: equal distances keep push order (sort_unstable_by leaves it open). */
+void inline_internal(const QueryCtx& qc, Queue& best, std::unordered_set<uint32_t>& visited, uint32_t beam_width,
+                     size_t l_search, const uint32_t* filter, uint32_t adaptive_samples, double adaptive_scale,
+                     SearchOut& out, std::vector<Matched>& matched) {
+    const View& v = qc.v;
+    const orc_index* ix = v.ix;
+    for (uint32_t p = ix->capacity; p < ix->capacity + ix->nstart; ++p) {
+        float d = qc.eval(p);
+        visited.insert(p);
+        best.insert(p, d);
+        if (is_match(filter, v.nslots(), p)) matched.push_back({p, d});
+    }
+    std::vector<uint32_t> beam;
+    std::vector<std::pair<uint32_t, float>> one_hop;
+    size_t sample_visited = 0, sample_matched = 0;
+    bool l_adjusted = false;
+    for (;;) {
+        beam.clear();
+        one_hop.clear();
+        uint32_t id;
+        float d;
+        while (beam.size() < beam_width && best.pop(&id, &d)) beam.push_back(id);
+        if (beam.empty()) break;
+        for (uint32_t b : beam) {
+            const uint32_t* adj;
+            uint32_t n = v.get_neighbors(b, &adj);
+            for (uint32_t j = 0; j < n; ++j) {
+                uint32_t nb = adj[j];
+                if (visited.insert(nb).second && nb < v.nslots()) one_hop.emplace_back(nb, qc.eval(nb));
+            }
+        }
+        for (auto& nb : one_hop) {
+            if (is_match(filter, v.nslots(), nb.first)) {
+                matched.push_back({nb.first, nb.second});
+                ++sample_matched;
+            }
+            best.insert(nb.first, nb.second);
+            ++sample_visited;
+        }
+        out.cmps += (uint32_t)one_hop.size();
+        out.hops += (uint32_t)beam.size();
+        if (adaptive_samples && !l_adjusted && sample_visited >= adaptive_samples) {
+            l_adjusted = true;
+            size_t new_l = compute_adaptive_l(l_search, sample_visited, sample_matched, adaptive_scale);
+            if (new_l > l_search) { /* SearchScratch::resize -> NeighborPriorityQueue::reconfigure, queue.rs:339-353 */
+                best.search_l = new_l;
+                best.capacity = new_l;
+                if (new_l < best.size()) {
+                    best.ids.resize(new_l);
+                    best.visited.resize(new_l);
+                    best.dist.resize(new_l);
+                    best.cursor = std::min(best.cursor, new_l);
+                }
+            }
+        }
+    }
+    std::stable_sort(matched.begin(), matched.end(), [](const Matched& a, const Matched& b) { return a.d < b.d; });
+}
+}  // namespace
+
+extern "C" {
+int32_t orc_adaptive_l(uint32_t base_l, uint32_t visited, uint32_t matched, double max_multiplier) {
+    return (int32_t)compute_adaptive_l(base_l, visited, matched, max_multiplier);
+}
+
+int32_t orc_inline_filter_search(const orc_index* ix, const void* query, uint32_t l_value, uint32_t beam_width,
+                                 uint32_t k, const uint32_t* filter_bits, uint32_t adaptive_samples,
+                                 double adaptive_scale, uint32_t* out_ids, float* out_dists, uint32_t* stats) {
+    if (!ix || !query || !filter_bits || l_value == 0 || beam_width == 0) return -1;
+    if (adaptive_samples && !(adaptive_scale >= 1.0)) return -1; /* AdaptiveLSearchError */
+    View v(ix);
+    QueryCtx qc(v, query, false);
+    Queue best((size_t)l_value + ix->nstart);
+    std::unordered_set<uint32_t> visited;
+    SearchOut so;
+    std::vector<Matched> matched;
+    inline_internal(qc, best, visited, beam_width, l_value, filter_bits, adaptive_samples, adaptive_scale, so, matched);
+    for (uint32_t i = 0; i < k; ++i) {
+        out_ids[i] = 0xFFFFFFFFu;
+        out_dists[i] = std::numeric_limits<float>::infinity();
+    }
+    /* matched_results.take(l_value) -> Translate (start points have no external id) -> first k */
+    uint32_t written = 0;
+    for (size_t i = 0; i < matched.size() && i < l_value && written < k; ++i) {
+        if (matched[i].id >= ix->capacity) continue;
+        out_ids[written] = matched[i].id;
+        out_dists[written] = matched[i].d;
+        ++written;
+    }
+    if (stats) {
+        stats[0] = so.cmps;
+        stats[1] = so.hops;
+        stats[2] = written;
+    }
+    return (int32_t)written;
+}
+
+/* MultihopFilterSearch, multihop_filter_search.rs:46-244 */
+int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_value, uint32_t beam_width, uint32_t k,
+                            const uint32_t* filter_bits, uint32_t* out_ids, float* out_dists, uint32_t* stats) {
+    if (!ix || !query || !filter_bits || l_value == 0 || beam_width == 0) return -1;
+    View v(ix);
+    QueryCtx qc(v, query, false);
+    Queue best((size_t)l_value + ix->nstart);
+    std::unordered_set<uint32_t> visited;
+    uint32_t cmps = 0, hops = 0;
+    for (uint32_t p = ix->capacity; p < ix->capacity + ix->nstart; ++p) {
+        visited.insert(p);
+        best.insert(p, qc.eval(p)); /* rejected start points stay in the queue; dropped in post-processing */
+    }
+    std::vector<uint32_t> beam;
+    std::vector<std::pair<uint32_t, float>> one_hop, two_hop;
+    std::vector<Matched> cand;
+    while (best.has_notvisited()) {
+        beam.clear();
+        one_hop.clear();
+        cand.clear();
+        two_hop.clear();
+        uint32_t id;
+        float d;
+        while (beam.size() < beam_width && best.pop(&id, &d)) beam.push_back(id);
+        for (uint32_t b : beam) {
+            const uint32_t* adj;
+            uint32_t n = v.get_neighbors(b, &adj);
+            for (uint32_t j = 0; j < n; ++j) {
+                uint32_t nb = adj[j];
+                if (visited.insert(nb).second && nb < v.nslots()) one_hop.emplace_back(nb, qc.eval(nb));
+            }
+        }
+        for (auto& nb : one_hop) {
+            if (is_match(filter_bits, v.nslots(), nb.first)) best.insert(nb.first, nb.second);
+            else cand.push_back({nb.first, nb.second});
+        }
+        cmps += (uint32_t)one_hop.size();
+        hops += (uint32_t)beam.size();
+        /* closest rejected nodes first (ORACLE TIE RULE: stable), at most max_degree / 2 of them */
+        std::stable_sort(cand.begin(), cand.end(), [](const Matched& a, const Matched& b) { return a.d < b.d; });
+        if (cand.size() > ix->max_degree / 2) cand.resize(ix->max_degree / 2);
+        /* expand_beam_accept_only: pred.eval_mut = is_match(id) && visited.insert(id) (labeled.rs:284-291) */
+        for (auto& c : cand) {
+            const uint32_t* adj;
+            uint32_t n = v.get_neighbors(c.id, &adj);
+            for (uint32_t j = 0; j < n; ++j) {
+                uint32_t nb = adj[j];
+                if (is_match(filter_bits, v.nslots(), nb) && visited.insert(nb).second && nb < v.nslots())
+                    two_hop.emplace_back(nb, qc.eval(nb));
+            }
+        }
+        for (auto& nb : two_hop) best.insert(nb.first, nb.second);
+        cmps += (uint32_t)two_hop.size();
+        hops += (uint32_t)cand.size();
+    }
+    for (uint32_t i = 0; i < k; ++i) {
+        out_ids[i] = 0xFFFFFFFFu;
+        out_dists[i] = std::numeric_limits<float>::infinity();
+    }
+    uint32_t written = 0;
+    size_t n = std::min(std::min(best.search_l, best.size()), (size_t)l_value + ix->nstart);
+    size_t taken = 0;
+    for (size_t i = 0; i < n && written < k; ++i) {
+        uint32_t id = best.ids[i];
+        /* .filter(not a rejected start point).take(l_value) then Translate drops every start point */
+        if (id >= ix->capacity && !is_match(filter_bits, v.nslots(), id)) continue;
+        if (taken++ >= l_value) break;
+        if (id >= ix->capacity) continue;
+        out_ids[written] = id;
+        out_dists[written] = best.dist[i];
+        ++written;
+    }
+    if (stats) {
+        stats[0] = cmps;
+        stats[1] = hops;
+        stats[2] = written;
+    }
+    return (int32_t)written;
+}
+
+/* FilteredRange, filtered_range_search.rs:111-330 */
+int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32_t starting_l, uint32_t beam_width,
+                                  float radius, int32_t has_inner, float inner_radius, float initial_slack,
+                                  float range_slack, uint64_t max_returned, const uint32_t* filter_bits,
+                                  uint32_t* out_ids, float* out_dists, uint64_t out_cap, uint32_t* stats) {
+    if (!ix || !query || !filter_bits || starting_l == 0 || beam_width == 0) return -1;
+    View v(ix);
+    QueryCtx qc(v, query, false);
+    Queue best((size_t)starting_l + ix->nstart);
+    std::unordered_set<uint32_t> visited;
+    SearchOut so;
+    std::vector<Matched> matched;
+    inline_internal(qc, best, visited, beam_width, starting_l, filter_bits, 0, 1.0, so, matched);
+    const uint64_t max_ret = max_returned ? max_returned : ~0ull;
+    std::vector<Matched> in_range;
+    size_t n = std::min(std::min(best.search_l, best.size()), (size_t)starting_l);
+    for (size_t i = 0; i < n; ++i)
+        if (best.dist[i] <= radius) in_range.push_back({best.ids[i], best.dist[i]});
+    for (auto& m : matched)
+        if (m.d <= radius) in_range.push_back(m);
+    /* fast_distance_total: distance then id; dedup_by equal ids (adjacent) */
+    std::sort(in_range.begin(), in_range.end(),
+              [](const Matched& a, const Matched& b) { return a.d < b.d || (a.d == b.d && a.id < b.id); });
+    in_range.erase(std::unique(in_range.begin(), in_range.end(),
+                               [](const Matched& a, const Matched& b) { return a.id == b.id; }),
+                   in_range.end());
+    std::vector<Matched> within;
+    for (auto& m : matched)
+        if (m.d <= radius) within.push_back(m);
+    bool second = false;
+    uint32_t cmps = so.cmps, hops = so.hops;
+    if (in_range.size() >= (size_t)((float)starting_l * initial_slack) && within.size() < max_ret) {
+        second = true;
+        visited.clear();
+        std::vector<uint32_t> frontier;
+        for (auto& m : in_range) {
+            visited.insert(m.id);
+            frontier.push_back(m.id);
+        }
+        size_t front = 0;
+        std::vector<uint32_t> beam;
+        std::vector<std::pair<uint32_t, float>> neighbors;
+        const float nav = radius * range_slack;
+        while (front < frontier.size() && within.size() < max_ret) {
+            beam.clear();
+            while (front < frontier.size() && beam.size() < beam_width) beam.push_back(frontier[front++]);
+            neighbors.clear();
+            for (uint32_t b : beam) {
+                const uint32_t* adj;
+                uint32_t len = v.get_neighbors(b, &adj);
+                for (uint32_t j = 0; j < len; ++j) {
+                    uint32_t nb = adj[j];
+                    if (visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, qc.eval(nb));
+                }
+            }
+            for (auto& nb : neighbors) {
+                if (nb.second <= nav) {
+                    frontier.push_back(nb.first);
+                    if (nb.second <= radius && is_match(filter_bits, v.nslots(), nb.first) && within.size() < max_ret)
+                        within.push_back({nb.first, nb.second});
+                }
+            }
+            cmps += (uint32_t)neighbors.size();
+            hops += (uint32_t)beam.size();
+        }
+    }
+    uint64_t written = 0, taken = 0;
+    for (auto& m : within) {
+        if (taken++ >= max_ret) break;
+        if (m.id >= ix->capacity) continue;
+        if (has_inner && m.d <= inner_radius) continue;
+        if (written >= out_cap) break;
+        out_ids[written] = m.id;
+        out_dists[written] = m.d;
+        ++written;
+    }
+    if (stats) {
+        stats[0] = cmps;
+        stats[1] = hops;
+        stats[2] = (uint32_t)written;
+        stats[3] = second ? 1u : 0u;
+    }
+    return (int32_t)written;
+}
+}  // extern "C"
+
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists) {
     if (!ix || !query) return -1;

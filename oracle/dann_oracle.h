@@ -116,6 +116,23 @@ int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starti
                          float range_slack, uint64_t max_returned, uint32_t* out_ids, float* out_dists,
                          uint64_t out_cap, uint32_t* stats);
 
+/* Filtered searches through graph/ext/labeled.rs (QueryLabelProvider == bitmap over slot ids, start points
+ * included; bit i of filter_bits[i >> 5]).
+ * InlineFilterSearch (search/inline_filter_search.rs:69-301): adaptive_samples == 0 means no AdaptiveL.
+ * MultihopFilterSearch (search/multihop_filter_search.rs:46-244).
+ * FilteredRange (search/filtered_range_search.rs:111-330): stats as orc_range_search but cmps/hops cumulative.
+ * ORACLE TIE RULE: the reference's sort_unstable_by(distance) calls are restated as stable sorts. */
+int32_t orc_adaptive_l(uint32_t base_l, uint32_t visited, uint32_t matched, double max_multiplier);
+int32_t orc_inline_filter_search(const orc_index* ix, const void* query, uint32_t l_value, uint32_t beam_width,
+                                 uint32_t k, const uint32_t* filter_bits, uint32_t adaptive_samples,
+                                 double adaptive_scale, uint32_t* out_ids, float* out_dists, uint32_t* stats);
+int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_value, uint32_t beam_width, uint32_t k,
+                            const uint32_t* filter_bits, uint32_t* out_ids, float* out_dists, uint32_t* stats);
+int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32_t starting_l, uint32_t beam_width,
+                                  float radius, int32_t has_inner, float inner_radius, float initial_slack,
+                                  float range_slack, uint64_t max_returned, const uint32_t* filter_bits,
+                                  uint32_t* out_ids, float* out_dists, uint64_t out_cap, uint32_t* stats);
+
 /* ExpandBeam::expand_beam (provider.rs:620-690) for a pre-filtered id list. */
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists);
