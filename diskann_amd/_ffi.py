@@ -30,6 +30,12 @@ class BuildConfig(C.Structure):
                 ("intra_batch_candidates", C.c_uint32), ("saturate_after_prune", C.c_uint32)]
 
 
+class Filter(C.Structure):
+    """dann_filter == a QueryLabelProvider (diskann/src/graph/ext/labeled.rs:44-68) as a bitmap over slots."""
+    _fields_ = [("mode", C.c_uint32), ("bits", C.c_void_p), ("stride_words", C.c_uint64),
+                ("adaptive_samples", C.c_uint32), ("adaptive_scale", C.c_double), ("matched_cap", C.c_uint32)]
+
+
 class SearchStats(C.Structure):
     _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32)]
 
@@ -67,6 +73,9 @@ SYMBOLS = {
     "dann_search_batch_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "dann_range_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _f32, _i32, _f32, _f32, _f32, _u32, _u32, _vp, _vp,
                                        _vp, _vp]),
+    "dann_filtered_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _P(Filter), _vp, _vp, _vp]),
+    "dann_filtered_range_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _f32, _i32, _f32, _f32, _f32, _u32, _u32,
+                                                _P(Filter), _vp, _vp, _vp, _vp]),
     "dann_rerank_batch": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
     "dann_rerank_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
     "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),

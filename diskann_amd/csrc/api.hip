@@ -9,6 +9,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "dann_device.h"
@@ -788,6 +789,234 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
             return DANN_EOVERFLOW;
         }
     return DANN_OK;
+}
+
+// ---- filtered searches ---------------------------------------------------------------------------
+// compute_adaptive_l (inline_filter_search.rs:283-301): f64, truncating casts, host libm
+static uint32_t adaptive_l(uint32_t base_l, uint32_t visited, uint32_t matched, double max_multiplier) {
+    if (matched == 0 || visited == 0) return (uint32_t)std::min<double>((double)base_l * max_multiplier, 4.0e9);
+    const double specificity = (double)matched / (double)visited;
+    double multiplier;
+    if (specificity >= 0.5) multiplier = 1.0;
+    else if (specificity >= 0.1) multiplier = 2.0;
+    else multiplier = std::pow(2.0, -std::log10(specificity));
+    multiplier = std::min(std::max(multiplier, 1.0), max_multiplier);
+    return (uint32_t)std::min<double>((double)base_l * multiplier, 4.0e9);
+}
+
+namespace {
+struct FilteredCall {
+    const void* queries;
+    uint32_t nq, l_value, beam, k;
+    const dann_filter* filter;
+    uint32_t* out_ids;
+    float* out_dists;
+    dann_search_stats* out_stats;
+    // FilteredRange only
+    bool range = false;
+    float radius = 0.f, inner_radius = 0.f, initial_slack = 1.f, range_slack = 1.f;
+    int32_t has_inner = 0;
+    uint32_t max_returned = 0;
+    uint32_t* out_second = nullptr;
+};
+}  // namespace
+
+static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
+    const dann_filter* f = c.filter;
+    if (!f || !f->bits || (f->mode != DANN_FILTER_INLINE && f->mode != DANN_FILTER_MULTIHOP)) {
+        set_error("filter: mode must be DANN_FILTER_INLINE or DANN_FILTER_MULTIHOP and bits non-null");
+        return DANN_EINVAL;
+    }
+    if (c.l_value == 0 || c.beam == 0) {
+        set_error("l_value and beam_width must be non-zero");
+        return DANN_EINVAL;
+    }
+    if (f->adaptive_samples && (f->mode != DANN_FILTER_INLINE || c.range)) {
+        set_error("AdaptiveL applies to InlineFilterSearch only");
+        return DANN_EINVAL;
+    }
+    if (f->adaptive_samples && !(f->adaptive_scale >= 1.0)) {
+        set_error("adaptive L scale factor must be >= 1.0");  // AdaptiveLSearchError::ScaleFactorLessThanOne
+        return DANN_EINVAL;
+    }
+    if (c.range && f->mode != DANN_FILTER_INLINE) {
+        set_error("FilteredRange runs on the inline filter search (filtered_range_search.rs:148-156)");
+        return DANN_EINVAL;
+    }
+    if (int32_t prc = pq_ready(idx)) return prc;
+    const uint32_t nslots = idx->nslots;
+    const uint64_t words = (nslots + 31) / 32;
+    if (f->stride_words && f->stride_words < words) {
+        set_error("filter stride %llu words is shorter than one bitmap (%llu words)",
+                  (unsigned long long)f->stride_words, (unsigned long long)words);
+        return DANN_EINVAL;
+    }
+    hipStream_t st = idx->stream;
+    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
+    const bool inl = f->mode == DANN_FILTER_INLINE;
+    SearchArgs a;
+    a.ix = idx->view();
+    a.l_value = c.l_value;
+    a.beam_width = c.beam;
+    a.k = c.k;
+    a.ht_entries = auto_visited_entries(idx, c.l_value, c.beam);
+    a.filter_mode = f->mode;
+    a.filter_stride = f->stride_words;
+    // AdaptiveL: table of new L for every (visited, matched) the decision can see
+    DevBuf btab;
+    const uint32_t cmax = std::max<uint32_t>((c.beam * idx->cfg.max_degree + 63u) & ~63u, (idx->cfg.num_start_points + 63u) & ~63u);
+    if (f->adaptive_samples) {
+        const uint64_t stride = (uint64_t)f->adaptive_samples + cmax;
+        if (stride * cmax > (64ull << 20)) {
+            set_error("AdaptiveL sample_count %u is too large for the decision table", f->adaptive_samples);
+            return DANN_EUNSUPPORTED;
+        }
+        std::vector<uint32_t> tab(stride * cmax);
+        uint32_t lmax = 0;
+        for (uint32_t dv = 0; dv < cmax; ++dv)
+            for (uint64_t m = 0; m < stride; ++m) {
+                const uint32_t v = f->adaptive_samples + dv;
+                const uint32_t nl = m <= v ? adaptive_l(c.l_value, v, (uint32_t)m, f->adaptive_scale) : c.l_value;
+                tab[dv * stride + m] = nl;
+                lmax = std::max(lmax, nl);
+            }
+        DANN_HIP(btab.alloc(tab.size() * 4));
+        DANN_HIP(hipMemcpyAsync(btab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+        DANN_HIP(hipStreamSynchronize(st));  // tab is a local
+        a.ad_samples = f->adaptive_samples;
+        a.ad_table = btab.as<uint32_t>();
+        a.ad_stride = (uint32_t)stride;
+        a.qcap_max = std::max(lmax, c.l_value + idx->cfg.num_start_points);
+    }
+    // per-launch scratch: the matched list and its sort keys; queries go through in chunks that keep it small
+    uint32_t m_cap = 0, key_cap = 0;
+    if (inl) {
+        m_cap = f->matched_cap ? f->matched_cap : std::min<uint32_t>(nslots, 8192);
+        m_cap = std::min<uint32_t>(std::max<uint32_t>(m_cap, 64), nslots);
+        key_cap = 1;
+        while (key_cap < m_cap + (c.range ? c.l_value : 0)) key_cap <<= 1;
+    }
+    uint64_t rcap = 0;
+    if (c.range) {
+        // matched_within_radius: every matched id of the first round within the radius (<= m_cap) plus the
+        // second round's appends, which stop at max_returned
+        rcap = c.max_returned ? c.max_returned : (uint64_t)4 * c.k + 1024;
+        rcap = std::max<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(rcap, m_cap), nslots), 1);
+    }
+    const uint64_t per_query = (uint64_t)m_cap * 8 + (uint64_t)key_cap * 8 + rcap * 8 + 64;
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c.nq, (1ull << 30) / per_query));
+    DevBuf bq, bi, bd, bs, bf, bmi, bmd, bk, bri, brd, bsec;
+    DANN_HIP(bq.alloc((size_t)chunk * qb + 16));
+    DANN_HIP(bi.alloc((size_t)chunk * c.k * 4));
+    DANN_HIP(bd.alloc((size_t)chunk * c.k * 4));
+    DANN_HIP(bs.alloc((size_t)chunk * sizeof(dann_search_stats)));
+    const size_t fwords = f->stride_words ? (size_t)f->stride_words * c.nq : (size_t)words;
+    DANN_HIP(bf.alloc(fwords * 4));
+    DANN_HIP(hipMemcpyAsync(bf.p, f->bits, fwords * 4, hipMemcpyHostToDevice, st));
+    if (inl) {
+        DANN_HIP(bmi.alloc((size_t)chunk * m_cap * 4));
+        DANN_HIP(bmd.alloc((size_t)chunk * m_cap * 4));
+        DANN_HIP(bk.alloc((size_t)chunk * key_cap * 8));
+        a.m_ids = bmi.as<uint32_t>();
+        a.m_d = bmd.as<float>();
+        a.m_keys = bk.as<unsigned long long>();
+        a.m_cap = m_cap;
+        a.key_cap = key_cap;
+    }
+    if (c.range) {
+        DANN_HIP(bri.alloc((size_t)chunk * rcap * 4));
+        DANN_HIP(brd.alloc((size_t)chunk * rcap * 4));
+        DANN_HIP(bsec.alloc((size_t)chunk * 4));
+        a.range_ids = bri.as<uint32_t>();
+        a.range_d = brd.as<float>();
+        a.range_second = bsec.as<uint32_t>();
+        a.range_cap = (uint32_t)rcap;
+        a.range_max = c.max_returned ? c.max_returned : 0xFFFFFFFFu;
+        a.range_thresh = (uint32_t)((float)c.l_value * c.initial_slack);
+        a.has_inner = c.has_inner ? 1u : 0u;
+        a.radius = c.radius;
+        a.inner_radius = c.inner_radius;
+        a.range_slack = c.range_slack;
+    }
+    a.out_ids = bi.as<uint32_t>();
+    a.out_dists = bd.as<float>();
+    a.stats = bs.as<dann_search_stats>();
+    a.queries = bq.p;
+    std::vector<dann_search_stats> stats(chunk);
+    for (uint32_t off = 0; off < c.nq; off += chunk) {
+        const uint32_t n = std::min(chunk, c.nq - off);
+        DANN_HIP(hipMemcpyAsync(bq.p, (const uint8_t*)c.queries + (size_t)off * qb, (size_t)n * qb, hipMemcpyHostToDevice, st));
+        a.nq = n;
+        a.filter = bf.as<uint32_t>() + (size_t)off * f->stride_words;
+        int32_t rc = search_with_retry(idx, a);
+        if (rc != DANN_OK) return rc;
+        DANN_HIP(hipMemcpyAsync(c.out_ids + (size_t)off * c.k, bi.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipMemcpyAsync(c.out_dists + (size_t)off * c.k, bd.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)n * sizeof(dann_search_stats), hipMemcpyDeviceToHost, st));
+        if (c.out_second)
+            DANN_HIP(hipMemcpyAsync(c.out_second + off, bsec.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        DANN_HIP(hipStreamSynchronize(st));
+        if (c.out_stats) memcpy(c.out_stats + off, stats.data(), (size_t)n * sizeof(dann_search_stats));
+        for (uint32_t i = 0; i < n; ++i)
+            if (stats[i].status) {
+                set_error("query %u: per-query scratch exhausted (matched list %u entries, result list %llu, visited "
+                          "table); raise dann_filter.matched_cap / out_cap", off + i, m_cap, (unsigned long long)rcap);
+                return DANN_EOVERFLOW;
+            }
+    }
+    return DANN_OK;
+}
+
+int32_t dann_filtered_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value,
+                                   uint32_t beam_width, uint32_t k, const dann_filter* filter, uint32_t* out_ids,
+                                   float* out_dists, dann_search_stats* out_stats) {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
+    FilteredCall c{queries, nq, l_value, beam_width, k, filter, out_ids, out_dists, out_stats};
+    return filtered_search(idx, c);
+}
+
+int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
+                                         uint32_t beam_width, float radius, int32_t has_inner_radius,
+                                         float inner_radius, float initial_slack, float range_slack,
+                                         uint32_t max_returned, uint32_t out_cap, const dann_filter* filter,
+                                         uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
+                                         uint32_t* out_second_round) {
+    CHECK_IDX(idx);
+    // RangeSearchError (range_search.rs:30-45, 93-131)
+    if (starting_l == 0 || beam_width == 0) {
+        set_error("l_value and beam width cannot be zero");
+        return DANN_EINVAL;
+    }
+    if (max_returned && max_returned < starting_l) {
+        set_error("max_returned must be greater than or equal to starting_l");
+        return DANN_EINVAL;
+    }
+    if (!(initial_slack >= 0.0f && initial_slack <= 1.0f)) {
+        set_error("initial_search_slack must be between 0 and 1.0");
+        return DANN_EINVAL;
+    }
+    if (!(range_slack >= 1.0f)) {
+        set_error("range_search_slack must be greater than or equal to 1.0");
+        return DANN_EINVAL;
+    }
+    if (has_inner_radius && inner_radius > radius) {
+        set_error("inner_radius must be less than or equal to radius");
+        return DANN_EINVAL;
+    }
+    if (nq == 0) return DANN_OK;
+    if (!queries || !out_ids || !out_dists || out_cap == 0) return DANN_EINVAL;
+    FilteredCall c{queries, nq, starting_l, beam_width, out_cap, filter, out_ids, out_dists, out_stats};
+    c.range = true;
+    c.radius = radius;
+    c.inner_radius = inner_radius;
+    c.initial_slack = initial_slack;
+    c.range_slack = range_slack;
+    c.has_inner = has_inner_radius;
+    c.max_returned = max_returned;
+    c.out_second = out_second_round;
+    return filtered_search(idx, c);
 }
 
 int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, const uint32_t* d_cand_ids,

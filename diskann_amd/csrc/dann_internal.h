@@ -52,35 +52,48 @@ struct IndexView {
 
 struct SearchArgs {
     IndexView ix;
-    const void* queries;     // nq rows of layer bytes, or nullptr when `qslots` is used
-    const uint32_t* qslots;  // insert-time search: query i = stored row qslots[i]
-    uint32_t nq;
-    uint32_t l_value;
-    uint32_t beam_width;
-    uint32_t k;
-    uint32_t ht_entries;     // per-query LDS visited-table entries (multiple of 64)
-    uint32_t* out_ids;       // nq x k (may be null in record mode)
-    float* out_dists;
-    dann_search_stats* stats;
-    uint32_t* rec_ids;       // nq x rec_stride (record mode) or null
-    float* rec_dists;
-    uint32_t rec_stride;
-    uint32_t* rec_n;
+    const void* queries = nullptr;     // nq rows of layer bytes, or nullptr when `qslots` is used
+    const uint32_t* qslots = nullptr;  // insert-time search: query i = stored row qslots[i]
+    uint32_t nq = 0;
+    uint32_t l_value = 0;
+    uint32_t beam_width = 0;
+    uint32_t k = 0;
+    uint32_t ht_entries = 0;     // per-query LDS visited-table entries (multiple of 64)
+    uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)
+    float* out_dists = nullptr;
+    dann_search_stats* stats = nullptr;
+    uint32_t* rec_ids = nullptr; // nq x rec_stride (record mode) or null
+    float* rec_dists = nullptr;
+    uint32_t rec_stride = 0;
+    uint32_t* rec_n = nullptr;
     // graph::search::Range (null range_ids = plain Knn): scratch list of in-range (id, dist) per query
-    uint32_t* range_ids;
-    float* range_d;
-    uint32_t* range_second;  // per query: did the second round run
-    uint32_t range_cap;      // entries per query in range_ids/range_d
-    uint32_t range_max;      // max_returned (0xFFFFFFFF = unlimited)
-    uint32_t range_thresh;   // (starting_l as f32 * initial_slack) as usize
-    uint32_t has_inner;
-    float radius, inner_radius, range_slack;
-    uint32_t* spill;         // pool of global-memory visited tables (all kEmpty between launches)
-    uint32_t* spill_next;    // pool allocation counter (zeroed before each launch)
-    uint32_t spill_slices;
-    uint32_t spill_bits;     // log2 entries per slice
-    uint32_t* fail_flag;     // set non-zero by any query that exhausts its scratch
-    const uint32_t* qmap;    // optional: process queries qmap[0..nq) (retry of overflowed queries)
+    uint32_t* range_ids = nullptr;
+    float* range_d = nullptr;
+    uint32_t* range_second = nullptr;  // per query: did the second round run
+    uint32_t range_cap = 0;      // entries per query in range_ids/range_d
+    uint32_t range_max = 0;      // max_returned (0xFFFFFFFF = unlimited)
+    uint32_t range_thresh = 0;   // (starting_l as f32 * initial_slack) as usize
+    uint32_t has_inner = 0;
+    float radius = 0.f, inner_radius = 0.f, range_slack = 1.f;
+    uint32_t* spill = nullptr;       // pool of global-memory visited tables (all kEmpty between launches)
+    uint32_t* spill_next = nullptr;  // pool allocation counter (zeroed before each launch)
+    uint32_t spill_slices = 0;
+    uint32_t spill_bits = 0;         // log2 entries per slice
+    uint32_t* fail_flag = nullptr;   // set non-zero by any query that exhausts its scratch
+    const uint32_t* qmap = nullptr;  // optional: process queries qmap[0..nq) (retry of overflowed queries)
+    // filtered searches (graph/ext/labeled.rs): QueryLabelProvider == bitmap over slot ids
+    uint32_t filter_mode = 0;        // 0 none, DANN_FILTER_INLINE, DANN_FILTER_MULTIHOP
+    const uint32_t* filter = nullptr;
+    uint64_t filter_stride = 0;      // words between the bitmaps of consecutive queries (0 = shared)
+    uint32_t* m_ids = nullptr;       // inline: matched_results per query in push order (nq x m_cap)
+    float* m_d = nullptr;
+    uint32_t m_cap = 0;
+    unsigned long long* m_keys = nullptr;  // sort scratch, nq x key_cap (key_cap a power of two)
+    uint32_t key_cap = 0;
+    uint32_t ad_samples = 0;         // AdaptiveL::sample_count (0 = none)
+    const uint32_t* ad_table = nullptr;  // new L for (visited - ad_samples, matched): row stride ad_stride
+    uint32_t ad_stride = 0;
+    uint32_t qcap_max = 0;           // largest queue capacity an adaptive resize can ask for (0 = l_value + nstart)
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream);

@@ -128,7 +128,52 @@ __device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32
     }
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM>
+// total order on non-NaN f32 as unsigned bits (NaN sorts last)
+__device__ __forceinline__ uint32_t ordered_bits(float d) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, d);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t o) {
+    return __builtin_bit_cast(float, (o >> 31) ? (o & 0x7FFFFFFFu) : ~o);
+}
+// ascending bitonic sort of n (power of two) 64-bit keys in global memory by one wave.  Keys written
+// by one lane are read by another in the next pass: agent-scope accesses (served by L2) + a drain.
+__device__ void wave_sort_keys(unsigned long long* keys, uint32_t n, uint32_t lane) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = lane; i < n; i += kWave) {
+                const uint32_t p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long y = __hip_atomic_load(keys + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        __hip_atomic_store(keys + i, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(keys + p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+__device__ __forceinline__ unsigned long long key_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void key_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t u32_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float f32_load(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// FILT = false compiles every filtered-search branch out (the plain Knn / Range / record kernels keep their
+// register budget); filtered launches use the generic-length instantiations.
+template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
 __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using S = Scheme<DT, OP, false>;
@@ -143,7 +188,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     const uint32_t qi = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;
     const uint32_t R = ix.max_degree;
     const uint32_t W = a.beam_width;
-    const uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207)
+    uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207); AdaptiveL may grow it
     const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
                                                                               : ((ix.nstart + 63u) & ~63u);
     const uint32_t qbytes = query_lds_bytes(ix);
@@ -215,6 +260,34 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     uint32_t* spill = nullptr;
     uint32_t spill_count = 0;
     const uint32_t spill_size = 1u << a.spill_bits, spill_mask = spill_size - 1u, spill_shift = 32u - a.spill_bits;
+
+    // filtered searches: QueryLabelProvider::is_match == one bit per slot (graph/ext/labeled.rs:44-68)
+    const uint32_t fmode = FILT ? a.filter_mode : 0u;
+    const uint32_t* fbits = a.filter ? a.filter + (uint64_t)qi * a.filter_stride : nullptr;
+    auto fmatch = [&](uint32_t id) -> bool { return id < ix.nslots && ((fbits[id >> 5] >> (id & 31u)) & 1u); };
+    uint32_t* m_ids = a.m_ids ? a.m_ids + (uint64_t)qi * a.m_cap : nullptr;
+    float* m_d = a.m_d ? a.m_d + (uint64_t)qi * a.m_cap : nullptr;
+    unsigned long long* m_keys = a.m_keys ? a.m_keys + (uint64_t)qi * a.key_cap : nullptr;
+    uint32_t nm = 0, sample_visited = 0, sample_matched = 0;
+    bool l_adjusted = false;
+    // inline filter search: accepted candidates of cand[0..nc) go to matched_results in emission order
+    auto append_matched = [&](uint32_t nc) -> uint32_t {
+        uint32_t added = 0;
+        for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+            const uint32_t c = c0 + lane;
+            const bool mt = c < nc && fmatch(cand_id[c]);
+            const uint64_t m = ballot64(mt);
+            const uint32_t r = nm + added + mbcnt(m);
+            if (mt && r < a.m_cap) {
+                m_ids[r] = cand_id[c];
+                m_d[r] = cand_d[c];
+            }
+            added += (uint32_t)__popcll(m);
+        }
+        nm += added;
+        if (nm > a.m_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+        return added;
+    };
 
     // distance of every candidate in cand_id[0..nc) -> cand_d
     auto gather = [&](uint32_t nc) {
@@ -371,7 +444,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     // expand `nb` nodes of beam[]: adjacency rows in pop order, ids in stored order, visited filter
     // (provider.rs:448-454); survivors go to cand_id[0..nc)
-    auto expand = [&](uint32_t nb) -> uint32_t {
+    // accept_only (expand_beam_accept_only, labeled.rs:196-214,284-291): ids that do not match the filter
+    // are skipped *before* the visited set sees them
+    auto expand = [&](uint32_t nb, bool accept_only = false) -> uint32_t {
         uint32_t nc = 0;
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t node = beam[b];
@@ -414,7 +489,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 const bool inb = j < len;
                 const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
-                if (inb && id != kEmpty) {
+                if (inb && id != kEmpty && (!accept_only || fmatch(id))) {
                     const int r = ht_visit(ht, ht_size, id, lds_open);
                     isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
                 }
@@ -440,7 +515,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         __syncthreads();
         gather(ns);
         __syncthreads();
-        cmps = ns;
+        // the filtered searches do not count the start points as comparisons (inline_filter_search.rs:186-197)
+        cmps = fmode ? 0u : ns;
+        if (fmode == DANN_FILTER_INLINE) append_matched(ns);
         for (uint32_t m0 = 0; m0 < ns; m0 += kWave) merge(m0, (ns - m0) < (uint32_t)kWave ? (ns - m0) : (uint32_t)kWave);
     }
 
@@ -514,7 +591,75 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         PH_T(ph3);
         PH_ADD(2, ph2, ph3);
         cmps += nc;
-        for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
+        if (fmode == DANN_FILTER_MULTIHOP) {
+            // multihop_search_internal (multihop_filter_search.rs:172-236); nc <= 64 (checked by the host)
+            const bool hasc = lane < nc;
+            const uint32_t cid = hasc ? cand_id[lane] : kEmpty;
+            const float cd = hasc ? cand_d[lane] : 0.0f;
+            const bool acc = hasc && fmatch(cid);
+            const bool rej = hasc && !acc;
+            const uint64_t am = ballot64(acc), rm = ballot64(rej);
+            const uint32_t na = (uint32_t)__popcll(am);
+            // rejected nodes closest first (stable), at most max_degree / 2 of them expand a second hop
+            uint32_t rank = 0;
+            for (uint64_t mm = rm; mm; mm &= mm - 1) {
+                const int j = __builtin_ctzll(mm);
+                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cd), j));
+                rank += ((dj < cd) | ((dj == cd) & ((uint32_t)j < lane))) ? 1u : 0u;
+            }
+            const uint32_t nrej = (uint32_t)__popcll(rm);
+            const uint32_t nsel = nrej < R / 2 ? nrej : R / 2;
+            __syncthreads();
+            if (acc) {  // accepted one-hop neighbours, emission order kept
+                const uint32_t r = mbcnt(am);
+                cand_id[r] = cid;
+                cand_d[r] = cd;
+            }
+            __syncthreads();
+            if (na) merge(0, na);
+            __syncthreads();
+            if (rej && rank < nsel) cand_id[rank] = cid;
+            __syncthreads();
+            const uint32_t sel = lane < nsel ? cand_id[lane] : kEmpty;
+            __syncthreads();
+            const uint32_t gsz = (cmax / R) < (uint32_t)kMaxBeam ? (cmax / R) : (uint32_t)kMaxBeam;
+            for (uint32_t b0 = 0; b0 < nsel && !status; b0 += gsz) {
+                const uint32_t gb = nsel - b0 < gsz ? nsel - b0 : gsz;
+                for (uint32_t t = 0; t < gb; ++t) {
+                    const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)sel, (int)(b0 + t));
+                    if (lane == 0) beam[t] = node;
+                }
+                __syncthreads();
+                const uint32_t nc2 = expand(gb, true);
+                if (status) break;
+                __syncthreads();
+                gather(nc2);
+                __syncthreads();
+                cmps += nc2;
+                for (uint32_t m0 = 0; m0 < nc2; m0 += kWave)
+                    merge(m0, (nc2 - m0) < (uint32_t)kWave ? (nc2 - m0) : (uint32_t)kWave);
+                __syncthreads();
+            }
+            if (status) break;
+            hops += nsel;
+        } else {
+            if (fmode == DANN_FILTER_INLINE) {
+                sample_matched += append_matched(nc);
+                sample_visited += nc;
+                if (status) break;
+            }
+            for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
+            // AdaptiveL (inline_filter_search.rs:262-277): one resize, decided from the hit rate so far; the new
+            // L comes from a table the host filled with compute_adaptive_l (f64 log10 / powf of the host libm)
+            if (a.ad_samples && !l_adjusted && sample_visited >= a.ad_samples) {
+                l_adjusted = true;
+                const uint32_t new_l = a.ad_table[(uint64_t)(sample_visited - a.ad_samples) * a.ad_stride + sample_matched];
+                if (new_l > a.l_value) {  // NeighborPriorityQueue::reconfigure (queue.rs:339-353)
+                    qcap = new_l;
+                    if (size > qcap) size = qcap;
+                }
+            }
+        }
         PH_T(ph4);
         PH_ADD(3, ph3, ph4);
         PH_ADD(4, ph0, ph4);
@@ -522,7 +667,183 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     // ---- graph::search::Range second phase (range_search.rs:283-316, 424-470) -----------------------
     uint32_t range_written = 0, range_second = 0;
-    if (a.range_ids && !status) {
+    // ---- inline filter search: matched_results sorted by distance (inline_filter_search.rs:279) ------------
+    // sort_unstable_by(distance) restated as a stable sort: key = ordered distance bits << 32 | push index
+    uint32_t nkeys = 0;
+    if (fmode == DANN_FILTER_INLINE && !status) {
+        nkeys = 1;
+        while (nkeys < nm) nkeys <<= 1;
+        __threadfence_block();
+        for (uint32_t i = lane; i < nkeys; i += kWave)
+            key_store(m_keys + i, i < nm ? ((unsigned long long)ordered_bits(f32_load(m_d + i)) << 32) | i : ~0ull);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nm > 1) wave_sort_keys(m_keys, nkeys, lane);
+    }
+    if (a.range_ids && fmode == DANN_FILTER_INLINE && !status) {
+        // ---- FilteredRange (filtered_range_search.rs:140-330) -------------------------------------------
+        uint32_t* wids = a.range_ids + (uint64_t)qi * a.range_cap;  // matched_within_radius
+        float* wds = a.range_d + (uint64_t)qi * a.range_cap;
+        // the matched entries within the radius are a prefix of the sorted list
+        uint32_t nw = 0;
+        for (uint32_t i0 = 0; i0 < nm; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            uint32_t id = kEmpty;
+            float d = 0.0f;
+            bool in = false;
+            if (i < nm) {
+                const unsigned long long key = key_load(m_keys + i);
+                d = from_ordered_bits((uint32_t)(key >> 32));
+                id = u32_load(m_ids + (uint32_t)key);
+                in = d <= a.radius;
+            }
+            const uint64_t m = ballot64(in);
+            const uint32_t r = nw + mbcnt(m);
+            if (in && r < a.range_cap) {
+                wids[r] = id;
+                wds[r] = d;
+            }
+            nw += (uint32_t)__popcll(m);
+        }
+        if (nw > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // in_range = (first starting_l queue entries + matched) within the radius, sorted by (distance, id),
+        // duplicates removed (:170-181)
+        uint32_t n2 = 0;
+        const uint32_t take = size < a.l_value ? size : a.l_value;
+        if (!status) {
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t p = (uint32_t)(s * kWave) + lane;
+                const bool in = p < take && qd[s] <= a.radius;
+                const uint64_t m = ballot64(in);
+                const uint32_t r = n2 + mbcnt(m);
+                if (in && r < a.key_cap)
+                    key_store(m_keys + r, ((unsigned long long)ordered_bits(qd[s]) << 32) | (qid[s] & ~kVisitedBit));
+                n2 += (uint32_t)__popcll(m);
+            }
+            for (uint32_t i0 = 0; i0 < nw; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                if (i < nw && n2 + i < a.key_cap)
+                    key_store(m_keys + n2 + i, ((unsigned long long)ordered_bits(f32_load(wds + i)) << 32) | u32_load(wids + i));
+            }
+            n2 += nw;
+            if (n2 > a.key_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+        }
+        uint32_t nf = 0;  // frontier length; frontier ids live in m_ids[] (the push-order list is dead now)
+        if (!status) {
+            uint32_t np2 = 1;
+            while (np2 < n2) np2 <<= 1;
+            for (uint32_t i = n2 + lane; i < np2; i += kWave) key_store(m_keys + i, ~0ull);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (n2 > 1) wave_sort_keys(m_keys, np2, lane);
+            for (uint32_t i0 = 0; i0 < n2; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                bool keep = false;
+                uint32_t id = kEmpty;
+                if (i < n2) {
+                    const unsigned long long key = key_load(m_keys + i);
+                    id = (uint32_t)key;
+                    keep = i == 0 || (uint32_t)key_load(m_keys + i - 1) != id;
+                }
+                const uint64_t m = ballot64(keep);
+                const uint32_t r = nf + mbcnt(m);
+                if (keep && r < a.m_cap) m_ids[r] = id;
+                nf += (uint32_t)__popcll(m);
+            }
+            if (nf > a.m_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!status && nf >= a.range_thresh && nw < a.range_max) {
+            range_second = 1;
+            // visited := ids of in_range; range_frontier := in_range (:190-199)
+            __syncthreads();
+            for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
+            if (spill) spill_wipe(spill, spill_size, lane);
+            __syncthreads();
+            lds_open = true;
+            ht_count = 0;
+            spill_count = 0;
+            pf_node = kEmpty;
+            for (uint32_t i0 = 0; i0 < nf && !status; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                const uint32_t cnt = (nf - i0) < (uint32_t)kWave ? (nf - i0) : (uint32_t)kWave;
+                if (lds_open && ht_count + cnt > ht_size - (ht_size >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                else if (i < nf) ht_visit(ht, ht_size, u32_load(m_ids + i), true);
+                ht_count += cnt;
+            }
+            __syncthreads();
+            const float nav = a.radius * a.range_slack;
+            uint32_t front = 0;
+            // filtered_range_search_internal (:263-330): cmps and hops keep accumulating
+            while (!status && front < nf && nw < a.range_max) {
+                const uint32_t nb = nf - front < W ? nf - front : W;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < nb) beam[lane] = u32_load(m_ids + front + lane);
+                front += nb;
+                __syncthreads();
+                const uint32_t nc = expand(nb);
+                if (status) break;
+                __syncthreads();
+                gather(nc);
+                __syncthreads();
+                cmps += nc;
+                hops += nb;
+                for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+                    const uint32_t c = c0 + lane;
+                    const bool has = c < nc;
+                    const uint32_t id = has ? cand_id[c] : kEmpty;
+                    const float d = has ? cand_d[c] : 0.0f;
+                    const bool fr = has && d <= nav;
+                    const uint64_t fm = ballot64(fr);
+                    const uint32_t rf = nf + mbcnt(fm);
+                    if (fr && rf < a.m_cap) m_ids[rf] = id;
+                    nf += (uint32_t)__popcll(fm);
+                    const bool mt = fr && d <= a.radius && fmatch(id);
+                    const uint64_t mm = ballot64(mt);
+                    const uint32_t rw = nw + mbcnt(mm);
+                    if (mt && rw < a.range_max && rw < a.range_cap) {
+                        wids[rw] = id;
+                        wds[rw] = d;
+                    }
+                    uint32_t add = (uint32_t)__popcll(mm);
+                    if (nw + add > a.range_max) add = a.range_max - nw;
+                    nw += add;
+                }
+                if (nf > a.m_cap || nw > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
+            }
+        }
+        // matched_within_radius.take(max_returned) -> start points dropped -> inner radius -> output
+        if (!status && a.out_ids) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+            float* od = a.out_dists + (uint64_t)qi * a.k;
+            const uint32_t lim = nw < a.range_max ? nw : a.range_max;
+            for (uint32_t i0 = 0; i0 < lim; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                uint32_t id = kEmpty;
+                float d = 0.0f;
+                if (i < lim) {
+                    id = u32_load(wids + i);
+                    d = f32_load(wds + i);
+                }
+                const bool ok = i < lim && id < ix.capacity && !(a.has_inner && d <= a.inner_radius);
+                const uint64_t m = ballot64(ok);
+                const uint32_t r = range_written + mbcnt(m);
+                if (ok && r < a.k) {
+                    oi[r] = id;
+                    od[r] = d;
+                }
+                range_written += (uint32_t)__popcll(m);
+            }
+            if (range_written > a.k) status = (uint32_t)(-DANN_EOVERFLOW);  // the reference's output Vec is unbounded
+            range_written = range_written < a.k ? range_written : a.k;
+            for (uint32_t r = range_written + lane; r < a.k; r += kWave) {
+                oi[r] = kEmpty;
+                od[r] = __builtin_inff();
+            }
+        }
+    }
+    if (a.range_ids && fmode != DANN_FILTER_INLINE && !status) {
         uint32_t* rids = a.range_ids + (uint64_t)qi * a.range_cap;
         float* rds = a.range_d + (uint64_t)qi * a.range_cap;
         const uint32_t max_ret = a.range_max < a.range_cap ? a.range_max : a.range_cap;  // list capacity
@@ -640,14 +961,50 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
     uint32_t written = range_written;
-    if (a.out_ids && !a.range_ids) {
+    if (a.out_ids && !a.range_ids && fmode == DANN_FILTER_INLINE) {
+        // matched_results.take(l_value) -> Translate drops start points -> first k (inline_filter_search.rs:131-139)
         uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
         float* od = a.out_dists + (uint64_t)qi * a.k;
+        const uint32_t lim = status ? 0u : (nm < a.l_value ? nm : a.l_value);
+        for (uint32_t i0 = 0; i0 < lim; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            uint32_t id = kEmpty;
+            float d = 0.0f;
+            if (i < lim) {
+                const unsigned long long key = key_load(m_keys + i);
+                d = from_ordered_bits((uint32_t)(key >> 32));
+                id = u32_load(m_ids + (uint32_t)key);
+            }
+            const bool res = i < lim && id < ix.capacity;
+            const uint64_t m = ballot64(res);
+            const uint32_t r = written + mbcnt(m);
+            if (res && r < a.k) {
+                oi[r] = id;
+                od[r] = d;
+            }
+            written += (uint32_t)__popcll(m);
+        }
+        written = written < a.k ? written : a.k;
+        for (uint32_t r = written + lane; r < a.k; r += kWave) {
+            oi[r] = kEmpty;
+            od[r] = __builtin_inff();
+        }
+    } else if (a.out_ids && !a.range_ids) {
+        uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+        float* od = a.out_dists + (uint64_t)qi * a.k;
+        uint32_t taken = 0;  // multihop: entries that are not rejected start points, first l_value of them
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
             const uint32_t id = qid[s] & ~kVisitedBit;
-            const bool res = p < size && id < ix.capacity;
+            bool res = p < size && id < ix.capacity;
+            if (fmode == DANN_FILTER_MULTIHOP) {
+                // best.iter().filter(not a rejected start point).take(l_value) (multihop_filter_search.rs:88-95)
+                const bool cnt = p < size && !(id >= ix.capacity && !fmatch(id));
+                const uint64_t cm = ballot64(cnt);
+                res = res && (taken + mbcnt(cm)) < a.l_value;
+                taken += (uint32_t)__popcll(cm);
+            }
             const uint64_t m = ballot64(res);
             const uint32_t r = written + mbcnt(m);
             if (res && r < a.k) {
@@ -677,9 +1034,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     }
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM>
+template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream) {
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM>;
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, FILT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -691,14 +1048,20 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream) {
     return DANN_OK;
 }
 
-template <int DT, int OP, bool NORM, int DIM>
-int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
-    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM>(a, lds, stream);
-    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM>(a, lds, stream);
-    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM>(a, lds, stream);
-    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM>(a, lds, stream);
+template <int DT, int OP, bool NORM, int DIM, bool FILT>
+int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
+    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, FILT>(a, lds, stream);
+    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, FILT>(a, lds, stream);
+    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, FILT>(a, lds, stream);
+    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, FILT>(a, lds, stream);
     set_error("search list size L + start points = %u exceeds the supported maximum of 512", qcap);
     return DANN_EUNSUPPORTED;
+}
+
+template <int DT, int OP, bool NORM, int DIM>
+int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
+    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, true>(a, qcap, lds, stream);
+    return launch_qs2<DT, OP, NORM, DIM, false>(a, qcap, lds, stream);
 }
 
 template <int DT>
@@ -746,7 +1109,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    const uint32_t qcap = a.l_value + a.ix.nstart;
+    const uint32_t qcap = std::max(a.l_value + a.ix.nstart, a.qcap_max);
     return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix)).total;
 }
 
@@ -798,7 +1161,12 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
         set_error("beam_width %u exceeds the supported maximum of %d", a.beam_width, kMaxBeam);
         return DANN_EUNSUPPORTED;
     }
-    const uint32_t qcap = a.l_value + a.ix.nstart;
+    const uint32_t qcap = std::max(a.l_value + a.ix.nstart, a.qcap_max);  // the queue registers cover AdaptiveL's resize
+    if (a.filter_mode == DANN_FILTER_MULTIHOP && cmax_of(a) > (uint32_t)kWave) {
+        set_error("multihop filter search supports beam_width * max_degree <= 64 (got %u x %u)", a.beam_width,
+                  a.ix.max_degree);
+        return DANN_EUNSUPPORTED;
+    }
     const size_t lds = search_lds_bytes(a);
     if (lds > 160 * 1024) {
         set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited table %u entries)", lds, a.ht_entries);
@@ -858,7 +1226,7 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     // automatic table size: calibrated 90th percentile for this (L, beam, mode), else the prior
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = ((uint64_t)a.l_value << 32) | ((uint64_t)a.beam_width << 8) | (a.rec_ids ? 1u : 0u) |
-                         (a.range_ids ? 2u : 0u);
+                         (a.range_ids ? 2u : 0u) | (a.filter_mode << 2);
     VisitedCalib* cal = nullptr;
     if (autosize) {
         cal = &idx->calib[key];

@@ -16,6 +16,7 @@ from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16,
                    COSINE_NORMALIZED, IBC_ALL, IBC_NONE)
 
 NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8, PQ: np.uint8}
+FILTER_INLINE, FILTER_MULTIHOP = 1, 2  # dann.h DANN_FILTER_*
 STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32)])
 
 
@@ -216,6 +217,59 @@ class Provider:
                                                  int(inner_radius is not None), inner_radius or 0.0, initial_slack,
                                                  range_slack, max_returned, cap, _p(ids), _p(dists), _p(stats),
                                                  _p(second)), "dann_range_search_batch")
+        return ids, dists, stats, second
+
+    # -- filtered searches (graph/ext/labeled.rs) -----------------------------------------
+    def _filter(self, mode, match, nq, adaptive=None, matched_cap=0):
+        """match: bool array over slots [0, capacity + nstart) (shared) or nq x nslots (per query)"""
+        nslots = self.capacity + self.num_start_points
+        m = np.asarray(match, dtype=bool)
+        m2 = m.reshape(1, -1) if m.ndim == 1 else m
+        if m2.shape[1] != nslots or m2.shape[0] not in (1, nq):
+            raise ValueError("filter must have capacity + start points entries per query")
+        words = (nslots + 31) // 32
+        padded = np.zeros((m2.shape[0], words * 32), bool)
+        padded[:, :nslots] = m2
+        bits = np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little")).view(np.uint32)
+        f = _ffi.Filter()
+        f.mode = mode
+        f.bits = bits.ctypes.data
+        f.stride_words = 0 if m2.shape[0] == 1 else words
+        f.adaptive_samples, f.adaptive_scale = adaptive if adaptive else (0, 1.0)
+        f.matched_cap = matched_cap
+        return f, bits  # keep `bits` alive for the duration of the call
+
+    def filtered_search(self, params, queries, k, match, mode=None, adaptive=None, matched_cap=0):
+        """InlineFilterSearch (default) or MultihopFilterSearch for a batch; returns (ids, dists, stats)."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        nq = q.shape[0]
+        f, keep = self._filter(mode or FILTER_INLINE, match, nq, adaptive, matched_cap)
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        stats = np.zeros(nq, STATS_DTYPE)
+        check(_ffi.lib().dann_filtered_search_batch(self._h, _p(q), nq, params.l_value, params.beam_width, k,
+                                                    C.byref(f), _p(ids), _p(dists), _p(stats)),
+              "dann_filtered_search_batch")
+        del keep
+        return ids, dists, stats
+
+    def filtered_range_search(self, queries, starting_l, radius, match, beam_width=1, inner_radius=None,
+                              initial_slack=1.0, range_slack=1.0, max_returned=0, out_cap=None, matched_cap=0):
+        """graph::search::FilteredRange for a batch; returns (ids, dists, stats, second_round)."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        nq = q.shape[0]
+        f, keep = self._filter(FILTER_INLINE, match, nq, None, matched_cap)
+        cap = int(out_cap or max_returned or 1024)
+        ids = np.empty((nq, cap), np.uint32)
+        dists = np.empty((nq, cap), np.float32)
+        stats = np.zeros(nq, STATS_DTYPE)
+        second = np.zeros(nq, np.uint32)
+        check(_ffi.lib().dann_filtered_range_search_batch(self._h, _p(q), nq, starting_l, beam_width, radius,
+                                                          int(inner_radius is not None), inner_radius or 0.0,
+                                                          initial_slack, range_slack, max_returned, cap, C.byref(f),
+                                                          _p(ids), _p(dists), _p(stats), _p(second)),
+              "dann_filtered_range_search_batch")
+        del keep
         return ids, dists, stats, second
 
     def rerank(self, queries, cand_ids, k):

@@ -188,6 +188,36 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
                                 float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
                                 uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                 uint32_t* out_second_round);
+/* ---- filtered searches (diskann/src/graph/ext/labeled.rs: a SearchAccessor wrapped with a QueryLabelProvider).
+ * The label provider crosses the boundary as a bitmap over slot ids: is_match(i) = bit (i & 31) of bits[i >> 5]
+ * for i in [0, capacity + num_start_points) -- start points are classified too (labeled.rs:166-175). */
+enum { DANN_FILTER_INLINE = 1, DANN_FILTER_MULTIHOP = 2 };
+typedef struct {
+    uint32_t mode;              /* DANN_FILTER_INLINE: InlineFilterSearch (search/inline_filter_search.rs:69-301);
+                                   DANN_FILTER_MULTIHOP: MultihopFilterSearch (search/multihop_filter_search.rs:46-244) */
+    const uint32_t* bits;       /* host memory */
+    uint64_t stride_words;      /* words between the bitmaps of consecutive queries; 0 = one bitmap for all queries */
+    uint32_t adaptive_samples;  /* inline only: AdaptiveL::sample_count, 0 = no AdaptiveL (:40-62) */
+    double adaptive_scale;      /* AdaptiveL::scale_factor, must be >= 1.0 */
+    uint32_t matched_cap;       /* inline only: capacity of the per-query matched list (every accepted id that was
+                                   compared); 0 = min(capacity + starts, 8192). Exceeding it is DANN_EOVERFLOW. */
+} dann_filter;
+/* index.search(InlineFilterSearch | MultihopFilterSearch, Filtered<Strategy>, ..) for nq queries; outputs as
+ * dann_search_batch.  Stats follow the reference: start points are not counted in cmps.  Ties: the reference sorts
+ * matched results / rejected candidates with sort_unstable_by(distance); equal distances keep arrival order here. */
+int32_t dann_filtered_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value,
+                                   uint32_t beam_width, uint32_t k, const dann_filter* filter, uint32_t* out_ids,
+                                   float* out_dists, dann_search_stats* out_stats);
+/* index.search(FilteredRange, ..) (search/filtered_range_search.rs:111-330); parameters and outputs as
+ * dann_range_search_batch, filter->mode must be DANN_FILTER_INLINE, AdaptiveL is not used (:148-156).
+ * cmps / hops accumulate over both rounds. */
+int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
+                                         uint32_t beam_width, float radius, int32_t has_inner_radius,
+                                         float inner_radius, float initial_slack, float range_slack,
+                                         uint32_t max_returned, uint32_t out_cap, const dann_filter* filter,
+                                         uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
+                                         uint32_t* out_second_round);
+
 /* Rerank post-processor (diskann-providers/src/model/graph/provider/async_/inmem/full_precision.rs:348-397):
  * full-precision distances query x stored row for every candidate id of a quantised search, sorted
  * ascending (equal distances keep candidate order; the reference's sort is unstable), first k returned.

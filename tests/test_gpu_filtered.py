@@ -1,0 +1,139 @@
+"""GPU parity of the filtered searches (inline filter incl. AdaptiveL, multihop, filtered range) against
+the oracle and the reference's golden cases, through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from filtered_cases import build
+from helpers import make_pair, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(g):
+    import diskann_amd as da
+    dim = g.data.shape[1]
+    ox = oracle.Index(oracle.F32, oracle.L2, dim, g.n, g.max_degree, g.start_vec)
+    g.fill(ox)
+    px = da.Provider(da.F32, da.L2, dim, g.n, g.max_degree, g.start_vec.reshape(1, -1))
+    g.fill(px)
+    return ox, px
+
+
+@pytest.fixture(scope="module")
+def cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "filtered_search.json")))
+
+
+def test_inline_golden_gpu(cases):
+    import diskann_amd as da
+    for c in cases["inline"]:
+        g = build(c["graph"])
+        _, px = _pair(g)
+        ids, dists, st = px.filtered_search(da.Knn(c["l"]), np.array(c["query"], np.float32), c["k"],
+                                            g.match(c["filter"]),
+                                            adaptive=tuple(c["adaptive"]) if c["adaptive"] else None)
+        n = int(st["result_count"][0])
+        assert [int(g.orig[i]) for i in ids[0, :n]] == c["result_ids"], c["name"]
+        assert [float(d) for d in dists[0, :n]] == c["result_distances"], c["name"]
+        assert (int(st["cmps"][0]), int(st["hops"][0])) == (c["comparisons"], c["hops"]), c["name"]
+
+
+def test_multihop_golden_gpu(cases):
+    import diskann_amd as da
+    for c in cases["multihop"]:
+        g = build(c["graph"], grid_size=c["grid_size"])
+        _, px = _pair(g)
+        ids, dists, st = px.filtered_search(da.Knn(c["l"]), np.array(c["query"], np.float32), c["k"],
+                                            g.match(c["filter"]), mode=da.FILTER_MULTIHOP)
+        n = int(st["result_count"][0])
+        assert [[int(g.orig[i]), float(d)] for i, d in zip(ids[0, :n], dists[0, :n])] == c["results"], c["name"]
+        assert (int(st["cmps"][0]), int(st["hops"][0])) == (c["comparisons"], c["hops"]), c["name"]
+
+
+def test_filtered_range_golden_gpu(cases):
+    for c in cases["filtered_range"]:
+        g = build("grid", c["grid_dims"], c["grid_size"])
+        ox, px = _pair(g)
+        q = np.array(c["query"], np.float32)
+        ids, dists, st, sec = px.filtered_range_search(q, c["starting_l"], c["radius"], g.match(c["filter"]),
+                                                       inner_radius=c["inner_radius"],
+                                                       max_returned=c["max_returned"], out_cap=256)
+        n = int(st["result_count"][0])
+        oi, od, ost = ox.filtered_range_search(q, c["starting_l"], c["radius"], g.match(c["filter"]),
+                                               inner_radius=c["inner_radius"], max_returned=c["max_returned"])
+        assert np.array_equal(ids[0, :n], oi) and np.array_equal(dists[0, :n], od), c["name"]
+        assert (int(st["cmps"][0]), int(st["hops"][0]), bool(sec[0])) == (c["comparisons"], c["hops"], c["second_round"])
+
+
+@pytest.mark.parametrize("frac", [0.5, 0.1, 0.01])
+def test_inline_random_vs_oracle(frac):
+    """random graph, random filter of the given selectivity, per-query bitmaps; fixed and adaptive L"""
+    import diskann_amd as da
+    rng = np.random.default_rng(11)
+    n, dim, R, nq = 3000, 24, 16, 40
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(oracle.F32, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    match = rng.random((nq, n + 1)) < frac
+    for adaptive in (None, (50, 8.0)):
+        ids, dists, st = px.filtered_search(da.Knn(20), queries, 10, match, adaptive=adaptive)
+        for qi in range(nq):
+            wn, wi, wd, ws = ox.inline_filter_search(queries[qi], 20, 10, match[qi], adaptive=adaptive)
+            assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), (qi, adaptive)
+            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["result_count"][qi])) == (int(ws[0]), int(ws[1]), wn)
+
+
+@pytest.mark.parametrize("frac", [0.5, 0.1])
+def test_multihop_random_vs_oracle(frac):
+    import diskann_amd as da
+    rng = np.random.default_rng(12)
+    n, dim, R, nq = 3000, 24, 16, 40
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(oracle.F32, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    match = rng.random(n + 1) < frac  # one shared bitmap
+    for W in (1, 2):
+        ids, dists, st = px.filtered_search(da.Knn(24, W), queries, 10, match, mode=da.FILTER_MULTIHOP)
+        for qi in range(nq):
+            wn, wi, wd, ws = ox.multihop_search(queries[qi], 24, 10, match, beam_width=W)
+            assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), (qi, W)
+            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["result_count"][qi])) == (int(ws[0]), int(ws[1]), wn)
+
+
+def test_filtered_range_random_vs_oracle():
+    import diskann_amd as da
+    rng = np.random.default_rng(13)
+    n, dim, R, nq = 3000, 8, 16, 30
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(oracle.F32, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    match = rng.random(n + 1) < 0.3
+    for radius, kw in ((2.0, {}), (4.0, {"max_returned": 40}), (3.0, {"inner_radius": 1.0, "range_slack": 1.3}),
+                       (3.0, {"initial_slack": 0.5, "beam_width": 2})):
+        ids, dists, st, sec = px.filtered_range_search(queries, 16, radius, match, out_cap=2048, **kw)
+        for qi in range(nq):
+            wi, wd, ws = ox.filtered_range_search(queries[qi], 16, radius, match, **kw)
+            m = int(st["result_count"][qi])
+            assert m == len(wi), (qi, radius, kw)
+            assert np.array_equal(ids[qi, :m], wi) and np.array_equal(dists[qi, :m].view(np.uint32), wd.view(np.uint32))
+            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(sec[qi])) == (int(ws[0]), int(ws[1]), int(ws[3]))
+
+
+def test_filter_errors():
+    import diskann_amd as da
+    g = build("hand_1d")
+    _, px = _pair(g)
+    q = np.array([2.0], np.float32)
+    with pytest.raises(da.DannError):  # AdaptiveLSearchError::ScaleFactorLessThanOne
+        px.filtered_search(da.Knn(5), q, 3, g.match("even"), adaptive=(5, 0.5))
+    with pytest.raises(da.DannError):  # AdaptiveL is an inline-search option
+        px.filtered_search(da.Knn(5), q, 3, g.match("even"), mode=da.FILTER_MULTIHOP, adaptive=(5, 2.0))
+    with pytest.raises(ValueError):
+        px.filtered_search(da.Knn(5), q, 3, np.ones(3, bool))
