@@ -42,6 +42,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxBeam = 16;
 constexpr int kGatherRows = 4;
+constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
 
 // optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
 #ifdef DANN_PHASE_CYCLES
@@ -370,6 +371,30 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         const uint64_t km = ballot64(nvalid);
         const uint32_t nv = (uint32_t)__popcll(km);
         if (nv == 0) return;
+        uint32_t shift[QS];
+        uint32_t pos_new = 0;
+        if (nv <= kRegMerge) {
+            // few survivors (the steady state once the queue is full): ranks straight from registers, one
+            // pass over the survivors -- no compaction, no LDS searches
+            uint32_t before = 0, lb = 0;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) shift[s] = 0;
+            for (uint64_t mm = km; mm; mm &= mm - 1) {
+                const int j = __builtin_ctzll(mm);
+                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), j));
+                before += ((dj < nd) | ((dj == nd) & ((uint32_t)j > lane))) ? 1u : 0u;
+                uint32_t c = 0;
+#pragma unroll
+                for (int s = 0; s < QS; ++s) {
+                    const bool in = (uint32_t)(s * kWave) + lane < size;
+                    shift[s] += (in & (dj <= qd[s])) ? 1u : 0u;
+                    c += (uint32_t)__popcll(ballot64(in & (qd[s] < dj)));
+                }
+                lb = ((int)lane == j) ? c : lb;
+            }
+            has = nvalid;
+            pos_new = before + lb;
+        } else {
         if (nv != n) {  // compact the survivors, emission order preserved
             const uint32_t cj = mbcnt(km);
             __syncthreads();
@@ -391,7 +416,6 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         if (has) snew[before] = nd;
         __syncthreads();
         // old elements: shift = #{new <= d_e}  (upper bound in snew[0..nv))
-        uint32_t shift[QS];
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             uint32_t lo = 0;
@@ -409,7 +433,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             const uint32_t t = lb + step;
             if (t <= size && oldd[t - 1] < nd) lb = t;
         }
-        const uint32_t pos_new = before + lb;
+        pos_new = before + lb;
+        }
         // scatter into the other half
         uint32_t* nxt_id = stage_id + (cur ^ 1u) * QCAPP;
         float* nxt_d = stage_d + (cur ^ 1u) * QCAPP;
