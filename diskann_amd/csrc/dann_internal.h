@@ -59,6 +59,7 @@ struct SearchArgs {
     uint32_t beam_width = 0;
     uint32_t k = 0;
     uint32_t ht_entries = 0;     // per-query LDS visited-table entries (multiple of 64)
+    uint32_t ht_prime = 0;       // probing modulus, set by search_with_retry: largest prime <= ht_entries
     uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)
     float* out_dists = nullptr;
     dann_search_stats* stats = nullptr;
@@ -96,7 +97,7 @@ struct SearchArgs {
     uint32_t qcap_max = 0;           // largest queue capacity an adaptive resize can ask for (0 = l_value + nstart)
 };
 
-int32_t launch_search(const SearchArgs& a, hipStream_t stream);
+int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out = nullptr);
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);
@@ -107,6 +108,7 @@ uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t 
 struct VisitedCalib {
     uint32_t cap_ids = 0;
     uint64_t calls = 0;
+    uint32_t waves = 0;  // occupancy the kernel's VGPRs allow (queries per CU); the table never costs more than that
 };
 
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,

@@ -32,6 +32,8 @@
 // in registers/LDS.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "dann_device.h"
 #include "dann_internal.h"
@@ -96,14 +98,17 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
 // after that it is frozen (lookups only) and new ids go to a spill table in global memory
 // claimed from a small pool -- rare, slower, still exact.
 enum : int { kPresent = 0, kInserted = 1, kAbsent = 2 };
-__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t size, uint32_t id, bool open) {
-    // table size is any multiple of 64: slot = mulhi(hash, size)
-    uint32_t h = __umulhi(id * 2654435761u, size);
+__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t mod, uint32_t id, bool open) {
+    // double hashing over a prime number of slots (<= the allocated entries): the wave waits for its slowest
+    // lane, and linear probing's cluster tails made that several times the mean probe count
+    uint32_t h = __umulhi(id * 2654435761u, mod);
+    const uint32_t step = 1u + __umulhi(id * 2246822519u + 0x9E3779B9u, mod - 1u);
     for (;;) {
         uint32_t old = open ? atomicCAS(&ht[h], kEmpty, id) : ht[h];
         if (old == kEmpty) return open ? kInserted : kAbsent;
         if (old == id) return kPresent;
-        h = (h + 1 == size) ? 0u : h + 1;
+        h += step;
+        h = h >= mod ? h - mod : h;
     }
 }
 // Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
     }
     const uint32_t ht_size = a.ht_entries;
+    const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size
     for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
     __syncthreads();
 
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 #endif
             uint32_t len = hit ? pf_len : arow[0];
             len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            if (lds_open && ht_count + len > ht_size - (ht_size >> 2)) {
+            if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
                 // freeze the LDS table, claim a spill table (kept once claimed)
                 lds_open = false;
                 if (!spill) {
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
                 if (inb && id != kEmpty && (!accept_only || fmatch(id))) {
-                    const int r = ht_visit(ht, ht_size, id, lds_open);
+                    const int r = ht_visit(ht, ht_mod, id, lds_open);
                     isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
                 }
                 const bool keep = isnew && id < ix.nslots;
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         const uint32_t ns = ix.nstart;
         for (uint32_t i = lane; i < ns; i += kWave) {
             cand_id[i] = ix.capacity + i;
-            ht_visit(ht, ht_size, ix.capacity + i, true);
+            ht_visit(ht, ht_mod, ix.capacity + i, true);
         }
         ht_count = ns;
         __syncthreads();
@@ -792,8 +798,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             for (uint32_t i0 = 0; i0 < nf && !status; i0 += kWave) {
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nf - i0) < (uint32_t)kWave ? (nf - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_size - (ht_size >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nf) ht_visit(ht, ht_size, u32_load(m_ids + i), true);
+                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                else if (i < nf) ht_visit(ht, ht_mod, u32_load(m_ids + i), true);
                 ht_count += cnt;
             }
             __syncthreads();
@@ -903,8 +909,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             for (uint32_t i0 = 0; i0 < nr && !status; i0 += kWave) {
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nr - i0) < (uint32_t)kWave ? (nr - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_size - (ht_size >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nr) ht_visit(ht, ht_size, rids[i], true);
+                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                else if (i < nr) ht_visit(ht, ht_mod, rids[i], true);
                 ht_count += cnt;
             }
             __syncthreads();
@@ -1060,8 +1066,15 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 }
 
 template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
-int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream) {
+int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
     auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, FILT>;
+    if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
+        hipFuncAttributes attr;
+        hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
+        if (e != hipSuccess) return hip_fail(e, "hipFuncGetAttributes");
+        *regs_out = attr.numRegs;
+        return DANN_OK;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1074,23 +1087,23 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream) {
 }
 
 template <int DT, int OP, bool NORM, int DIM, bool FILT>
-int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
-    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, FILT>(a, lds, stream);
-    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, FILT>(a, lds, stream);
-    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, FILT>(a, lds, stream);
-    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, FILT>(a, lds, stream);
+int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
+    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, FILT>(a, lds, stream, regs_out);
+    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, FILT>(a, lds, stream, regs_out);
+    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, FILT>(a, lds, stream, regs_out);
+    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, FILT>(a, lds, stream, regs_out);
     set_error("search list size L + start points = %u exceeds the supported maximum of 512", qcap);
     return DANN_EUNSUPPORTED;
 }
 
 template <int DT, int OP, bool NORM, int DIM>
-int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
-    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, true>(a, qcap, lds, stream);
-    return launch_qs2<DT, OP, NORM, DIM, false>(a, qcap, lds, stream);
+int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
+    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, true>(a, qcap, lds, stream, regs_out);
+    return launch_qs2<DT, OP, NORM, DIM, false>(a, qcap, lds, stream, regs_out);
 }
 
 template <int DT>
-int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream) {
+int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
     int op;
     bool norm;
     if (!resolve_metric(a.ix.dtype, a.ix.metric, &op, &norm)) {
@@ -1099,20 +1112,20 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
     }
     if (op == OP_L2) {
         if constexpr (DT == DT_F32 || DT == DT_F16) {
-            if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream);
+            if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream, regs_out);
         }
         if constexpr (DT == DT_SQ8) {
-            if (norm) return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream);
+            if (norm) return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream, regs_out);
         }
-        return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream);
+        return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream, regs_out);
     }
     if (op == OP_IP) {
         if constexpr (DT == DT_F32 || DT == DT_F16) {
-            if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream);
+            if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream, regs_out);
         }
-        return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream);
+        return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream, regs_out);
     }
-    if constexpr (DT != DT_SQ8 && DT != DT_PQ) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream);
+    if constexpr (DT != DT_SQ8 && DT != DT_PQ) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream, regs_out);
     return DANN_EUNSUPPORTED;
 }
 
@@ -1141,19 +1154,20 @@ size_t search_lds_bytes(const SearchArgs& a) {
 // ---- sizing of the LDS visited table ---------------------------------------------------------
 // The table trades occupancy (LDS per query) against probe length and the spill rate; results
 // never depend on it.  Measured on MI355X (1M x 128 f32, R = 32, L = 10..250): LDS is allocated in
-// 1280-byte granules (128 per CU), beyond 16 queries per CU extra occupancy buys less than a
-// sparser table, and the best size sits at the top of the occupancy step that holds about the
-// 90th percentile of comparisons per query at 75 % load.
-constexpr uint32_t kLdsGranule = 1280, kLdsGranules = 128, kUsefulWaves = 16, kHistBins = 512;
+// 1280-byte granules (128 per CU), occupancy is capped by the kernel's VGPRs anyway (16 queries per CU
+// for the 128-d f32 kernel, 24 for the integer kernels) so LDS up to that point is free, and the best
+// size sits at the top of the occupancy step that holds about the 90th percentile of comparisons
+// per query at 75 % load.
+constexpr uint32_t kLdsGranule = 1280, kLdsGranules = 128, kHistBins = 512;
 
-uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids) {
+uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids, uint32_t useful_waves) {
     a.ht_entries = 0;
     const int64_t other = (int64_t)search_lds_bytes(a);
     uint64_t need = ((uint64_t)((double)cap_ids / 0.75) + 63) / 64 * 64;
     need = std::min<uint64_t>(std::max<uint64_t>(need, 256), 32768);
     const uint64_t granules = ((uint64_t)other + need * 4 + kLdsGranule - 1) / kLdsGranule;
     if (granules > kLdsGranules) return (uint32_t)need;
-    const uint32_t waves = std::min<uint32_t>(kLdsGranules / (uint32_t)granules, kUsefulWaves);
+    const uint32_t waves = std::min<uint32_t>(kLdsGranules / (uint32_t)granules, useful_waves);
     const int64_t top = ((int64_t)(kLdsGranules / waves) * kLdsGranule - other) / 4 / 64 * 64;
     return (uint32_t)std::min<int64_t>(std::max<int64_t>(top, (int64_t)need), 32768);
 }
@@ -1163,6 +1177,20 @@ uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids) {
 uint32_t prior_visited_cap(const SearchArgs& a) {
     const double l = (double)(a.range_ids ? std::max<uint32_t>(a.l_value, 64) : a.l_value) + a.beam_width;
     return (uint32_t)(1.3 * 4.3 * (double)a.ix.max_degree * pow(l, 0.55)) + a.ix.nstart;
+}
+
+uint32_t largest_prime_leq(uint32_t n) {
+    for (uint32_t c = n | 1u; c >= 3; c -= 2) {
+        if (c > n) continue;
+        bool prime = true;
+        for (uint32_t d = 3; d * d <= c; d += 2)
+            if (c % d == 0) {
+                prime = false;
+                break;
+            }
+        if (prime) return c;
+    }
+    return 2;
 }
 
 __global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uint32_t* hist) {
@@ -1176,7 +1204,7 @@ __global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uin
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
+int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
     if (a.nq == 0) return DANN_OK;
     if (a.l_value == 0 || a.beam_width == 0) {
         set_error("l_value and beam_width must be non-zero (KnnSearchError, knn_search.rs:27-33)");
@@ -1193,17 +1221,17 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream) {
         return DANN_EUNSUPPORTED;
     }
     const size_t lds = search_lds_bytes(a);
-    if (lds > 160 * 1024) {
+    if (lds > 160 * 1024 && !regs_out) {
         set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited table %u entries)", lds, a.ht_entries);
         return DANN_EOVERFLOW;
     }
     switch (a.ix.dtype) {
-        case DT_F32: return launch_dt<DT_F32>(a, qcap, lds, stream);
-        case DT_F16: return launch_dt<DT_F16>(a, qcap, lds, stream);
-        case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream);
-        case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream);
-        case DT_SQ8: return launch_dt<DT_SQ8>(a, qcap, lds, stream);
-        case DT_PQ: return launch_dt<DT_PQ>(a, qcap, lds, stream);
+        case DT_F32: return launch_dt<DT_F32>(a, qcap, lds, stream, regs_out);
+        case DT_F16: return launch_dt<DT_F16>(a, qcap, lds, stream, regs_out);
+        case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream, regs_out);
+        case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream, regs_out);
+        case DT_SQ8: return launch_dt<DT_SQ8>(a, qcap, lds, stream, regs_out);
+        case DT_PQ: return launch_dt<DT_PQ>(a, qcap, lds, stream, regs_out);
     }
     set_error("bad dtype %d", a.ix.dtype);
     return DANN_EINVAL;
@@ -1255,13 +1283,27 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     VisitedCalib* cal = nullptr;
     if (autosize) {
         cal = &idx->calib[key];
-        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a));
+        if (!cal->waves) {  // queries per CU the registers of this instantiation allow (512 VGPRs per SIMD lane)
+            int regs = 0;
+            a.ht_entries = 256;
+            int32_t qrc = launch_search(a, st, &regs);
+            if (qrc != DANN_OK) return qrc;
+            const uint32_t per_simd = regs > 0 ? 512u / (((uint32_t)regs + 7u) & ~7u) : 4u;
+            cal->waves = 4u * std::min<uint32_t>(std::max<uint32_t>(per_simd, 1u), 8u);
+            if (getenv("DANN_DEBUG")) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal->waves);
+        }
+        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->waves);
+        if (getenv("DANN_DEBUG") && (cal->calls & (cal->calls - 1)) == 0)
+            fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u entries, %zu B LDS\n", a.l_value, a.beam_width,
+                    cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->cap_ids ? "p90" : "prior", a.ht_entries,
+                    search_lds_bytes(a));
     }
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;
     a.fail_flag = idx->h_flag;
     // HIP events bracket exactly the beam-search launches, on the stream they run on
-    auto timed_launch = [&](const SearchArgs& args) -> int32_t {
+    auto timed_launch = [&](SearchArgs& args) -> int32_t {
+        args.ht_prime = largest_prime_leq(args.ht_entries);
         DANN_HIP(hipEventRecord(idx->ev0, st));
         int32_t r = launch_search(args, st);
         if (r != DANN_OK) return r;
