@@ -69,6 +69,8 @@ __device__ __forceinline__ F4 load4(const __half* p) {
 }
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(__half x) { return __half2float(x); }
 
 
 // Raw (unconverted) loads: converting inside a predicated block makes hipcc wait for each load
@@ -268,9 +270,22 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
                                                      const bool (&active)[U], int dim, int v, float (&out)[U]) {
     constexpr int G = 2 * NACC, TRIP = 4 * G;
     const int full_end = dim & ~7;
+    const int rem = dim & 7;
     FAcc<OP> acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u].init();
+    // the partial block's elements (dim % 8 != 0) are requested first, raw, so they travel with the main
+    // loads instead of costing a second dependent round trip after them (dim = 100: 2.4x)
+    RT ty[U][4];
+    if (rem) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * (v & 1) + i;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (l < rem && active[u]) ty[u][i] = rows[u][full_end + l];
+        }
+    }
     // T trips of loads are issued before the first FMA: U*T 16-byte requests in flight per lane
     constexpr int T = 4;
     for (int e0 = 4 * v; e0 < full_end; e0 += TRIP * T) {
@@ -293,10 +308,8 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
             }
         }
     }
-    const int rem = dim & 7;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const RT* row = rows[u];
         const bool act = active[u];
         auto partial = [&](float(&a)[4], int which) {
             if (rem == 0 || !act) return;
@@ -306,7 +319,7 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
                 float x = 0.0f, y = 0.0f;
                 if (l < rem) {
                     x = load1(q + full_end + l);
-                    y = load1(row + full_end + l);
+                    y = to_f32(ty[u][i]);
                 }
                 if (OP == OP_L2) {
                     float c = x - y;
