@@ -26,7 +26,7 @@ shutil.copy(f"{G}/{tag}_kernel_trace.csv", f"{P}/{name}_kernel_trace.csv")
 
 trace = None
 for row in csv.DictReader(open(f"{G}/{tag}_kernel_trace.csv")):
-    if "beam_search_kernel<0, 0, false, 1, 128>" in row["kernel"]:
+    if "beam_search_kernel<0, 0, false, 1, 128" in row["kernel"]:
         trace = row
 rows, vals, durs = [], {}, []
 for path in sorted(glob.glob(f"{G}/{tag}_pmc_*.csv")):
@@ -47,7 +47,7 @@ summary = {
               f"launch (grid {nq} workgroups x 64)",
     "workload": {"nq": nq, "L": bench["config"]["L"], "beam_width": bench["config"]["beam_width"], "n": 1000000,
                  "dim": 128},
-    "kernel": "beam_search_kernel<F32, L2, QS=1, DIM=128>",
+    "kernel": "beam_search_kernel<F32, L2, QS=1, DIM=128, FILT=0>",
     "FETCH_SIZE_kb_per_launch": fetch_kb,
     "WRITE_SIZE_kb_per_launch": write_kb,
     "fetch_correction": "x2 on gfx950 for 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
