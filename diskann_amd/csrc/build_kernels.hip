@@ -707,10 +707,16 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     sa.spill = nullptr;
     sa.spill_next = nullptr;
     sa.spill_slices = sa.spill_bits = 0;
-    uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes
+    uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes [6] max record
     DANN_HIP(hipMemsetAsync(meta, 0, 64, st));
+    sa.rec_max = meta + 6;
     int32_t rc = search_with_retry(idx, sa);
     if (rc != DANN_OK) return rc;
+    // the pool's LDS footprint follows the longest record of this batch, not the worst-case bound
+    uint32_t h_recmax = 0;
+    DANN_HIP(hipMemcpyAsync(&h_recmax, meta + 6, 4, hipMemcpyDeviceToHost, st));
+    DANN_HIP(hipStreamSynchronize(st));
+    h_recmax = std::min<uint32_t>(std::max<uint32_t>(h_recmax, 32), s.rec_stride);
     PoolArgs pa;
     pa.ix = ix;
     pa.cfg = pc;
@@ -723,7 +729,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     pa.cand = cand;
     pa.n = n;
     pa.pos0 = lo;
-    pa.pcap = next_pow2(s.rec_stride + nex);
+    pa.pcap = next_pow2(h_recmax + nex);
     pa.force_saturate = 0;
     pa.out = d_pending_out;
     pa.out_stride = s.pend_stride;

@@ -67,6 +67,7 @@ struct SearchArgs {
     float* rec_dists = nullptr;
     uint32_t rec_stride = 0;
     uint32_t* rec_n = nullptr;
+    uint32_t* rec_max = nullptr; // optional: atomicMax of the record lengths of this launch
     // graph::search::Range (null range_ids = plain Knn): scratch list of in-range (id, dist) per query
     uint32_t* range_ids = nullptr;
     float* range_d = nullptr;

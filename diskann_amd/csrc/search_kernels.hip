@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
         if (status && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.rec_n) a.rec_n[qi] = nrec;
+        if (a.rec_max) atomicMax(a.rec_max, nrec);
         if (a.range_second) a.range_second[qi] = range_second;
     }
 }
