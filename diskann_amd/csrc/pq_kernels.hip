@@ -79,6 +79,107 @@ __global__ void sq8_compress_kernel(const float* x, uint32_t n, uint32_t dim, co
     o[dim + 3] = (uint8_t)(u >> 24);
 }
 
+// kmeans::square_norm (diskann-quantization/src/algorithms/kmeans/common.rs:8-62): four 8-lane accumulators over
+// 32-element trips, combined (s0+s1)+(s2+s3), remaining 8-blocks and the zero-padded tail into the combined vector,
+// then sum_tree.  One thread emulates the 8 lanes.
+__device__ float pq_square_norm(const float* x, uint32_t len) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t i = 0;
+    if (i + 32 <= len) {
+        float a[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) a[b][l] = 0.0f;
+        while (i + 32 <= len) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const float v = x[i + 8 * b + l];
+                    a[b][l] = __builtin_fmaf(v, v, a[b][l]);
+                }
+            i += 32;
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) s[l] = (a[0][l] + a[1][l]) + (a[2][l] + a[3][l]);
+    }
+    while (i + 8 <= len) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float v = x[i + l];
+            s[l] = __builtin_fmaf(v, v, s[l]);
+        }
+        i += 8;
+    }
+    if (len - i) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float v = (i + l < len) ? x[i + l] : 0.0f;
+            s[l] = __builtin_fmaf(v, v, s[l]);
+        }
+    }
+    return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
+}
+
+// TransposedTable::compress_into -> Chunk::find_closest (product/tables/transposed/table.rs:382-403,
+// pivots.rs:253-345): block = 256 rows x one chunk; the chunk's pivot slab and norms live in LDS (every thread
+// reads the same pivot element: broadcast), each thread keeps the reference's 8 lane-wise running minima.
+__global__ __launch_bounds__(256) void pq_compress_kernel(const float* pivots, uint32_t ncenters, const uint32_t* offsets,
+                                                          uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n,
+                                                          uint8_t* codes, unsigned long long* first_bad) {
+    extern __shared__ __attribute__((aligned(16))) float pq_smem[];
+    const uint32_t c = blockIdx.y;
+    const uint32_t s0 = offsets[c], len = offsets[c + 1] - s0;
+    float* slab = pq_smem;                  // ncenters x len
+    float* norms = pq_smem + ncenters * len;  // ncenters
+    for (uint32_t t = threadIdx.x; t < ncenters * len; t += blockDim.x)
+        slab[t] = pivots[(uint64_t)(t / len) * dim + s0 + (t % len)];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < ncenters; j += blockDim.x) norms[j] = pq_square_norm(slab + j * len, len);
+    __syncthreads();
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* x = rows + r * dim + s0;
+    float best_d[8];
+    uint32_t best_i[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        best_d[l] = __builtin_inff();
+        best_i[l] = 0xFFFFFFFFu;
+    }
+    for (uint32_t j0 = 0; j0 < ncenters; j0 += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const uint32_t j = j0 + l;
+            if (j < ncenters) {
+                const float* pj = slab + j * len;
+                float ip = 0.0f;
+                for (uint32_t d = 0; d < len; ++d) ip = __builtin_fmaf(x[d], pj[d], ip);
+                const float score = norms[j] - (ip + ip);
+                if (score < best_d[l]) {
+                    best_d[l] = score;
+                    best_i[l] = j;
+                }
+            }
+        }
+    }
+    float md = 3.402823466e+38f;
+    uint32_t mi = 0xFFFFFFFFu;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+        if (best_d[l] < md) {
+            md = best_d[l];
+            mi = best_i[l];
+        }
+    const bool finite = (md - md) == 0.0f;
+    if (!finite || mi == 0xFFFFFFFFu) {
+        atomicMin(first_bad, r * nchunks + c);
+        mi = 0;
+    }
+    codes[r * nchunks + c] = (uint8_t)mi;
+}
+
 struct Buf {
     void* p = nullptr;
     ~Buf() {
@@ -171,6 +272,64 @@ int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nch
 }
 
 }  // extern "C"
+
+extern "C" int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets,
+                                    uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n, uint8_t* codes) {
+    using namespace dann;
+    if (!pivots || !chunk_offsets || !rows || !codes || nchunks == 0 || dim == 0) return DANN_EINVAL;
+    if (ncenters == 0 || ncenters > 256) {  // TableCompressionError::CannotCompressToByte
+        set_error("num centers (%u) must be at most 256 to compress into a byte vector", ncenters);
+        return DANN_EINVAL;
+    }
+    if (chunk_offsets[0] != 0 || chunk_offsets[nchunks] != dim) {
+        set_error("chunk offsets must start at 0 and end at dim");
+        return DANN_EINVAL;
+    }
+    uint32_t maxlen = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        if (chunk_offsets[c + 1] <= chunk_offsets[c]) return DANN_EINVAL;
+        maxlen = std::max(maxlen, chunk_offsets[c + 1] - chunk_offsets[c]);
+    }
+    if (n == 0) return DANN_OK;
+    const size_t lds = ((size_t)ncenters * maxlen + ncenters) * 4;
+    if (lds > 160 * 1024) {
+        set_error("PQ chunk of %u dimensions x %u centres does not fit the 160 KiB LDS slab", maxlen, ncenters);
+        return DANN_EUNSUPPORTED;
+    }
+    if (device >= 0) DANN_HIP(hipSetDevice(device));
+    if (lds > 64 * 1024)
+        DANN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_compress_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Buf dp, doff, dx, dc, dbad;
+    DANN_HIP(hipMalloc(&dp.p, (size_t)ncenters * dim * 4));
+    DANN_HIP(hipMalloc(&doff.p, (size_t)(nchunks + 1) * 4));
+    DANN_HIP(hipMalloc(&dbad.p, 8));
+    DANN_HIP(hipMemcpy(dp.p, pivots, (size_t)ncenters * dim * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemcpy(doff.p, chunk_offsets, (size_t)(nchunks + 1) * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemset(dbad.p, 0xFF, 8));
+    // rows go through in slabs of <= 1 GiB
+    const uint64_t slab_rows = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)dim * 4));
+    const uint64_t cap = std::min<uint64_t>(n, slab_rows);
+    DANN_HIP(hipMalloc(&dx.p, cap * dim * 4));
+    DANN_HIP(hipMalloc(&dc.p, cap * nchunks));
+    for (uint64_t off = 0; off < n; off += cap) {
+        const uint64_t m = std::min<uint64_t>(cap, n - off);
+        DANN_HIP(hipMemcpy(dx.p, rows + off * dim, m * dim * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pq_compress_kernel, dim3((uint32_t)((m + 255) / 256), nchunks), dim3(256), lds, 0,
+                           (const float*)dp.p, ncenters, (const uint32_t*)doff.p, nchunks, dim, (const float*)dx.p, m,
+                           (uint8_t*)dc.p, (unsigned long long*)dbad.p);
+        DANN_HIP(hipGetLastError());
+        DANN_HIP(hipMemcpy(codes + off * nchunks, dc.p, m * nchunks, hipMemcpyDeviceToHost));
+        unsigned long long bad = ~0ull;
+        DANN_HIP(hipMemcpy(&bad, dbad.p, 8, hipMemcpyDeviceToHost));
+        if (bad != ~0ull) {  // TableBatchCompressionError::InfinityOrNaN(chunk, row)
+            set_error("a value of infinity or NaN was observed while compressing chunk %llu of batch input %llu",
+                      bad % nchunks, off + bad / nchunks);
+            return DANN_EINVAL;
+        }
+    }
+    return DANN_OK;
+}
 
 extern "C" int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift,
                                      float scale, void* out) {

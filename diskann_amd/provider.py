@@ -386,3 +386,14 @@ def pq_scan(lut, codes, ids, offsets, device=-1):
     check(_ffi.lib().dann_pq_scan(device, _p(lut), lut.shape[0], lut.shape[1], _p(codes), codes.shape[0], _p(ids),
                                   _p(off), _p(out)), "dann_pq_scan")
     return out
+
+
+def pq_compress(pivots, chunk_offsets, rows, device=-1):
+    """TransposedTable::compress_into for a batch: codes[n, nchunks] (u8)."""
+    piv = np.ascontiguousarray(pivots, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    x = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, piv.shape[1])
+    codes = np.empty((x.shape[0], off.size - 1), np.uint8)
+    check(_ffi.lib().dann_pq_compress(device, _p(piv), piv.shape[0], _p(off), off.size - 1, piv.shape[1], _p(x),
+                                      x.shape[0], _p(codes)), "dann_pq_compress")
+    return codes

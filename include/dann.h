@@ -270,6 +270,14 @@ int32_t dann_pq_build_lut(int32_t device, int32_t metric, const float* pivots, c
 int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nchunks, const uint8_t* codes,
                      uint64_t npoints, const uint32_t* ids, const uint64_t* offsets, float* out);
 
+/* TransposedTable::compress_into for a batch (diskann-quantization/src/product/tables/transposed/table.rs:382-403,
+ * 465-530; Chunk::find_closest, pivots.rs:253-345): codes[r][c] = index of the pivot of chunk c closest (L2) to
+ * row r's chunk, with the reference's arithmetic (|p|^2 - 2 x.p, fma chain in dimension order) and its lane-wise
+ * tie rule.  pivots: ncenters (<= 256) x dim f32; rows: n x dim f32; codes: n x nchunks u8.  Host pointers.
+ * DANN_EINVAL when a chunk is infinitely far from / NaN against every pivot (InfinityOrNaN). */
+int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets,
+                         uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n, uint8_t* codes);
+
 /* ---- on-disk formats of the reference (so a GPU-built index loads in the reference and vice versa)
  * graph: diskann-providers/src/storage/bin.rs:234-380 -- 24-byte header {u64 file_size, u32 max_degree,
  *        u32 start_point, u64 num_start_points} then per node {u32 len, len x u32}, nodes in slot order

@@ -108,6 +108,10 @@ def lib():
     L.orc_medoid_f32.argtypes = [vp, u64, u32, vp]
     L.orc_pq_build_lut.restype = None
     L.orc_pq_build_lut.argtypes = [i32, vp, vp, vp, u32, u32, vp, vp]
+    L.orc_pq_compress.restype = C.c_int64
+    L.orc_pq_compress.argtypes = [vp, u32, vp, u32, u32, vp, u64, vp]
+    L.orc_pq_square_norms.restype = i32
+    L.orc_pq_square_norms.argtypes = [vp, u32, vp, u32, u32, vp]
     L.orc_pq_lookup.restype = f32
     L.orc_pq_lookup.argtypes = [vp, vp, u32]
     L.orc_sq8_compress.restype = None
@@ -357,3 +361,13 @@ def medoid_f32(data):
     mean = np.empty(data.shape[1], np.float32)
     r = lib().orc_medoid_f32(_p(data), data.shape[0], data.shape[1], _p(mean))
     return int(r), mean
+
+
+def pq_compress(pivots, chunk_offsets, rows):
+    """TransposedTable::compress_into for a batch: returns (status, codes[n, nchunks])"""
+    piv = np.ascontiguousarray(pivots, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    x = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, piv.shape[1])
+    codes = np.zeros((x.shape[0], off.size - 1), np.uint8)
+    rc = lib().orc_pq_compress(_p(piv), piv.shape[0], _p(off), off.size - 1, piv.shape[1], _p(x), x.shape[0], _p(codes))
+    return int(rc), codes

@@ -1439,6 +1439,86 @@ float orc_pq_lookup(const float* lut, const uint8_t* code, uint32_t nchunks) {
     return accum;
 }
 
+/* ---- PQ compression: TransposedTable::compress_into -> Chunk::find_closest
+ * (diskann-quantization/src/product/tables/transposed/table.rs:382-403, pivots.rs:253-345, 785-905).
+ * score(j) = |p_j|^2 - (ip_j + ip_j), ip_j = fma chain over the chunk's dimensions in order, |p_j|^2 from
+ * kmeans::square_norm (algorithms/kmeans/common.rs:8-62).  Minimum tracked per SIMD lane (j mod 8) with
+ * strict `<`, lanes scanned in order with strict `<` from f32::MAX: lexicographic min of (score, j % 8, j). */
+static float pq_square_norm(const float* x, size_t len) {
+    F8 s = f8_zero();
+    size_t i = 0;
+    float v[8];
+    if (i + 32 <= len) {
+        F8 acc[4] = {f8_zero(), f8_zero(), f8_zero(), f8_zero()};
+        while (i + 32 <= len) {
+            for (int b = 0; b < 4; ++b) {
+                load8(x + i + 8 * b, 8, v);
+                for (int l = 0; l < 8; ++l) acc[b].v[l] = std::fma(v[l], v[l], acc[b].v[l]);
+            }
+            i += 32;
+        }
+        s = f8_add(f8_add(acc[0], acc[1]), f8_add(acc[2], acc[3]));
+    }
+    while (i + 8 <= len) {
+        load8(x + i, 8, v);
+        for (int l = 0; l < 8; ++l) s.v[l] = std::fma(v[l], v[l], s.v[l]);
+        i += 8;
+    }
+    if (len - i) {
+        load8(x + i, (int)(len - i), v);
+        for (int l = 0; l < 8; ++l) s.v[l] = std::fma(v[l], v[l], s.v[l]);
+    }
+    return f8_sum_tree(s);
+}
+
+int32_t orc_pq_square_norms(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
+                            uint32_t dim, float* norms /* nchunks x ncenters */) {
+    for (uint32_t c = 0; c < nchunks; ++c)
+        for (uint32_t j = 0; j < ncenters; ++j)
+            norms[(size_t)c * ncenters + j] =
+                pq_square_norm(pivots + (size_t)j * dim + chunk_offsets[c], chunk_offsets[c + 1] - chunk_offsets[c]);
+    return 0;
+}
+
+int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
+                        uint32_t dim, const float* rows, uint64_t n, uint8_t* codes) {
+    if (!pivots || !chunk_offsets || !rows || !codes || ncenters == 0 || ncenters > 256) return -1;
+    std::vector<float> norms((size_t)nchunks * ncenters);
+    orc_pq_square_norms(pivots, ncenters, chunk_offsets, nchunks, dim, norms.data());
+    for (uint64_t r = 0; r < n; ++r) {
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t s0 = chunk_offsets[c], len = chunk_offsets[c + 1] - s0;
+            const float* x = rows + r * dim + s0;
+            float best_d[8];
+            uint32_t best_i[8];
+            for (int l = 0; l < 8; ++l) {
+                best_d[l] = std::numeric_limits<float>::infinity();
+                best_i[l] = 0xFFFFFFFFu;
+            }
+            for (uint32_t j = 0; j < ncenters; ++j) {
+                const float* p = pivots + (size_t)j * dim + s0;
+                float ip = 0.0f;
+                for (uint32_t d = 0; d < len; ++d) ip = std::fma(x[d], p[d], ip);
+                const float score = norms[(size_t)c * ncenters + j] - (ip + ip);
+                if (score < best_d[j & 7]) {
+                    best_d[j & 7] = score;
+                    best_i[j & 7] = j;
+                }
+            }
+            float md = std::numeric_limits<float>::max();
+            uint32_t mi = 0xFFFFFFFFu;
+            for (int l = 0; l < 8; ++l)
+                if (best_d[l] < md) {
+                    md = best_d[l];
+                    mi = best_i[l];
+                }
+            if (!std::isfinite(md) || mi == 0xFFFFFFFFu) return -(int64_t)(2 + r * nchunks + c); /* InfinityOrNaN(chunk, row) */
+            codes[r * nchunks + c] = (uint8_t)mi;
+        }
+    }
+    return 0;
+}
+
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,
                       float* compensation) {
     const float inverse_scale = 255.0f / scale;

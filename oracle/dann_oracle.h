@@ -160,6 +160,14 @@ void orc_pq_build_lut(int32_t metric, const float* pivots /*256 x dim*/, const f
                       const uint32_t* chunk_offsets /*nchunks+1*/, uint32_t nchunks, uint32_t dim,
                       const float* query, float* lut /*nchunks x 256*/);
 float orc_pq_lookup(const float* lut, const uint8_t* code, uint32_t nchunks);
+/* PQ compression, TransposedTable::compress_into (diskann-quantization/src/product/tables/transposed/table.rs:382-403,
+ * pivots.rs:253-345): code[r][c] = the pivot of chunk c closest to row r's chunk (lane-wise tie rule, see .cpp).
+ * pivots: ncenters (<= 256) x dim.  Returns 0, -1 on bad arguments, or -(2 + r * nchunks + c) when every score of
+ * (row r, chunk c) is infinite / NaN (TableCompressionError::InfinityOrNaN). */
+int32_t orc_pq_square_norms(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
+                            uint32_t dim, float* norms);
+int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
+                        uint32_t dim, const float* rows, uint64_t n, uint8_t* codes);
 /* SQ-8: ScalarQuantizer::compress + compensated distances
  * (diskann-quantization/src/scalar/quantizer.rs:189-236,407-430, vectors.rs:171-338). */
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,

@@ -205,3 +205,38 @@ def test_pq_beam_search(metric, nchunks):
     with pytest.raises(da.DannError) as e:
         gix.insert_batch(da.build_config(4, 8, 10), [0])
     assert e.value.status in (da._ffi.EUNSUPPORTED, da._ffi.EINVAL)
+
+
+def test_pq_compress_reference_pattern_gpu():
+    """the reference's Chunk::find_closest test pattern (pivots.rs:1295-1411) through dann_pq_compress"""
+    import diskann_amd as da
+    for total, dim in ((1, 1), (7, 3), (16, 8), (17, 9), (71, 15), (103, 16), (256, 7)):
+        data = (np.arange(total)[:, None] + np.arange(dim)[None, :]).astype(np.float32)
+        off = np.array([0, dim], np.uint32)
+        codes = da.pq_compress(data, off, data + np.float32(0.125))
+        assert np.array_equal(codes[:, 0], np.arange(total) % 256), (total, dim)
+        assert da.pq_compress(data, off, np.zeros((1, dim), np.float32))[0, 0] == 0
+        for bad in (np.inf, -np.inf, np.nan):
+            with pytest.raises(da.DannError):
+                da.pq_compress(data, off, np.full((3, dim), bad, np.float32))
+        tied = data.copy()
+        tied[0] = data[-1]
+        assert da.pq_compress(tied, off, data[-1:])[0, 0] == 0
+
+
+@pytest.mark.parametrize("dim,off", [(24, [0, 5, 8, 16, 24]), (128, list(range(0, 129, 8))), (100, [0, 33, 66, 100])])
+def test_pq_compress_vs_oracle(dim, off):
+    import diskann_amd as da
+    rng = np.random.default_rng(21)
+    off = np.array(off, np.uint32)
+    for ncenters in (256, 37):
+        piv = rng.standard_normal((ncenters, dim)).astype(np.float32)
+        x = rng.standard_normal((1500, dim)).astype(np.float32)
+        x[:64] = piv[rng.integers(0, ncenters, 64)]  # exact hits
+        piv[5] = piv[14]                             # duplicated centres: the lane-wise tie rule decides
+        rc, want = oracle.pq_compress(piv, off, x)
+        assert rc == 0
+        got = da.pq_compress(piv, off, x)
+        assert np.array_equal(got, want)
+    with pytest.raises(da.DannError):
+        da.pq_compress(np.zeros((300, dim), np.float32), off, x)  # CannotCompressToByte

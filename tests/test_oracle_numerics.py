@@ -118,3 +118,46 @@ def test_sq8_formulas():
     ip = L.orc_sq8_distance(oracle.INNER_PRODUCT, codes[0].ctypes.data, comp[0], codes[1].ctypes.data, comp[1], dim,
                             scale, float((shift * shift).sum()))
     assert abs(-ip - float((recon[0] * recon[1]).sum())) <= 1e-3 * max(1.0, abs(ip))
+
+
+def test_pq_compress_reference_pattern():
+    """Chunk::find_closest known answers, restated from the reference's own test
+    (diskann-quantization/src/product/tables/transposed/pivots.rs:1165-1170, 1295-1411): centres
+    data[i][j] = i + j, query (i + j) + 0.125 -> i; zero query -> 0; non-finite queries are errors; a copy of the
+    last centre in slot 0 wins the tie."""
+    for total in list(range(1, 18)) + [64, 71, 96, 103, 255, 256]:
+        for dim in (1, 2, 3, 7, 8, 9, 15, 16):
+            data = (np.arange(total)[:, None] + np.arange(dim)[None, :]).astype(np.float32)
+            off = np.array([0, dim], np.uint32)
+            queries = data + np.float32(0.125)
+            rc, codes = oracle.pq_compress(data, off, queries)
+            assert rc == 0 and np.array_equal(codes[:, 0], np.arange(total) % 256), (total, dim)
+            rc, codes = oracle.pq_compress(data, off, np.zeros((1, dim), np.float32))
+            assert rc == 0 and codes[0, 0] == 0
+            for bad in (np.inf, -np.inf, np.nan):
+                rc, _ = oracle.pq_compress(data, off, np.full((1, dim), bad, np.float32))
+                assert rc < -1, (total, dim, bad)
+            tied = data.copy()
+            tied[0] = data[-1]
+            rc, codes = oracle.pq_compress(tied, off, data[-1:])
+            assert rc == 0 and codes[0, 0] == 0, (total, dim)
+
+
+def test_pq_compress_matches_bruteforce_and_chunking():
+    rng = np.random.default_rng(5)
+    dim, off = 24, np.array([0, 5, 8, 16, 24], np.uint32)
+    piv = rng.standard_normal((256, dim)).astype(np.float32)
+    x = rng.standard_normal((300, dim)).astype(np.float32)
+    rc, codes = oracle.pq_compress(piv, off, x)
+    assert rc == 0
+    for c in range(4):
+        s, e = int(off[c]), int(off[c + 1])
+        d = ((x[:, None, s:e].astype(np.float64) - piv[None, :, s:e].astype(np.float64)) ** 2).sum(-1)
+        best = d.min(1)
+        got = d[np.arange(x.shape[0]), codes[:, c]]
+        assert np.all(got <= best * (1 + 1e-5) + 1e-6)
+    # lane-wise tie rule: equal scores in lanes 1 (index 9) and 2 (index 2) -> the lower lane wins, not the lower index
+    piv2 = np.full((16, 2), 10.0, np.float32)
+    piv2[9] = piv2[2] = [1.0, 1.0]
+    rc, codes = oracle.pq_compress(piv2, np.array([0, 2], np.uint32), np.array([[1.0, 1.0]], np.float32))
+    assert rc == 0 and codes[0, 0] == 9
