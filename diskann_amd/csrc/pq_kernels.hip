@@ -9,6 +9,8 @@
 // so one thread evaluates one (chunk, centroid) entry by walking the 4-accumulator x 8-lane
 // schedule sequentially -- the same emulation the CPU oracle uses, hence bit-identical.  The
 // scan adds LUT entries in chunk order in f32, one lane per candidate, LUT staged in LDS.
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 #include "dann_device.h"
@@ -180,6 +182,121 @@ __global__ __launch_bounds__(256) void pq_compress_kernel(const float* pivots, u
     codes[r * nchunks + c] = (uint8_t)mi;
 }
 
+// ---- Lloyd iterations of the PQ trainer (product/train.rs:96-226, kmeans/lloyds.rs:23-438) ----------------
+// |x|^2 of every (row, chunk): kmeans::square_norm
+__global__ __launch_bounds__(256) void pq_data_norms_kernel(const float* data, uint64_t n, uint32_t dim,
+                                                            const uint32_t* offsets, float* norms) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (r >= n) return;
+    norms[(uint64_t)c * n + r] = pq_square_norm(data + r * dim + offsets[c], offsets[c + 1] - offsets[c]);
+}
+__global__ void pq_center_norms_kernel(const float* centers, uint32_t ncenters, uint32_t dim, const uint32_t* offsets,
+                                       float* norms) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (j >= ncenters) return;
+    norms[c * ncenters + j] = pq_square_norm(centers + (uint64_t)j * dim + offsets[c], offsets[c + 1] - offsets[c]);
+}
+// distances_in_place (lloyds.rs:23-260): score = ((n_c - ip) - ip) + |x|^2, first strictly smaller centre wins
+__global__ __launch_bounds__(256) void pq_assign_kernel(const float* data, uint64_t n, uint32_t dim,
+                                                        const uint32_t* offsets, const float* centers, uint32_t ncenters,
+                                                        const float* cnorms, const float* dnorms, uint32_t* assign,
+                                                        float* best_out) {
+    extern __shared__ __attribute__((aligned(16))) float pq_smem[];
+    const uint32_t c = blockIdx.y;
+    const uint32_t s0 = offsets[c], len = offsets[c + 1] - s0;
+    float* slab = pq_smem;
+    float* cn = pq_smem + ncenters * len;
+    for (uint32_t t = threadIdx.x; t < ncenters * len; t += blockDim.x)
+        slab[t] = centers[(uint64_t)(t / len) * dim + s0 + (t % len)];
+    for (uint32_t j = threadIdx.x; j < ncenters; j += blockDim.x) cn[j] = cnorms[c * ncenters + j];
+    __syncthreads();
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* x = data + r * dim + s0;
+    const float dn = dnorms[(uint64_t)c * n + r];
+    float best = __builtin_inff();
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j < ncenters; ++j) {
+        const float* pj = slab + j * len;
+        float ip = 0.0f;
+        for (uint32_t d = 0; d < len; ++d) ip = __builtin_fmaf(pj[d], x[d], ip);
+        const float sc = ((cn[j] - ip) - ip) + dn;
+        if (sc < best) {
+            best = sc;
+            bi = j;
+        }
+    }
+    assign[(uint64_t)c * n + r] = bi;
+    best_out[(uint64_t)c * n + r] = best;
+}
+// residual: SIMD lane l sums the points with index = l (mod 8) in order, then sum_tree (lloyds.rs:201, 254-259).
+// One block per chunk; tiles are staged through LDS so the eight sequential chains read at LDS speed.
+__global__ __launch_bounds__(256) void pq_residual_kernel(const float* best, uint64_t n, float* residuals,
+                                                          uint32_t* bad_assign, const uint32_t* assign) {
+    __shared__ float tile[2048];
+    __shared__ float lanes[8];
+    const uint32_t c = blockIdx.x;
+    const float* b = best + (uint64_t)c * n;
+    float acc = 0.0f;
+    bool bad = false;
+    for (uint64_t t0 = 0; t0 < n; t0 += 2048) {
+        for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) {
+            tile[i] = (t0 + i < n) ? b[t0 + i] : 0.0f;
+            if (t0 + i < n && assign[(uint64_t)c * n + t0 + i] == 0xFFFFFFFFu) bad = true;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const uint64_t lim = (n - t0) < 2048 ? (n - t0) : 2048;
+            for (uint32_t i = threadIdx.x; i < lim; i += 8) acc = acc + tile[i];
+        }
+        __syncthreads();
+    }
+    if (bad) atomicExch(bad_assign, 1u);
+    if (threadIdx.x < 8) lanes[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        residuals[c] = ((lanes[0] + lanes[4]) + (lanes[2] + lanes[6])) + ((lanes[1] + lanes[5]) + (lanes[3] + lanes[7]));
+}
+__global__ void pq_iota_kernel(uint32_t* v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void pq_hist_kernel(const uint32_t* assign, uint64_t n, uint32_t ncenters, uint32_t* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && assign[i] < ncenters) atomicAdd(&counts[assign[i]], 1u);
+}
+// update_centroids (lloyds.rs:273-296): f64 sums in row order; block = one centre of one chunk, thread = dimension.
+// `order` lists the rows of each centre in increasing row order (stable radix sort by centre).
+__global__ void pq_update_kernel(const float* data, uint32_t dim, uint32_t s0, uint32_t len, const uint32_t* order,
+                                 const uint32_t* counts, const uint32_t* starts, float* centers) {
+    const uint32_t j = blockIdx.x, d = threadIdx.x;
+    if (d >= len) return;
+    const uint32_t cnt = counts[j];
+    const uint32_t* list = order + starts[j];
+    double sum = 0.0;
+    uint32_t i = 0;
+    for (; i + 4 <= cnt; i += 4) {  // loads issued together, adds in order
+        const float v0 = data[(uint64_t)list[i] * dim + s0 + d], v1 = data[(uint64_t)list[i + 1] * dim + s0 + d];
+        const float v2 = data[(uint64_t)list[i + 2] * dim + s0 + d], v3 = data[(uint64_t)list[i + 3] * dim + s0 + d];
+        sum += (double)v0;
+        sum += (double)v1;
+        sum += (double)v2;
+        sum += (double)v3;
+    }
+    for (; i < cnt; ++i) sum += (double)data[(uint64_t)list[i] * dim + s0 + d];
+    centers[(uint64_t)j * dim + s0 + d] = (float)(sum / (double)(cnt > 1u ? cnt : 1u));
+}
+__global__ void pq_scan_counts_kernel(const uint32_t* counts, uint32_t ncenters, uint32_t* starts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < ncenters; ++j) {
+            starts[j] = acc;
+            acc += counts[j];
+        }
+    }
+}
+
 struct Buf {
     void* p = nullptr;
     ~Buf() {
@@ -328,6 +445,99 @@ extern "C" int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_
             return DANN_EINVAL;
         }
     }
+    return DANN_OK;
+}
+
+extern "C" int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n, uint32_t dim,
+                                  const uint32_t* chunk_offsets, uint32_t nchunks, uint32_t ncenters, float* centers,
+                                  uint32_t max_reps, uint32_t* assignments, float* residuals) {
+    using namespace dann;
+    if (!data || !chunk_offsets || !centers || nchunks == 0 || dim == 0 || ncenters == 0) return DANN_EINVAL;
+    if (n == 0 || n > 0xFFFFFFFFull) return DANN_EINVAL;
+    if (chunk_offsets[0] != 0 || chunk_offsets[nchunks] != dim) {
+        set_error("chunk offsets must start at 0 and end at dim");
+        return DANN_EINVAL;
+    }
+    uint32_t maxlen = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        if (chunk_offsets[c + 1] <= chunk_offsets[c]) return DANN_EINVAL;
+        maxlen = std::max(maxlen, chunk_offsets[c + 1] - chunk_offsets[c]);
+    }
+    const size_t lds = ((size_t)ncenters * maxlen + ncenters) * 4;
+    if (lds > 160 * 1024 || maxlen > 1024) {
+        set_error("PQ chunk of %u dimensions x %u centres does not fit the 160 KiB LDS slab", maxlen, ncenters);
+        return DANN_EUNSUPPORTED;
+    }
+    if (device >= 0) DANN_HIP(hipSetDevice(device));
+    if (lds > 64 * 1024)
+        DANN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_assign_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Buf dx, doff, dcen, dcn, ddn, dasg, dbest, dres, dord, dord2, dkeys2, dcounts, dstarts, dtmp, dbad;
+    DANN_HIP(hipMalloc(&dx.p, n * dim * 4));
+    DANN_HIP(hipMalloc(&doff.p, (size_t)(nchunks + 1) * 4));
+    DANN_HIP(hipMalloc(&dcen.p, (size_t)ncenters * dim * 4));
+    DANN_HIP(hipMalloc(&dcn.p, (size_t)nchunks * ncenters * 4));
+    DANN_HIP(hipMalloc(&ddn.p, (size_t)nchunks * n * 4));
+    DANN_HIP(hipMalloc(&dasg.p, (size_t)nchunks * n * 4));
+    DANN_HIP(hipMalloc(&dbest.p, (size_t)nchunks * n * 4));
+    DANN_HIP(hipMalloc(&dres.p, (size_t)nchunks * 4));
+    DANN_HIP(hipMalloc(&dord.p, n * 4));
+    DANN_HIP(hipMalloc(&dord2.p, n * 4));
+    DANN_HIP(hipMalloc(&dkeys2.p, n * 4));
+    DANN_HIP(hipMalloc(&dcounts.p, (size_t)ncenters * 4));
+    DANN_HIP(hipMalloc(&dstarts.p, (size_t)ncenters * 4));
+    DANN_HIP(hipMalloc(&dbad.p, 4));
+    DANN_HIP(hipMemset(dbad.p, 0, 4));
+    DANN_HIP(hipMemcpy(dx.p, data, n * dim * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemcpy(doff.p, chunk_offsets, (size_t)(nchunks + 1) * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemcpy(dcen.p, centers, (size_t)ncenters * dim * 4, hipMemcpyHostToDevice));
+    int key_bits = 1;
+    while ((1u << key_bits) < ncenters && key_bits < 32) ++key_bits;
+    size_t tmp_bytes = 0;
+    DANN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)dasg.p, (uint32_t*)dkeys2.p,
+                                                (const uint32_t*)dord.p, (uint32_t*)dord2.p, (int)n, 0, key_bits));
+    DANN_HIP(hipMalloc(&dtmp.p, tmp_bytes + 16));
+    const dim3 rows_grid((uint32_t)((n + 255) / 256), nchunks);
+    hipLaunchKernelGGL(pq_data_norms_kernel, rows_grid, dim3(256), 0, 0, (const float*)dx.p, n, dim,
+                       (const uint32_t*)doff.p, (float*)ddn.p);
+    hipLaunchKernelGGL(pq_center_norms_kernel, dim3((ncenters + 255) / 256, nchunks), dim3(256), 0, 0,
+                       (const float*)dcen.p, ncenters, dim, (const uint32_t*)doff.p, (float*)dcn.p);
+    hipLaunchKernelGGL(pq_iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t*)dord.p, n);
+    for (uint32_t rep = 0; rep < max_reps; ++rep) {
+        hipLaunchKernelGGL(pq_assign_kernel, rows_grid, dim3(256), lds, 0, (const float*)dx.p, n, dim,
+                           (const uint32_t*)doff.p, (const float*)dcen.p, ncenters, (const float*)dcn.p,
+                           (const float*)ddn.p, (uint32_t*)dasg.p, (float*)dbest.p);
+        hipLaunchKernelGGL(pq_residual_kernel, dim3(nchunks), dim3(256), 0, 0, (const float*)dbest.p, n, (float*)dres.p,
+                           (uint32_t*)dbad.p, (const uint32_t*)dasg.p);
+        uint32_t bad = 0;
+        DANN_HIP(hipMemcpy(&bad, dbad.p, 4, hipMemcpyDeviceToHost));
+        if (bad) {
+            set_error("k-means assignment saw only NaN scores for some row (non-finite data or centres)");
+            return DANN_EINVAL;
+        }
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t* asg = (const uint32_t*)dasg.p + (size_t)c * n;
+            DANN_HIP(hipMemsetAsync(dcounts.p, 0, (size_t)ncenters * 4, 0));
+            hipLaunchKernelGGL(pq_hist_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, asg, n, ncenters,
+                               (uint32_t*)dcounts.p);
+            hipLaunchKernelGGL(pq_scan_counts_kernel, dim3(1), dim3(1), 0, 0, (const uint32_t*)dcounts.p, ncenters,
+                               (uint32_t*)dstarts.p);
+            size_t tb = tmp_bytes;
+            DANN_HIP(hipcub::DeviceRadixSort::SortPairs(dtmp.p, tb, asg, (uint32_t*)dkeys2.p, (const uint32_t*)dord.p,
+                                                        (uint32_t*)dord2.p, (int)n, 0, key_bits));
+            const uint32_t s0 = chunk_offsets[c], len = chunk_offsets[c + 1] - s0;
+            hipLaunchKernelGGL(pq_update_kernel, dim3(ncenters), dim3((len + 63) / 64 * 64), 0, 0, (const float*)dx.p, dim,
+                               s0, len, (const uint32_t*)dord2.p, (const uint32_t*)dcounts.p,
+                               (const uint32_t*)dstarts.p, (float*)dcen.p);
+        }
+        if (rep != max_reps - 1)
+            hipLaunchKernelGGL(pq_center_norms_kernel, dim3((ncenters + 255) / 256, nchunks), dim3(256), 0, 0,
+                               (const float*)dcen.p, ncenters, dim, (const uint32_t*)doff.p, (float*)dcn.p);
+        DANN_HIP(hipGetLastError());
+    }
+    DANN_HIP(hipMemcpy(centers, dcen.p, (size_t)ncenters * dim * 4, hipMemcpyDeviceToHost));
+    if (assignments) DANN_HIP(hipMemcpy(assignments, dasg.p, (size_t)nchunks * n * 4, hipMemcpyDeviceToHost));
+    if (residuals) DANN_HIP(hipMemcpy(residuals, dres.p, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
     return DANN_OK;
 }
 

@@ -397,3 +397,15 @@ def pq_compress(pivots, chunk_offsets, rows, device=-1):
     check(_ffi.lib().dann_pq_compress(device, _p(piv), piv.shape[0], _p(off), off.size - 1, piv.shape[1], _p(x),
                                       x.shape[0], _p(codes)), "dann_pq_compress")
     return codes
+
+
+def pq_lloyds(data, chunk_offsets, centers, max_reps, device=-1):
+    """Lloyd iterations of the PQ trainer on the GPU; returns (centers, assignments[nchunks, n], residuals)."""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    cen = np.ascontiguousarray(centers, dtype=np.float32).copy()
+    assign = np.empty((off.size - 1, x.shape[0]), np.uint32)
+    res = np.empty(off.size - 1, np.float32)
+    check(_ffi.lib().dann_pq_lloyds(device, _p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, cen.shape[0], _p(cen),
+                                    max_reps, _p(assign), _p(res)), "dann_pq_lloyds")
+    return cen, assign, res

@@ -278,6 +278,17 @@ int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nch
 int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets,
                          uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n, uint8_t* codes);
 
+/* PQ training minus the seeding: the Lloyd iterations of LightPQTrainingParameters::train
+ * (diskann-quantization/src/product/train.rs:96-226 -> algorithms/kmeans/lloyds.rs:23-438) for every chunk, with the
+ * reference's arithmetic (assignment scores ((n_c - ip) - ip) + |x|^2, first strictly smaller centre; f64 centroid
+ * sums in row order; empty clusters become the zero vector).  `centers` (ncenters x dim f32) carries the initial
+ * centres in -- k-means++ (kmeans/plusplus.rs, seeded per chunk from rand's StdRng) stays with the caller -- and the
+ * trained pivots out.  data: n x dim f32.  Optional outputs: assignments nchunks x n (those of the last assignment
+ * step, as lloyds_inner returns them), residuals nchunks.  Host pointers. */
+int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets,
+                       uint32_t nchunks, uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments,
+                       float* residuals);
+
 /* ---- on-disk formats of the reference (so a GPU-built index loads in the reference and vice versa)
  * graph: diskann-providers/src/storage/bin.rs:234-380 -- 24-byte header {u64 file_size, u32 max_degree,
  *        u32 start_point, u64 num_start_points} then per node {u32 len, len x u32}, nodes in slot order

@@ -112,6 +112,8 @@ def lib():
     L.orc_pq_compress.argtypes = [vp, u32, vp, u32, u32, vp, u64, vp]
     L.orc_pq_square_norms.restype = i32
     L.orc_pq_square_norms.argtypes = [vp, u32, vp, u32, u32, vp]
+    L.orc_pq_lloyds.restype = i32
+    L.orc_pq_lloyds.argtypes = [vp, u64, u32, vp, u32, u32, vp, u32, vp, vp]
     L.orc_pq_lookup.restype = f32
     L.orc_pq_lookup.argtypes = [vp, vp, u32]
     L.orc_sq8_compress.restype = None
@@ -371,3 +373,17 @@ def pq_compress(pivots, chunk_offsets, rows):
     codes = np.zeros((x.shape[0], off.size - 1), np.uint8)
     rc = lib().orc_pq_compress(_p(piv), piv.shape[0], _p(off), off.size - 1, piv.shape[1], _p(x), x.shape[0], _p(codes))
     return int(rc), codes
+
+
+def pq_lloyds(data, chunk_offsets, centers, max_reps):
+    """Lloyd iterations of the PQ trainer for every chunk; returns (centers, assignments[nchunks, n], residuals)"""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    cen = np.ascontiguousarray(centers, dtype=np.float32).copy()
+    assign = np.zeros((off.size - 1, x.shape[0]), np.uint32)
+    res = np.zeros(off.size - 1, np.float32)
+    rc = lib().orc_pq_lloyds(_p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, cen.shape[0], _p(cen), max_reps,
+                             _p(assign), _p(res))
+    if rc < 0:
+        raise RuntimeError(f"orc_pq_lloyds failed: {rc}")
+    return cen, assign, res

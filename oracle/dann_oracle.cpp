@@ -1519,6 +1519,66 @@ int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* 
     return 0;
 }
 
+/* ---- PQ training: Lloyd's iterations of LightPQTrainingParameters::train per chunk
+ * (diskann-quantization/src/product/train.rs:96-226 -> algorithms/kmeans/lloyds.rs:23-438).
+ * The k-means++ seeding (kmeans/plusplus.rs, rand's StdRng) is the caller's: `centers` holds the initial
+ * centres.  Assignment: score(c) = ((n_c - ip) - ip) + |x|^2 with ip an fma chain over the chunk's dimensions,
+ * first strictly smaller wins in centre order (lloyds.rs:66-200, 262-270).  Residual: per SIMD lane (point index
+ * mod 8) in point order, then sum_tree (:201, :254-257).  Update: f64 sums in row order, divided by max(count, 1)
+ * (:273-296).  Norms of the centres are refreshed between iterations only (:334-350).
+ * centers: ncenters x dim (chunk columns concatenated), assignments: nchunks x n (last assignment step),
+ * residuals: nchunks. */
+int32_t orc_pq_lloyds(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
+                      uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments, float* residuals) {
+    if (!data || !chunk_offsets || !centers || ncenters == 0 || n == 0) return -1;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t s0 = chunk_offsets[c], len = chunk_offsets[c + 1] - s0;
+        std::vector<float> dnorm(n), cnorm(ncenters);
+        for (uint64_t r = 0; r < n; ++r) dnorm[r] = pq_square_norm(data + r * dim + s0, len);
+        for (uint32_t j = 0; j < ncenters; ++j) cnorm[j] = pq_square_norm(centers + (size_t)j * dim + s0, len);
+        std::vector<uint32_t> assign(n, 0);
+        float residual = 0.0f;
+        for (uint32_t rep = 0; rep < max_reps; ++rep) {
+            float lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint64_t r = 0; r < n; ++r) {
+                const float* x = data + r * dim + s0;
+                float best = std::numeric_limits<float>::infinity();
+                uint32_t bi = 0xFFFFFFFFu;
+                for (uint32_t j = 0; j < ncenters; ++j) {
+                    const float* p = centers + (size_t)j * dim + s0;
+                    float ip = 0.0f;
+                    for (uint32_t d = 0; d < len; ++d) ip = std::fma(p[d], x[d], ip);
+                    const float sc = ((cnorm[j] - ip) - ip) + dnorm[r];
+                    if (sc < best) {
+                        best = sc;
+                        bi = j;
+                    }
+                }
+                assign[r] = bi;
+                lanes[r & 7] = lanes[r & 7] + best;
+            }
+            residual = ((lanes[0] + lanes[4]) + (lanes[2] + lanes[6])) + ((lanes[1] + lanes[5]) + (lanes[3] + lanes[7]));
+            std::vector<double> sums((size_t)ncenters * len, 0.0);
+            std::vector<uint32_t> counts(ncenters, 0);
+            for (uint64_t r = 0; r < n; ++r) {
+                const uint32_t j = assign[r];
+                if (j >= ncenters) return -2; /* every score NaN: the reference would index out of bounds */
+                counts[j] += 1;
+                for (uint32_t d = 0; d < len; ++d) sums[(size_t)j * len + d] += (double)data[r * dim + s0 + d];
+            }
+            for (uint32_t j = 0; j < ncenters; ++j) {
+                const double cnt = (double)std::max<uint32_t>(counts[j], 1);
+                for (uint32_t d = 0; d < len; ++d) centers[(size_t)j * dim + s0 + d] = (float)(sums[(size_t)j * len + d] / cnt);
+            }
+            if (rep != max_reps - 1)
+                for (uint32_t j = 0; j < ncenters; ++j) cnorm[j] = pq_square_norm(centers + (size_t)j * dim + s0, len);
+        }
+        if (assignments) std::memcpy(assignments + (size_t)c * n, assign.data(), n * 4);
+        if (residuals) residuals[c] = residual;
+    }
+    return 0;
+}
+
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,
                       float* compensation) {
     const float inverse_scale = 255.0f / scale;

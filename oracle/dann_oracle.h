@@ -168,6 +168,12 @@ int32_t orc_pq_square_norms(const float* pivots, uint32_t ncenters, const uint32
                             uint32_t dim, float* norms);
 int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
                         uint32_t dim, const float* rows, uint64_t n, uint8_t* codes);
+/* PQ training minus the seeding: the Lloyd iterations of LightPQTrainingParameters::train
+ * (product/train.rs:96-226, algorithms/kmeans/lloyds.rs:23-438) for every chunk; `centers` (ncenters x dim)
+ * carries the initial centres in and the trained pivots out.  assignments: nchunks x n (optional), residuals:
+ * nchunks (optional). */
+int32_t orc_pq_lloyds(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
+                      uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments, float* residuals);
 /* SQ-8: ScalarQuantizer::compress + compensated distances
  * (diskann-quantization/src/scalar/quantizer.rs:189-236,407-430, vectors.rs:171-338). */
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,

