@@ -95,10 +95,21 @@ struct SearchArgs {
     uint32_t ad_samples = 0;         // AdaptiveL::sample_count (0 = none)
     const uint32_t* ad_table = nullptr;  // new L for (visited - ad_samples, matched): row stride ad_stride
     uint32_t ad_stride = 0;
+    unsigned long long* phase_cycles = nullptr;  // -DDANN_PHASE_CYCLES builds only
     uint32_t qcap_max = 0;           // largest queue capacity an adaptive resize can ask for (0 = l_value + nstart)
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out = nullptr);
+// one translation unit per row type (search_<type>.hip) holds the kernel instantiations
+#define DANN_DECL_LAUNCH(name) \
+    int32_t launch_search_##name(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out)
+DANN_DECL_LAUNCH(f32);
+DANN_DECL_LAUNCH(f16);
+DANN_DECL_LAUNCH(u8);
+DANN_DECL_LAUNCH(i8);
+DANN_DECL_LAUNCH(sq8);
+DANN_DECL_LAUNCH(pq);
+#undef DANN_DECL_LAUNCH
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);

@@ -30,1111 +30,13 @@
 //      through an LDS staging buffer.
 // HBM traffic per query = cmps * row bytes + hops * adjacency row; everything else stays
 // in registers/LDS.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-
-#include "dann_device.h"
-#include "dann_internal.h"
+#include "search_kernel_impl.h"
 
 namespace dann {
+#ifdef DANN_PHASE_CYCLES
+unsigned long long* dann_phase_buffer();
+#endif
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kMaxBeam = 16;
-constexpr int kGatherRows = 4;
-constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
-
-// optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
-#ifdef DANN_PHASE_CYCLES
-__device__ unsigned long long g_phase_cycles[8];
-#define PH_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define PH_ADD(idx, t0, t1) ph_acc[idx] += (t1) - (t0)
-#else
-#define PH_T(var)
-#define PH_ADD(idx, t0, t1)
-#endif  // rows in flight per lane group in the fixed-length gather
-
-struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, stage_id_off, stage_d_off, snew_off, beam_off, q_off, total;
-};
-
-__host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
-
-// bytes of the staged query: f32 vector (float rows), raw bytes (integer rows), lookup table (PQ rows)
-__host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
-    if (ix.dtype == DT_PQ) return ix.pq_chunks * 1024u;
-    if (ix.dtype == DT_U8 || ix.dtype == DT_I8 || ix.dtype == DT_SQ8) return ix.layer_bytes;
-    return ix.dim * 4u;
-}
-
-__host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
-                                                       uint32_t qbytes) {
-    SearchLds l;
-    uint32_t off = 0;
-    l.q_off = off;
-    off += round16(qbytes);
-    l.ht_off = off;
-    off += ht_entries * 4u;  // any multiple of 64
-    l.cand_id_off = off;
-    off += round16(cmax * 4u);
-    l.cand_d_off = off;
-    off += round16(cmax * 4u);
-    l.stage_id_off = off;  // two buffers of qcap entries each (current / next queue image)
-    off += round16(2u * qcap * 4u);
-    l.stage_d_off = off;
-    off += round16(2u * qcap * 4u);
-    l.snew_off = off;      // the surviving new distances of one merge, sorted
-    off += 64u * 4u;
-    l.beam_off = off;
-    off += round16(kMaxBeam * 4u);
-    l.total = off;
-    return l;
-}
-
-// exact visited set: open addressing, linear probing, ds_cmpst.  == hashbrown::HashSet::insert
-// (glue.rs:542-549).  Two levels: the LDS table takes ids until it is 75 % full ("open");
-// after that it is frozen (lookups only) and new ids go to a spill table in global memory
-// claimed from a small pool -- rare, slower, still exact.
-enum : int { kPresent = 0, kInserted = 1, kAbsent = 2 };
-__device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t mod, uint32_t id, bool open) {
-    // double hashing over a prime number of slots (<= the allocated entries): the wave waits for its slowest
-    // lane, and linear probing's cluster tails made that several times the mean probe count
-    uint32_t h = __umulhi(id * 2654435761u, mod);
-    const uint32_t step = 1u + __umulhi(id * 2246822519u + 0x9E3779B9u, mod - 1u);
-    for (;;) {
-        uint32_t old = open ? atomicCAS(&ht[h], kEmpty, id) : ht[h];
-        if (old == kEmpty) return open ? kInserted : kAbsent;
-        if (old == id) return kPresent;
-        h += step;
-        h = h >= mod ? h - mod : h;
-    }
-}
-// Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
-// every probe is an agent-scope atomic, and the table is wiped with write-through (sc1) 16-byte
-// stores drained by s_waitcnt before the busy flag is released -- no release/acquire fences, which
-// cost microseconds each at this occupancy (MI355X_MICROARCH.md, inter-workgroup visibility).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void spill_wipe(uint32_t* table, uint32_t entries, uint32_t lane) {
-    const u32x4 e = {kEmpty, kEmpty, kEmpty, kEmpty};
-    for (uint32_t i = lane * 4u; i < entries; i += kWave * 4u) {
-        uint32_t* p = table + i;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32_t shift, uint32_t id) {
-    uint32_t h = (id * 2246822519u) >> shift;
-    for (;;) {
-        uint32_t old = atomicCAS(&gt[h], kEmpty, id);
-        if (old == kEmpty) return true;
-        if (old == id) return false;
-        h = (h + 1) & mask;
-    }
-}
-
-// total order on non-NaN f32 as unsigned bits (NaN sorts last)
-__device__ __forceinline__ uint32_t ordered_bits(float d) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, d);
-    return (u >> 31) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(uint32_t o) {
-    return __builtin_bit_cast(float, (o >> 31) ? (o & 0x7FFFFFFFu) : ~o);
-}
-// ascending bitonic sort of n (power of two) 64-bit keys in global memory by one wave.  Keys written
-// by one lane are read by another in the next pass: agent-scope accesses (served by L2) + a drain.
-__device__ void wave_sort_keys(unsigned long long* keys, uint32_t n, uint32_t lane) {
-    for (uint32_t k = 2; k <= n; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = lane; i < n; i += kWave) {
-                const uint32_t p = i ^ j;
-                if (p > i) {
-                    const unsigned long long x = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long y = __hip_atomic_load(keys + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        __hip_atomic_store(keys + i, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(keys + p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-}
-__device__ __forceinline__ unsigned long long key_load(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void key_store(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t u32_load(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float f32_load(const float* p) {
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// FILT = false compiles every filtered-search branch out (the plain Knn / Range / record kernels keep their
-// register budget); filtered launches use the generic-length instantiations.
-template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
-__global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using S = Scheme<DT, OP, false>;
-    constexpr int G = (DIM > 0) ? S::G : S::GS;  // fixed-length path: narrow groups, query slice in registers
-    constexpr int GROUPS = kWave / G;
-    constexpr bool kInt = S::kInt;
-    using QT = typename std::conditional<kInt, uint8_t, float>::type;
-    using RT = typename RowType<DT>::type;
-
-    const IndexView& ix = a.ix;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t qi = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;
-    const uint32_t R = ix.max_degree;
-    const uint32_t W = a.beam_width;
-    uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207); AdaptiveL may grow it
-    const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
-                                                                              : ((ix.nstart + 63u) & ~63u);
-    const uint32_t qbytes = query_lds_bytes(ix);
-    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
-    const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
-    QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
-    uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
-    uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
-    float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
-    uint32_t* stage_id = reinterpret_cast<uint32_t*>(smem + L.stage_id_off);
-    float* stage_d = reinterpret_cast<float*>(smem + L.stage_d_off);
-    float* snew = reinterpret_cast<float*>(smem + L.snew_off);
-    constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
-    uint32_t cur = 0;                       // which half of stage_* mirrors the queue
-    uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
-
-    // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
-    {
-        if constexpr (DT == DT_PQ) {
-            // populate_chunk_distances_impl (fixed_chunk_pq_table.rs:152-192): the lookup table of this
-            // query, built straight into LDS: entry (chunk, centroid) = metric(query chunk, pivot chunk)
-            const float* q = reinterpret_cast<const float*>(a.queries) + (uint64_t)qi * ix.dim;
-            float* lut = reinterpret_cast<float*>(qs);
-            const uint32_t total = ix.pq_chunks * 256u;
-            for (uint32_t t = lane; t < total; t += kWave) {
-                const uint32_t chunk = t >> 8, centroid = t & 255u;
-                const uint32_t s0 = ix.pq_offsets[chunk], e0 = ix.pq_offsets[chunk + 1];
-                const float raw = simd_op_seq<OP == OP_L2>(q + s0, ix.pq_pivots + (uint64_t)centroid * ix.dim + s0, e0 - s0);
-                lut[t] = (OP == OP_L2) ? raw : -raw;
-            }
-        } else {
-        const uint8_t* qsrc = a.qslots ? ix.rows + (uint64_t)a.qslots[qi] * ix.row_stride
-                                       : reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
-        if constexpr (kInt) {
-            for (uint32_t i = lane; i < ix.layer_bytes; i += kWave) reinterpret_cast<uint8_t*>(qs)[i] = qsrc[i];
-        } else {
-            const RT* src = reinterpret_cast<const RT*>(qsrc);
-            for (uint32_t i = lane; i < ix.dim; i += kWave) reinterpret_cast<float*>(qs)[i] = load1(src + i);
-        }
-        }
-    }
-    const uint32_t ht_size = a.ht_entries;
-    const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size
-    for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
-    __syncthreads();
-
-    const int g = lane / G, v = lane % G;
-    // query slice of this lane in registers for the fixed-length float path
-    constexpr int NTQ = (DIM > 0 && !kInt) ? DIM / (4 * G) : 1;
-    F4 xq[NTQ];
-    if constexpr (DIM > 0 && !kInt) {
-#pragma unroll
-        for (int t = 0; t < NTQ; ++t) xq[t] = load4(reinterpret_cast<const float*>(qs) + t * 4 * G + 4 * v);
-    }
-
-    // ---- queue state: entry p at lane p % 64, slot p / 64 ------------------------------
-    uint32_t qid[QS];
-    float qd[QS];
-#pragma unroll
-    for (int s = 0; s < QS; ++s) {
-        qid[s] = kEmpty;
-        qd[s] = 0.0f;
-    }
-    uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
-    uint32_t pf_node = kEmpty, pf_len = 0, pf_val = kEmpty;
-    bool lds_open = true;
-#ifdef DANN_PHASE_CYCLES
-    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    uint32_t* spill = nullptr;
-    uint32_t spill_count = 0;
-    const uint32_t spill_size = 1u << a.spill_bits, spill_mask = spill_size - 1u, spill_shift = 32u - a.spill_bits;
-
-    // filtered searches: QueryLabelProvider::is_match == one bit per slot (graph/ext/labeled.rs:44-68)
-    const uint32_t fmode = FILT ? a.filter_mode : 0u;
-    const uint32_t* fbits = a.filter ? a.filter + (uint64_t)qi * a.filter_stride : nullptr;
-    auto fmatch = [&](uint32_t id) -> bool { return id < ix.nslots && ((fbits[id >> 5] >> (id & 31u)) & 1u); };
-    uint32_t* m_ids = a.m_ids ? a.m_ids + (uint64_t)qi * a.m_cap : nullptr;
-    float* m_d = a.m_d ? a.m_d + (uint64_t)qi * a.m_cap : nullptr;
-    unsigned long long* m_keys = a.m_keys ? a.m_keys + (uint64_t)qi * a.key_cap : nullptr;
-    uint32_t nm = 0, sample_visited = 0, sample_matched = 0;
-    bool l_adjusted = false;
-    // inline filter search: accepted candidates of cand[0..nc) go to matched_results in emission order
-    auto append_matched = [&](uint32_t nc) -> uint32_t {
-        uint32_t added = 0;
-        for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
-            const uint32_t c = c0 + lane;
-            const bool mt = c < nc && fmatch(cand_id[c]);
-            const uint64_t m = ballot64(mt);
-            const uint32_t r = nm + added + mbcnt(m);
-            if (mt && r < a.m_cap) {
-                m_ids[r] = cand_id[c];
-                m_d[r] = cand_d[c];
-            }
-            added += (uint32_t)__popcll(m);
-        }
-        nm += added;
-        if (nm > a.m_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-        return added;
-    };
-
-    // distance of every candidate in cand_id[0..nc) -> cand_d
-    auto gather = [&](uint32_t nc) {
-        if constexpr (DIM > 0 && !kInt) {
-            constexpr int U = kGatherRows;
-            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
-                const RT* rows[U];
-                bool act[U];
-                float out[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t c = c0 + u * GROUPS + g;
-                    act[u] = c < nc;
-                    uint32_t id = act[u] ? cand_id[c] : 0u;
-                    rows[u] = reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride);
-                }
-                group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, out);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t c = c0 + u * GROUPS + g;
-                    if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
-                }
-            }
-        } else if constexpr (DT == DT_PQ) {
-            // pq_dist_lookup_single (fixed_chunk_pq_table.rs:82-100): one lane per candidate, table entries
-            // added in chunk order in f32; code rows read 16 bytes at a time
-            const float* lut = reinterpret_cast<const float*>(qs);
-            for (uint32_t c = lane; c < nc; c += kWave) {
-                const uint8_t* code = ix.rows + (uint64_t)cand_id[c] * ix.row_stride;
-                float accum = 0.0f;
-                for (uint32_t b0 = 0; b0 < ix.pq_chunks; b0 += 16) {
-                    const uint4 w = *reinterpret_cast<const uint4*>(code + b0);
-                    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const uint32_t ch = b0 + i;
-                        if (ch < ix.pq_chunks) accum += lut[ch * 256u + ((ws[i >> 2] >> (8 * (i & 3))) & 255u)];
-                    }
-                }
-                cand_d[c] = accum;
-            }
-        } else {
-            constexpr int U = S::kWide ? 2 : kGatherRows;
-            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
-                const uint8_t* rows[U];
-                bool act[U];
-                float out[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t c = c0 + u * GROUPS + g;
-                    act[u] = c < nc;
-                    uint32_t id = act[u] ? cand_id[c] : 0u;
-                    rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
-                }
-                group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, out);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t c = c0 + u * GROUPS + g;
-                    if (act[u] && v == 0)
-                        cand_d[c] = finish_distance<DT, OP, NORM>(out[u], reinterpret_cast<const uint8_t*>(qs), rows[u],
-                                                                  ix.dim, sqp);
-                }
-            }
-        }
-    };
-
-    // merge cand[m0 .. m0+n) (n <= 64) into the queue.
-    // Exactness: the sequential inserts keep the best `qcap` elements under the total order
-    // (distance asc, insertion time desc), so (1) when the queue is full a candidate worse
-    // than its last element can be dropped up front (queue.rs:142-146), (2) a surviving
-    // candidate j lands at  #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)},
-    // (3) an old element e moves up by #{surviving j: d_j <= d_e}.
-    auto merge = [&](uint32_t m0, uint32_t n) {
-        const float* oldd = stage_d + cur * QCAPP;
-        bool has = lane < n;
-        float nd = has ? cand_d[m0 + lane] : 0.0f;
-        uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
-        bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
-        if (size == qcap && qcap > 0) nvalid = nvalid && !(oldd[size - 1] < nd);
-        const uint64_t km = ballot64(nvalid);
-        const uint32_t nv = (uint32_t)__popcll(km);
-        if (nv == 0) return;
-        uint32_t shift[QS];
-        uint32_t pos_new = 0;
-        if (nv <= kRegMerge) {
-            // few survivors (the steady state once the queue is full): ranks straight from registers, one
-            // pass over the survivors -- no compaction, no LDS searches
-            uint32_t before = 0, lb = 0;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) shift[s] = 0;
-            for (uint64_t mm = km; mm; mm &= mm - 1) {
-                const int j = __builtin_ctzll(mm);
-                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), j));
-                before += ((dj < nd) | ((dj == nd) & ((uint32_t)j > lane))) ? 1u : 0u;
-                uint32_t c = 0;
-#pragma unroll
-                for (int s = 0; s < QS; ++s) {
-                    const bool in = (uint32_t)(s * kWave) + lane < size;
-                    shift[s] += (in & (dj <= qd[s])) ? 1u : 0u;
-                    c += (uint32_t)__popcll(ballot64(in & (qd[s] < dj)));
-                }
-                lb = ((int)lane == j) ? c : lb;
-            }
-            has = nvalid;
-            pos_new = before + lb;
-        } else {
-        if (nv != n) {  // compact the survivors, emission order preserved
-            const uint32_t cj = mbcnt(km);
-            __syncthreads();
-            if (nvalid) {
-                cand_d[m0 + cj] = nd;
-                cand_id[m0 + cj] = nid;
-            }
-            __syncthreads();
-            has = lane < nv;
-            nd = has ? cand_d[m0 + lane] : 0.0f;
-            nid = has ? cand_id[m0 + lane] : kEmpty;
-        }
-        // rank among the survivors
-        uint32_t before = 0;
-        for (uint32_t jj = 0; jj < nv; ++jj) {
-            const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), jj));
-            before += ((dj < nd) | ((dj == nd) & (jj > lane))) ? 1u : 0u;
-        }
-        if (has) snew[before] = nd;
-        __syncthreads();
-        // old elements: shift = #{new <= d_e}  (upper bound in snew[0..nv))
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            uint32_t lo = 0;
-#pragma unroll
-            for (uint32_t step = 64; step > 0; step >>= 1) {
-                const uint32_t t = lo + step;
-                if (t <= nv && snew[t - 1] <= qd[s]) lo = t;
-            }
-            shift[s] = lo;
-        }
-        // new elements: #{old < d_j}  (lower bound in the queue image)
-        uint32_t lb = 0;
-#pragma unroll
-        for (uint32_t step = QCAPP; step > 0; step >>= 1) {
-            const uint32_t t = lb + step;
-            if (t <= size && oldd[t - 1] < nd) lb = t;
-        }
-        pos_new = before + lb;
-        }
-        // scatter into the other half
-        uint32_t* nxt_id = stage_id + (cur ^ 1u) * QCAPP;
-        float* nxt_d = stage_d + (cur ^ 1u) * QCAPP;
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint32_t p = (uint32_t)(s * kWave) + lane;
-            if (p < size) {
-                const uint32_t np = p + shift[s];
-                if (np < qcap) {
-                    nxt_id[np] = qid[s];
-                    nxt_d[np] = qd[s];
-                }
-            }
-        }
-        if (has && pos_new < qcap) {
-            nxt_id[pos_new] = nid;
-            nxt_d[pos_new] = nd;
-        }
-        const uint32_t total = size + nv;
-        size = total < qcap ? total : qcap;
-        cur ^= 1u;
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint32_t p = (uint32_t)(s * kWave) + lane;
-            if (p < size) {
-                qid[s] = nxt_id[p];
-                qd[s] = nxt_d[p];
-            }
-        }
-    };
-
-    // expand `nb` nodes of beam[]: adjacency rows in pop order, ids in stored order, visited filter
-    // (provider.rs:448-454); survivors go to cand_id[0..nc)
-    // accept_only (expand_beam_accept_only, labeled.rs:196-214,284-291): ids that do not match the filter
-    // are skipped *before* the visited set sees them
-    auto expand = [&](uint32_t nb, bool accept_only = false) -> uint32_t {
-        uint32_t nc = 0;
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t node = beam[b];
-            const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
-            const bool hit = (node == pf_node);
-#ifdef DANN_PHASE_CYCLES
-            ph_acc[hit ? 5 : 6] += 1;
-#endif
-            uint32_t len = hit ? pf_len : arow[0];
-            len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
-                // freeze the LDS table, claim a spill table (kept once claimed)
-                lds_open = false;
-                if (!spill) {
-                    uint32_t slice = kEmpty;
-                    if (a.spill) {
-                        // slices are recycled inside a launch: busy flag per slice, rotating start
-                        if (lane == 0) {
-                            uint32_t* busy = a.spill_next + 16;
-                            uint32_t s = atomicAdd(a.spill_next, 1u) % a.spill_slices;
-                            for (uint32_t t = 0; t < 2u * a.spill_slices; ++t) {
-                                if (atomicCAS(&busy[s], 0u, 1u) == 0u) {
-                                    slice = s;
-                                    break;
-                                }
-                                s = (s + 1 == a.spill_slices) ? 0u : s + 1;
-                            }
-                        }
-                        slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
-                    }
-                    if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
-                }
-            }
-            if (!lds_open && (!spill || spill_count + len > spill_size - (spill_size >> 2))) {
-                status = (uint32_t)(-DANN_EOVERFLOW);
-                break;
-            }
-            for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
-                const uint32_t j = j0 + lane;
-                const bool inb = j < len;
-                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
-                bool isnew = false;
-                if (inb && id != kEmpty && (!accept_only || fmatch(id))) {
-                    const int r = ht_visit(ht, ht_mod, id, lds_open);
-                    isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
-                }
-                const bool keep = isnew && id < ix.nslots;
-                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                if (keep) cand_id[nc + mbcnt(km)] = id;
-                nc += (uint32_t)__popcll(km);
-                if (lds_open) ht_count += (uint32_t)__popcll(nm);
-                else spill_count += (uint32_t)__popcll(nm);
-            }
-        }
-        return nc;
-    };
-
-    // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958) ---
-    {
-        const uint32_t ns = ix.nstart;
-        for (uint32_t i = lane; i < ns; i += kWave) {
-            cand_id[i] = ix.capacity + i;
-            ht_visit(ht, ht_mod, ix.capacity + i, true);
-        }
-        ht_count = ns;
-        __syncthreads();
-        gather(ns);
-        __syncthreads();
-        // the filtered searches do not count the start points as comparisons (inline_filter_search.rs:186-197)
-        cmps = fmode ? 0u : ns;
-        if (fmode == DANN_FILTER_INLINE) append_matched(ns);
-        for (uint32_t m0 = 0; m0 < ns; m0 += kWave) merge(m0, (ns - m0) < (uint32_t)kWave ? (ns - m0) : (uint32_t)kWave);
-    }
-
-    // ---- beam loop ----------------------------------------------------------------------
-    for (;;) {
-        PH_T(ph0);
-        // pop up to W closest unexpanded entries (queue.rs:297-313)
-        uint32_t nb = 0;
-        for (uint32_t w = 0; w < W; ++w) {
-            bool found = false;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                if (found) continue;
-                const bool cand = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
-                const uint64_t m = ballot64(cand);
-                if (m) {
-                    const int l = __builtin_ctzll(m);
-                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l);
-                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l));
-                    if ((int)lane == l) qid[s] |= kVisitedBit;
-                    if (lane == 0) {
-                        beam[nb] = id;
-                        if (a.rec_ids) {  // VisitedSearchRecord::record (search/record.rs:86-93)
-                            if (nrec < a.rec_stride) {
-                                a.rec_ids[(uint64_t)qi * a.rec_stride + nrec] = id;
-                                a.rec_dists[(uint64_t)qi * a.rec_stride + nrec] = d;
-                            }
-                        }
-                    }
-                    if (a.rec_ids) {
-                        if (nrec >= a.rec_stride) status = (uint32_t)(-DANN_EOVERFLOW);
-                        ++nrec;
-                    }
-                    ++nb;
-                    found = true;
-                }
-            }
-            if (!found) break;
-        }
-        if (nb == 0 || status) break;
-        hops += nb;
-        __syncthreads();
-        PH_T(ph1);
-        PH_ADD(0, ph0, ph1);
-
-        const uint32_t nc = expand(nb);
-        if (status) break;
-        __syncthreads();
-        PH_T(ph2);
-        PH_ADD(1, ph1, ph2);
-        // speculative adjacency prefetch: while the candidate rows are in flight, fetch the
-        // adjacency row of the best unexpanded entry of the *current* queue; if no new
-        // candidate beats it, the next hop starts without a dependent HBM round trip.
-        pf_node = kEmpty;
-        if (W == 1 && R <= (uint32_t)kWave) {
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                if (pf_node != kEmpty) continue;
-                const bool cnd = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
-                const uint64_t m = ballot64(cnd);
-                if (m) pf_node = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], __builtin_ctzll(m));
-            }
-            if (pf_node != kEmpty) {
-                const uint32_t* prow = ix.adj + (uint64_t)pf_node * ix.adj_stride;
-                pf_len = prow[0];
-                pf_val = lane < R ? prow[1 + lane] : kEmpty;
-            }
-        }
-        gather(nc);
-        __syncthreads();
-        PH_T(ph3);
-        PH_ADD(2, ph2, ph3);
-        cmps += nc;
-        if (fmode == DANN_FILTER_MULTIHOP) {
-            // multihop_search_internal (multihop_filter_search.rs:172-236); nc <= 64 (checked by the host)
-            const bool hasc = lane < nc;
-            const uint32_t cid = hasc ? cand_id[lane] : kEmpty;
-            const float cd = hasc ? cand_d[lane] : 0.0f;
-            const bool acc = hasc && fmatch(cid);
-            const bool rej = hasc && !acc;
-            const uint64_t am = ballot64(acc), rm = ballot64(rej);
-            const uint32_t na = (uint32_t)__popcll(am);
-            // rejected nodes closest first (stable), at most max_degree / 2 of them expand a second hop
-            uint32_t rank = 0;
-            for (uint64_t mm = rm; mm; mm &= mm - 1) {
-                const int j = __builtin_ctzll(mm);
-                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cd), j));
-                rank += ((dj < cd) | ((dj == cd) & ((uint32_t)j < lane))) ? 1u : 0u;
-            }
-            const uint32_t nrej = (uint32_t)__popcll(rm);
-            const uint32_t nsel = nrej < R / 2 ? nrej : R / 2;
-            __syncthreads();
-            if (acc) {  // accepted one-hop neighbours, emission order kept
-                const uint32_t r = mbcnt(am);
-                cand_id[r] = cid;
-                cand_d[r] = cd;
-            }
-            __syncthreads();
-            if (na) merge(0, na);
-            __syncthreads();
-            if (rej && rank < nsel) cand_id[rank] = cid;
-            __syncthreads();
-            const uint32_t sel = lane < nsel ? cand_id[lane] : kEmpty;
-            __syncthreads();
-            const uint32_t gsz = (cmax / R) < (uint32_t)kMaxBeam ? (cmax / R) : (uint32_t)kMaxBeam;
-            for (uint32_t b0 = 0; b0 < nsel && !status; b0 += gsz) {
-                const uint32_t gb = nsel - b0 < gsz ? nsel - b0 : gsz;
-                for (uint32_t t = 0; t < gb; ++t) {
-                    const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)sel, (int)(b0 + t));
-                    if (lane == 0) beam[t] = node;
-                }
-                __syncthreads();
-                const uint32_t nc2 = expand(gb, true);
-                if (status) break;
-                __syncthreads();
-                gather(nc2);
-                __syncthreads();
-                cmps += nc2;
-                for (uint32_t m0 = 0; m0 < nc2; m0 += kWave)
-                    merge(m0, (nc2 - m0) < (uint32_t)kWave ? (nc2 - m0) : (uint32_t)kWave);
-                __syncthreads();
-            }
-            if (status) break;
-            hops += nsel;
-        } else {
-            if (fmode == DANN_FILTER_INLINE) {
-                sample_matched += append_matched(nc);
-                sample_visited += nc;
-                if (status) break;
-            }
-            for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
-            // AdaptiveL (inline_filter_search.rs:262-277): one resize, decided from the hit rate so far; the new
-            // L comes from a table the host filled with compute_adaptive_l (f64 log10 / powf of the host libm)
-            if (a.ad_samples && !l_adjusted && sample_visited >= a.ad_samples) {
-                l_adjusted = true;
-                const uint32_t new_l = a.ad_table[(uint64_t)(sample_visited - a.ad_samples) * a.ad_stride + sample_matched];
-                if (new_l > a.l_value) {  // NeighborPriorityQueue::reconfigure (queue.rs:339-353)
-                    qcap = new_l;
-                    if (size > qcap) size = qcap;
-                }
-            }
-        }
-        PH_T(ph4);
-        PH_ADD(3, ph3, ph4);
-        PH_ADD(4, ph0, ph4);
-    }
-
-    // ---- graph::search::Range second phase (range_search.rs:283-316, 424-470) -----------------------
-    uint32_t range_written = 0, range_second = 0;
-    // ---- inline filter search: matched_results sorted by distance (inline_filter_search.rs:279) ------------
-    // sort_unstable_by(distance) restated as a stable sort: key = ordered distance bits << 32 | push index
-    uint32_t nkeys = 0;
-    if (fmode == DANN_FILTER_INLINE && !status) {
-        nkeys = 1;
-        while (nkeys < nm) nkeys <<= 1;
-        __threadfence_block();
-        for (uint32_t i = lane; i < nkeys; i += kWave)
-            key_store(m_keys + i, i < nm ? ((unsigned long long)ordered_bits(f32_load(m_d + i)) << 32) | i : ~0ull);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nm > 1) wave_sort_keys(m_keys, nkeys, lane);
-    }
-    if (a.range_ids && fmode == DANN_FILTER_INLINE && !status) {
-        // ---- FilteredRange (filtered_range_search.rs:140-330) -------------------------------------------
-        uint32_t* wids = a.range_ids + (uint64_t)qi * a.range_cap;  // matched_within_radius
-        float* wds = a.range_d + (uint64_t)qi * a.range_cap;
-        // the matched entries within the radius are a prefix of the sorted list
-        uint32_t nw = 0;
-        for (uint32_t i0 = 0; i0 < nm; i0 += kWave) {
-            const uint32_t i = i0 + lane;
-            uint32_t id = kEmpty;
-            float d = 0.0f;
-            bool in = false;
-            if (i < nm) {
-                const unsigned long long key = key_load(m_keys + i);
-                d = from_ordered_bits((uint32_t)(key >> 32));
-                id = u32_load(m_ids + (uint32_t)key);
-                in = d <= a.radius;
-            }
-            const uint64_t m = ballot64(in);
-            const uint32_t r = nw + mbcnt(m);
-            if (in && r < a.range_cap) {
-                wids[r] = id;
-                wds[r] = d;
-            }
-            nw += (uint32_t)__popcll(m);
-        }
-        if (nw > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // in_range = (first starting_l queue entries + matched) within the radius, sorted by (distance, id),
-        // duplicates removed (:170-181)
-        uint32_t n2 = 0;
-        const uint32_t take = size < a.l_value ? size : a.l_value;
-        if (!status) {
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const uint32_t p = (uint32_t)(s * kWave) + lane;
-                const bool in = p < take && qd[s] <= a.radius;
-                const uint64_t m = ballot64(in);
-                const uint32_t r = n2 + mbcnt(m);
-                if (in && r < a.key_cap)
-                    key_store(m_keys + r, ((unsigned long long)ordered_bits(qd[s]) << 32) | (qid[s] & ~kVisitedBit));
-                n2 += (uint32_t)__popcll(m);
-            }
-            for (uint32_t i0 = 0; i0 < nw; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                if (i < nw && n2 + i < a.key_cap)
-                    key_store(m_keys + n2 + i, ((unsigned long long)ordered_bits(f32_load(wds + i)) << 32) | u32_load(wids + i));
-            }
-            n2 += nw;
-            if (n2 > a.key_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-        }
-        uint32_t nf = 0;  // frontier length; frontier ids live in m_ids[] (the push-order list is dead now)
-        if (!status) {
-            uint32_t np2 = 1;
-            while (np2 < n2) np2 <<= 1;
-            for (uint32_t i = n2 + lane; i < np2; i += kWave) key_store(m_keys + i, ~0ull);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (n2 > 1) wave_sort_keys(m_keys, np2, lane);
-            for (uint32_t i0 = 0; i0 < n2; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                bool keep = false;
-                uint32_t id = kEmpty;
-                if (i < n2) {
-                    const unsigned long long key = key_load(m_keys + i);
-                    id = (uint32_t)key;
-                    keep = i == 0 || (uint32_t)key_load(m_keys + i - 1) != id;
-                }
-                const uint64_t m = ballot64(keep);
-                const uint32_t r = nf + mbcnt(m);
-                if (keep && r < a.m_cap) m_ids[r] = id;
-                nf += (uint32_t)__popcll(m);
-            }
-            if (nf > a.m_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (!status && nf >= a.range_thresh && nw < a.range_max) {
-            range_second = 1;
-            // visited := ids of in_range; range_frontier := in_range (:190-199)
-            __syncthreads();
-            for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
-            if (spill) spill_wipe(spill, spill_size, lane);
-            __syncthreads();
-            lds_open = true;
-            ht_count = 0;
-            spill_count = 0;
-            pf_node = kEmpty;
-            for (uint32_t i0 = 0; i0 < nf && !status; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                const uint32_t cnt = (nf - i0) < (uint32_t)kWave ? (nf - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nf) ht_visit(ht, ht_mod, u32_load(m_ids + i), true);
-                ht_count += cnt;
-            }
-            __syncthreads();
-            const float nav = a.radius * a.range_slack;
-            uint32_t front = 0;
-            // filtered_range_search_internal (:263-330): cmps and hops keep accumulating
-            while (!status && front < nf && nw < a.range_max) {
-                const uint32_t nb = nf - front < W ? nf - front : W;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane < nb) beam[lane] = u32_load(m_ids + front + lane);
-                front += nb;
-                __syncthreads();
-                const uint32_t nc = expand(nb);
-                if (status) break;
-                __syncthreads();
-                gather(nc);
-                __syncthreads();
-                cmps += nc;
-                hops += nb;
-                for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
-                    const uint32_t c = c0 + lane;
-                    const bool has = c < nc;
-                    const uint32_t id = has ? cand_id[c] : kEmpty;
-                    const float d = has ? cand_d[c] : 0.0f;
-                    const bool fr = has && d <= nav;
-                    const uint64_t fm = ballot64(fr);
-                    const uint32_t rf = nf + mbcnt(fm);
-                    if (fr && rf < a.m_cap) m_ids[rf] = id;
-                    nf += (uint32_t)__popcll(fm);
-                    const bool mt = fr && d <= a.radius && fmatch(id);
-                    const uint64_t mm = ballot64(mt);
-                    const uint32_t rw = nw + mbcnt(mm);
-                    if (mt && rw < a.range_max && rw < a.range_cap) {
-                        wids[rw] = id;
-                        wds[rw] = d;
-                    }
-                    uint32_t add = (uint32_t)__popcll(mm);
-                    if (nw + add > a.range_max) add = a.range_max - nw;
-                    nw += add;
-                }
-                if (nf > a.m_cap || nw > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-            }
-        }
-        // matched_within_radius.take(max_returned) -> start points dropped -> inner radius -> output
-        if (!status && a.out_ids) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
-            float* od = a.out_dists + (uint64_t)qi * a.k;
-            const uint32_t lim = nw < a.range_max ? nw : a.range_max;
-            for (uint32_t i0 = 0; i0 < lim; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                uint32_t id = kEmpty;
-                float d = 0.0f;
-                if (i < lim) {
-                    id = u32_load(wids + i);
-                    d = f32_load(wds + i);
-                }
-                const bool ok = i < lim && id < ix.capacity && !(a.has_inner && d <= a.inner_radius);
-                const uint64_t m = ballot64(ok);
-                const uint32_t r = range_written + mbcnt(m);
-                if (ok && r < a.k) {
-                    oi[r] = id;
-                    od[r] = d;
-                }
-                range_written += (uint32_t)__popcll(m);
-            }
-            if (range_written > a.k) status = (uint32_t)(-DANN_EOVERFLOW);  // the reference's output Vec is unbounded
-            range_written = range_written < a.k ? range_written : a.k;
-            for (uint32_t r = range_written + lane; r < a.k; r += kWave) {
-                oi[r] = kEmpty;
-                od[r] = __builtin_inff();
-            }
-        }
-    }
-    if (a.range_ids && fmode != DANN_FILTER_INLINE && !status) {
-        uint32_t* rids = a.range_ids + (uint64_t)qi * a.range_cap;
-        float* rds = a.range_d + (uint64_t)qi * a.range_cap;
-        const uint32_t max_ret = a.range_max < a.range_cap ? a.range_max : a.range_cap;  // list capacity
-        // in_range = the first starting_l queue entries within the radius (start points included)
-        uint32_t nr = 0;
-        const uint32_t take = size < a.l_value ? size : a.l_value;
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint32_t p = (uint32_t)(s * kWave) + lane;
-            const bool in = p < take && qd[s] <= a.radius;
-            const uint64_t m = ballot64(in);
-            const uint32_t r = nr + mbcnt(m);
-            if (in && r < a.range_cap) {
-                rids[r] = qid[s] & ~kVisitedBit;
-                rds[r] = qd[s];
-            }
-            nr += (uint32_t)__popcll(m);
-        }
-        if (nr > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-        const uint32_t init_hops = hops;
-        if (!status && nr >= a.range_thresh && nr < a.range_max) {
-            range_second = 1;
-            // visited := ids of in_range only (range_search.rs:297-301)
-            __syncthreads();
-            for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
-            if (spill) spill_wipe(spill, spill_size, lane);
-            __syncthreads();
-            lds_open = true;
-            ht_count = 0;
-            spill_count = 0;
-            pf_node = kEmpty;
-            for (uint32_t i0 = 0; i0 < nr && !status; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                const uint32_t cnt = (nr - i0) < (uint32_t)kWave ? (nr - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nr) ht_visit(ht, ht_mod, rids[i], true);
-                ht_count += cnt;
-            }
-            __syncthreads();
-            const float rlimit = a.radius * a.range_slack;
-            uint32_t front = 0;
-            while (!status && front < nr && nr < a.range_max) {
-                // next beam: up to W ids from the front of the frontier (== in_range in arrival order)
-                uint32_t nb = nr - front < W ? nr - front : W;
-                __threadfence_block();  // rids[] written and re-read by this wave only
-                if (lane < nb) beam[lane] = rids[front + lane];
-                front += nb;
-                __syncthreads();
-                const uint32_t nc = expand(nb);
-                if (status) break;
-                __syncthreads();
-                gather(nc);
-                __syncthreads();
-                hops += nb;
-                // append survivors in emission order while the list has room
-                for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
-                    const uint32_t c = c0 + lane;
-                    const bool in = c < nc && cand_d[c] <= rlimit;
-                    const uint64_t m = ballot64(in);
-                    const uint32_t r = nr + mbcnt(m);
-                    if (in && r < a.range_max) {
-                        if (r < a.range_cap) {
-                            rids[r] = cand_id[c];
-                            rds[r] = cand_d[c];
-                        }
-                    }
-                    uint32_t add = (uint32_t)__popcll(m);
-                    if (nr + add > a.range_max) add = a.range_max - nr;
-                    nr += add;
-                    if (nr > a.range_cap) status = (uint32_t)(-DANN_EOVERFLOW);
-                }
-            }
-            hops = init_hops + hops;  // the reference adds the cumulative counter to the initial one (:308-314)
-        }
-        (void)max_ret;
-        // post-process: start points dropped, inner/outer radius filter, output buffer capacity k
-        if (!status && a.out_ids) {
-            __threadfence_block();
-            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
-            float* od = a.out_dists + (uint64_t)qi * a.k;
-            for (uint32_t i0 = 0; i0 < nr; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                uint32_t id = kEmpty;
-                float d = 0.0f;
-                if (i < nr) {
-                    id = rids[i];
-                    d = rds[i];
-                }
-                const bool ok = i < nr && id < ix.capacity && !(a.has_inner && d <= a.inner_radius) && d <= a.radius;
-                const uint64_t m = ballot64(ok);
-                const uint32_t r = range_written + mbcnt(m);
-                if (ok && r < a.k) {
-                    oi[r] = id;
-                    od[r] = d;
-                }
-                range_written += (uint32_t)__popcll(m);
-            }
-            range_written = range_written < a.k ? range_written : a.k;
-            for (uint32_t r = range_written + lane; r < a.k; r += kWave) {
-                oi[r] = kEmpty;
-                od[r] = __builtin_inff();
-            }
-        }
-    }
-
-#ifdef DANN_PHASE_CYCLES
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph_acc[i]);
-#endif
-    if (spill) {  // hand the spill table back clean
-        __syncthreads();
-        spill_wipe(spill, spill_size, lane);
-        __syncthreads();
-        if (lane == 0) atomicExch(a.spill_next + 16 + (uint32_t)((spill - a.spill) >> a.spill_bits), 0u);
-    }
-    // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
-    uint32_t written = range_written;
-    if (a.out_ids && !a.range_ids && fmode == DANN_FILTER_INLINE) {
-        // matched_results.take(l_value) -> Translate drops start points -> first k (inline_filter_search.rs:131-139)
-        uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
-        float* od = a.out_dists + (uint64_t)qi * a.k;
-        const uint32_t lim = status ? 0u : (nm < a.l_value ? nm : a.l_value);
-        for (uint32_t i0 = 0; i0 < lim; i0 += kWave) {
-            const uint32_t i = i0 + lane;
-            uint32_t id = kEmpty;
-            float d = 0.0f;
-            if (i < lim) {
-                const unsigned long long key = key_load(m_keys + i);
-                d = from_ordered_bits((uint32_t)(key >> 32));
-                id = u32_load(m_ids + (uint32_t)key);
-            }
-            const bool res = i < lim && id < ix.capacity;
-            const uint64_t m = ballot64(res);
-            const uint32_t r = written + mbcnt(m);
-            if (res && r < a.k) {
-                oi[r] = id;
-                od[r] = d;
-            }
-            written += (uint32_t)__popcll(m);
-        }
-        written = written < a.k ? written : a.k;
-        for (uint32_t r = written + lane; r < a.k; r += kWave) {
-            oi[r] = kEmpty;
-            od[r] = __builtin_inff();
-        }
-    } else if (a.out_ids && !a.range_ids) {
-        uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
-        float* od = a.out_dists + (uint64_t)qi * a.k;
-        uint32_t taken = 0;  // multihop: entries that are not rejected start points, first l_value of them
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint32_t p = (uint32_t)(s * kWave) + lane;
-            const uint32_t id = qid[s] & ~kVisitedBit;
-            bool res = p < size && id < ix.capacity;
-            if (fmode == DANN_FILTER_MULTIHOP) {
-                // best.iter().filter(not a rejected start point).take(l_value) (multihop_filter_search.rs:88-95)
-                const bool cnt = p < size && !(id >= ix.capacity && !fmatch(id));
-                const uint64_t cm = ballot64(cnt);
-                res = res && (taken + mbcnt(cm)) < a.l_value;
-                taken += (uint32_t)__popcll(cm);
-            }
-            const uint64_t m = ballot64(res);
-            const uint32_t r = written + mbcnt(m);
-            if (res && r < a.k) {
-                oi[r] = id;
-                od[r] = qd[s];
-            }
-            written += (uint32_t)__popcll(m);
-        }
-        written = written < a.k ? written : a.k;
-        for (uint32_t r = written + lane; r < a.k; r += kWave) {
-            oi[r] = kEmpty;
-            od[r] = __builtin_inff();
-        }
-    }
-    if (lane == 0) {
-        if (a.stats) {
-            dann_search_stats st;
-            st.cmps = cmps;
-            st.hops = hops;
-            st.result_count = written;
-            st.status = status;
-            a.stats[qi] = st;
-        }
-        if (status && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (a.rec_n) a.rec_n[qi] = nrec;
-        if (a.rec_max) atomicMax(a.rec_max, nrec);
-        if (a.range_second) a.range_second[qi] = range_second;
-    }
-}
-
-template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
-int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, FILT>;
-    if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
-        hipFuncAttributes attr;
-        hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
-        if (e != hipSuccess) return hip_fail(e, "hipFuncGetAttributes");
-        *regs_out = attr.numRegs;
-        return DANN_OK;
-    }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(kWave), lds, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
-    return DANN_OK;
-}
-
-template <int DT, int OP, bool NORM, int DIM, bool FILT>
-int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, FILT>(a, lds, stream, regs_out);
-    set_error("search list size L + start points = %u exceeds the supported maximum of 512", qcap);
-    return DANN_EUNSUPPORTED;
-}
-
-template <int DT, int OP, bool NORM, int DIM>
-int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, true>(a, qcap, lds, stream, regs_out);
-    return launch_qs2<DT, OP, NORM, DIM, false>(a, qcap, lds, stream, regs_out);
-}
-
-template <int DT>
-int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    int op;
-    bool norm;
-    if (!resolve_metric(a.ix.dtype, a.ix.metric, &op, &norm)) {
-        set_error("metric %d is not defined for dtype %d", a.ix.metric, a.ix.dtype);
-        return DANN_EUNSUPPORTED;
-    }
-    if (op == OP_L2) {
-        if constexpr (DT == DT_F32 || DT == DT_F16) {
-            if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream, regs_out);
-        }
-        if constexpr (DT == DT_SQ8) {
-            if (norm) return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream, regs_out);
-        }
-        return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream, regs_out);
-    }
-    if (op == OP_IP) {
-        if constexpr (DT == DT_F32 || DT == DT_F16) {
-            if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream, regs_out);
-        }
-        return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream, regs_out);
-    }
-    if constexpr (DT != DT_SQ8 && DT != DT_PQ) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream, regs_out);
-    return DANN_EUNSUPPORTED;
-}
-
-uint32_t cmax_of(const SearchArgs& a) {
-    uint32_t c1 = (a.beam_width * a.ix.max_degree + 63u) & ~63u, c2 = (a.ix.nstart + 63u) & ~63u;
-    return c1 > c2 ? c1 : c2;
-}
-uint32_t qs_of(uint32_t qcap) { return qcap <= 64 ? 1 : qcap <= 128 ? 2 : qcap <= 256 ? 4 : 8; }
 
 // collect the indices of queries whose status is non-zero
 __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint32_t* qmap, uint32_t n, uint32_t* count,
@@ -1227,24 +129,31 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
         return DANN_EOVERFLOW;
     }
     switch (a.ix.dtype) {
-        case DT_F32: return launch_dt<DT_F32>(a, qcap, lds, stream, regs_out);
-        case DT_F16: return launch_dt<DT_F16>(a, qcap, lds, stream, regs_out);
-        case DT_U8: return launch_dt<DT_U8>(a, qcap, lds, stream, regs_out);
-        case DT_I8: return launch_dt<DT_I8>(a, qcap, lds, stream, regs_out);
-        case DT_SQ8: return launch_dt<DT_SQ8>(a, qcap, lds, stream, regs_out);
-        case DT_PQ: return launch_dt<DT_PQ>(a, qcap, lds, stream, regs_out);
+        case DT_F32: return launch_search_f32(a, qcap, lds, stream, regs_out);
+        case DT_F16: return launch_search_f16(a, qcap, lds, stream, regs_out);
+        case DT_U8: return launch_search_u8(a, qcap, lds, stream, regs_out);
+        case DT_I8: return launch_search_i8(a, qcap, lds, stream, regs_out);
+        case DT_SQ8: return launch_search_sq8(a, qcap, lds, stream, regs_out);
+        case DT_PQ: return launch_search_pq(a, qcap, lds, stream, regs_out);
     }
     set_error("bad dtype %d", a.ix.dtype);
     return DANN_EINVAL;
 }
 
 #ifdef DANN_PHASE_CYCLES
-extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 64);
-    if (reset) {
-        unsigned long long z[8] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, 64);
+static unsigned long long* g_phase_buf = nullptr;  // debug builds: per-phase cycle sums (SearchArgs::phase_cycles)
+unsigned long long* dann_phase_buffer() {
+    if (!g_phase_buf) {
+        if (hipMalloc((void**)&g_phase_buf, 64) != hipSuccess) return nullptr;
+        (void)hipMemset(g_phase_buf, 0, 64);
     }
+    return g_phase_buf;
+}
+extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) {
+    unsigned long long* b = dann_phase_buffer();
+    if (!b) return DANN_EHIP;
+    if (out) (void)hipMemcpy(out, b, 64, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(b, 0, 64);
     return 0;
 }
 #endif
@@ -1305,6 +214,9 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     // HIP events bracket exactly the beam-search launches, on the stream they run on
     auto timed_launch = [&](SearchArgs& args) -> int32_t {
         args.ht_prime = largest_prime_leq(args.ht_entries);
+#ifdef DANN_PHASE_CYCLES
+        args.phase_cycles = dann_phase_buffer();
+#endif
         DANN_HIP(hipEventRecord(idx->ev0, st));
         int32_t r = launch_search(args, st);
         if (r != DANN_OK) return r;

@@ -1,7 +1,7 @@
 import sys, os, subprocess, ctypes as C
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
 src=os.path.join(R,'diskann_amd','csrc'); out='/tmp/libdann_prof.so'
-cmd=['/opt/rocm/bin/hipcc','--offload-arch=gfx950','-O3','-std=c++17','-fPIC','-ffp-contract=off','-fno-gpu-flush-denormals-to-zero','-DDANN_PHASE_CYCLES','-shared','-o',out]+[os.path.join(src,f) for f in ('api.hip','search_kernels.hip','distance_kernels.hip','build_kernels.hip','pq_kernels.hip')]
+cmd=['/opt/rocm/bin/hipcc','--offload-arch=gfx950','-O3','-std=c++17','-fPIC','-ffp-contract=off','-fno-gpu-flush-denormals-to-zero','-DDANN_PHASE_CYCLES','-shared','-o',out]+[os.path.join(src,f) for f in ('api.hip','search_kernels.hip','search_f32.hip','search_f16.hip','search_u8.hip','search_i8.hip','search_sq8.hip','search_pq.hip','distance_kernels.hip','build_kernels.hip','pq_kernels.hip')]
 subprocess.check_call(cmd)
 import diskann_amd._ffi as ffi
 ffi.LIB_PATH=out

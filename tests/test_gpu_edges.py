@@ -38,10 +38,10 @@ def test_large_L_and_wide_beam():
     adj = random_graph(rng, n, R, nstart=2)
     oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:2], R)   # two start points
     q = rand_vectors(rng, oracle.F32, 12, dim)
-    for L, W, k in ((510, 1, 100), (500, 16, 500), (129, 7, 1), (64, 16, 64)):
+    for L, W, k in ((510, 1, 100), (500, 16, 500), (129, 7, 1), (64, 16, 64), (600, 1, 10), (1022, 2, 300)):
         _check(oix, gix, q, L, W, k)
     with pytest.raises(da.DannError) as e:
-        gix.search(da.Knn(600), q, 10)          # L + start points > 512: explicit, not silent
+        gix.search(da.Knn(1023), q, 10)         # L + start points > 1024: explicit, not silent
     assert e.value.status == da._ffi.EUNSUPPORTED
     with pytest.raises(da.DannError):
         gix.search(da.Knn(10, 17), q, 10)
