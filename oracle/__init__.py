@@ -94,6 +94,12 @@ def lib():
     L.orc_multihop_search.argtypes = [P(OrcIndex), vp, u32, u32, u32, vp, vp, vp, vp]
     L.orc_filtered_range_search.restype = i32
     L.orc_filtered_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, vp, u64, vp]
+    L.orc_paged_begin.restype = vp
+    L.orc_paged_begin.argtypes = [P(OrcIndex), vp, u32]
+    L.orc_paged_next.restype = i32
+    L.orc_paged_next.argtypes = [vp, u32, vp, vp]
+    L.orc_paged_end.restype = None
+    L.orc_paged_end.argtypes = [vp]
     L.orc_range_search.restype = i32
     L.orc_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, u64, vp]
     L.orc_expand_beam.restype = i32
@@ -295,6 +301,27 @@ class Index:
         if n < 0:
             raise RuntimeError(f"orc_filtered_range_search failed: {n}")
         return ids[:n].copy(), dists[:n].copy(), stats
+
+    def paged_search(self, query, l_value, page_size, max_pages=None):
+        """all pages of index.paged_search(query, l_value) with next_page(page_size) until an empty page"""
+        q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])
+        h = lib().orc_paged_begin(C.byref(self._c), _p(q), l_value)
+        if not h:
+            raise RuntimeError("orc_paged_begin failed")
+        pages = []
+        try:
+            while max_pages is None or len(pages) < max_pages:
+                ids = np.empty(page_size, np.uint32)
+                dists = np.empty(page_size, np.float32)
+                n = lib().orc_paged_next(h, page_size, _p(ids), _p(dists))
+                if n < 0:
+                    raise RuntimeError(f"orc_paged_next failed: {n}")
+                if n == 0:
+                    break
+                pages.append((ids[:n].copy(), dists[:n].copy()))
+        finally:
+            lib().orc_paged_end(h)
+        return pages
 
     def expand_beam(self, query, ids):
         q = np.ascontiguousarray(query, dtype=NP_DTYPE[self.dtype])

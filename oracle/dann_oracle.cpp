@@ -413,6 +413,7 @@ float sq8_similarity(int metric, const uint8_t* x, const uint8_t* y, uint32_t di
  * ====================================================================== */
 struct Queue {
     size_t capacity, search_l, cursor = 0;
+    bool auto_resizable = false; /* auto_resizable_with_search_param_l (queue.rs:95-105): never drops */
     std::vector<uint32_t> ids;
     std::vector<uint8_t> visited;
     std::vector<float> dist;
@@ -433,7 +434,11 @@ struct Queue {
     void insert(uint32_t id, float d) {
         if (std::isnan(d)) return;
         size_t n = size();
-        if (n == capacity && n > 0 && dist[n - 1] < d) return;
+        if (auto_resizable) {
+            if (n == capacity) capacity += std::max<size_t>(1, capacity >> 1); /* reserve: 1.5x (:117-121) */
+        } else if (n == capacity && n > 0 && dist[n - 1] < d) {
+            return;
+        }
         if (capacity == 0) return;
         size_t pos = n > 0 ? lower_bound(d) : 0;
         if (n == capacity) {
@@ -445,6 +450,14 @@ struct Queue {
         visited.insert(visited.begin() + pos, 0);
         dist.insert(dist.begin() + pos, d);
         if (pos < cursor) cursor = pos;
+    }
+    /* drain_best :174-180 */
+    void drain_best(size_t count) {
+        count = std::min(count, size());
+        ids.erase(ids.begin(), ids.begin() + count);
+        visited.erase(visited.begin(), visited.begin() + count);
+        dist.erase(dist.begin(), dist.begin() + count);
+        cursor = 0;
     }
     /* has_notvisited_node :316-318 */
     bool has_notvisited() const { return cursor < std::min(search_l, size()); }
@@ -1243,6 +1256,108 @@ int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32
     return (int32_t)written;
 }
 }  // extern "C"
+
+/* ======================================================================
+ * paged search: DiskANNIndex::paged_search (index.rs:2075-2155) + PagedSearch::next_page (search/paged.rs:53-149)
+ * ====================================================================== */
+struct orc_paged {
+    const orc_index* ix;
+    View v;
+    std::vector<uint8_t> qbytes;
+    QueryCtx* qc;
+    Queue best;
+    std::unordered_set<uint32_t> visited;
+    std::vector<std::pair<uint32_t, float>> computed;
+    size_t next_index;
+    uint32_t l_value;
+    SearchOut so;
+    orc_paged(const orc_index* i, size_t cap) : ix(i), v(i), qc(nullptr), best(cap), next_index(0), l_value(0) {}
+};
+
+orc_paged* orc_paged_begin(const orc_index* ix, const void* query, uint32_t l_value) {
+    if (!ix || !query || l_value == 0) return nullptr;
+    orc_paged* s = new orc_paged(ix, (size_t)l_value + ix->nstart);
+    s->best.auto_resizable = true;
+    s->qbytes.assign((const uint8_t*)query, (const uint8_t*)query + query_bytes(ix));
+    s->qc = new QueryCtx(s->v, s->qbytes.data(), false);
+    s->l_value = l_value;
+    /* the start points seed the visited set and are expanded, but are not candidates themselves (:2117-2141) */
+    for (uint32_t p = ix->capacity; p < ix->capacity + ix->nstart; ++p) s->visited.insert(p);
+    std::vector<std::pair<uint32_t, float>> neighbors;
+    for (uint32_t p = ix->capacity; p < ix->capacity + ix->nstart; ++p) {
+        const uint32_t* adj;
+        uint32_t n = s->v.get_neighbors(p, &adj);
+        for (uint32_t j = 0; j < n; ++j) {
+            uint32_t nb = adj[j];
+            if (s->visited.insert(nb).second && nb < s->v.nslots()) neighbors.emplace_back(nb, s->qc->eval(nb));
+        }
+    }
+    for (auto& nb : neighbors) s->best.insert(nb.first, nb.second);
+    s->computed.assign(l_value, std::make_pair(0u, 0.0f));
+    s->next_index = l_value;
+    return s;
+}
+
+int32_t orc_paged_next(orc_paged* s, uint32_t k, uint32_t* out_ids, float* out_dists) {
+    if (!s || !out_ids || !out_dists) return -1;
+    if (k > s->l_value || k == 0) return -1; /* "k should be less than or equal to search_param_l" / "> 0" */
+    uint32_t n = 0;
+    size_t avail = s->computed.size() > s->next_index ? s->computed.size() - s->next_index : 0;
+    size_t from_cache = std::min<size_t>(k, avail);
+    for (size_t i = 0; i < from_cache; ++i) {
+        out_ids[n] = s->computed[s->next_index + i].first;
+        out_dists[n] = s->computed[s->next_index + i].second;
+        ++n;
+    }
+    s->next_index += from_cache;
+    if (n == k) return (int32_t)n;
+    /* resume: search_internal does not re-seed because the visited set is not empty (index.rs:1948-1958) */
+    {
+        const View& v = s->v;
+        std::vector<std::pair<uint32_t, float>> neighbors;
+        uint32_t id;
+        float d;
+        while (s->best.has_notvisited()) {
+            if (!s->best.pop(&id, &d)) break;
+            neighbors.clear();
+            const uint32_t* adj;
+            uint32_t len = v.get_neighbors(id, &adj);
+            for (uint32_t j = 0; j < len; ++j) {
+                uint32_t nb = adj[j];
+                if (s->visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, s->qc->eval(nb));
+            }
+            for (auto& nb : neighbors) s->best.insert(nb.first, nb.second);
+            s->so.cmps += (uint32_t)neighbors.size();
+            s->so.hops += 1;
+        }
+    }
+    /* filter_search_candidates (:126-149) over best.iter() = the first min(search_l, size) entries */
+    size_t total = 0, lim = std::min(s->best.search_l, s->best.size());
+    std::vector<std::pair<uint32_t, float>> cand;
+    for (size_t i = 0; i < lim; ++i) {
+        ++total;
+        if (s->best.ids[i] >= s->ix->capacity) continue;
+        cand.emplace_back(s->best.ids[i], s->best.dist[i]);
+        if (cand.size() >= k) break;
+    }
+    s->best.drain_best(total);
+    s->computed = cand;
+    s->next_index = 0;
+    size_t leftover = std::min<size_t>(k - n, s->computed.size());
+    for (size_t i = 0; i < leftover; ++i) {
+        out_ids[n] = s->computed[i].first;
+        out_dists[n] = s->computed[i].second;
+        ++n;
+    }
+    s->next_index += leftover;
+    return (int32_t)n;
+}
+
+void orc_paged_end(orc_paged* s) {
+    if (!s) return;
+    delete s->qc;
+    delete s;
+}
 
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists) {

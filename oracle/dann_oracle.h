@@ -133,6 +133,14 @@ int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32
                                   float range_slack, uint64_t max_returned, const uint32_t* filter_bits,
                                   uint32_t* out_ids, float* out_dists, uint64_t out_cap, uint32_t* stats);
 
+/* Paged search: DiskANNIndex::paged_search (diskann/src/graph/index.rs:2075-2155) + PagedSearch::next_page
+ * (search/paged.rs:53-149).  The queue is the auto-resizable variant (queue.rs:95-121): nothing is ever dropped.
+ * next returns the number of results of the page (0 = exhausted) or < 0 (k == 0 or k > l_value). */
+typedef struct orc_paged orc_paged;
+orc_paged* orc_paged_begin(const orc_index* ix, const void* query, uint32_t l_value);
+int32_t orc_paged_next(orc_paged* s, uint32_t k, uint32_t* out_ids, float* out_dists);
+void orc_paged_end(orc_paged* s);
+
 /* ExpandBeam::expand_beam (provider.rs:620-690) for a pre-filtered id list. */
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists);

@@ -128,6 +128,19 @@ def filtered():
     print("filtered cases:", {k: len(v) for k, v in out.items()})
 
 
+def paged():
+    out = []
+    for path in sorted(glob.glob(f"{REF}/diskann/test/generated/graph/test/cases/paged_search/*.json")):
+        c = json.load(open(path))["payload"]
+        out.append({"source": os.path.relpath(path, REF), "name": os.path.basename(path)[:-5], "grid_dims": c["dims"],
+                    "grid_size": c["grid_size"], "query": c["query"], "search_l": c["search_l"],
+                    "page_size": c["page_size"], "pages": c["pages"], "total_results": c["total_results"],
+                    # single_page asks for one page only (paged_search.rs:196-199)
+                    "max_pages": 1 if os.path.basename(path) == "single_page.json" else None})
+    json.dump(out, open(f"{HERE}/paged_search.json", "w"), separators=(",", ":"))
+    print("paged cases:", len(out))
+
+
 def f16_table():
     bits = np.zeros(65536, np.uint32)
     seen = np.zeros(65536, bool)
@@ -157,4 +170,5 @@ if __name__ == "__main__":
     grid_insert()
     range_search()
     filtered()
+    paged()
     f16_table()

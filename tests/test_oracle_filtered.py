@@ -74,3 +74,17 @@ def test_filtered_range_golden(cases):
             assert [r[1] for r in got] == [r[1] for r in c["results"]]
         else:
             assert got == c["results"], c["name"]
+
+
+def test_paged_search_golden(golden_dir):
+    """diskann/test/generated/graph/test/cases/paged_search: every page, ids and distances"""
+    cases = json.load(open(os.path.join(golden_dir, "paged_search.json")))
+    assert len(cases) == 3
+    for c in cases:
+        g = build("grid", c["grid_dims"], c["grid_size"])
+        ix = _oracle_index(g)
+        pages = ix.paged_search(np.array(c["query"], np.float32), c["search_l"], c["page_size"],
+                                max_pages=c["max_pages"])
+        got = [[[int(i), float(d)] for i, d in zip(ids, dists)] for ids, dists in pages]
+        assert got == c["pages"], c["name"]
+        assert sum(len(p) for p in got) == c["total_results"]
