@@ -76,6 +76,9 @@ SYMBOLS = {
     "dann_filtered_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _P(Filter), _vp, _vp, _vp]),
     "dann_filtered_range_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _f32, _i32, _f32, _f32, _f32, _u32, _u32,
                                                 _P(Filter), _vp, _vp, _vp, _vp]),
+    "dann_paged_begin": (_i32, [_vp, _vp, _u32, _u32, _u32, _P(_vp)]),
+    "dann_paged_next": (_i32, [_vp, _u32, _vp, _vp, _vp]),
+    "dann_paged_end": (_i32, [_vp]),
     "dann_rerank_batch": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
     "dann_rerank_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp]),
     "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),

@@ -44,6 +44,37 @@ def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_si
                        int(saturate_after_prune))
 
 
+class PagedSearch:
+    """graph::search::PagedSearch (diskann/src/graph/search/paged.rs) for nq queries."""
+
+    def __init__(self, provider, queries, l_value, list_cap=0):
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[provider.dtype]).reshape(-1, provider.row_elems)
+        self.nq = q.shape[0]
+        self._h = C.c_void_p()
+        self._provider = provider  # keeps the index alive
+        check(_ffi.lib().dann_paged_begin(provider._h, _p(q), self.nq, int(l_value), int(list_cap), C.byref(self._h)),
+              "dann_paged_begin")
+
+    def next_page(self, k):
+        """(ids[nq, k], dists[nq, k], counts[nq]); counts == 0 where the search is exhausted"""
+        ids = np.empty((self.nq, k), np.uint32)
+        dists = np.empty((self.nq, k), np.float32)
+        counts = np.zeros(self.nq, np.uint32)
+        check(_ffi.lib().dann_paged_next(self._h, int(k), _p(ids), _p(dists), _p(counts)), "dann_paged_next")
+        return ids, dists, counts
+
+    def close(self):
+        if self._h:
+            _ffi.lib().dann_paged_end(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Provider:
     """diskann_inmem::Provider<Full<T>, u32> + DiskANNIndex, resident in one GPU's HBM."""
 
@@ -271,6 +302,10 @@ class Provider:
               "dann_filtered_range_search_batch")
         del keep
         return ids, dists, stats, second
+
+    def paged_search(self, queries, l_value, list_cap=0):
+        """DiskANNIndex::paged_search for a batch: returns a PagedSearch session (next_page(k), close())."""
+        return PagedSearch(self, queries, l_value, list_cap)
 
     def rerank(self, queries, cand_ids, k):
         """Rerank post-processor: full-precision distances for the candidates of a quantised search."""

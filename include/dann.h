@@ -218,6 +218,19 @@ int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, u
                                          uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                          uint32_t* out_second_round);
 
+/* ---- paged search: DiskANNIndex::paged_search + PagedSearch::next_page (diskann/src/graph/index.rs:2075-2155,
+ * diskann/src/graph/search/paged.rs:53-149) for nq queries at once.  The session owns the reference's per-search
+ * scratch on the device: the auto-resizable candidate list (nothing is ever dropped, queue.rs:95-121), the visited
+ * set and the tail of the last computed page.  list_cap bounds the list per query (0 = min(capacity + starts,
+ * max(16384, 64 * l_value))); exceeding it is DANN_EOVERFLOW.  next_page: k results per query (k <= l_value, errors
+ * as paged.rs:57-64), out_ids/out_dists nq x k (unwritten 0xFFFFFFFF / +inf), out_counts[q] = results of the page
+ * (0 = exhausted).  Pages never overlap; within a page distances are non-decreasing.  Not for DANN_PQ. */
+typedef struct dann_paged dann_paged;
+int32_t dann_paged_begin(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t list_cap,
+                         dann_paged** out);
+int32_t dann_paged_next(dann_paged* session, uint32_t k, uint32_t* out_ids, float* out_dists, uint32_t* out_counts);
+int32_t dann_paged_end(dann_paged* session);
+
 /* Rerank post-processor (diskann-providers/src/model/graph/provider/async_/inmem/full_precision.rs:348-397):
  * full-precision distances query x stored row for every candidate id of a quantised search, sorted
  * ascending (equal distances keep candidate order; the reference's sort is unstable), first k returned.

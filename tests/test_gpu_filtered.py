@@ -137,3 +137,54 @@ def test_filter_errors():
         px.filtered_search(da.Knn(5), q, 3, g.match("even"), mode=da.FILTER_MULTIHOP, adaptive=(5, 2.0))
     with pytest.raises(ValueError):
         px.filtered_search(da.Knn(5), q, 3, np.ones(3, bool))
+
+
+def test_paged_golden_gpu(golden_dir):
+    """the reference's paged_search golden cases, page by page, through dann_paged_*"""
+    cases = json.load(open(os.path.join(golden_dir, "paged_search.json")))
+    for c in cases:
+        g = build("grid", c["grid_dims"], c["grid_size"])
+        _, px = _pair(g)
+        s = px.paged_search(np.array(c["query"], np.float32), c["search_l"])
+        pages = []
+        while c["max_pages"] is None or len(pages) < c["max_pages"]:
+            ids, dists, counts = s.next_page(c["page_size"])
+            n = int(counts[0])
+            if n == 0:
+                break
+            pages.append([[int(i), float(d)] for i, d in zip(ids[0, :n], dists[0, :n])])
+        s.close()
+        assert pages == c["pages"], c["name"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8", "f16"])
+def test_paged_random_vs_oracle(dtype):
+    """a batch of paged sessions on a random graph: every page of every query equals the oracle's, for page sizes
+    that do and do not divide L, until exhaustion; k > L and k == 0 are errors"""
+    import diskann_amd as da
+    from helpers import rand_vectors
+    odt = {"f32": oracle.F32, "u8": oracle.U8, "f16": oracle.F16}[dtype]
+    rng = np.random.default_rng(17)
+    n, dim, R, nq = 1500, 20, 12, 16
+    data = rand_vectors(rng, odt, n, dim)
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(odt, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rand_vectors(rng, odt, nq, dim)
+    for L, k, max_pages in ((24, 7, 40), (16, 16, 12), (40, 1, 60)):
+        s = px.paged_search(queries, L)
+        want = [ox.paged_search(queries[qi], L, k, max_pages=max_pages) for qi in range(nq)]
+        for page in range(max_pages):
+            ids, dists, counts = s.next_page(k)
+            for qi in range(nq):
+                if page < len(want[qi]):
+                    wi, wd = want[qi][page]
+                    m = int(counts[qi])
+                    assert m == len(wi), (qi, page, L, k)
+                    assert np.array_equal(ids[qi, :m], wi) and np.array_equal(dists[qi, :m].view(np.uint32), wd.view(np.uint32))
+                else:
+                    assert counts[qi] == 0
+        with pytest.raises(da.DannError):
+            s.next_page(L + 1)
+        with pytest.raises(da.DannError):
+            s.next_page(0)
+        s.close()
