@@ -132,11 +132,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook: DANN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (exercises the multi-rank code path on a
+    # 1-GPU box; never used for reported numbers)
+    one_dev = os.environ.get("DANN_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -213,7 +221,7 @@ def main():
             chosen = sweep[-1]
         rec, st = evaluate(chosen, W)
     if world > 1:  # all ranks use rank 0's L so the work per GPU is the same
-        t = torch.tensor([chosen], device=dev)
+        t = torch.tensor([chosen], device=torch.device("cpu") if one_dev else dev)
         dist.broadcast(t, 0)
         if int(t.item()) != chosen:
             chosen = int(t.item())
@@ -232,7 +240,7 @@ def main():
     elapsed = time.perf_counter() - tstart
     kernel_ms, launches = prov.kernel_time(0)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=torch.device("cpu") if one_dev else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
