@@ -199,3 +199,26 @@ def test_visited_overflow_is_retried():
     oi, od, oc, ost = oix.search_batch(data[:40], 64, 1, 10)
     assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
     assert np.array_equal(ost[:, 0], gst["cmps"]) and not gst["status"].any()
+
+
+def test_spill_tables_recycled_under_load():
+    """20 000 concurrent queries with a 256-entry LDS table: nearly every query continues in a global-memory spill
+    table, the 512 tables of the pool are claimed, wiped and handed on dozens of times within the launch (across XCDs).
+    Results and counters must equal those of a launch with ample LDS tables, and the oracle's on a sample."""
+    rng = np.random.default_rng(19)
+    n, dim, R, nq = 20000, 16, 32, 20000
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    queries = rand_vectors(rng, oracle.F32, nq, dim)
+    gix.set_visited_bits(0)
+    ri, rd, rst = gix.search(da.Knn(48), queries, 10)
+    for rep in range(3):
+        gix.set_visited_bits(256)
+        gi, gd, gst = gix.search(da.Knn(48), queries, 10)
+        assert not gst["status"].any()
+        assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd))
+        assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"])
+    oi, od, oc, ost = oix.search_batch(queries[:200], 48, 1, 10)
+    assert np.array_equal(ri[:200], oi) and np.array_equal(ost[:, 0], rst["cmps"][:200])
+    assert rst["cmps"].mean() > 256  # the forced table really was too small
