@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--max-degree", type=int, default=32)
     ap.add_argument("--pruned-degree", type=int, default=28)
     ap.add_argument("--l-build", type=int, default=100)
-    ap.add_argument("--growth", type=float, default=0.02)
+    ap.add_argument("--growth", type=float, default=0.05)
     ap.add_argument("--max-batch", type=int, default=16384)
     ap.add_argument("--beam-width", type=int, default=1)
     ap.add_argument("--L", type=int, default=0, help="fixed L (0 = first L of the sweep with recall >= target)")
