@@ -167,7 +167,7 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
                         const uint32_t rp = have ? sel[l + g] : 0u;
                         if (have && rp < i) {
                             const uint8_t* y = ix.rows + (uint64_t)sid[rp] * ix.row_stride;
-                            d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(xi, y, (int)ix.dim, v),
+                            d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(reinterpret_cast<const uint8_t*>(xi), y, (int)ix.dim, v),
                                                               reinterpret_cast<const uint8_t*>(xi), y, ix.dim,
                                                               SqParams{ix.sq_k, ix.sq_shift_norm_sq});
                         }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kWave) void pool_prune_kernel(PoolArgs a) {
                 p %= a.n;
                 const uint32_t id = a.locs[p];
                 const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
-                float d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)a.ix.dim, v),
+                float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(reinterpret_cast<const uint8_t*>(x), y, (int)a.ix.dim, v),
                                                         reinterpret_cast<const uint8_t*>(x), y, a.ix.dim,
                                                         SqParams{a.ix.sq_k, a.ix.sq_shift_norm_sq});
                 if (v == 0) {
@@ -338,7 +338,7 @@ __device__ void fill_list_distances(const IndexView& ix, uint32_t loc, uint32_t*
         const uint32_t r = r0 + g;
         if (r < cnt) {
             const uint8_t* y = ix.rows + (uint64_t)pid[r] * ix.row_stride;
-            float d = finish_distance<DT, OP, NORM>(group_distance<DT, OP, true, 0>(x, y, (int)ix.dim, v),
+            float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(reinterpret_cast<const uint8_t*>(x), y, (int)ix.dim, v),
                                                     reinterpret_cast<const uint8_t*>(x), y, ix.dim,
                                                     SqParams{ix.sq_k, ix.sq_shift_norm_sq});
             if (v == 0) pd[r] = d;

@@ -230,6 +230,76 @@ __device__ __forceinline__ float group_distance_raw(const QT* __restrict__ q, co
 }
 
 
+// Stored row x stored row (RobustPrune's primitive) with every load of a T-trip window -- both rows -- issued
+// before the first FMA.  group_distance_raw's run-time loop waits for each trip's loads before issuing the next
+// trip's: four dependent round trips per 128-d distance, which is what the lazy prune scan then spends its time on.
+// Same arithmetic, element order and partial-block rule as group_distance_raw.
+template <int NACC, int OP, typename RT>
+__device__ __forceinline__ float group_distance_pair(const RT* __restrict__ x, const RT* __restrict__ y, int dim, int v) {
+    constexpr int G = 2 * NACC, TRIP = 4 * G;
+    const int full_end = dim & ~7, rem = dim & 7;
+    FAcc<OP> acc;
+    acc.init();
+    RT tx[4], ty[4];
+    if (rem) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * (v & 1) + i;
+            if (l < rem) {
+                tx[i] = x[full_end + l];
+                ty[i] = y[full_end + l];
+            }
+        }
+    }
+    constexpr int T = 4;
+    for (int e0 = 4 * v; e0 < full_end; e0 += TRIP * T) {
+        Raw4<RT> xs[T], ys[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+            if (e < full_end) {
+                xs[t].load(x + e);
+                ys[t].load(y + e);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int e = e0 + t * TRIP;
+            if (e < full_end) acc.step(xs[t].get(), ys[t].get());
+        }
+    }
+    auto partial = [&](float(&a)[4], int which) {
+        if (rem == 0) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * (v & 1) + i;
+            float xv = 0.0f, yv = 0.0f;
+            if (l < rem) {
+                xv = to_f32(tx[i]);
+                yv = to_f32(ty[i]);
+            }
+            if (OP == OP_L2) {
+                const float c = xv - yv;
+                a[i] = __builtin_fmaf(c, c, a[i]);
+            } else if (which == 0) {
+                a[i] = __builtin_fmaf(xv, yv, a[i]);
+            } else if (which == 1) {
+                a[i] = __builtin_fmaf(xv, xv, a[i]);
+            } else {
+                a[i] = __builtin_fmaf(yv, yv, a[i]);
+            }
+        }
+    };
+    float s = finish_vec<NACC>(acc.s, [&](float(&a)[4]) { partial(a, 0); });
+    if (OP == OP_COS) {
+        float nx = finish_vec<NACC>(acc.nx, [&](float(&a)[4]) { partial(a, 1); });
+        float ny = finish_vec<NACC>(acc.ny, [&](float(&a)[4]) { partial(a, 2); });
+        return cosine_finish(nx, ny, s);
+    }
+    return s;
+}
+
+
 // Fixed-length variant with the query slice of this lane preloaded in registers
 // (DIM % (8*NACC) == 0, so there is neither an epilogue block nor a partial block).
 // `U` rows are processed together: all U*NT row loads are issued before the first FMA so
@@ -629,6 +699,18 @@ __device__ __forceinline__ float group_distance(const QT* q, const uint8_t* row,
     }
 }
 
+
+// stored row x stored row with the prune-path association (Scheme<DT, OP, true>)
+template <int DT, int OP>
+__device__ __forceinline__ float group_distance_rows(const uint8_t* x, const uint8_t* y, int dim, int v) {
+    if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {
+        return group_distance_int<OP, DT == DT_I8>(x, y, dim, v);
+    } else {
+        using RT = typename RowType<DT>::type;
+        return group_distance_pair<Scheme<DT, OP, true>::NACC, OP, RT>(reinterpret_cast<const RT*>(x),
+                                                                       reinterpret_cast<const RT*>(y), dim, v);
+    }
+}
 
 template <int DT, int OP, bool PAIR, int U, typename QT>
 __device__ __forceinline__ void group_distance_many(const QT* q, const uint8_t* const (&rows)[U],
