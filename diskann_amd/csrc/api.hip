@@ -234,6 +234,9 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->d_fail) (void)hipFree(idx->d_fail);
     if (idx->h_flag) (void)hipHostFree(idx->h_flag);
     if (idx->d_spill) (void)hipFree(idx->d_spill);
+    for (void* p : idx->stage)
+        if (p) (void)hipFree(p);
+    if (idx->h_stage) (void)hipHostFree(idx->h_stage);
     if (idx->d_pq_pivots) (void)hipFree(idx->d_pq_pivots);
     if (idx->d_pq_offsets) (void)hipFree(idx->d_pq_offsets);
     if (idx->build_scratch && idx->build_scratch_free) idx->build_scratch_free(idx->build_scratch);
@@ -670,22 +673,56 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
-    DevBuf bq, bi, bd, bs;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
-    DANN_HIP(bq.alloc((size_t)nq * qb + 16));
-    DANN_HIP(bi.alloc((size_t)nq * k * 4));
-    DANN_HIP(bd.alloc((size_t)nq * k * 4));
-    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->stream));
-    int32_t rc = search_device(idx, bq.p, nullptr, nq, l_value, beam_width, k, bi.as<uint32_t>(), bd.as<float>(),
-                               bs.as<dann_search_stats>(), nullptr, nullptr, 0, nullptr);
-    if (rc != DANN_OK) return rc;
+    // device staging owned by the index (grow-only): [0] queries, [1] ids | dists | stats in one block
+    const size_t ids_b = ((size_t)nq * k * 4 + 15) & ~(size_t)15, st_b = (size_t)nq * sizeof(dann_search_stats);
+    const size_t need[2] = {(size_t)nq * qb + 16, 2 * ids_b + st_b + 16};
+    for (int i = 0; i < 2; ++i)
+        if (idx->stage_bytes[i] < need[i]) {
+            if (idx->stage[i]) (void)hipFree(idx->stage[i]);
+            idx->stage[i] = nullptr;
+            idx->stage_bytes[i] = 0;
+            const size_t sz = need[i] + need[i] / 4;
+            DANN_HIP(hipMalloc(&idx->stage[i], sz));
+            idx->stage_bytes[i] = sz;
+        }
+    void* bq = idx->stage[0];
+    uint8_t* ob = reinterpret_cast<uint8_t*>(idx->stage[1]);
+    uint32_t* bi = reinterpret_cast<uint32_t*>(ob);
+    float* bd = reinterpret_cast<float*>(ob + ids_b);
+    dann_search_stats* bs = reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b);
+    // small batches go through pinned host memory: one H2D and one D2H, both truly asynchronous (copies from / to
+    // pageable memory cost tens of microseconds each on ROCm 7.2, which is the latency regime's whole budget)
+    const size_t in_b = (size_t)nq * qb, out_b = 2 * ids_b + st_b;
+    const bool pinned = in_b + out_b <= (1u << 20);
+    if (pinned && idx->h_stage_bytes < in_b + out_b) {
+        if (idx->h_stage) (void)hipHostFree(idx->h_stage);
+        idx->h_stage = nullptr;
+        idx->h_stage_bytes = 0;
+        DANN_HIP(hipHostMalloc(&idx->h_stage, 1u << 20, hipHostMallocDefault));
+        idx->h_stage_bytes = 1u << 20;
+    }
     std::vector<dann_search_stats> stats(nq);
-    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (pinned) {
+        uint8_t* hs = reinterpret_cast<uint8_t*>(idx->h_stage);
+        memcpy(hs, queries, in_b);
+        DANN_HIP(hipMemcpyAsync(bq, hs, in_b, hipMemcpyHostToDevice, idx->stream));
+        int32_t rc = search_device(idx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
+        if (rc != DANN_OK) return rc;
+        DANN_HIP(hipMemcpyAsync(hs + in_b, ob, out_b, hipMemcpyDeviceToHost, idx->stream));
+        DANN_HIP(hipStreamSynchronize(idx->stream));
+        memcpy(out_ids, hs + in_b, (size_t)nq * k * 4);
+        memcpy(out_dists, hs + in_b + ids_b, (size_t)nq * k * 4);
+        memcpy(stats.data(), hs + in_b + 2 * ids_b, st_b);
+    } else {
+        DANN_HIP(hipMemcpyAsync(bq, queries, in_b, hipMemcpyHostToDevice, idx->stream));
+        int32_t rc = search_device(idx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
+        if (rc != DANN_OK) return rc;
+        DANN_HIP(hipMemcpyAsync(out_ids, bi, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+        DANN_HIP(hipMemcpyAsync(out_dists, bd, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+        DANN_HIP(hipMemcpyAsync(stats.data(), bs, st_b, hipMemcpyDeviceToHost, idx->stream));
+        DANN_HIP(hipStreamSynchronize(idx->stream));
+    }
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i) {
         if (stats[i].status) {

@@ -155,6 +155,11 @@ struct dann_index {
     void* build_scratch = nullptr;            // owned by build_kernels.hip
     void (*build_scratch_free)(void*) = nullptr;
     uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
+    // grow-only device staging for the host-pointer search entry (no hipMalloc / hipFree per call)
+    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    void* h_stage = nullptr;     // pinned host staging for small batches (one H2D + one D2H per call)
+    size_t h_stage_bytes = 0;
     dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries)
     std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
     // one stream, one pair of events and one set of scratch buffers per index: calls that launch
