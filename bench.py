@@ -379,12 +379,12 @@ def main():
 
 
 def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, Lf32, full_prov):
-    # ScalarQuantizer parameters in the spirit of scalar/train.rs (standard_deviations = 2): one global
-    # scale, per-dimension shift
-    mean = base.mean(0)
-    std = float(base.std())
-    shift = (mean - 2.0 * std).cpu().numpy().astype(np.float32)
-    scale = float(np.float32(4.0 * std))
+    # ScalarQuantizationParameters::train (scalar/train.rs:33-52, standard_deviations = 2, the reference's default)
+    # on a 131 072-row sample, through the library
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    sample = base[torch.randperm(args.n, generator=g, device=dev)[:min(args.n, 131072)]].cpu().numpy()
+    shift, scale, _ = da.sq8_train(sample, 2.0, device=local)
     snorm = float(np.float32((shift ** 2).sum(dtype=np.float32)))
     codes = da.sq8_compress(base.cpu().numpy(), shift, scale, device=local)
     qcodes = da.sq8_compress(queries.cpu().numpy(), shift, scale, device=local)

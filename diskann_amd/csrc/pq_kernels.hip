@@ -12,6 +12,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 #include "dann_device.h"
 #include "dann_internal.h"
@@ -297,6 +299,50 @@ __global__ void pq_scan_counts_kernel(const uint32_t* counts, uint32_t ncenters,
     }
 }
 
+// ---- ScalarQuantizationParameters::train (scalar/train.rs:33-52; utils.rs:109-140, 180-199) ------------------
+// Every statistic is an f64 sum in row order, so each sum is one sequential chain: one thread per dimension walks
+// the rows (a wave reads 64 consecutive columns of a row per step -- coalesced), rows' norms are computed one thread
+// per row and then summed by a single chain staged through LDS.
+__global__ void sq_col_sum_kernel(const float* data, uint64_t n, uint32_t dim, const double* means, double* out) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    double acc = 0.0;
+    if (!means) {
+        for (uint64_t r = 0; r < n; ++r) acc += (double)data[r * dim + d];
+    } else {
+        const double m = means[d];
+        for (uint64_t r = 0; r < n; ++r) {
+            const double df = (double)data[r * dim + d] - m;
+            acc += df * df;
+        }
+    }
+    out[d] = acc / (double)n;
+}
+__global__ void sq_row_norm_kernel(const float* data, uint64_t n, uint32_t dim, double* norms) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double sq = 0.0;
+    for (uint32_t d = 0; d < dim; ++d) {
+        const double x = (double)data[r * dim + d];
+        sq += x * x;
+    }
+    norms[r] = __builtin_sqrt(sq);  // correctly rounded (checked against the oracle in tests)
+}
+__global__ __launch_bounds__(256) void sq_chain_sum_kernel(const double* v, uint64_t n, double* out) {
+    __shared__ double tile[1024];
+    double acc = 0.0;
+    for (uint64_t t0 = 0; t0 < n; t0 += 1024) {
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) tile[i] = (t0 + i < n) ? v[t0 + i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t lim = (n - t0) < 1024 ? (n - t0) : 1024;
+            for (uint32_t i = 0; i < lim; ++i) acc = acc + tile[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = acc / (double)n;
+}
+
 struct Buf {
     void* p = nullptr;
     ~Buf() {
@@ -538,6 +584,44 @@ extern "C" int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n,
     DANN_HIP(hipMemcpy(centers, dcen.p, (size_t)ncenters * dim * 4, hipMemcpyDeviceToHost));
     if (assignments) DANN_HIP(hipMemcpy(assignments, dasg.p, (size_t)nchunks * n * 4, hipMemcpyDeviceToHost));
     if (residuals) DANN_HIP(hipMemcpy(residuals, dres.p, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    return DANN_OK;
+}
+
+extern "C" int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t dim, double standard_deviations,
+                                  float* shift, float* scale, float* mean_norm) {
+    using namespace dann;
+    if (!data || !shift || !scale || n == 0 || dim == 0) return DANN_EINVAL;
+    if (!(standard_deviations > 0.0)) {  // Positive<f64>
+        set_error("standard_deviations must be positive");
+        return DANN_EINVAL;
+    }
+    if (device >= 0) DANN_HIP(hipSetDevice(device));
+    Buf dx, dm, dv, dn, dmn;
+    DANN_HIP(hipMalloc(&dx.p, n * dim * 4));
+    DANN_HIP(hipMalloc(&dm.p, (size_t)dim * 8));
+    DANN_HIP(hipMalloc(&dv.p, (size_t)dim * 8));
+    DANN_HIP(hipMalloc(&dn.p, n * 8));
+    DANN_HIP(hipMalloc(&dmn.p, 8));
+    DANN_HIP(hipMemcpy(dx.p, data, n * dim * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sq_col_sum_kernel, dim3((dim + 63) / 64), dim3(64), 0, 0, (const float*)dx.p, n, dim,
+                       (const double*)nullptr, (double*)dm.p);
+    hipLaunchKernelGGL(sq_col_sum_kernel, dim3((dim + 63) / 64), dim3(64), 0, 0, (const float*)dx.p, n, dim,
+                       (const double*)dm.p, (double*)dv.p);
+    hipLaunchKernelGGL(sq_row_norm_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (const float*)dx.p, n, dim,
+                       (double*)dn.p);
+    hipLaunchKernelGGL(sq_chain_sum_kernel, dim3(1), dim3(256), 0, 0, (const double*)dn.p, n, (double*)dmn.p);
+    DANN_HIP(hipGetLastError());
+    std::vector<double> means(dim), var(dim);
+    double mn = 0.0;
+    DANN_HIP(hipMemcpy(means.data(), dm.p, (size_t)dim * 8, hipMemcpyDeviceToHost));
+    DANN_HIP(hipMemcpy(var.data(), dv.p, (size_t)dim * 8, hipMemcpyDeviceToHost));
+    DANN_HIP(hipMemcpy(&mn, dmn.p, 8, hipMemcpyDeviceToHost));
+    double mx = 0.0;
+    for (uint32_t d = 0; d < dim; ++d) mx = std::max(mx, var[d]);
+    const double p = std::sqrt(mx) * standard_deviations;
+    *scale = (float)(2.0 * p);
+    for (uint32_t d = 0; d < dim; ++d) shift[d] = (float)(means[d] - p);
+    if (mean_norm) *mean_norm = (float)mn;
     return DANN_OK;
 }
 

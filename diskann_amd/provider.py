@@ -444,3 +444,14 @@ def pq_lloyds(data, chunk_offsets, centers, max_reps, device=-1):
     check(_ffi.lib().dann_pq_lloyds(device, _p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, cen.shape[0], _p(cen),
                                     max_reps, _p(assign), _p(res)), "dann_pq_lloyds")
     return cen, assign, res
+
+
+def sq8_train(data, standard_deviations=2.0, device=-1):
+    """ScalarQuantizationParameters::train on the GPU: (shift[dim] f32, scale, mean_norm)."""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    shift = np.empty(x.shape[1], np.float32)
+    scale = np.zeros(1, np.float32)
+    mn = np.zeros(1, np.float32)
+    check(_ffi.lib().dann_sq8_train(device, _p(x), x.shape[0], x.shape[1], float(standard_deviations), _p(shift),
+                                    _p(scale), _p(mn)), "dann_sq8_train")
+    return shift, float(scale[0]), float(mn[0])

@@ -318,6 +318,13 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
  * (FixedChunkPQTable::new, fixed_chunk_pq_table.rs:105-140) */
 int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets);
 
+/* ScalarQuantizationParameters::train (diskann-quantization/src/scalar/train.rs:33-52): shift[d] = mean_d - p,
+ * scale = 2p with p = standard_deviations * sqrt(max_d variance_d) (f64 statistics in row order, utils.rs:109-199);
+ * mean_norm (optional) = mean L2 norm of the rows.  data: n x dim f32, host pointers.  The reference's default is
+ * standard_deviations = 2. */
+int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t dim, double standard_deviations,
+                       float* shift, float* scale, float* mean_norm);
+
 /* ---- scalar quantisation: ScalarQuantizer::compress_into for 8 bits
  * (diskann-quantization/src/scalar/quantizer.rs:189-236, 395-430): code = round(clamp((x - shift) *
  * 255/scale, 0, 255)), compensation = scale/255 * sum(code * shift).  x: n x dim f32, shift: dim f32,

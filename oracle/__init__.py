@@ -120,6 +120,8 @@ def lib():
     L.orc_pq_square_norms.argtypes = [vp, u32, vp, u32, u32, vp]
     L.orc_pq_lloyds.restype = i32
     L.orc_pq_lloyds.argtypes = [vp, u64, u32, vp, u32, u32, vp, u32, vp, vp]
+    L.orc_sq8_train.restype = None
+    L.orc_sq8_train.argtypes = [vp, u64, u32, C.c_double, vp, vp, vp]
     L.orc_pq_lookup.restype = f32
     L.orc_pq_lookup.argtypes = [vp, vp, u32]
     L.orc_sq8_compress.restype = None
@@ -414,3 +416,13 @@ def pq_lloyds(data, chunk_offsets, centers, max_reps):
     if rc < 0:
         raise RuntimeError(f"orc_pq_lloyds failed: {rc}")
     return cen, assign, res
+
+
+def sq8_train(data, standard_deviations=2.0):
+    """ScalarQuantizationParameters::train: returns (shift[dim] f32, scale f32, mean_norm f32)"""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    shift = np.empty(x.shape[1], np.float32)
+    scale = np.zeros(1, np.float32)
+    mn = np.zeros(1, np.float32)
+    lib().orc_sq8_train(_p(x), x.shape[0], x.shape[1], float(standard_deviations), _p(shift), _p(scale), _p(mn))
+    return shift, scale[0], mn[0]

@@ -1694,6 +1694,42 @@ int32_t orc_pq_lloyds(const float* data, uint64_t n, uint32_t dim, const uint32_
     return 0;
 }
 
+/* ScalarQuantizationParameters::train (diskann-quantization/src/scalar/train.rs:33-52) with its statistics
+ * helpers (utils.rs:109-140, 180-199): f64 sums in row order. */
+void orc_sq8_train(const float* data, uint64_t n, uint32_t dim, double standard_deviations, float* shift,
+                   float* scale, float* mean_norm) {
+    std::vector<double> means(dim, 0.0), var(dim, 0.0);
+    double norm_sum = 0.0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const float* row = data + r * dim;
+        for (uint32_t d = 0; d < dim; ++d) means[d] += (double)row[d];
+        double sq = 0.0;
+        for (uint32_t d = 0; d < dim; ++d) {
+            const double x = (double)row[d];
+            sq += x * x;
+        }
+        norm_sum = norm_sum + std::sqrt(sq);
+    }
+    const double mn = norm_sum / (double)n;
+    for (uint32_t d = 0; d < dim; ++d) means[d] /= (double)n;
+    for (uint64_t r = 0; r < n; ++r) {
+        const float* row = data + r * dim;
+        for (uint32_t d = 0; d < dim; ++d) {
+            const double df = (double)row[d] - means[d];
+            var[d] += df * df;
+        }
+    }
+    double mx = 0.0;
+    for (uint32_t d = 0; d < dim; ++d) {
+        var[d] /= (double)n;
+        mx = std::max(mx, var[d]); /* fold(0.0, f64::max) */
+    }
+    const double p = std::sqrt(mx) * standard_deviations;
+    *scale = (float)(2.0 * p);
+    for (uint32_t d = 0; d < dim; ++d) shift[d] = (float)(means[d] - p);
+    if (mean_norm) *mean_norm = (float)mn;
+}
+
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,
                       float* compensation) {
     const float inverse_scale = 255.0f / scale;

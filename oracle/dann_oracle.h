@@ -182,6 +182,10 @@ int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* 
  * nchunks (optional). */
 int32_t orc_pq_lloyds(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
                       uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments, float* residuals);
+/* SQ training: ScalarQuantizationParameters::train (diskann-quantization/src/scalar/train.rs:33-52, utils.rs:109-199):
+ * shift[d] = mean_d - p, scale = 2p, p = standard_deviations * sqrt(max_d variance_d); f64 sums in row order. */
+void orc_sq8_train(const float* data, uint64_t n, uint32_t dim, double standard_deviations, float* shift,
+                   float* scale, float* mean_norm);
 /* SQ-8: ScalarQuantizer::compress + compensated distances
  * (diskann-quantization/src/scalar/quantizer.rs:189-236,407-430, vectors.rs:171-338). */
 void orc_sq8_compress(const float* x, uint32_t dim, const float* shift, float scale, uint8_t* code,

@@ -262,3 +262,18 @@ def test_pq_lloyds_vs_oracle(n, dim, off, k):
     # trained pivots feed the compressor: every row lands on its assigned centre or a closer one after the update
     codes = da.pq_compress(gc, off, x)
     assert codes.shape == (n, len(off) - 1)
+
+
+@pytest.mark.parametrize("n,dim", [(1000, 12), (4097, 128), (333, 7)])
+def test_sq8_train_vs_oracle(n, dim):
+    """ScalarQuantizationParameters::train: shift, scale and mean norm equal the oracle's bit for bit"""
+    import diskann_amd as da
+    rng = np.random.default_rng(41)
+    x = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 5.0, dim) + rng.uniform(-3, 3, dim)).astype(np.float32)
+    for sd in (1.0, 1.5, 2.0):
+        ws, wc, wm = oracle.sq8_train(x, sd)
+        gs, gc, gm = da.sq8_train(x, sd)
+        assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        assert np.float32(gc) == wc and np.float32(gm) == wm
+    with pytest.raises(da.DannError):
+        da.sq8_train(x, 0.0)

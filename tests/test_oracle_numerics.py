@@ -189,3 +189,29 @@ def test_pq_lloyds_against_naive():
     init2[0] = 1e6
     cen2, asg2, _ = oracle.pq_lloyds(x, [0, dim], init2, 2)
     assert not (asg2 == 0).any() and np.all(cen2[0] == 0)
+
+
+def test_sq8_train_matches_reference_contract():
+    """scalar/train.rs:66-128 (test_train): scale = 2 * std * max column std within 1e-7 relative, shift =
+    (mean - std * max column std) as f32 exactly, mean_norm = mean row norm as f32"""
+    rng = np.random.default_rng(2)
+    for nrows, ncols in ((10, 16), (7, 8), (500, 33)):
+        x = (rng.standard_normal((nrows, ncols)) * rng.uniform(0.5, 3, ncols)).astype(np.float32)
+        xd = x.astype(np.float64)
+        means = np.zeros(ncols)
+        for r in range(nrows):
+            means += xd[r]
+        means /= nrows
+        var = np.zeros(ncols)
+        for r in range(nrows):
+            var += (xd[r] - means) ** 2
+        var /= nrows
+        smax = np.sqrt(var.max())
+        for sd in (1.0, 1.5, 2.0):
+            shift, scale, mn = oracle.sq8_train(x, sd)
+            assert abs(float(scale) - sd * 2.0 * smax) / (sd * 2.0 * smax) < 1e-7
+            assert np.array_equal(shift, (means - sd * smax).astype(np.float32))
+        norms = 0.0
+        for r in range(nrows):
+            norms += np.sqrt((xd[r] * xd[r]).cumsum()[-1])
+        assert mn == np.float32(norms / nrows)
