@@ -1269,6 +1269,7 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
 }
 
 // ---- diagnostics -----------------------------------------------------------------------------
+int32_t dann_abi_version(void) { return DANN_ABI_VERSION; }
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) {
     if (!idx || which < 0 || which > 4) return DANN_EINVAL;
     if (total_ms) *total_ms = idx->clocks[which].total_ms;

@@ -332,6 +332,10 @@ int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t d
 int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift, float scale,
                           void* out);
 
+/* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
+#define DANN_ABI_VERSION 1
+int32_t dann_abi_version(void);
+
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* thread-local message of the last failing call on this thread; returns its length */
 int32_t dann_last_error(char* buf, uint64_t len);
