@@ -52,10 +52,10 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     off += round16(cmax * 4u);
     l.cand_d_off = off;
     off += round16(cmax * 4u);
-    l.stage_id_off = off;  // two buffers of qcap entries each (current / next queue image)
-    off += round16(2u * qcap * 4u);
-    l.stage_d_off = off;
-    off += round16(2u * qcap * 4u);
+    l.stage_id_off = off;  // the queue image: every merge scatters the register-resident queue here and reloads it.
+    off += round16(qcap * 4u);  // One buffer is enough: nothing is read from it between the first scatter write and
+    l.stage_d_off = off;        // the reload (ranks come from registers or were taken before), and one wave's LDS
+    off += round16(qcap * 4u);  // operations retire in order.
     l.snew_off = off;      // the surviving new distances of one merge, sorted
     off += 64u * 4u;
     l.beam_off = off;
@@ -179,7 +179,6 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     float* stage_d = reinterpret_cast<float*>(smem + L.stage_d_off);
     float* snew = reinterpret_cast<float*>(smem + L.snew_off);
     constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
-    uint32_t cur = 0;                       // which half of stage_* mirrors the queue
     uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
 
     // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     // candidate j lands at  #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)},
     // (3) an old element e moves up by #{surviving j: d_j <= d_e}.
     auto merge = [&](uint32_t m0, uint32_t n) {
-        const float* oldd = stage_d + cur * QCAPP;
+        const float* oldd = stage_d;
         bool has = lane < n;
         float nd = has ? cand_d[m0 + lane] : 0.0f;
         uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
@@ -413,8 +412,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         pos_new = before + lb;
         }
         // scatter into the other half
-        uint32_t* nxt_id = stage_id + (cur ^ 1u) * QCAPP;
-        float* nxt_d = stage_d + (cur ^ 1u) * QCAPP;
+        uint32_t* nxt_id = stage_id;
+        float* nxt_d = stage_d;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
         const uint32_t total = size + nv;
         size = total < qcap ? total : qcap;
-        cur ^= 1u;
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
