@@ -1,6 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-sed -i 's/for mb in (16384, 65536):/for mb in (16384,):/' $R/scratch/build_phases.py
 rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o t -- python $R/scratch/build_phases.py > /tmp/pb.log 2>&1
 grep max_batch /tmp/pb.log
 python $R/profiles/summarize_rocprof.py trace /tmp/pb/t_results.db $R/gpurun_out/build_trace.csv 14
