@@ -233,7 +233,8 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     // recalibrate on calls 1, 2, 4, 8, ... of this key (a 512-bin histogram of cmps, 2 KiB D2H)
     if (cal && a.stats && !a.qmap && !a.range_ids && a.nq >= 256) {
         cal->calls += 1;
-        if ((cal->calls & (cal->calls - 1)) == 0) {
+        // insert-time searches run on a growing graph (comparisons grow with it): recalibrate on every batch
+        if ((cal->calls & (cal->calls - 1)) == 0 || a.rec_ids) {
             uint32_t* d_hist = a.spill_next + 16 + idx->spill_slices;
             DANN_HIP(hipMemsetAsync(d_hist, 0, kHistBins * 4, st));
             hipLaunchKernelGGL(cmps_hist_kernel, dim3(std::min<uint32_t>((a.nq + 255) / 256, 256)), dim3(256), 0, st,
