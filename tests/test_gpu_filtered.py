@@ -188,3 +188,21 @@ def test_paged_random_vs_oracle(dtype):
         with pytest.raises(da.DannError):
             s.next_page(0)
         s.close()
+
+
+def test_inline_many_queries_cross_chunks():
+    """more queries than one scratch chunk holds (matched list + sort keys are per-launch scratch): the host entry
+    walks the batch in chunks and the per-query bitmaps must follow"""
+    import diskann_amd as da
+    rng = np.random.default_rng(23)
+    n, dim, R, nq = 3000, 16, 16, 24000
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(oracle.F32, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    match = rng.random((nq, n + 1)) < 0.2
+    ids, dists, st = px.filtered_search(da.Knn(16), queries, 5, match, matched_cap=3001)
+    for qi in list(range(0, nq, 997)) + [nq - 1]:
+        wn, wi, wd, ws = ox.inline_filter_search(queries[qi], 16, 5, match[qi])
+        assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), qi
+        assert (int(st["cmps"][qi]), int(st["hops"][qi])) == (int(ws[0]), int(ws[1]))
