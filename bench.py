@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--beam-width", type=int, default=1)
     ap.add_argument("--L", type=int, default=0, help="fixed L (0 = first L of the sweep with recall >= target)")
     ap.add_argument("--target-recall", type=float, default=0.95)
-    ap.add_argument("--cpu-queries", type=int, default=4000)
+    ap.add_argument("--cpu-queries", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sq8", action="store_true")
     ap.add_argument("--no-pq", action="store_true")
@@ -513,7 +513,19 @@ def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
     oix = oracle.Index(oracle.F32, oracle.L2, args.dim, args.n, args.max_degree, start)
     oix.rows[:args.n, :] = base_h.view(np.uint8).reshape(args.n, -1)
     oix.adj[:] = adj
-    cores = os.cpu_count() or 1
+    # host cores this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes expose 256
+    # logical CPUs but cap the container at 16 CPUs' worth of time; more threads than that only measure a burst)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota_note = ""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            lim = max(1, int(np.ceil(int(q) / int(per))))
+            if lim < cores:
+                cores = lim
+                quota_note = f" (cgroup cpu.max {q}/{per})"
+    except (OSError, ValueError):
+        pass
     nqc = min(args.cpu_queries, queries_h.shape[0])
     qs = queries_h[:nqc]
     oix.search_batch(qs[:256], L, W, k, threads=cores, fast=True)  # warm
@@ -530,7 +542,8 @@ def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
         "unit": "queries/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {nqc} of the {queries_h.shape[0]} queries, same graph/L/beam, best of 3, {cores} threads",
+        "sample": f"first {nqc} of the {queries_h.shape[0]} queries, same graph/L/beam, best of 3, {cores} threads"
+                  f"{quota_note}",
         "ids_identical_to_gpu": same,
     }
 

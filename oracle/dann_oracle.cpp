@@ -408,6 +408,51 @@ float sq8_similarity(int metric, const uint8_t* x, const uint8_t* y, uint32_t di
     return 1.0f - sim;
 }
 
+/* hashbrown::HashSet<u32> stand-in for the visited set (glue.rs:542-549): an exact set with open addressing
+ * (power-of-two slots, linear probing, grown at 7/8 load) so that the timed CPU baseline is not handicapped by
+ * std::unordered_set's node allocations.  Slot value = id + 1, 0 = free. */
+struct IdSet {
+    std::vector<uint64_t> slots;
+    size_t count = 0, mask = 0;
+    struct Result {
+        bool second;
+    };
+    static uint64_t mix(uint32_t id) { return (uint64_t)id * 0x9E3779B97F4A7C15ull; }
+    void rehash(size_t cap) {
+        std::vector<uint64_t> old;
+        old.swap(slots);
+        slots.assign(cap, 0);
+        mask = cap - 1;
+        for (uint64_t v : old)
+            if (v) {
+                size_t h = (size_t)(mix((uint32_t)(v - 1)) >> 32) & mask;
+                while (slots[h]) h = (h + 1) & mask;
+                slots[h] = v;
+            }
+    }
+    void reserve(size_t n) {
+        size_t cap = 16;
+        while (cap * 7 / 8 < n) cap <<= 1;
+        if (cap > slots.size()) rehash(cap);
+    }
+    Result insert(uint32_t id) {
+        if (slots.empty() || (count + 1) * 8 > slots.size() * 7) rehash(slots.empty() ? 16 : slots.size() * 2);
+        const uint64_t v = (uint64_t)id + 1;
+        size_t h = (size_t)(mix(id) >> 32) & mask;
+        while (slots[h]) {
+            if (slots[h] == v) return {false};
+            h = (h + 1) & mask;
+        }
+        slots[h] = v;
+        ++count;
+        return {true};
+    }
+    void clear() {
+        std::fill(slots.begin(), slots.end(), 0);
+        count = 0;
+    }
+};
+
 /* ======================================================================
  * NeighborPriorityQueue  (diskann/src/neighbor/queue.rs:68-475)
  * ====================================================================== */
@@ -425,10 +470,7 @@ struct Queue {
     size_t size() const { return ids.size(); }
     /* get_lower_bound :229-280 -- first index with dist >= d */
     size_t lower_bound(float d) const {
-        size_t n = dist.size();
-        for (size_t i = 0; i < n; ++i)
-            if (dist[i] >= d) return i;
-        return n;
+        return (size_t)(std::lower_bound(dist.begin(), dist.end(), d) - dist.begin());
     }
     /* insert :130-171 */
     void insert(uint32_t id, float d) {
@@ -551,7 +593,7 @@ struct SearchOut {
 /* DiskANNIndex::search_internal (index.rs:1933-2000) through the inmem2
  * SearchAccessor (provider.rs:408-480).  The visited set is hashbrown::HashSet<u32>
  * (scratch.rs:48, glue.rs:542-549) == any exact set. */
-void search_internal(const QueryCtx& qc, Queue& best, std::unordered_set<uint32_t>& visited, uint32_t beam_width,
+void search_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t beam_width,
                      SearchOut& out) {
     const View& v = qc.v;
     const orc_index* ix = v.ix;
@@ -596,7 +638,7 @@ int32_t search_one(const orc_index* ix, const void* query, uint32_t l_value, uin
     QueryCtx qc(v, query, fast);
     /* queue capacity == search_l == L + num_start_points (scratch.rs:199-207) */
     Queue best((size_t)l_value + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     visited.reserve((size_t)(1.1 * ix->max_degree * 1.3 * l_value) + 1);
     SearchOut so;
     so.record = record;
@@ -914,7 +956,7 @@ int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starti
     View v(ix);
     QueryCtx qc(v, query, false);
     Queue best((size_t)starting_l + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     SearchOut so;
     search_internal(qc, best, visited, beam_width, so);
     const uint32_t init_cmps = so.cmps, init_hops = so.hops;
@@ -995,7 +1037,7 @@ struct Matched {
 };
 /* inline_filter_search_internal, inline_filter_search.rs:166-281.  matched is returned sorted by
  * distance; ORACLE TIE RULE: equal distances keep push order (sort_unstable_by leaves it open). */
-void inline_internal(const QueryCtx& qc, Queue& best, std::unordered_set<uint32_t>& visited, uint32_t beam_width,
+void inline_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t beam_width,
                      size_t l_search, const uint32_t* filter, uint32_t adaptive_samples, double adaptive_scale,
                      SearchOut& out, std::vector<Matched>& matched) {
     const View& v = qc.v;
@@ -1067,7 +1109,7 @@ int32_t orc_inline_filter_search(const orc_index* ix, const void* query, uint32_
     View v(ix);
     QueryCtx qc(v, query, false);
     Queue best((size_t)l_value + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     SearchOut so;
     std::vector<Matched> matched;
     inline_internal(qc, best, visited, beam_width, l_value, filter_bits, adaptive_samples, adaptive_scale, so, matched);
@@ -1098,7 +1140,7 @@ int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_v
     View v(ix);
     QueryCtx qc(v, query, false);
     Queue best((size_t)l_value + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     uint32_t cmps = 0, hops = 0;
     for (uint32_t p = ix->capacity; p < ix->capacity + ix->nstart; ++p) {
         visited.insert(p);
@@ -1180,7 +1222,7 @@ int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32
     View v(ix);
     QueryCtx qc(v, query, false);
     Queue best((size_t)starting_l + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     SearchOut so;
     std::vector<Matched> matched;
     inline_internal(qc, best, visited, beam_width, starting_l, filter_bits, 0, 1.0, so, matched);
@@ -1266,7 +1308,7 @@ struct orc_paged {
     std::vector<uint8_t> qbytes;
     QueryCtx* qc;
     Queue best;
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     std::vector<std::pair<uint32_t, float>> computed;
     size_t next_index;
     uint32_t l_value;
@@ -1399,7 +1441,7 @@ int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, ui
     /* insert_search_accessor == search_accessor (glue.rs:932-939); beam width 1, L = l_build */
     QueryCtx qc(v, v.row(slot), false);
     Queue best((size_t)cfg->l_build + ix->nstart);
-    std::unordered_set<uint32_t> visited;
+    IdSet visited;
     std::vector<std::pair<uint32_t, float>> rec;
     SearchOut so;
     so.record = &rec;
@@ -1436,7 +1478,7 @@ int32_t orc_multi_insert(orc_index* ix, const orc_build_config* cfg, const uint3
         if (id >= ix->capacity) return -3;
         QueryCtx qc(v, v.row(id), false);
         Queue best((size_t)cfg->l_build + ix->nstart);
-        std::unordered_set<uint32_t> visited;
+        IdSet visited;
         std::vector<std::pair<uint32_t, float>> rec;
         SearchOut so;
         so.record = &rec;
