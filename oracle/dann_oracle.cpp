@@ -590,6 +590,13 @@ struct SearchOut {
     std::vector<std::pair<uint32_t, float>>* record = nullptr;
 };
 
+inline void prefetch_row(const uint8_t* p, size_t bytes) {
+    const size_t lines = (bytes + 63) / 64;
+    if (!lines) return;
+    _mm_prefetch((const char*)p + 64 * (lines - 1), _MM_HINT_T0);
+    for (size_t i = 0; i + 1 < lines; ++i) _mm_prefetch((const char*)p + 64 * i, _MM_HINT_T0);
+}
+
 /* DiskANNIndex::search_internal (index.rs:1933-2000) through the inmem2
  * SearchAccessor (provider.rs:408-480).  The visited set is hashbrown::HashSet<u32>
  * (scratch.rs:48, glue.rs:542-549) == any exact set. */
@@ -603,8 +610,9 @@ void search_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t b
         best.insert(p, qc.eval(p));
         out.cmps += 1;
     }
-    std::vector<uint32_t> beam;
+    std::vector<uint32_t> beam, ids;
     std::vector<std::pair<uint32_t, float>> neighbors;
+    const size_t row_bytes = v.ix->dtype == ORC_PQ ? v.ix->pq_chunks : layer_bytes(v.ix->dtype, v.ix->dim);
     if (beam_width == 0) beam_width = 1;
     while (best.has_notvisited()) {
         beam.clear();
@@ -618,10 +626,19 @@ void search_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t b
         for (uint32_t b : beam) {
             const uint32_t* adj;
             uint32_t n = v.get_neighbors(b, &adj);
+            /* retain(pred.eval_mut(i) && in_bounds(i)), provider.rs:453-454, then expand_beam_inner with its
+             * software prefetch `lookahead` (8) rows ahead, last cache line first (provider.rs:581-602, 620-690) */
+            ids.clear();
             for (uint32_t j = 0; j < n; ++j) {
                 uint32_t nb = adj[j];
-                /* retain(pred.eval_mut(i) && in_bounds(i)), provider.rs:453-454 */
-                if (visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, qc.eval(nb));
+                if (visited.insert(nb).second && nb < v.nslots()) ids.push_back(nb);
+            }
+            const size_t len = ids.size(), look = std::min<size_t>(8, len);
+            for (size_t j = 0; j < look; ++j) prefetch_row(v.row(ids[j]), row_bytes);
+            size_t ahead = look == 0 ? len : look;
+            for (size_t j = 0; j < len; ++j) {
+                if (ahead != len) prefetch_row(v.row(ids[ahead++]), row_bytes);
+                neighbors.emplace_back(ids[j], qc.eval(ids[j]));
             }
         }
         for (auto& nb : neighbors) best.insert(nb.first, nb.second);
