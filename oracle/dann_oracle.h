@@ -7,10 +7,14 @@
  * `cpu_baseline` leg may load it -- and only as the checker / the timed CPU
  * baseline, never as part of the shipped product path (diskann_amd/).
  *
- * Parity pins: grid_search golden JSONs (18 cases), f16 conversion table, the
- * in-source provider smoke expectations, PQ/SQ known-answer tests -- see
- * tests/golden/ and tests/test_oracle_*.py.  The reference itself (Rust) cannot
- * be compiled in this image (no cargo/rustc), so there is no oracle/_ref.
+ * Parity pins (tests/golden/, tests/test_oracle_*.py): the reference's own golden JSONs --
+ * grid_search (18 cases: ids, distances, comparisons, hops), range_search (5), inline (12,
+ * incl. AdaptiveL), multihop (2), filtered_range_search (7), paged_search (3, page by page),
+ * grid_insert (1-D cases exact, tie-heavy 3-D / 4-D lattices soft) -- the exhaustive f16
+ * conversion table, the in-source provider `smoke` expectations, compute_adaptive_l's unit
+ * tests, the PQ lookup KAT and the Chunk::find_closest test pattern, the SQ training
+ * contract.  The reference itself (Rust) cannot be compiled in this image (no cargo/rustc),
+ * so there is no oracle/_ref.
  *
  * Enum values equal include/dann.h (and the reference's `#[repr(C)] Metric`,
  * diskann-vector/src/distance/metric.rs:8-20).
