@@ -633,6 +633,7 @@ struct DeviceGuard {
 // persistent per-index scratch for batched inserts
 struct BuildScratch {
     uint32_t batch_cap = 0, rec_stride = 0, pend_stride = 0, degree = 0;
+    bool bootstrap_too_big = false;  // set when a batch needed the bootstrap with more members than its pool holds
     DevBuf slots, rec_ids, rec_d, rec_n, stats, pending, pending2, keys_in, keys_out, seg_start, seg_len, meta, sort_tmp;
     size_t sort_tmp_bytes = 0;
 };
@@ -805,6 +806,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         la.out_stride = s.pend_stride;
         la.err = meta + 3;
         if (la.pcap > kMaxPool) {
+            // nothing has been written to the graph yet: the caller may insert the same points in smaller batches
+            s.bootstrap_too_big = true;
             set_error("bootstrap of a %u-point batch into a nearly empty graph is not supported (cap %u); "
                       "use a geometric batch schedule (dann_build)", n, kMaxPool);
             return DANN_EUNSUPPORTED;
@@ -953,17 +956,26 @@ int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first
     std::vector<uint32_t> ids;
     uint32_t done = 0;
     int32_t batches = 0;
+    uint32_t limit = max_batch;  // shrinks when a batch turns out to need a bootstrap larger than the pool
     while (done < n) {
         // geometric schedule: batch = clamp(ceil(inserted * growth), 1, max_batch)
         uint32_t b = (uint32_t)std::ceil((double)(first + done) * (double)growth);
-        b = std::max<uint32_t>(1, std::min(b, max_batch));
+        b = std::max<uint32_t>(1, std::min(b, limit));
         b = std::min(b, n - done);
         ids.resize(b);
         for (uint32_t i = 0; i < b; ++i) ids[i] = first + done + i;
         DANN_HIP(hipMemcpyAsync(s.slots.p, ids.data(), (size_t)b * 4, hipMemcpyHostToDevice, idx->stream));
         DANN_HIP(hipStreamSynchronize(idx->stream));
+        s.bootstrap_too_big = false;
         rc = insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), b);
+        if (rc == DANN_EUNSUPPORTED && s.bootstrap_too_big && b > 1) {
+            // multi_insert's bootstrap test (index.rs:926-931) fired for a batch whose members do not fit one prune
+            // pool; the graph is untouched at that point, so the same points go in as two smaller batches
+            limit = std::max<uint32_t>(1, b / 2);
+            continue;
+        }
         if (rc != DANN_OK) return rc;
+        limit = std::min<uint32_t>(max_batch, limit * 2 > limit ? limit * 2 : limit);
         done += b;
         ++batches;
     }

@@ -226,3 +226,28 @@ def test_single_insert_equals_batch_of_one():
     lens = oix.adj[:, 0]
     mask = np.arange(maxdeg)[None, :] < lens[:, None]
     assert np.array_equal(gix.download_graph()[:, 1:][mask], oix.adj[:, 1:][mask])
+
+
+def test_build_splits_batches_that_need_an_oversized_bootstrap():
+    """An aggressive schedule (growth 1.0) makes multi_insert's bootstrap test fire for batches larger than one prune
+    pool; dann_build re-inserts those points in smaller batches (the graph is untouched when the test fires) instead of
+    failing, and the result is a normal graph."""
+    rng = np.random.default_rng(29)
+    n, dim, R = 14000, 16, 24
+    centers = rng.random((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+    p = da.Provider(da.F32, da.L2, dim, n, R, data[:1].copy())
+    p.set_elements(0, data)
+    cfg = da.build_config(20, R, 48, intra_batch_candidates=da.IBC_NONE)
+    nb = p.build(cfg, 0, n, 1.0, 1 << 20)
+    assert nb > 14                       # more batches than the pure doubling schedule
+    adj = p.download_graph()
+    assert adj[:n, 0].min() >= 1 and adj[:n, 0].mean() > 10
+    q = data[rng.choice(n, 200, replace=False)] + 0.01
+    ids, d, st = p.search(da.Knn(40), q, 1)
+    truth = ((q[:, None, :] - data[None]) ** 2).sum(-1).argmin(1)
+    assert (ids[:, 0] == truth).mean() > 0.9
+    with pytest.raises(da.DannError):    # a single oversized batch still reports the limit
+        p2 = da.Provider(da.F32, da.L2, dim, n, R, data[:1].copy())
+        p2.set_elements(0, data)
+        p2.insert_batch(cfg, np.arange(8000, dtype=np.uint32))
