@@ -344,6 +344,9 @@ def main():
             copy_gbs = 2 * buf.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del buf, dst
             out["roofline"]["measured_copy_GBps"] = copy_gbs
+            rd = C.c_double(0.0)
+            if lib.dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd)) == 0:
+                out["roofline"]["measured_stream_read_GBps"] = rd.value
             out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         # configs[2], int8 scalar-quantised variant: same data compressed to SQ-8 (128 B + 4 B rows),
         # index built on the GPU over the codes, recall measured against the exact f32 ground truth
@@ -366,7 +369,8 @@ def main():
             wl = pm["workload"]
             if (wl["nq"], wl["L"], wl["beam_width"], wl["n"], wl["dim"]) == (args.nq, chosen, W, args.n, args.dim):
                 out["roofline"]["traffic"] = pm["hbm_bytes_per_launch_corrected"]
-                out["roofline"]["traffic_source"] = "profiles/pmc_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+                out["roofline"]["traffic_source"] = ("profiles/pmc_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB); fabric-side "
+                                                     "bytes = HBM + 256 MiB Infinity Cache hits")
         except (OSError, KeyError, ValueError):
             pass
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

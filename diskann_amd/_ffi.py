@@ -99,6 +99,7 @@ SYMBOLS = {
     "dann_pq_lloyds": (_i32, [_i32, _vp, _u64, _u32, _vp, _u32, _u32, _vp, _u32, _vp, _vp]),
     "dann_pq_scan": (_i32, [_i32, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "dann_abi_version": (_i32, []),
+    "dann_debug_stream_read_gbps": (_i32, [_i32, _u64, _u32, _P(C.c_double)]),
     "dann_last_error": (_i32, [C.c_char_p, _u64]),
     "dann_kernel_time": (_i32, [_vp, _i32, _P(C.c_double), _P(_u64)]),
     "dann_kernel_time_reset": (_i32, [_vp]),

@@ -332,6 +332,10 @@ int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t d
 int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift, float scale,
                           void* out);
 
+/* diagnostic: bandwidth (GB/s) of a plain streaming read of `bytes` bytes of HBM on `device` (16-byte loads, four in
+ * flight per lane), averaged over `reps` launches -- the achievable line to hold next to the 8 TB/s peak */
+int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps);
+
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
 #define DANN_ABI_VERSION 1
 int32_t dann_abi_version(void);
