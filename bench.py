@@ -181,7 +181,7 @@ def main():
     k = 10
     d_ids = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
     d_dists = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
-    d_stats = torch.empty((args.nq, 4), dtype=torch.int32, device=dev)
+    d_stats = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
 
     def run_search(L, W):
         _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), args.nq, L, W, k,
@@ -402,7 +402,7 @@ def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoi
     dq = torch.from_numpy(qcodes).to(dev)
     d_ids = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
     d_d = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
-    d_st = torch.empty((args.nq, 4), dtype=torch.int32, device=dev)
+    d_st = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
 
     def run(L):
         _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(dq.data_ptr()), args.nq, L, W, k,
@@ -471,7 +471,7 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                        pq_pivots=pivots_h, pq_offsets=bounds)
     prov.set_elements(0, codes_h)
     prov.upload_graph(full_prov.download_graph())
-    d_st = torch.empty((args.nq, 4), dtype=torch.int32, device=dev)
+    d_st = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
     d_out = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
     d_outd = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
 

@@ -20,7 +20,7 @@ class Config(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("metric", C.c_int32), ("dim", C.c_uint32), ("capacity", C.c_uint32),
                 ("max_degree", C.c_uint32), ("num_start_points", C.c_uint32), ("row_stride", C.c_uint32),
                 ("device", C.c_int32), ("sq_scale", C.c_float), ("sq_shift_norm_sq", C.c_float),
-                ("pq_chunks", C.c_uint32)]
+                ("pq_chunks", C.c_uint32), ("inline_tags", C.c_uint32)]
 
 
 class BuildConfig(C.Structure):
@@ -37,7 +37,8 @@ class Filter(C.Structure):
 
 
 class SearchStats(C.Structure):
-    _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32)]
+    _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32),
+                ("written", C.c_uint32)]
 
 
 # every symbol include/dann.h declares: name -> (restype, argtypes)
@@ -54,6 +55,8 @@ SYMBOLS = {
     "dann_set_elements": (_i32, [_vp, _u32, _u32, _vp, _u64]),
     "dann_get_element": (_i32, [_vp, _u32, _vp, _u64]),
     "dann_upload_store": (_i32, [_vp, _vp, _u64, _u32]),
+    "dann_set_tags": (_i32, [_vp, _u32, _u32, _vp]),
+    "dann_get_tags": (_i32, [_vp, _u32, _u32, _vp]),
     "dann_set_external_ids": (_i32, [_vp, _u32, _u32, _vp]),
     "dann_to_external": (_i32, [_vp, _vp, _u64, _vp]),
     "dann_get_neighbors": (_i32, [_vp, _u32, _vp, _u32, _P(_u32)]),

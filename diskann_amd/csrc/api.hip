@@ -110,12 +110,13 @@ dann::IndexView dann_index::view() const {
     v.pq_pivots = d_pq_pivots;
     v.pq_offsets = d_pq_offsets;
     v.pq_chunks = cfg.pq_chunks;
+    v.tag_off = cfg.inline_tags ? layer_bytes : 0u;
     return v;
 }
 
 extern "C" {
 
-int32_t dann_last_error(char* buf, uint64_t len) {
+int32_t dann_last_error(char* buf, uint64_t len) try {
     size_t n = strlen(g_err);
     if (buf && len) {
         size_t c = n < len - 1 ? n : len - 1;
@@ -123,23 +124,23 @@ int32_t dann_last_error(char* buf, uint64_t len) {
         buf[c] = 0;
     }
     return (int32_t)n;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_layer_bytes(int32_t dtype, uint32_t dim) {
+int32_t dann_layer_bytes(int32_t dtype, uint32_t dim) try {
     if (!valid_dtype(dtype)) {
         set_error("bad dtype %d", dtype);
         return DANN_EINVAL;
     }
     return (int32_t)layer_bytes_of(dtype, dim);
-}
+} DANN_CATCH_ALL
 
-int32_t dann_inmem2_row_stride(int32_t dtype, uint32_t dim) {
+int32_t dann_inmem2_row_stride(int32_t dtype, uint32_t dim) try {
     int32_t b = dann_layer_bytes(dtype, dim);
     if (b < 0) return b;
     return (b + 1 + 31) / 32 * 32;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64_t start_len, dann_index** out) {
+int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64_t start_len, dann_index** out) try {
     if (!cfg || !out) {
         set_error("null argument");
         return DANN_EINVAL;
@@ -186,6 +187,11 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
         delete idx;
         return DANN_EINVAL;
     }
+    if (idx->cfg.inline_tags && idx->cfg.row_stride <= lb) {
+        set_error("inline_tags needs row_stride > %u payload bytes (the tag byte follows the payload, store.rs:133-158)", lb);
+        delete idx;
+        return DANN_EINVAL;
+    }
     idx->nslots = cfg->capacity + cfg->num_start_points;
     int dev = cfg->device;
     if (dev < 0) {
@@ -220,12 +226,21 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
                              lb, lb, cfg->num_start_points, hipMemcpyHostToDevice, idx->stream);
         if (e != hipSuccess) return fail(e, "hipMemcpy2D(start rows)");
     }
+    if (idx->cfg.inline_tags) {  // dynamic slots AVAILABLE (0, the memset above), start points FROZEN (store.rs:766-772)
+        idx->h_tags.assign(idx->nslots, 0);
+        if (cfg->num_start_points) {
+            std::fill(idx->h_tags.begin() + cfg->capacity, idx->h_tags.end(), (uint8_t)255);
+            e = hipMemset2DAsync(idx->d_rows + (size_t)cfg->capacity * idx->cfg.row_stride + lb, idx->cfg.row_stride, 255, 1,
+                                 cfg->num_start_points, idx->stream);
+            if (e != hipSuccess) return fail(e, "hipMemset2D(start tags)");
+        }
+    }
     if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
     *out = idx;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_index_destroy(dann_index* idx) {
+int32_t dann_index_destroy(dann_index* idx) try {
     if (!idx) return DANN_OK;
     DeviceGuard guard(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
@@ -245,15 +260,15 @@ int32_t dann_index_destroy(dann_index* idx) {
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_index_max_degree(const dann_index* idx) { return idx ? (int32_t)idx->cfg.max_degree : DANN_EINVAL; }
 
-int32_t dann_index_get_config(const dann_index* idx, dann_config* out) {
+int32_t dann_index_get_config(const dann_index* idx, dann_config* out) try {
     if (!idx || !out) return DANN_EINVAL;
     *out = idx->cfg;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 #define CHECK_IDX(idx)                                  \
     if (!(idx)) {                                       \
@@ -263,7 +278,7 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out) {
     std::lock_guard<std::recursive_mutex> _lock((idx)->mu); \
     DeviceGuard _guard((idx)->device)
 
-int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) {
+int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) try {
     CHECK_IDX(idx);
     if (n == 0) return DANN_OK;
     if (!rows) return DANN_EINVAL;
@@ -279,15 +294,45 @@ int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, cons
     }
     DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride, idx->cfg.row_stride, rows,
                               idx->layer_bytes, idx->layer_bytes, n, hipMemcpyHostToDevice, idx->stream));
+    if (idx->cfg.inline_tags) {  // Slot::publish (store.rs:776-782)
+        DANN_HIP(hipMemset2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride + idx->layer_bytes,
+                                  idx->cfg.row_stride, 254, 1, n, idx->stream));
+        std::fill(idx->h_tags.begin() + first_slot, idx->h_tags.begin() + first_slot + n, (uint8_t)254);
+    }
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len) {
+int32_t dann_set_tags(dann_index* idx, uint32_t first_slot, uint32_t n, const uint8_t* tags) try {
+    CHECK_IDX(idx);
+    if (n == 0) return DANN_OK;
+    if (!tags) return DANN_EINVAL;
+    if (!idx->cfg.inline_tags) {
+        set_error("dann_set_tags: the index was created without inline_tags");
+        return DANN_EUNSUPPORTED;
+    }
+    if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
+    DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride + idx->layer_bytes,
+                              idx->cfg.row_stride, tags, 1, 1, n, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    memcpy(idx->h_tags.data() + first_slot, tags, n);
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_get_tags(const dann_index* idx, uint32_t first_slot, uint32_t n, uint8_t* tags) try {
+    if (!idx || (n && !tags)) return DANN_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
+    if (!idx->cfg.inline_tags) memset(tags, 254, n);  // a store without tags: every slot readable
+    else memcpy(tags, idx->h_tags.data() + first_slot, n);
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len) try {
     return dann_set_elements(idx, slot, 1, bytes, len);
-}
+} DANN_CATCH_ALL
 
-int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len) {
+int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len) try {
     CHECK_IDX(idx);
     if (!bytes) return DANN_EINVAL;
     if (len != idx->layer_bytes) {
@@ -299,20 +344,30 @@ int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint
                             idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows) {
+int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows) try {
     CHECK_IDX(idx);
     if (!base) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
     if (stride < idx->layer_bytes) return DANN_ELENGTH;
-    DANN_HIP(hipMemcpy2DAsync(idx->d_rows, idx->cfg.row_stride, base, stride, idx->layer_bytes, nrows,
+    // with inline_tags the tag byte that follows each payload travels with it (needs stride > payload)
+    const bool tags = idx->cfg.inline_tags != 0;
+    if (tags && stride <= idx->layer_bytes) {
+        set_error("dann_upload_store: inline_tags needs a source stride > %u payload bytes", idx->layer_bytes);
+        return DANN_ELENGTH;
+    }
+    DANN_HIP(hipMemcpy2DAsync(idx->d_rows, idx->cfg.row_stride, base, stride, idx->layer_bytes + (tags ? 1u : 0u), nrows,
                               hipMemcpyHostToDevice, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (tags) {
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(base) + idx->layer_bytes;
+        for (uint32_t i = 0; i < nrows; ++i) idx->h_tags[i] = b[(size_t)i * stride];
+    }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets) {
+int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets) try {
     CHECK_IDX(idx);
     if (!pivots || !chunk_offsets) return DANN_EINVAL;
     if (idx->cfg.dtype != DT_PQ) {
@@ -335,10 +390,10 @@ int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* 
     DANN_HIP(hipMemcpyAsync(idx->d_pq_offsets, chunk_offsets, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- external ids ------------------------------------------------------------------------
-int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, const uint64_t* ext_ids) {
+int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, const uint64_t* ext_ids) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     if (n == 0) return DANN_OK;
@@ -347,9 +402,9 @@ int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, 
     if (idx->ext_ids.empty()) idx->ext_ids.assign(idx->cfg.capacity, ~0ull);
     memcpy(idx->ext_ids.data() + first_slot, ext_ids, (size_t)n * 8);
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64_t n, uint64_t* out_ext) {
+int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64_t n, uint64_t* out_ext) try {
     if (!idx || (n && (!slot_ids || !out_ext))) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     for (uint64_t i = 0; i < n; ++i) {
@@ -358,10 +413,10 @@ int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64
         else out_ext[i] = idx->ext_ids.empty() ? (uint64_t)s : idx->ext_ids[s];
     }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- adjacency ---------------------------------------------------------------------------
-int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len) {
+int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, uint32_t cap, uint32_t* out_len) try {
     CHECK_IDX(idx);
     if (!out_len) return DANN_EINVAL;
     if (slot >= idx->nslots) {
@@ -377,9 +432,9 @@ int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, 
     if (len > cap || (len && !out)) return DANN_ETOOLONG;
     if (len) memcpy(out, row.data() + 1, (size_t)len * 4);
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) {
+int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) try {
     CHECK_IDX(idx);
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     if (n > idx->cfg.max_degree) {
@@ -394,10 +449,11 @@ int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, 
                             hipMemcpyHostToDevice, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) {
-    if (!idx) return DANN_EINVAL;
+int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) try {
+    CHECK_IDX(idx);  // recursive mutex: the get / set calls below re-enter it
+    if (n && !ids) return DANN_EINVAL;
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     std::vector<uint32_t> cur(idx->cfg.max_degree);
     uint32_t len = 0;
@@ -407,9 +463,9 @@ int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* id
     uint32_t take = std::min(n, slack);
     for (uint32_t i = 0; i < take; ++i) cur[len + i] = ids[i];
     return dann_set_neighbors(idx, slot, cur.data(), len + take);
-}
+} DANN_CATCH_ALL
 
-int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t n, const uint32_t* lists) {
+int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t n, const uint32_t* lists) try {
     CHECK_IDX(idx);
     if (n == 0) return DANN_OK;
     if (!slots || !lists) return DANN_EINVAL;
@@ -424,9 +480,9 @@ int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t
     }
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) {
+int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) try {
     CHECK_IDX(idx);
     if (!adj) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
@@ -434,9 +490,9 @@ int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) 
                             idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows) {
+int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows) try {
     CHECK_IDX(idx);
     if (!adj) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
@@ -444,10 +500,10 @@ int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows
                             idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- distances ---------------------------------------------------------------------------
-int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const void* y, uint64_t ylen, float* out) {
+int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const void* y, uint64_t ylen, float* out) try {
     CHECK_IDX(idx);
     if (!x || !y || !out) return DANN_EINVAL;
     if (xlen != idx->layer_bytes || ylen != idx->layer_bytes) {
@@ -467,9 +523,9 @@ int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const
     DANN_HIP(hipMemcpyAsync(out, d_out, 4, hipMemcpyDeviceToHost, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint32_t* b, uint32_t n, float* out) {
+int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint32_t* b, uint32_t n, float* out) try {
     CHECK_IDX(idx);
     if (n == 0) return DANN_OK;
     if (!a || !b || !out) return DANN_EINVAL;
@@ -487,9 +543,9 @@ int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint
     DANN_HIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len, dann_query** out) {
+int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len, dann_query** out) try {
     CHECK_IDX(idx);
     if (!query || !out) return DANN_EINVAL;
     *out = nullptr;
@@ -514,15 +570,15 @@ int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len
     }
     *out = q;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_query_destroy(dann_query* q) {
+int32_t dann_query_destroy(dann_query* q) try {
     if (!q) return DANN_OK;
     DeviceGuard guard(q->idx->device);
     if (q->d_query) (void)hipFree(q->d_query);
     delete q;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // shared by dann_query_distance / dann_expand_beam: search-path kernel over a temporary row
 // set or stored rows
@@ -543,7 +599,7 @@ static int32_t expand_on_device(const dann_index* idx, const IndexView& view, co
     return DANN_OK;
 }
 
-int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, float* out) {
+int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, float* out) try {
     if (!q || !row || !out) return DANN_EINVAL;
     const dann_index* idx = q->idx;
     DeviceGuard guard(idx->device);
@@ -559,10 +615,10 @@ int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, 
     v.nslots = 1;
     uint32_t zero = 0;
     return expand_on_device(idx, v, q->d_query, &zero, 1, out);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, uint32_t* out_ids, float* out_dists,
-                         uint32_t* out_n) {
+                         uint32_t* out_n) try {
     if (!q || !out_n) return DANN_EINVAL;
     const dann_index* idx = q->idx;
     DeviceGuard guard(idx->device);
@@ -571,15 +627,20 @@ int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, u
     if (!ids || !out_ids || !out_dists) return DANN_EINVAL;
     for (uint32_t i = 0; i < n; ++i)
         if (ids[i] >= idx->nslots) return DANN_EBOUNDS;
-    int32_t rc = expand_on_device(idx, idx->view(), q->d_query, ids, n, out_dists);
-    if (rc != DANN_OK) return rc;
-    memcpy(out_ids, ids, (size_t)n * 4);  // every slot of the snapshot is readable (no tags)
-    *out_n = n;
-    return DANN_OK;
-}
+    // read_in_bounds(i) -> None for a slot whose tag is not readable: skipped, not counted (provider.rs:681-686)
+    uint32_t m = 0;
+    {
+        std::lock_guard<std::recursive_mutex> lock(idx->mu);
+        for (uint32_t i = 0; i < n; ++i)
+            if (!idx->cfg.inline_tags || idx->h_tags[ids[i]] >= 254) out_ids[m++] = ids[i];
+    }
+    *out_n = m;
+    if (m == 0) return DANN_OK;
+    return expand_on_device(idx, idx->view(), q->d_query, out_ids, m, out_dists);
+} DANN_CATCH_ALL
 
 int32_t dann_expand_beam_batch(const dann_index* cidx, const void* queries, uint32_t nq, const uint32_t* ids,
-                               const uint64_t* offsets, float* out_dists) {
+                               const uint64_t* offsets, float* out_dists) try {
     dann_index* idx = const_cast<dann_index*>(cidx);
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
@@ -608,8 +669,11 @@ int32_t dann_expand_beam_batch(const dann_index* cidx, const void* queries, uint
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(out_dists, bd.p, total * 4, hipMemcpyDeviceToHost, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
+    if (idx->cfg.inline_tags)  // the positional batch form cannot drop entries: unreadable slots report NaN
+        for (uint64_t i = 0; i < total; ++i)
+            if (idx->h_tags[ids[i]] < 254) out_dists[i] = __builtin_nanf("");
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- search --------------------------------------------------------------------------------
 static int32_t pq_ready(const dann_index* idx) {
@@ -660,16 +724,27 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
 
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
-                                 dann_search_stats* d_out_stats) {
+                                 dann_search_stats* d_out_stats) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
+    if (!d_out_stats) {  // the overflow retry needs per-query status: index-owned stats when the caller passes none
+        const size_t need = (size_t)nq * sizeof(dann_search_stats);
+        if (idx->stage_bytes[2] < need) {
+            if (idx->stage[2]) (void)hipFree(idx->stage[2]);
+            idx->stage[2] = nullptr;
+            idx->stage_bytes[2] = 0;
+            DANN_HIP(hipMalloc(&idx->stage[2], need + need / 4));
+            idx->stage_bytes[2] = need + need / 4;
+        }
+        d_out_stats = reinterpret_cast<dann_search_stats*>(idx->stage[2]);
+    }
     return search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
                          nullptr, nullptr, 0, nullptr);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
-                          uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) {
+                          uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
@@ -732,13 +807,13 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
         }
     }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
                                 uint32_t beam_width, float radius, int32_t has_inner_radius, float inner_radius,
                                 float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
                                 uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
-                                uint32_t* out_second_round) {
+                                uint32_t* out_second_round) try {
     CHECK_IDX(idx);
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
@@ -826,7 +901,7 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
             return DANN_EOVERFLOW;
         }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- filtered searches ---------------------------------------------------------------------------
 // compute_adaptive_l (inline_filter_search.rs:283-301): f64, truncating casts, host libm
@@ -1006,20 +1081,20 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
 
 int32_t dann_filtered_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value,
                                    uint32_t beam_width, uint32_t k, const dann_filter* filter, uint32_t* out_ids,
-                                   float* out_dists, dann_search_stats* out_stats) {
+                                   float* out_dists, dann_search_stats* out_stats) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
     FilteredCall c{queries, nq, l_value, beam_width, k, filter, out_ids, out_dists, out_stats};
     return filtered_search(idx, c);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
                                          uint32_t beam_width, float radius, int32_t has_inner_radius,
                                          float inner_radius, float initial_slack, float range_slack,
                                          uint32_t max_returned, uint32_t out_cap, const dann_filter* filter,
                                          uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
-                                         uint32_t* out_second_round) {
+                                         uint32_t* out_second_round) try {
     CHECK_IDX(idx);
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
@@ -1054,10 +1129,10 @@ int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, u
     c.max_returned = max_returned;
     c.out_second = out_second_round;
     return filtered_search(idx, c);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, const uint32_t* d_cand_ids,
-                                 uint32_t cand_stride, uint32_t k, uint32_t* d_out_ids, float* d_out_dists) {
+                                 uint32_t cand_stride, uint32_t k, uint32_t* d_out_ids, float* d_out_dists) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!d_queries || !d_cand_ids || !d_out_ids || !d_out_dists || k == 0) return DANN_EINVAL;
@@ -1066,10 +1141,10 @@ int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_
                              idx->stream);
     });
     return rc;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_rerank_batch(dann_index* idx, const void* queries, uint32_t nq, const uint32_t* cand_ids,
-                          uint32_t cand_stride, uint32_t k, uint32_t* out_ids, float* out_dists) {
+                          uint32_t cand_stride, uint32_t k, uint32_t* out_ids, float* out_dists) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!queries || !cand_ids || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
@@ -1087,11 +1162,11 @@ int32_t dann_rerank_batch(dann_index* idx, const void* queries, uint32_t nq, con
     DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
     DANN_HIP(hipStreamSynchronize(idx->stream));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,
                                  uint32_t* rec_ids, float* rec_dists, uint32_t rec_stride, uint32_t* rec_n,
-                                 dann_search_stats* out_stats) {
+                                 dann_search_stats* out_stats) try {
     CHECK_IDX(idx);
     if (nq == 0) return DANN_OK;
     if (!slots || !rec_ids || !rec_dists || !rec_n || rec_stride == 0) return DANN_EINVAL;
@@ -1122,7 +1197,7 @@ int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_
             return DANN_EOVERFLOW;
         }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- on-disk formats ---------------------------------------------------------------------------
 struct File {
@@ -1132,7 +1207,7 @@ struct File {
     }
 };
 
-int32_t dann_save_graph(const dann_index* idx, const char* path) {
+int32_t dann_save_graph(const dann_index* idx, const char* path) try {
     CHECK_IDX(idx);
     if (!path) return DANN_EINVAL;
     const uint32_t w = idx->cfg.max_degree + 1;
@@ -1160,10 +1235,10 @@ int32_t dann_save_graph(const dann_index* idx, const char* path) {
         return DANN_EINVAL;
     }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, uint64_t* out_num_start,
-                        uint64_t* out_num_points) {
+                        uint64_t* out_num_points) try {
     CHECK_IDX(idx);
     if (!path) return DANN_EINVAL;
     File in;
@@ -1189,6 +1264,12 @@ int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, 
             set_error("%s: truncated adjacency list %llu", path, (unsigned long long)npts);
             return DANN_ELENGTH;
         }
+        // a list can be neither longer than what the header / this index allow nor than the rest of the file
+        if (len > std::max(max_degree, idx->cfg.max_degree) || 4ull * len > file_size - pos) {
+            set_error("%s: adjacency list %llu claims %u neighbours (header max degree %u)", path,
+                      (unsigned long long)npts, len, max_degree);
+            return DANN_ETOOLONG;
+        }
         buf.resize(len);
         if (len && fread(buf.data(), 4, len, in.f) != len) {
             set_error("%s: truncated adjacency list %llu", path, (unsigned long long)npts);
@@ -1212,9 +1293,9 @@ int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, 
     if (out_num_start) *out_num_start = nstart;
     if (out_num_points) *out_num_points = npts;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t first_slot, uint32_t n) {
+int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t first_slot, uint32_t n) try {
     CHECK_IDX(idx);
     if (!path) return DANN_EINVAL;
     if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
@@ -1238,9 +1319,9 @@ int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t 
         return DANN_EINVAL;
     }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n) {
+int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n) try {
     CHECK_IDX(idx);
     if (!path) return DANN_EINVAL;
     File in;
@@ -1266,28 +1347,28 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
     if (rc != DANN_OK) return rc;
     if (out_n) *out_n = n;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 // ---- diagnostics -----------------------------------------------------------------------------
 int32_t dann_abi_version(void) { return DANN_ABI_VERSION; }
-int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) {
+int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) try {
     if (!idx || which < 0 || which > 4) return DANN_EINVAL;
     if (total_ms) *total_ms = idx->clocks[which].total_ms;
     if (launches) *launches = idx->clocks[which].launches;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_kernel_time_reset(dann_index* idx) {
+int32_t dann_kernel_time_reset(dann_index* idx) try {
     if (!idx) return DANN_EINVAL;
     for (auto& c : idx->clocks) c = KernelClock();
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) {
+int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) try {
     // 0 = automatic; 6..15 = log2(entries); >= 64 = explicit entry count (rounded up to a multiple of 64)
     if (!idx || (bits != 0 && bits < 64 && (bits < 6 || bits > 15)) || bits > 32768) return DANN_EINVAL;
     idx->visited_bits = bits;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 }  // extern "C"

@@ -641,9 +641,7 @@ struct BuildScratch {
 int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uint32_t degree) {
     if (batch <= s.batch_cap && rec_stride == s.rec_stride && degree == s.degree) return DANN_OK;
     const uint32_t cap = std::max<uint32_t>(batch, 1024);
-    s.batch_cap = cap;
-    s.rec_stride = rec_stride;
-    s.degree = degree;
+    s.batch_cap = 0;  // committed only after every allocation succeeded (a failed hipMalloc must not pass the cache test)
     s.pend_stride = degree + 1;
     const size_t nkeys = (size_t)cap * degree;
     DANN_HIP(s.slots.alloc((size_t)cap * 4));
@@ -663,6 +661,9 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
                                                (int)nkeys, 0, 64, nullptr));
     s.sort_tmp_bytes = tmp;
     DANN_HIP(s.sort_tmp.alloc(tmp));
+    s.batch_cap = cap;
+    s.rec_stride = rec_stride;
+    s.degree = degree;
     return DANN_OK;
 }
 
@@ -773,7 +774,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
     int32_t rc;
     auto aggregate = [&](uint32_t* h_meta) -> int32_t {
         const uint32_t total = n * s.degree;
-        DANN_HIP(hipMemsetAsync(meta, 0, 16, st));
+        DANN_HIP(hipMemsetAsync(meta, 0, 12, st));  // nseg, nkeys, maxseg -- the error word meta[3] is sticky
         hipLaunchKernelGGL(make_keys_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slots, pending,
                            s.pend_stride, n, s.degree, s.keys_in.as<uint64_t>());
         size_t tmp = s.sort_tmp_bytes;
@@ -877,7 +878,7 @@ static BuildScratch& scratch_of(dann_index* idx) {
 
 extern "C" {
 
-int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) {
+int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
@@ -896,13 +897,13 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), n);
-}
+} DANN_CATCH_ALL
 
 // multi-GPU build: phase 1 on a slice of the batch, phase 2 with the all-gathered pending rows.
 // d_pending_* are DEVICE pointers ((pruned_degree + 1) u32 per row) so that they can be the send /
 // receive buffers of an RCCL all-gather.
 int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
-                                     uint32_t lo, uint32_t hi, uint32_t* d_pending_out) {
+                                     uint32_t lo, uint32_t hi, uint32_t* d_pending_out) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
@@ -919,10 +920,10 @@ int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* c
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     return batch_candidates(idx, *cfg, s, s.slots.as<uint32_t>(), n, lo, hi, d_pending_out);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
-                                 const uint32_t* d_pending_all) {
+                                 const uint32_t* d_pending_all) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
@@ -938,10 +939,10 @@ int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, 
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     return batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all);
-}
+} DANN_CATCH_ALL
 
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
-                   uint32_t max_batch) {
+                   uint32_t max_batch) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
@@ -980,11 +981,11 @@ int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first
         ++batches;
     }
     return batches;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* locs, uint32_t n,
                          const uint32_t* pool_ids, const float* pool_dists, const uint64_t* offsets,
-                         int32_t force_saturate, uint32_t* out_adj) {
+                         int32_t force_saturate, uint32_t* out_adj) try {
     if (!idx) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
     DeviceGuard guard(idx->device);
@@ -1041,6 +1042,6 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
     DANN_HIP(hipMemcpyAsync(out_adj, dout.p, (size_t)n * ostride * 4, hipMemcpyDeviceToHost, st));
     DANN_HIP(hipStreamSynchronize(st));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 }  // extern "C"

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -22,6 +24,21 @@ int32_t hip_fail(hipError_t e, const char* what);
         hipError_t _e = (call);                               \
         if (_e != hipSuccess) return ::dann::hip_fail(_e, #call); \
     } while (0)
+
+// every extern "C" entry point is a function-try-block closed by this: nothing unwinds across the C boundary
+#define DANN_CATCH_ALL                                          \
+    catch (const std::bad_alloc&) {                             \
+        ::dann::set_error("out of host memory");                \
+        return DANN_ENOMEM;                                     \
+    }                                                           \
+    catch (const std::exception& e) {                           \
+        ::dann::set_error("internal error: %s", e.what());      \
+        return DANN_EINVAL;                                     \
+    }                                                           \
+    catch (...) {                                               \
+        ::dann::set_error("internal error");                    \
+        return DANN_EINVAL;                                     \
+    }
 
 struct KernelClock {
     double total_ms = 0.0;
@@ -48,6 +65,9 @@ struct IndexView {
     const float* pq_pivots;
     const uint32_t* pq_offsets;
     uint32_t pq_chunks;
+    // inline concurrency tags (dann_config::inline_tags): byte offset of a row's tag (== layer_bytes), 0 = none.
+    // A slot is readable iff tag >= 254 (Tag::can_read, diskann-inmem/src/tag.rs:86-133).
+    uint32_t tag_off;
 };
 
 struct SearchArgs {
@@ -162,6 +182,7 @@ struct dann_index {
     size_t h_stage_bytes = 0;
     dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries)
     std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
+    std::vector<uint8_t> h_tags;    // inline_tags: host mirror of the tag bytes (the reference's Store::tags, store.rs:150)
     // one stream, one pair of events and one set of scratch buffers per index: calls that launch
     // work are serialised per handle (they would serialise on the stream anyway)
     mutable std::recursive_mutex mu;

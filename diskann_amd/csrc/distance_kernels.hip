@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
 }  // namespace
 }  // namespace dann
 
-extern "C" int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps) {
+extern "C" int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps) try {
     using namespace dann;
     if (!gbps || bytes < (1u << 20) || reps == 0) return DANN_EINVAL;
     if (device >= 0) DANN_HIP(hipSetDevice(device));
@@ -439,4 +439,4 @@ extern "C" int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, u
     (void)hipFree(buf);
     (void)hipFree(sink);
     return DANN_OK;
-}
+} DANN_CATCH_ALL

@@ -116,7 +116,9 @@ __global__ __launch_bounds__(kWave) void paged_kernel(PagedArgs a) {
             const uint32_t j = j0 + lane;
             const uint32_t id = j < len ? arow[1 + j] : kEmpty;
             const bool isnew = id != kEmpty && visit(id);
-            const bool keep = isnew && id < ix.nslots;
+            // unreadable slots (inline tag below PUBLISHED) are skipped after the visited insert (provider.rs:681-686)
+            const bool keep = isnew && id < ix.nslots &&
+                              (!ix.tag_off || ix.rows[(uint64_t)id * ix.row_stride + ix.tag_off] >= 254);
             const uint64_t nm = ballot64(isnew), km = ballot64(keep);
             if (keep) cand_id[nc + mbcnt(km)] = id;
             nc += (uint32_t)__popcll(km);
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(kWave) void paged_kernel(PagedArgs a) {
         st.hops = hops;
         st.result_count = 0;
         st.status = status;
+        st.written = 0;
         a.stats[qi] = st;
     }
 }
@@ -386,7 +389,7 @@ struct dann_paged {
 extern "C" {
 
 int32_t dann_paged_begin(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t list_cap,
-                         dann_paged** out) {
+                         dann_paged** out) try {
     if (!idx || !out) return DANN_EINVAL;
     *out = nullptr;
     if (!queries || nq == 0 || l_value == 0) {
@@ -466,9 +469,9 @@ int32_t dann_paged_begin(dann_index* idx, const void* queries, uint32_t nq, uint
     a.init = 0;
     *out = s;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_paged_next(dann_paged* s, uint32_t k, uint32_t* out_ids, float* out_dists, uint32_t* out_counts) {
+int32_t dann_paged_next(dann_paged* s, uint32_t k, uint32_t* out_ids, float* out_dists, uint32_t* out_counts) try {
     if (!s || !out_ids || !out_dists) return DANN_EINVAL;
     if (k == 0) {
         set_error("k should be greater than 0");  // paged.rs:62-64
@@ -515,12 +518,12 @@ int32_t dann_paged_next(dann_paged* s, uint32_t k, uint32_t* out_ids, float* out
             return DANN_EOVERFLOW;
         }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
-int32_t dann_paged_end(dann_paged* s) {
+int32_t dann_paged_end(dann_paged* s) try {
     if (!s) return DANN_EINVAL;
     delete s;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 }  // extern "C"

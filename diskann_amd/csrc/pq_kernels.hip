@@ -358,7 +358,7 @@ using namespace dann;
 extern "C" {
 
 int32_t dann_pq_build_lut(int32_t device, int32_t metric, const float* pivots, const uint32_t* chunk_offsets,
-                          uint32_t nchunks, uint32_t dim, const float* queries, uint32_t nq, float* lut) {
+                          uint32_t nchunks, uint32_t dim, const float* queries, uint32_t nq, float* lut) try {
     if (!pivots || !chunk_offsets || !queries || !lut || nchunks == 0 || dim == 0) return DANN_EINVAL;
     if (metric != M_L2 && metric != M_IP) {
         set_error("PQ lookup tables exist for L2 and inner product only");
@@ -391,10 +391,10 @@ int32_t dann_pq_build_lut(int32_t device, int32_t metric, const float* pivots, c
     DANN_HIP(hipGetLastError());
     DANN_HIP(hipMemcpy(lut, dl.p, lut_bytes, hipMemcpyDeviceToHost));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nchunks, const uint8_t* codes,
-                     uint64_t npoints, const uint32_t* ids, const uint64_t* offsets, float* out) {
+                     uint64_t npoints, const uint32_t* ids, const uint64_t* offsets, float* out) try {
     if (!lut || !codes || !ids || !offsets || !out || nchunks == 0) return DANN_EINVAL;
     if (nq == 0) return DANN_OK;
     const uint64_t total = offsets[nq];
@@ -432,12 +432,12 @@ int32_t dann_pq_scan(int32_t device, const float* lut, uint32_t nq, uint32_t nch
     DANN_HIP(hipGetLastError());
     DANN_HIP(hipMemcpy(out, dout.p, total * 4, hipMemcpyDeviceToHost));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 }  // extern "C"
 
 extern "C" int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets,
-                                    uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n, uint8_t* codes) {
+                                    uint32_t nchunks, uint32_t dim, const float* rows, uint64_t n, uint8_t* codes) try {
     using namespace dann;
     if (!pivots || !chunk_offsets || !rows || !codes || nchunks == 0 || dim == 0) return DANN_EINVAL;
     if (ncenters == 0 || ncenters > 256) {  // TableCompressionError::CannotCompressToByte
@@ -492,11 +492,11 @@ extern "C" int32_t dann_pq_compress(int32_t device, const float* pivots, uint32_
         }
     }
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 extern "C" int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n, uint32_t dim,
                                   const uint32_t* chunk_offsets, uint32_t nchunks, uint32_t ncenters, float* centers,
-                                  uint32_t max_reps, uint32_t* assignments, float* residuals) {
+                                  uint32_t max_reps, uint32_t* assignments, float* residuals) try {
     using namespace dann;
     if (!data || !chunk_offsets || !centers || nchunks == 0 || dim == 0 || ncenters == 0) return DANN_EINVAL;
     if (n == 0 || n > 0xFFFFFFFFull) return DANN_EINVAL;
@@ -585,10 +585,10 @@ extern "C" int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n,
     if (assignments) DANN_HIP(hipMemcpy(assignments, dasg.p, (size_t)nchunks * n * 4, hipMemcpyDeviceToHost));
     if (residuals) DANN_HIP(hipMemcpy(residuals, dres.p, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 extern "C" int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t dim, double standard_deviations,
-                                  float* shift, float* scale, float* mean_norm) {
+                                  float* shift, float* scale, float* mean_norm) try {
     using namespace dann;
     if (!data || !shift || !scale || n == 0 || dim == 0) return DANN_EINVAL;
     if (!(standard_deviations > 0.0)) {  // Positive<f64>
@@ -623,10 +623,10 @@ extern "C" int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n,
     for (uint32_t d = 0; d < dim; ++d) shift[d] = (float)(means[d] - p);
     if (mean_norm) *mean_norm = (float)mn;
     return DANN_OK;
-}
+} DANN_CATCH_ALL
 
 extern "C" int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift,
-                                     float scale, void* out) {
+                                     float scale, void* out) try {
     using namespace dann;
     if (!x || !shift || !out || dim == 0 || !(scale > 0.0f)) return DANN_EINVAL;
     if (n == 0) return DANN_OK;
@@ -642,4 +642,4 @@ extern "C" int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n,
     DANN_HIP(hipGetLastError());
     DANN_HIP(hipMemcpy(out, dout.p, (size_t)n * (dim + 4), hipMemcpyDeviceToHost));
     return DANN_OK;
-}
+} DANN_CATCH_ALL

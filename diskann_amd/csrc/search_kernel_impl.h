@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 constexpr int kMaxBeam = 16;
 constexpr int kGatherRows = 4;
 constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
+constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
 
 // optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
 #ifdef DANN_PHASE_CYCLES
@@ -266,8 +267,12 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         return added;
     };
 
-    // distance of every candidate in cand_id[0..nc) -> cand_d
-    auto gather = [&](uint32_t nc) {
+    // distance of every candidate in cand_id[0..nc) -> cand_d.  Stores with inline tags (ix.tag_off, store.rs:133-158):
+    // the tag byte of each row is requested together with the row (no extra round trip), an unreadable slot
+    // (tag < PUBLISHED) is marked kEmpty and compacted away afterwards -- expand_beam_inner skips it after the
+    // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
+    const uint32_t tag_off = ix.tag_off;
+    auto gather = [&](uint32_t nc) -> uint32_t {
         if constexpr (DIM > 0 && !kInt) {
             constexpr int U = kGatherRows;
             for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
@@ -281,11 +286,20 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     uint32_t id = act[u] ? cand_id[c] : 0u;
                     rows[u] = reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride);
                 }
+                uint8_t tg[U];
+                if (tag_off) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        tg[u] = (act[u] && v == 0) ? reinterpret_cast<const uint8_t*>(rows[u])[tag_off] : (uint8_t)255;
+                }
                 group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, out);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     uint32_t c = c0 + u * GROUPS + g;
-                    if (act[u] && v == 0) cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
+                    if (act[u] && v == 0) {
+                        cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
+                        if (tag_off && tg[u] < kTagPublished) cand_id[c] = kEmpty;
+                    }
                 }
             }
         } else if constexpr (DT == DT_PQ) {
@@ -294,6 +308,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             const float* lut = reinterpret_cast<const float*>(qs);
             for (uint32_t c = lane; c < nc; c += kWave) {
                 const uint8_t* code = ix.rows + (uint64_t)cand_id[c] * ix.row_stride;
+                const uint8_t tg = tag_off ? code[tag_off] : (uint8_t)255;
                 float accum = 0.0f;
                 for (uint32_t b0 = 0; b0 < ix.pq_chunks; b0 += 16) {
                     const uint4 w = *reinterpret_cast<const uint4*>(code + b0);
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     }
                 }
                 cand_d[c] = accum;
+                if (tg < kTagPublished) cand_id[c] = kEmpty;
             }
         } else {
             constexpr int U = S::kWide ? 2 : kGatherRows;
@@ -319,16 +335,43 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     uint32_t id = act[u] ? cand_id[c] : 0u;
                     rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
                 }
+                uint8_t tg[U];
+                if (tag_off) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) tg[u] = (act[u] && v == 0) ? rows[u][tag_off] : (uint8_t)255;
+                }
                 group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, out);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     uint32_t c = c0 + u * GROUPS + g;
-                    if (act[u] && v == 0)
+                    if (act[u] && v == 0) {
                         cand_d[c] = finish_distance<DT, OP, NORM>(out[u], reinterpret_cast<const uint8_t*>(qs), rows[u],
                                                                   ix.dim, sqp);
+                        if (tag_off && tg[u] < kTagPublished) cand_id[c] = kEmpty;
+                    }
                 }
             }
         }
+        if (!tag_off) return nc;
+        // drop the unreadable slots, emission order kept (forward compaction: writes never pass the reads)
+        uint32_t w = 0;
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+            const uint32_t c = c0 + lane;
+            const uint32_t id = c < nc ? cand_id[c] : kEmpty;
+            const float d = c < nc ? cand_d[c] : 0.0f;
+            const bool ok = id != kEmpty;
+            const uint64_t m = ballot64(ok);
+            __syncthreads();
+            if (ok) {
+                const uint32_t r = w + mbcnt(m);
+                cand_id[r] = id;
+                cand_d[r] = d;
+            }
+            w += (uint32_t)__popcll(m);
+            __syncthreads();
+        }
+        return w;
     };
 
     // merge cand[m0 .. m0+n) (n <= 64) into the queue.
@@ -513,7 +556,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
         ht_count = ns;
         __syncthreads();
-        gather(ns);
+        gather(ns);  // start points are FROZEN slots: always readable (store.rs:766-772)
         __syncthreads();
         // the filtered searches do not count the start points as comparisons (inline_filter_search.rs:186-197)
         cmps = fmode ? 0u : ns;
@@ -563,7 +606,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         PH_T(ph1);
         PH_ADD(0, ph0, ph1);
 
-        const uint32_t nc = expand(nb);
+        const uint32_t nc_seen = expand(nb);
         if (status) break;
         __syncthreads();
         PH_T(ph2);
@@ -586,7 +629,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 pf_val = lane < R ? prow[1 + lane] : kEmpty;
             }
         }
-        gather(nc);
+        const uint32_t nc = gather(nc_seen);
         __syncthreads();
         PH_T(ph3);
         PH_ADD(2, ph2, ph3);
@@ -630,10 +673,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     if (lane == 0) beam[t] = node;
                 }
                 __syncthreads();
-                const uint32_t nc2 = expand(gb, true);
+                const uint32_t nc2_seen = expand(gb, true);
                 if (status) break;
                 __syncthreads();
-                gather(nc2);
+                const uint32_t nc2 = gather(nc2_seen);
                 __syncthreads();
                 cmps += nc2;
                 for (uint32_t m0 = 0; m0 < nc2; m0 += kWave)
@@ -781,10 +824,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 if (lane < nb) beam[lane] = u32_load(m_ids + front + lane);
                 front += nb;
                 __syncthreads();
-                const uint32_t nc = expand(nb);
+                const uint32_t nc_seen = expand(nb);
                 if (status) break;
                 __syncthreads();
-                gather(nc);
+                const uint32_t nc = gather(nc_seen);
                 __syncthreads();
                 cmps += nc;
                 hops += nb;
@@ -892,10 +935,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 if (lane < nb) beam[lane] = rids[front + lane];
                 front += nb;
                 __syncthreads();
-                const uint32_t nc = expand(nb);
+                const uint32_t nc_seen = expand(nb);
                 if (status) break;
                 __syncthreads();
-                gather(nc);
+                const uint32_t nc = gather(nc_seen);
                 __syncthreads();
                 hops += nb;
                 // append survivors in emission order while the list has room
@@ -1024,7 +1067,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             dann_search_stats st;
             st.cmps = cmps;
             st.hops = hops;
-            st.result_count = written;
+            // Translate::post_process counts a push only while the buffer still has room afterwards
+            // (provider.rs:933-944, search_output_buffer.rs:107-124): k - 1 when the buffer of length k fills
+            st.result_count = (!a.range_ids && a.k && written == a.k) ? a.k - 1u : written;
+            st.written = written;
             st.status = status;
             a.stats[qi] = st;
         }

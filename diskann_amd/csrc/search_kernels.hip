@@ -149,13 +149,13 @@ unsigned long long* dann_phase_buffer() {
     }
     return g_phase_buf;
 }
-extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) {
+extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) try {
     unsigned long long* b = dann_phase_buffer();
     if (!b) return DANN_EHIP;
     if (out) (void)hipMemcpy(out, b, 64, hipMemcpyDeviceToHost);
     if (reset) (void)hipMemset(b, 0, 64);
     return 0;
-}
+} DANN_CATCH_ALL
 #endif
 
 int32_t search_with_retry(dann_index* idx, SearchArgs a) {
@@ -207,6 +207,18 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u entries, %zu B LDS\n", a.l_value, a.beam_width,
                     cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->cap_ids ? "p90" : "prior", a.ht_entries,
                     search_lds_bytes(a));
+    }
+    // the start points are inserted unconditionally and the first hop needs room before the freeze test can
+    // trigger: the open table must hold nstart + W * R ids below its 75 % load limit, or ht_visit could probe a
+    // full table forever (explicit dann_set_visited_bits sizes and small calibrated sizes are grown, never results)
+    {
+        const uint64_t floor_ids = (uint64_t)a.ix.nstart + (uint64_t)a.beam_width * a.ix.max_degree + 1;
+        while (a.ht_entries < 32768 && (uint64_t)largest_prime_leq(a.ht_entries) * 3 / 4 <= floor_ids) a.ht_entries *= 2;
+        if ((uint64_t)largest_prime_leq(a.ht_entries) * 3 / 4 <= floor_ids) {
+            set_error("visited table: %u start points + beam %u x degree %u do not fit the largest LDS table", a.ix.nstart,
+                      a.beam_width, a.ix.max_degree);
+            return DANN_EINVAL;
+        }
     }
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;

@@ -17,7 +17,8 @@ from ._ffi import (BuildConfig, Config, DannError, SearchStats, check, F32, F16,
 
 NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np.uint8, PQ: np.uint8}
 FILTER_INLINE, FILTER_MULTIHOP = 1, 2  # dann.h DANN_FILTER_*
-STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32)])
+STATS_DTYPE = np.dtype([("cmps", np.uint32), ("hops", np.uint32), ("result_count", np.uint32), ("status", np.uint32),
+                        ("written", np.uint32)])
 
 
 def _p(a):
@@ -48,7 +49,7 @@ class PagedSearch:
     """graph::search::PagedSearch (diskann/src/graph/search/paged.rs) for nq queries."""
 
     def __init__(self, provider, queries, l_value, list_cap=0):
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[provider.dtype]).reshape(-1, provider.row_elems)
+        q = np.ascontiguousarray(queries, dtype=provider.query_dtype).reshape(-1, provider.query_elems)
         self.nq = q.shape[0]
         self._h = C.c_void_p()
         self._provider = provider  # keeps the index alive
@@ -79,7 +80,7 @@ class Provider:
     """diskann_inmem::Provider<Full<T>, u32> + DiskANNIndex, resident in one GPU's HBM."""
 
     def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, row_stride=0, device=-1,
-                 sq_scale=0.0, sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None):
+                 sq_scale=0.0, sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None, inline_tags=False):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
         self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim  # SQ-8 rows carry a trailing f32 compensation
@@ -93,7 +94,8 @@ class Provider:
         sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.row_elems)
         self.num_start_points = sp.shape[0]
         cfg = Config(dtype, metric, self.dim, self.capacity, self.max_degree, self.num_start_points, row_stride,
-                     device, sq_scale, sq_shift_norm_sq, pq_chunks)
+                     device, sq_scale, sq_shift_norm_sq, pq_chunks, int(bool(inline_tags)))
+        self.inline_tags = bool(inline_tags)
         h = C.c_void_p()
         check(_ffi.lib().dann_index_create(C.byref(cfg), _p(sp), sp.nbytes, C.byref(h)), "dann_index_create")
         self._h = h
@@ -135,6 +137,16 @@ class Provider:
     def upload_store(self, raw_rows):
         raw = np.ascontiguousarray(raw_rows, dtype=np.uint8)
         check(_ffi.lib().dann_upload_store(self._h, _p(raw), raw.shape[1], raw.shape[0]), "dann_upload_store")
+
+    def set_tags(self, first_slot, tags):
+        """raw inline tag bytes (tag.rs: 0 AVAILABLE, 1 OWNED, 2 RETIRING, 254 PUBLISHED, 255 FROZEN)"""
+        t = np.ascontiguousarray(tags, dtype=np.uint8)
+        check(_ffi.lib().dann_set_tags(self._h, first_slot, t.size, _p(t)), "dann_set_tags")
+
+    def get_tags(self, first_slot, n):
+        t = np.empty(n, np.uint8)
+        check(_ffi.lib().dann_get_tags(self._h, first_slot, n, _p(t)), "dann_get_tags")
+        return t
 
     # -- IdMap / Translate ------------------------------------------------------
     def set_external_ids(self, first_slot, ext_ids):
@@ -214,7 +226,7 @@ class Provider:
             _ffi.lib().dann_query_destroy(h)
 
     def expand_beam_batch(self, queries, ids, offsets):
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         out = np.empty(ids.size, np.float32)
@@ -237,7 +249,7 @@ class Provider:
     def range_search(self, queries, starting_l, radius, beam_width=1, inner_radius=None, initial_slack=1.0,
                      range_slack=1.0, max_returned=0, out_cap=None):
         """graph::search::Range for a batch; returns (ids, dists, stats, second_round)."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         nq = q.shape[0]
         cap = int(out_cap or max_returned or 1024)
         ids = np.empty((nq, cap), np.uint32)
@@ -272,7 +284,7 @@ class Provider:
 
     def filtered_search(self, params, queries, k, match, mode=None, adaptive=None, matched_cap=0):
         """InlineFilterSearch (default) or MultihopFilterSearch for a batch; returns (ids, dists, stats)."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         nq = q.shape[0]
         f, keep = self._filter(mode or FILTER_INLINE, match, nq, adaptive, matched_cap)
         ids = np.empty((nq, k), np.uint32)
@@ -287,7 +299,7 @@ class Provider:
     def filtered_range_search(self, queries, starting_l, radius, match, beam_width=1, inner_radius=None,
                               initial_slack=1.0, range_slack=1.0, max_returned=0, out_cap=None, matched_cap=0):
         """graph::search::FilteredRange for a batch; returns (ids, dists, stats, second_round)."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         nq = q.shape[0]
         f, keep = self._filter(FILTER_INLINE, match, nq, None, matched_cap)
         cap = int(out_cap or max_returned or 1024)
@@ -309,7 +321,7 @@ class Provider:
 
     def rerank(self, queries, cand_ids, k):
         """Rerank post-processor: full-precision distances for the candidates of a quantised search."""
-        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
         c = np.ascontiguousarray(cand_ids, dtype=np.uint32).reshape(q.shape[0], -1)
         ids = np.empty((q.shape[0], k), np.uint32)
         d = np.empty((q.shape[0], k), np.float32)

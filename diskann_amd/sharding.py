@@ -75,21 +75,42 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
     candidates (insert-time search + RobustPrune) for its `partition` of the batch positions, the
     pending adjacency rows are all-gathered (RCCL over xGMI when the process group is "nccl": the
     only exchange step of the build), and every rank applies the same graph update, so the replicas
-    stay byte-identical to a single-GPU dann_build.  Returns the number of batches."""
+    stay byte-identical to a single-GPU dann_build.  The batch schedule is dann_build's, including its
+    fallback: a batch whose bootstrap (index.rs:926-938) would not fit one prune pool leaves the graph
+    untouched and is re-inserted as smaller batches -- the test runs in the commit phase on identical
+    data, so every rank takes the same decision.  Returns the number of batches."""
+    import math
+
     import torch
+
+    from ._ffi import DannError, EUNSUPPORTED
     dev = torch.device("cuda", provider.device)
     width = cfg.pruned_degree + 1
-    batches = 0
-    for start, b in batch_schedule(first, n, growth, max_batch):
+    g = float(np.float32(growth))
+    done, batches, limit = 0, 0, max_batch
+    while done < n:
+        b = int(math.ceil((first + done) * g))
+        b = max(1, min(b, limit))
+        b = min(b, n - done)
+        start = first + done
         slots = np.arange(start, start + b, dtype=np.uint32)
         lo, hi = partition(b, world, rank)
         longest = partition(b, world, 0)[1]
         mine = torch.zeros((max(longest, 1), width), dtype=torch.int32, device=dev)
+        # the fill above runs on torch's stream, the library writes `mine` from the index's own stream
+        torch.cuda.synchronize(dev)
         provider.insert_batch_candidates(cfg, slots, lo, hi, mine.data_ptr())
         if world > 1:
             import torch.distributed as dist
-            gathered = torch.empty((world, max(longest, 1), width), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(gathered, mine, group=group)
+            backend = dist.get_backend(group)
+            if backend == "gloo":  # CPU collective (tests: several ranks on one device)
+                mine_h = mine.cpu()
+                gathered_h = torch.empty((world, max(longest, 1), width), dtype=torch.int32)
+                dist.all_gather_into_tensor(gathered_h, mine_h, group=group)
+                gathered = gathered_h.to(dev)
+            else:
+                gathered = torch.empty((world, max(longest, 1), width), dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(gathered, mine, group=group)
             parts = []
             for r in range(world):
                 a, z = partition(b, world, r)
@@ -98,6 +119,14 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
         else:
             pending = mine[:b].contiguous()
         torch.cuda.synchronize(dev)
-        provider.insert_batch_commit(cfg, slots, pending.data_ptr())
+        try:
+            provider.insert_batch_commit(cfg, slots, pending.data_ptr())
+        except DannError as e:
+            if e.status == EUNSUPPORTED and b > 1:
+                limit = max(1, b // 2)
+                continue
+            raise
+        limit = min(max_batch, limit * 2)
+        done += b
         batches += 1
     return batches

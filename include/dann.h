@@ -42,7 +42,8 @@ typedef enum {
     DANN_SQ8 = 4,
     /* product-quantised rows: `pq_chunks` code bytes per row; queries are full-precision f32 vectors,
      * distances are lookup-table sums (diskann-providers/src/model/pq/fixed_chunk_pq_table.rs:82-192).
-     * The pivot table is attached with dann_set_pq_table(); search / expand_beam only (re-rank the
+     * The pivot table is attached with dann_set_pq_table(); search entry points only -- the fine-grained
+     * seam for PQ rows is dann_pq_build_lut / dann_pq_scan, dann_expand_beam returns DANN_EINVAL -- (re-rank the
      * candidates on a full-precision index with dann_rerank_batch). */
     DANN_PQ = 5
 } dann_dtype;
@@ -85,6 +86,13 @@ typedef struct {
     float sq_scale;            /* DANN_SQ8 only: ScalarQuantizer::scale()                   */
     float sq_shift_norm_sq;    /* DANN_SQ8 only: ScalarQuantizer::shift_square_norm()       */
     uint32_t pq_chunks;        /* DANN_PQ only: code bytes per row (number of PQ chunks)    */
+    uint32_t inline_tags;      /* 1: every row carries the reference's 1-byte concurrency tag right after its
+                                  payload (Store layout, store.rs:133-158; needs row_stride > payload bytes, e.g.
+                                  dann_inmem2_row_stride()).  A slot whose tag is below Tag::PUBLISHED (254,
+                                  tag.rs:86-133) is not readable: searches skip it after the visited insert and
+                                  do not count it (provider.rs:448-473, 681-686).  dann_upload_store() then copies
+                                  the tag bytes verbatim, dann_set_element(s) publishes the slots it writes,
+                                  start points are FROZEN (255).  0: no tags, every slot readable.            */
 } dann_config;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs:14-41) */
@@ -103,9 +111,14 @@ typedef struct {
 typedef struct {
     uint32_t cmps;
     uint32_t hops;
-    uint32_t result_count; /* entries written (the reference's Translate post-processor reports
-                              k-1 when the buffer fills, provider.rs:933-944; we report k)   */
+    uint32_t result_count; /* SearchStats::result_count as the inmem2 provider reports it: its Translate
+                              post-processor counts a push only while the buffer still has room afterwards
+                              (provider.rs:933-944, search_output_buffer.rs:107-124), i.e. k-1 when the output
+                              buffer of length k fills, else the number written.  Range searches (unbounded
+                              output Vec) report the number written.                                  */
     uint32_t status;       /* 0 ok, else DANN_E* negated (per-query overflow reporting)      */
+    uint32_t written;      /* entries actually written to out_ids / out_dists (what the reference's other
+                              post-processors, e.g. the test provider's, return as the count)         */
 } dann_search_stats;
 
 /* ---- layer / lifetime ---------------------------------------------------------- */
@@ -125,8 +138,14 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out);
 int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len);
 int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len);
 int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len);
-/* upload a whole diskann-inmem Store buffer verbatim (rows at `stride`, tag bytes ignored) */
+/* upload a whole diskann-inmem Store buffer verbatim (rows at `stride`; with dann_config::inline_tags the tag
+ * byte after each payload is uploaded too and decides readability, otherwise tag bytes are ignored) */
 int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows);
+/* inline concurrency tags of slots [first_slot, first_slot + n) (inline_tags indexes only; tag.rs:86-133:
+ * 0 AVAILABLE, 1 OWNED, 2 RETIRING, 254 PUBLISHED, 255 FROZEN; readable iff >= 254).  The host keeps the
+ * reference's mirror of the tags (store.rs:150) for the fine-grained dann_expand_beam seam. */
+int32_t dann_set_tags(dann_index* idx, uint32_t first_slot, uint32_t n, const uint8_t* tags);
+int32_t dann_get_tags(const dann_index* idx, uint32_t first_slot, uint32_t n, uint8_t* tags);
 
 /* ---- external ids: IdMap / Translate post-processing (diskann-inmem/src/ids.rs:18-107, provider.rs:899-950).
  * Search results are slot ids; these helpers keep the slot -> external id table and translate result
@@ -337,7 +356,7 @@ int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t d
 int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
-#define DANN_ABI_VERSION 1
+#define DANN_ABI_VERSION 2
 int32_t dann_abi_version(void);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

@@ -46,6 +46,7 @@ class OrcIndex(C.Structure):
         ("pq_pivots", C.c_void_p),
         ("pq_offsets", C.c_void_p),
         ("pq_chunks", C.c_uint32),
+        ("tag_offset", C.c_uint32),
     ]
 
 
@@ -150,7 +151,7 @@ class Index:
     """Host-side arrays in the diskann-inmem layout + the oracle's algorithms over them."""
 
     def __init__(self, dtype, metric, dim, capacity, max_degree, start_rows, row_stride=None, sq_scale=0.0,
-                 sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None):
+                 sq_shift_norm_sq=0.0, pq_pivots=None, pq_offsets=None, tags=False):
         self.dtype, self.metric, self.dim = dtype, metric, int(dim)
         self.capacity, self.max_degree = int(capacity), int(max_degree)
         self.row_elems = self.dim + 4 if dtype == SQ8 else self.dim
@@ -171,22 +172,41 @@ class Index:
         n = self.capacity + self.nstart
         self.rows = np.zeros((n, self.row_stride), dtype=np.uint8)
         self.adj = np.zeros((n, self.max_degree + 1), dtype=np.uint32)
+        # inline tags of the diskann-inmem Store (store.rs:133-158): one byte right after the payload; needs the
+        # reference stride (payload + 1 rounded up).  Start points are FROZEN (255), other slots AVAILABLE (0)
+        # until set_row / set_rows publishes them (254).
+        self.tag_offset = 0
+        if tags:
+            assert self.row_stride > self.row_bytes, "inline tags need row_stride > payload bytes"
+            self.tag_offset = self.row_bytes
         for i in range(self.nstart):
             self.set_row(self.capacity + i, start_rows[i])
+            if tags:
+                self.rows[self.capacity + i, self.tag_offset] = 255
         self._c = OrcIndex(dtype, metric, self.dim, self.capacity, self.nstart, self.max_degree,
                            self.row_stride, self.rows.ctypes.data, self.adj.ctypes.data, sq_scale, sq_shift_norm_sq,
                            self.pq_pivots.ctypes.data if dtype == PQ else None,
-                           self.pq_offsets.ctypes.data if dtype == PQ else None, pq_chunks)
+                           self.pq_offsets.ctypes.data if dtype == PQ else None, pq_chunks, self.tag_offset)
 
     # -- storage ------------------------------------------------------------
     def set_row(self, slot, vec):
         vec = np.ascontiguousarray(vec, dtype=NP_DTYPE[self.dtype]).reshape(-1)
         assert vec.size == self.row_elems
         self.rows[slot, : self.row_bytes] = vec.view(np.uint8)
+        if self.tag_offset:
+            self.rows[slot, self.tag_offset] = 254  # Slot::publish (store.rs:776-782)
 
     def set_rows(self, first, mat):
         mat = np.ascontiguousarray(mat, dtype=NP_DTYPE[self.dtype]).reshape(-1, self.row_elems)
         self.rows[first: first + mat.shape[0], : self.row_bytes] = mat.view(np.uint8).reshape(mat.shape[0], -1)
+        if self.tag_offset:
+            self.rows[first: first + mat.shape[0], self.tag_offset] = 254
+
+    def set_tags(self, first, tags):
+        """raw tag bytes of slots [first, first + len(tags)) (0 AVAILABLE, 1 OWNED, 2 RETIRING, 254 PUBLISHED, 255 FROZEN)"""
+        assert self.tag_offset, "index was created without inline tags"
+        t = np.asarray(tags, dtype=np.uint8)
+        self.rows[first: first + t.size, self.tag_offset] = t
 
     def row(self, slot):
         return self.rows[slot, : self.row_bytes].view(NP_DTYPE[self.dtype])

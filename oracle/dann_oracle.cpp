@@ -527,6 +527,10 @@ struct View {
     uint32_t nslots() const { return ix->capacity + ix->nstart; }
     const uint8_t* row(uint32_t id) const { return ix->rows + (size_t)id * ix->row_stride; }
     uint32_t* adj_row(uint32_t id) const { return ix->adj + (size_t)id * (ix->max_degree + 1); }
+    /* Reader::read_in_bounds (store.rs:693-723): the slot's inline tag byte sits right after the payload and the
+     * row is readable iff Tag::can_read, i.e. tag >= PUBLISHED = 254 (tag.rs:86-133).  tag_offset == 0: a store
+     * without tags (every slot readable). */
+    bool readable(uint32_t id) const { return ix->tag_offset == 0 || row(id)[ix->tag_offset] >= 254; }
     /* Neighbors::get, neighbors.rs:124-163 (length clamped to max_degree) */
     uint32_t get_neighbors(uint32_t id, const uint32_t** out) const {
         uint32_t* r = adj_row(id);
@@ -631,7 +635,7 @@ void search_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t b
             ids.clear();
             for (uint32_t j = 0; j < n; ++j) {
                 uint32_t nb = adj[j];
-                if (visited.insert(nb).second && nb < v.nslots()) ids.push_back(nb);
+                if (visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) ids.push_back(nb);
             }
             const size_t len = ids.size(), look = std::min<size_t>(8, len);
             for (size_t j = 0; j < look; ++j) prefetch_row(v.row(ids[j]), row_bytes);
@@ -1000,7 +1004,7 @@ int32_t orc_range_search(const orc_index* ix, const void* query, uint32_t starti
                 uint32_t len = v.get_neighbors(b, &adj);
                 for (uint32_t j = 0; j < len; ++j) {
                     uint32_t nb = adj[j];
-                    if (visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, qc.eval(nb));
+                    if (visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) neighbors.emplace_back(nb, qc.eval(nb));
                 }
             }
             for (auto& nb : neighbors)
@@ -1081,7 +1085,7 @@ void inline_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t b
             uint32_t n = v.get_neighbors(b, &adj);
             for (uint32_t j = 0; j < n; ++j) {
                 uint32_t nb = adj[j];
-                if (visited.insert(nb).second && nb < v.nslots()) one_hop.emplace_back(nb, qc.eval(nb));
+                if (visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) one_hop.emplace_back(nb, qc.eval(nb));
             }
         }
         for (auto& nb : one_hop) {
@@ -1179,7 +1183,7 @@ int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_v
             uint32_t n = v.get_neighbors(b, &adj);
             for (uint32_t j = 0; j < n; ++j) {
                 uint32_t nb = adj[j];
-                if (visited.insert(nb).second && nb < v.nslots()) one_hop.emplace_back(nb, qc.eval(nb));
+                if (visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) one_hop.emplace_back(nb, qc.eval(nb));
             }
         }
         for (auto& nb : one_hop) {
@@ -1197,7 +1201,7 @@ int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_v
             uint32_t n = v.get_neighbors(c.id, &adj);
             for (uint32_t j = 0; j < n; ++j) {
                 uint32_t nb = adj[j];
-                if (is_match(filter_bits, v.nslots(), nb) && visited.insert(nb).second && nb < v.nslots())
+                if (is_match(filter_bits, v.nslots(), nb) && visited.insert(nb).second && nb < v.nslots() && v.readable(nb))
                     two_hop.emplace_back(nb, qc.eval(nb));
             }
         }
@@ -1282,7 +1286,7 @@ int32_t orc_filtered_range_search(const orc_index* ix, const void* query, uint32
                 uint32_t len = v.get_neighbors(b, &adj);
                 for (uint32_t j = 0; j < len; ++j) {
                     uint32_t nb = adj[j];
-                    if (visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, qc.eval(nb));
+                    if (visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) neighbors.emplace_back(nb, qc.eval(nb));
                 }
             }
             for (auto& nb : neighbors) {
@@ -1348,7 +1352,7 @@ orc_paged* orc_paged_begin(const orc_index* ix, const void* query, uint32_t l_va
         uint32_t n = s->v.get_neighbors(p, &adj);
         for (uint32_t j = 0; j < n; ++j) {
             uint32_t nb = adj[j];
-            if (s->visited.insert(nb).second && nb < s->v.nslots()) neighbors.emplace_back(nb, s->qc->eval(nb));
+            if (s->visited.insert(nb).second && nb < s->v.nslots() && s->v.readable(nb)) neighbors.emplace_back(nb, s->qc->eval(nb));
         }
     }
     for (auto& nb : neighbors) s->best.insert(nb.first, nb.second);
@@ -1383,7 +1387,7 @@ int32_t orc_paged_next(orc_paged* s, uint32_t k, uint32_t* out_ids, float* out_d
             uint32_t len = v.get_neighbors(id, &adj);
             for (uint32_t j = 0; j < len; ++j) {
                 uint32_t nb = adj[j];
-                if (s->visited.insert(nb).second && nb < v.nslots()) neighbors.emplace_back(nb, s->qc->eval(nb));
+                if (s->visited.insert(nb).second && nb < v.nslots() && v.readable(nb)) neighbors.emplace_back(nb, s->qc->eval(nb));
             }
             for (auto& nb : neighbors) s->best.insert(nb.first, nb.second);
             s->so.cmps += (uint32_t)neighbors.size();
@@ -1426,6 +1430,7 @@ int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* 
     uint32_t m = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (ids[i] >= v.nslots()) return -3;
+        if (!v.readable(ids[i])) continue; /* read_in_bounds -> None: skipped, not counted (provider.rs:681-686) */
         out_ids[m] = ids[i];
         out_dists[m] = qc.eval(ids[i]);
         ++m;

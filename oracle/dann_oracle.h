@@ -61,6 +61,11 @@ typedef struct {
     const float* pq_pivots;      /* ORC_PQ: 256 x dim */
     const uint32_t* pq_offsets;  /* ORC_PQ: pq_chunks + 1 */
     uint32_t pq_chunks;
+    /* inline concurrency tags (store.rs:133-158, tag.rs): byte offset of the tag inside a row (the reference puts
+     * it right after the payload: dim * sizeof(T)), 0 = no tags / every slot readable.  A slot whose tag is below
+     * Tag::PUBLISHED (254) is skipped by expand_beam after the visited insert and is not counted (provider.rs:448-473,
+     * 681-686). */
+    uint32_t tag_offset;
 } orc_index;
 
 /* graph::config::Builder (diskann/src/graph/config/mod.rs:261-338, defaults.rs) */

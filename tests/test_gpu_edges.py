@@ -16,7 +16,7 @@ def _check(oix, gix, queries, L, W, k):
     assert np.array_equal(oi, gi), (L, W, k)
     assert np.array_equal(bits(od), bits(gd)), (L, W, k)
     assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"]), (L, W, k)
-    assert np.array_equal(oc, gst["result_count"])
+    assert np.array_equal(oc, gst["written"]) and np.array_equal(ost[:, 2], gst["result_count"])
 
 
 @pytest.mark.parametrize("R", [1, 3, 63, 64, 65, 100])

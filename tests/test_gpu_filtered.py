@@ -36,7 +36,7 @@ def test_inline_golden_gpu(cases):
         ids, dists, st = px.filtered_search(da.Knn(c["l"]), np.array(c["query"], np.float32), c["k"],
                                             g.match(c["filter"]),
                                             adaptive=tuple(c["adaptive"]) if c["adaptive"] else None)
-        n = int(st["result_count"][0])
+        n = int(st["written"][0])
         assert [int(g.orig[i]) for i in ids[0, :n]] == c["result_ids"], c["name"]
         assert [float(d) for d in dists[0, :n]] == c["result_distances"], c["name"]
         assert (int(st["cmps"][0]), int(st["hops"][0])) == (c["comparisons"], c["hops"]), c["name"]
@@ -49,7 +49,7 @@ def test_multihop_golden_gpu(cases):
         _, px = _pair(g)
         ids, dists, st = px.filtered_search(da.Knn(c["l"]), np.array(c["query"], np.float32), c["k"],
                                             g.match(c["filter"]), mode=da.FILTER_MULTIHOP)
-        n = int(st["result_count"][0])
+        n = int(st["written"][0])
         assert [[int(g.orig[i]), float(d)] for i, d in zip(ids[0, :n], dists[0, :n])] == c["results"], c["name"]
         assert (int(st["cmps"][0]), int(st["hops"][0])) == (c["comparisons"], c["hops"]), c["name"]
 
@@ -62,7 +62,7 @@ def test_filtered_range_golden_gpu(cases):
         ids, dists, st, sec = px.filtered_range_search(q, c["starting_l"], c["radius"], g.match(c["filter"]),
                                                        inner_radius=c["inner_radius"],
                                                        max_returned=c["max_returned"], out_cap=256)
-        n = int(st["result_count"][0])
+        n = int(st["written"][0])
         oi, od, ost = ox.filtered_range_search(q, c["starting_l"], c["radius"], g.match(c["filter"]),
                                                inner_radius=c["inner_radius"], max_returned=c["max_returned"])
         assert np.array_equal(ids[0, :n], oi) and np.array_equal(dists[0, :n], od), c["name"]
@@ -85,7 +85,7 @@ def test_inline_random_vs_oracle(frac):
         for qi in range(nq):
             wn, wi, wd, ws = ox.inline_filter_search(queries[qi], 20, 10, match[qi], adaptive=adaptive)
             assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), (qi, adaptive)
-            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["result_count"][qi])) == (int(ws[0]), int(ws[1]), wn)
+            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["written"][qi])) == (int(ws[0]), int(ws[1]), wn)
 
 
 @pytest.mark.parametrize("frac", [0.5, 0.1])
@@ -103,7 +103,7 @@ def test_multihop_random_vs_oracle(frac):
         for qi in range(nq):
             wn, wi, wd, ws = ox.multihop_search(queries[qi], 24, 10, match, beam_width=W)
             assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), (qi, W)
-            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["result_count"][qi])) == (int(ws[0]), int(ws[1]), wn)
+            assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["written"][qi])) == (int(ws[0]), int(ws[1]), wn)
 
 
 def test_filtered_range_random_vs_oracle():
@@ -120,7 +120,7 @@ def test_filtered_range_random_vs_oracle():
         ids, dists, st, sec = px.filtered_range_search(queries, 16, radius, match, out_cap=2048, **kw)
         for qi in range(nq):
             wi, wd, ws = ox.filtered_range_search(queries[qi], 16, radius, match, **kw)
-            m = int(st["result_count"][qi])
+            m = int(st["written"][qi])
             assert m == len(wi), (qi, radius, kw)
             assert np.array_equal(ids[qi, :m], wi) and np.array_equal(dists[qi, :m].view(np.uint32), wd.view(np.uint32))
             assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(sec[qi])) == (int(ws[0]), int(ws[1]), int(ws[3]))

@@ -215,3 +215,42 @@ def test_sq8_train_matches_reference_contract():
         for r in range(nrows):
             norms += np.sqrt((xd[r] * xd[r]).cumsum()[-1])
         assert mn == np.float32(norms / nrows)
+
+
+def test_unreadable_slots_equal_a_graph_without_them():
+    """Tag rule of the oracle (expand_beam_inner skips a slot whose tag is below PUBLISHED after the visited insert,
+    uncounted: provider.rs:448-473, 681-686) against an independent formulation: the same search on a graph whose
+    adjacency lists never mention the unreadable slots returns the same ids, distances, cmps and hops."""
+    from helpers import rand_vectors, random_graph
+    rng = np.random.default_rng(4242)
+    n, dim, R = 3000, 24, 16
+    stride = oracle.inmem2_stride(oracle.F32, dim)
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    holes = rng.choice(n, 700, replace=False)
+    tagged = oracle.Index(oracle.F32, oracle.L2, dim, n, R, data[:1], row_stride=stride, tags=True)
+    tagged.set_rows(0, data)
+    tagged.adj[:] = adj
+    for h in holes:
+        tagged.set_tags(int(h), [int(rng.integers(0, 254))])
+    clean = oracle.Index(oracle.F32, oracle.L2, dim, n, R, data[:1])
+    clean.set_rows(0, data)
+    hole_mask = np.zeros(n + 1, bool)
+    hole_mask[holes] = True
+    for i in range(n + 1):
+        ids = adj[i, 1:1 + adj[i, 0]]
+        clean.set_neighbors(i, ids[~hole_mask[ids]])
+    q = rand_vectors(rng, oracle.F32, 30, dim)
+    for L, W in ((10, 1), (50, 1), (50, 3)):
+        a = tagged.search_batch(q, L, W, 10)
+        b = clean.search_batch(q, L, W, 10)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                  y.view(np.uint32) if y.dtype == np.float32 else y), (L, W)
+    # all slots published: tags change nothing
+    tagged.set_tags(0, np.full(n, 254, np.uint8))
+    plain = oracle.Index(oracle.F32, oracle.L2, dim, n, R, data[:1])
+    plain.set_rows(0, data)
+    plain.adj[:] = adj
+    a, b = tagged.search_batch(q, 40, 2, 10), plain.search_batch(q, 40, 2, 10)
+    assert all(np.array_equal(x, y) for x, y in zip(a[::2], b[::2]))
