@@ -39,20 +39,21 @@ def search_sharded(search_fn, queries, k, rank=0, world=1, group=None):
     import torch.distributed as dist
     # pad every shard to the longest one (lengths differ by at most 1)
     longest = partition(nq, world, 0)[1] - partition(nq, world, 0)[0]
-    pad_i = torch.zeros((longest, k), dtype=torch.int64)
-    pad_d = torch.zeros((longest, k), dtype=torch.float32)
-    pad_i[: hi - lo] = torch.from_numpy(ids.astype(np.int64))
-    pad_d[: hi - lo] = torch.from_numpy(dists)
-    all_i = [torch.zeros_like(pad_i) for _ in range(world)]
-    all_d = [torch.zeros_like(pad_d) for _ in range(world)]
-    dist.all_gather(all_i, pad_i, group=group)
-    dist.all_gather(all_d, pad_d, group=group)
+    # RCCL ("nccl") gathers device tensors, gloo host tensors; the bits of ids and distances travel as int32
+    tdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    pad = torch.zeros((2, longest, k), dtype=torch.int32)
+    pad[0, : hi - lo] = torch.from_numpy(ids.view(np.int32))
+    pad[1, : hi - lo] = torch.from_numpy(dists.view(np.int32))
+    pad = pad.reshape(-1).to(tdev)
+    allp = torch.empty(world * pad.numel(), dtype=torch.int32, device=tdev)
+    dist.all_gather_into_tensor(allp, pad, group=group)
+    allp = allp.cpu().numpy().reshape(world, 2, longest, k)
     out_i = np.empty((nq, k), np.uint32)
     out_d = np.empty((nq, k), np.float32)
     for r in range(world):
         a, b = partition(nq, world, r)
-        out_i[a:b] = all_i[r][: b - a].numpy().astype(np.uint32)
-        out_d[a:b] = all_d[r][: b - a].numpy()
+        out_i[a:b] = allp[r, 0, : b - a].view(np.uint32)
+        out_d[a:b] = allp[r, 1, : b - a].view(np.float32)
     return out_i, out_d
 
 
@@ -104,13 +105,14 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
             import torch.distributed as dist
             backend = dist.get_backend(group)
             if backend == "gloo":  # CPU collective (tests: several ranks on one device)
-                mine_h = mine.cpu()
-                gathered_h = torch.empty((world, max(longest, 1), width), dtype=torch.int32)
+                mine_h = mine.cpu().reshape(-1)
+                gathered_h = torch.empty(world * mine_h.numel(), dtype=torch.int32)
                 dist.all_gather_into_tensor(gathered_h, mine_h, group=group)
-                gathered = gathered_h.to(dev)
+                gathered = gathered_h.to(dev).reshape(world, max(longest, 1), width)
             else:
-                gathered = torch.empty((world, max(longest, 1), width), dtype=torch.int32, device=dev)
-                dist.all_gather_into_tensor(gathered, mine, group=group)
+                gathered = torch.empty(world * mine.numel(), dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(gathered, mine.reshape(-1), group=group)
+                gathered = gathered.reshape(world, max(longest, 1), width)
             parts = []
             for r in range(world):
                 a, z = partition(b, world, r)

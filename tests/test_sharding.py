@@ -1,6 +1,6 @@
 """Multi-GPU path on CPU: world_size-2 gloo run of the query-sharding logic.  The search callable
 is the oracle here (no GPU in this container); on the GPU box the same function wraps
-Provider.search (tests/test_gpu_sharding.py)."""
+Provider.search (tests/test_gpu_sharding.py, two ranks on one GPU)."""
 import os
 import subprocess
 import sys
@@ -57,3 +57,20 @@ def test_sharded_search_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launcher_rules(monkeypatch):
+    """bench.py --gpus N: under a launcher it must agree with WORLD_SIZE; without one and N <= 1 it runs in-process."""
+    import argparse
+    import sys as _sys
+    _sys.path.insert(0, ROOT)
+    import bench
+    import pytest
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    bench.maybe_spawn(argparse.Namespace(gpus=2))
+    bench.maybe_spawn(argparse.Namespace(gpus=None))
+    with pytest.raises(SystemExit):
+        bench.maybe_spawn(argparse.Namespace(gpus=8))
+    monkeypatch.delenv("WORLD_SIZE")
+    bench.maybe_spawn(argparse.Namespace(gpus=1))
+    bench.maybe_spawn(argparse.Namespace(gpus=None))
