@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# working sets far beyond the 256 MiB Infinity Cache, "n:dim:dist:R:pruned:l_build": the headline's row shape at 10 M
+# points (6.4 GB; the generator's per-blob density kept: 2 560 blobs) and config 5's row shape (1 M x 768, 3.3 GB)
+LARGE_DEFAULT = "10000000:128:sift_like:1:2560:32:28:100,1000000:768:sift_like:64:56:128"
 
 
 def parse():
@@ -42,7 +45,8 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
-    ap.add_argument("--large", default="auto", help="roofline_large workload 'n:dim:dist:R:pruned:l_build' or 'none'")
+    ap.add_argument("--large", default="auto",
+                    help="roofline_large workloads, comma-separated 'n:dim:dist:R:pruned:l_build', or 'none'")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=1_000_000)
@@ -70,6 +74,8 @@ def parse():
                          "all-gather of the pending adjacency rows) instead of one independent build per rank")
     ap.add_argument("--visited-bits", type=int, default=0)
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
+    if len(sys.argv) == 1 and os.environ.get("DANN_BENCH_ARGV"):  # a rank spawned by maybe_spawn()
+        return ap.parse_args(json.loads(os.environ["DANN_BENCH_ARGV"]))
     return ap.parse_args()
 
 
@@ -92,10 +98,12 @@ def maybe_spawn(args):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
+        # the script's own flags travel in the environment: torch.distributed.run's argparse rejects script flags that
+        # abbreviate one of its options (--n is "ambiguous" with --nnodes / --nproc-per-node) even after the script path
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
-            "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", DANN_BENCH_ARGV=json.dumps(sys.argv[1:]),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus is not None and int(ws) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with the launcher's WORLD_SIZE={ws}")
@@ -138,7 +146,8 @@ def main():
     if args.only_large:
         rd = C.c_double(0.0)
         _ffi.lib().dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd))
-        print(json.dumps({"roofline_large": large_variant(args, torch, da, _ffi.lib(), _ffi, dev, local, 10,
+        spec = (LARGE_DEFAULT if args.large == "auto" else args.large).split(",")[0]
+        print(json.dumps({"roofline_large": large_variant(args, spec, torch, da, _ffi.lib(), _ffi, dev, local, 10,
                                                           args.beam_width, rd.value or None)}), flush=True)
         return
 
@@ -431,11 +440,15 @@ def main():
             del base, queries, gt
             prov.close()
             torch.cuda.empty_cache()
-            try:
-                out["roofline_large"] = large_variant(args, torch, da, lib, _ffi, dev, local, k, W,
-                                                      out["roofline"].get("measured_stream_read_GBps"))
-            except Exception as e:
-                out["roofline_large"] = {"error": str(e)[:300]}
+            specs = LARGE_DEFAULT if args.large == "auto" else args.large
+            for i, spec in enumerate(specs.split(",")):
+                key = "roofline_large" if i == 0 else f"roofline_large_d{spec.split(':')[1]}"
+                try:
+                    out[key] = large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W,
+                                             out["roofline"].get("measured_stream_read_GBps"))
+                except Exception as e:
+                    out[key] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -631,13 +644,12 @@ def uniform_variant(args, torch, da, lib, _ffi, dev, local, k, W):
     return res
 
 
-def large_variant(args, torch, da, lib, _ffi, dev, local, k, W, stream_read_gbps):
+def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_read_gbps):
     """The beam-search kernel on an index whose working set is >> the 256 MiB Infinity Cache: by default 10 M x 128 f32
     (5.1 GB of rows + 1.3 GB of adjacency), the headline generator with the per-blob density kept (2 560 blobs).  Recall
     is measured on the first 10 000 queries of the 100 000-query batch, the kernel is timed with HIP events over the
     whole batch, and a sample of the queries is re-run through the CPU oracle on the same graph bytes."""
     import oracle
-    spec = "10000000:128:sift_like:1:2560:32:28:100" if args.large == "auto" else args.large
     f = spec.split(":")
     n, dim = int(f[0]), int(f[1])
     dist = ":".join(f[2:-3])

@@ -211,6 +211,11 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
     };
     if (!guard.ok) return fail(hipErrorInvalidDevice, "hipSetDevice");
     hipError_t e;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            idx->num_cus = (uint32_t)cus;
+    }
     if ((e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&idx->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&idx->ev1)) != hipSuccess) return fail(e, "hipEventCreate");

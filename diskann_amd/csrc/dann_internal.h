@@ -117,6 +117,7 @@ struct SearchArgs {
     uint32_t ad_stride = 0;
     unsigned long long* phase_cycles = nullptr;  // -DDANN_PHASE_CYCLES builds only
     uint32_t qcap_max = 0;           // largest queue capacity an adaptive resize can ask for (0 = l_value + nstart)
+    uint32_t tune = 0;               // kTune* bits, chosen per launch by search_with_retry (never affect results)
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out = nullptr);
@@ -165,6 +166,7 @@ struct dann_index {
     uint32_t layer_bytes = 0;
     uint32_t nslots = 0;
     uint32_t visited_bits = 0;
+    uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     float* d_pq_pivots = nullptr;
     uint32_t* d_pq_offsets = nullptr;
     uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]

@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 constexpr int kMaxBeam = 16;
 constexpr int kGatherRows = 4;
 constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
+constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
 constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
 
 // optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
@@ -29,7 +30,7 @@ constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (disk
 #endif  // rows in flight per lane group in the fixed-length gather
 
 struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, stage_id_off, stage_d_off, snew_off, beam_off, q_off, total;
+    uint32_t ht_off, cand_id_off, cand_d_off, stage_off, snew_off, beam_off, q_off, total;
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -53,11 +54,11 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     off += round16(cmax * 4u);
     l.cand_d_off = off;
     off += round16(cmax * 4u);
-    l.stage_id_off = off;  // the queue image: every merge scatters the register-resident queue here and reloads it.
-    off += round16(qcap * 4u);  // One buffer is enough: nothing is read from it between the first scatter write and
-    l.stage_d_off = off;        // the reload (ranks come from registers or were taken before), and one wave's LDS
-    off += round16(qcap * 4u);  // operations retire in order.
-    l.snew_off = off;      // the surviving new distances of one merge, sorted
+    l.stage_off = off;  // the queue image, (id, distance bits) pairs: every merge scatters the register-resident queue
+    off += round16(qcap * 8u);  // here and reloads it (one 8-byte LDS access per entry).  One buffer is enough: nothing
+                                // is read from it between the first scatter write and the reload (ranks come from
+                                // registers or were taken before), and one wave's LDS operations retire in order.
+    l.snew_off = off;      // the surviving new distances of one merge, sorted (slow path) / their slots (fast path)
     off += 64u * 4u;
     l.beam_off = off;
     off += round16(kMaxBeam * 4u);
@@ -82,6 +83,25 @@ __device__ __forceinline__ int ht_visit(uint32_t* ht, uint32_t mod, uint32_t id,
         h += step;
         h = h >= mod ? h - mod : h;
     }
+}
+// insert into the open table (the hot path of every hop): first probe straight-line for all lanes, the double-hashing
+// loop only runs when some lane collided.  Same probe sequence as ht_visit.  Returns true when `id` was not yet present.
+__device__ __forceinline__ bool ht_insert_open(uint32_t* ht, uint32_t mod, uint32_t id, bool active) {
+    uint32_t h = __umulhi(id * 2654435761u, mod);
+    uint32_t old = active ? atomicCAS(&ht[h], kEmpty, id) : id;
+    bool isnew = active && old == kEmpty;
+    bool pending = active && old != kEmpty && old != id;
+    if (ballot64(pending)) {
+        const uint32_t step = 1u + __umulhi(id * 2246822519u + 0x9E3779B9u, mod - 1u);
+        while (pending) {
+            h += step;
+            h = h >= mod ? h - mod : h;
+            old = atomicCAS(&ht[h], kEmpty, id);
+            isnew = old == kEmpty;
+            pending = old != kEmpty && old != id;
+        }
+    }
+    return isnew;
 }
 // Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
 // every probe is an agent-scope atomic, and the table is wiped with write-through (sc1) 16-byte
@@ -176,8 +196,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
     float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
-    uint32_t* stage_id = reinterpret_cast<uint32_t*>(smem + L.stage_id_off);
-    float* stage_d = reinterpret_cast<float*>(smem + L.stage_d_off);
+    uint2* stage = reinterpret_cast<uint2*>(smem + L.stage_off);
+    auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     float* snew = reinterpret_cast<float*>(smem + L.snew_off);
     constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
     uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
@@ -209,7 +229,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     }
     const uint32_t ht_size = a.ht_entries;
     const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size
-    for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
+    {   // wipe the visited table with 16-byte stores (ht_size is a multiple of 64, the table 16-byte aligned)
+        const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+        for (uint32_t i = lane * 4u; i < ht_size; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
+    }
     __syncthreads();
 
     const int g = lane / G, v = lane % G;
@@ -230,10 +253,11 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         qd[s] = 0.0f;
     }
     uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
-    uint32_t pf_node = kEmpty, pf_len = 0, pf_val = kEmpty;
+    uint32_t pf_node = kEmpty, pf_len = 0, pf_val = kEmpty, node0 = kEmpty;
+    uint32_t pf_dummy = 0;  // landing register of the row-prefetch loads (latency mode)
     bool lds_open = true;
 #ifdef DANN_PHASE_CYCLES
-    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     uint32_t* spill = nullptr;
     uint32_t spill_count = 0;
@@ -381,38 +405,60 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     // candidate j lands at  #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)},
     // (3) an old element e moves up by #{surviving j: d_j <= d_e}.
     auto merge = [&](uint32_t m0, uint32_t n) {
-        const float* oldd = stage_d;
         bool has = lane < n;
         float nd = has ? cand_d[m0 + lane] : 0.0f;
         uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
         bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
-        if (size == qcap && qcap > 0) nvalid = nvalid && !(oldd[size - 1] < nd);
+        if (size == qcap && qcap > 0) nvalid = nvalid && !(stage_dist(size - 1) < nd);
         const uint64_t km = ballot64(nvalid);
         const uint32_t nv = (uint32_t)__popcll(km);
+#ifdef DANN_PHASE_CYCLES
+        ph_acc[8] += nv;
+        ph_acc[9] += nv > kRegMerge ? 1 : 0;
+        ph_acc[10] += 1;
+#endif
         if (nv == 0) return;
+        PH_T(phm0);
         uint32_t shift[QS];
         uint32_t pos_new = 0;
-        if (nv <= kRegMerge) {
-            // few survivors (the steady state once the queue is full): ranks straight from registers, one
-            // pass over the survivors -- no compaction, no LDS searches
-            uint32_t before = 0, lb = 0;
+        if (QS <= 4 && nv <= kRegMerge) {
+            // few survivors (the steady state once the queue is full; queues beyond 256 entries always take the
+            // LDS path below, whose cost does not grow with the number of register slots).  One pass over them gives every survivor its
+            // rank among the survivors (`before`) and every queue entry e the number of survivors that go in front
+            // of it (shift_e = #{j: d_j <= d_e}) -- VALU only, no cross-lane reduction.  The queue is sorted, so
+            // shift is non-decreasing along it, and the survivor of rank r lands right after the last entry with
+            // shift <= r:  slot(r) = r + #{e: shift_e <= r}  (== r + #{e: d_e < d_j}, the lower bound of (3)).
+            // Entry p therefore owns the ranks [shift_{p-1}, shift_p) and writes their slots r + p; ranks past the
+            // last entry default to r + size.
+            uint32_t before = 0;
 #pragma unroll
             for (int s = 0; s < QS; ++s) shift[s] = 0;
             for (uint64_t mm = km; mm; mm &= mm - 1) {
                 const int j = __builtin_ctzll(mm);
                 const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), j));
-                before += ((dj < nd) | ((dj == nd) & ((uint32_t)j > lane))) ? 1u : 0u;
-                uint32_t c = 0;
+                before += (dj < nd) ? 1u : 0u;
+                before += ((dj == nd) & ((uint32_t)j > lane)) ? 1u : 0u;
 #pragma unroll
-                for (int s = 0; s < QS; ++s) {
-                    const bool in = (uint32_t)(s * kWave) + lane < size;
-                    shift[s] += (in & (dj <= qd[s])) ? 1u : 0u;
-                    c += (uint32_t)__popcll(ballot64(in & (qd[s] < dj)));
+                for (int s = 0; s < QS; ++s) shift[s] += (dj <= qd[s]) ? 1u : 0u;  // entries >= size: never scattered
+            }
+            uint32_t* slot = reinterpret_cast<uint32_t*>(snew);
+            if (lane < nv) slot[lane] = lane + size;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t p = (uint32_t)(s * kWave) + lane;
+                uint32_t prev = __shfl_up(shift[s], 1);  // shift of entry p - 1
+                if (s == 0) {
+                    prev = lane == 0 ? 0u : prev;
+                } else {
+                    const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)shift[s > 0 ? s - 1 : 0], kWave - 1);
+                    prev = lane == 0 ? carry : prev;
                 }
-                lb = ((int)lane == j) ? c : lb;
+                if (p < size)
+                    for (uint32_t r = prev; r < shift[s]; ++r) slot[r] = r + p;
             }
             has = nvalid;
-            pos_new = before + lb;
+            __builtin_amdgcn_wave_barrier();  // one wave: LDS accesses retire in program order
+            pos_new = nvalid ? slot[before] : 0u;
         } else {
         if (nv != n) {  // compact the survivors, emission order preserved
             const uint32_t cj = mbcnt(km);
@@ -450,28 +496,22 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 #pragma unroll
         for (uint32_t step = QCAPP; step > 0; step >>= 1) {
             const uint32_t t = lb + step;
-            if (t <= size && oldd[t - 1] < nd) lb = t;
+            if (t <= size && stage_dist(t - 1) < nd) lb = t;
         }
         pos_new = before + lb;
         }
-        // scatter into the other half
-        uint32_t* nxt_id = stage_id;
-        float* nxt_d = stage_d;
+        PH_T(phm1);
+        PH_ADD(11, phm0, phm1);
+        // scatter into the queue image, then reload
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
             if (p < size) {
                 const uint32_t np = p + shift[s];
-                if (np < qcap) {
-                    nxt_id[np] = qid[s];
-                    nxt_d[np] = qd[s];
-                }
+                if (np < qcap) stage[np] = make_uint2(qid[s], __builtin_bit_cast(uint32_t, qd[s]));
             }
         }
-        if (has && pos_new < qcap) {
-            nxt_id[pos_new] = nid;
-            nxt_d[pos_new] = nd;
-        }
+        if (has && pos_new < qcap) stage[pos_new] = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
         const uint32_t total = size + nv;
         size = total < qcap ? total : qcap;
         __syncthreads();
@@ -479,8 +519,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
             if (p < size) {
-                qid[s] = nxt_id[p];
-                qd[s] = nxt_d[p];
+                const uint2 e = stage[p];
+                qid[s] = e.x;
+                qd[s] = __builtin_bit_cast(float, e.y);
             }
         }
     };
@@ -489,10 +530,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     // (provider.rs:448-454); survivors go to cand_id[0..nc)
     // accept_only (expand_beam_accept_only, labeled.rs:196-214,284-291): ids that do not match the filter
     // are skipped *before* the visited set sees them
-    auto expand = [&](uint32_t nb, bool accept_only = false) -> uint32_t {
+    auto expand = [&](uint32_t nb, bool accept_only = false, bool node_in_reg = false) -> uint32_t {
         uint32_t nc = 0;
         for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t node = beam[b];
+            const uint32_t node = node_in_reg ? node0 : beam[b];  // the main loop's single pop stays in a register
             const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
             const bool hit = (node == pf_node);
 #ifdef DANN_PHASE_CYCLES
@@ -527,14 +568,17 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 status = (uint32_t)(-DANN_EOVERFLOW);
                 break;
             }
+            PH_T(phv0);
             for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
                 const uint32_t j = j0 + lane;
                 const bool inb = j < len;
                 const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
-                if (inb && id != kEmpty && (!accept_only || fmatch(id))) {
-                    const int r = ht_visit(ht, ht_mod, id, lds_open);
-                    isnew = (r == kInserted) || (r == kAbsent && spill_insert(spill, spill_mask, spill_shift, id));
+                const bool act = inb && id != kEmpty && (!accept_only || fmatch(id));
+                if (lds_open) {
+                    isnew = ht_insert_open(ht, ht_mod, id, act);
+                } else if (act) {  // frozen LDS table: lookup, then the spill table in global memory
+                    isnew = ht_visit(ht, ht_mod, id, false) == kAbsent && spill_insert(spill, spill_mask, spill_shift, id);
                 }
                 const bool keep = isnew && id < ix.nslots;
                 const uint64_t nm = ballot64(isnew), km = ballot64(keep);
@@ -543,6 +587,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 if (lds_open) ht_count += (uint32_t)__popcll(nm);
                 else spill_count += (uint32_t)__popcll(nm);
             }
+            PH_T(phv1);
+            PH_ADD(7, phv0, phv1);
         }
         return nc;
     };
@@ -564,11 +610,47 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         for (uint32_t m0 = 0; m0 < ns; m0 += kWave) merge(m0, (ns - m0) < (uint32_t)kWave ? (ns - m0) : (uint32_t)kWave);
     }
 
+    uint32_t* const rec_i = a.rec_ids ? a.rec_ids + (uint64_t)qi * a.rec_stride : nullptr;  // wave-uniform
+    float* const rec_d = a.rec_ids ? a.rec_dists + (uint64_t)qi * a.rec_stride : nullptr;
     // ---- beam loop ----------------------------------------------------------------------
     for (;;) {
         PH_T(ph0);
         // pop up to W closest unexpanded entries (queue.rs:297-313)
         uint32_t nb = 0;
+        uint32_t pf_next = kEmpty;  // W == 1: the best entry still unexpanded after this pop (the prefetch target)
+        if (W == 1) {
+            // one scan: the first unexpanded entry is popped (kept in a register, no LDS round trip), the second one
+            // is the node the next hop will expand unless a new candidate beats it
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                if (pf_next != kEmpty) continue;
+                const bool cand = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
+                uint64_t m = ballot64(cand);
+                if (!found && m) {
+                    const int l = __builtin_ctzll(m);
+                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l);
+                    if ((int)lane == l) qid[s] |= kVisitedBit;
+                    node0 = id;
+                    if (rec_i) {  // VisitedSearchRecord::record (search/record.rs:86-93)
+                        if (nrec < a.rec_stride) {
+                            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l));
+                            if (lane == 0) {
+                                rec_i[nrec] = id;
+                                rec_d[nrec] = d;
+                            }
+                        } else {
+                            status = (uint32_t)(-DANN_EOVERFLOW);
+                        }
+                        ++nrec;
+                    }
+                    nb = 1;
+                    found = true;
+                    m &= m - 1;
+                }
+                if (found && m) pf_next = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], __builtin_ctzll(m));
+            }
+        } else
         for (uint32_t w = 0; w < W; ++w) {
             bool found = false;
 #pragma unroll
@@ -583,14 +665,12 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     if ((int)lane == l) qid[s] |= kVisitedBit;
                     if (lane == 0) {
                         beam[nb] = id;
-                        if (a.rec_ids) {  // VisitedSearchRecord::record (search/record.rs:86-93)
-                            if (nrec < a.rec_stride) {
-                                a.rec_ids[(uint64_t)qi * a.rec_stride + nrec] = id;
-                                a.rec_dists[(uint64_t)qi * a.rec_stride + nrec] = d;
-                            }
+                        if (rec_i && nrec < a.rec_stride) {  // VisitedSearchRecord::record (search/record.rs:86-93)
+                            rec_i[nrec] = id;
+                            rec_d[nrec] = d;
                         }
                     }
-                    if (a.rec_ids) {
+                    if (rec_i) {
                         if (nrec >= a.rec_stride) status = (uint32_t)(-DANN_EOVERFLOW);
                         ++nrec;
                     }
@@ -602,11 +682,11 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         }
         if (nb == 0 || status) break;
         hops += nb;
-        __syncthreads();
+        if (W > 1) __syncthreads();
         PH_T(ph1);
         PH_ADD(0, ph0, ph1);
 
-        const uint32_t nc_seen = expand(nb);
+        const uint32_t nc_seen = expand(nb, false, W == 1);
         if (status) break;
         __syncthreads();
         PH_T(ph2);
@@ -616,13 +696,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         // candidate beats it, the next hop starts without a dependent HBM round trip.
         pf_node = kEmpty;
         if (W == 1 && R <= (uint32_t)kWave) {
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                if (pf_node != kEmpty) continue;
-                const bool cnd = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
-                const uint64_t m = ballot64(cnd);
-                if (m) pf_node = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], __builtin_ctzll(m));
-            }
+            pf_node = pf_next;
             if (pf_node != kEmpty) {
                 const uint32_t* prow = ix.adj + (uint64_t)pf_node * ix.adj_stride;
                 pf_len = prow[0];
@@ -630,6 +704,31 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             }
         }
         const uint32_t nc = gather(nc_seen);
+        // latency mode (few queries in flight, bandwidth to spare): touch the rows of the predicted next node's
+        // neighbours, one dword per 128-byte line, so that the next hop's gather is served by L2 instead of HBM when
+        // the prediction holds.  Pure prefetch: no visited-set side effect, nothing ever waits for these loads.  They
+        // all land in one scratch register the compiler keeps reserved (the empty asm "uses" it one hop later, after
+        // that hop's gather has drained the in-order load queue; the loop exit drains it explicitly).
+        asm volatile("" ::"v"(pf_dummy));
+        if ((a.tune & kTuneRowPrefetch) && pf_node != kEmpty && ix.layer_bytes <= 512u) {
+            const uint32_t plen = pf_len < R ? pf_len : R;
+            if (lane < plen && pf_val < ix.nslots) {
+                const uint8_t* prow = ix.rows + (uint64_t)pf_val * ix.row_stride;
+                const uint32_t last = ix.layer_bytes - 4u;
+                const uint8_t* p1 = prow + (128u < last ? 128u : last);
+                const uint8_t* p2 = prow + (256u < last ? 256u : last);
+                const uint8_t* p3 = prow + (384u < last ? 384u : last);
+                const uint8_t* p4 = prow + last;
+                asm volatile(
+                    "global_load_dword %0, %1, off\n\t"
+                    "global_load_dword %0, %2, off\n\t"
+                    "global_load_dword %0, %3, off\n\t"
+                    "global_load_dword %0, %4, off\n\t"
+                    "global_load_dword %0, %5, off"
+                    : "=&v"(pf_dummy)
+                    : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4));
+            }
+        }
         __syncthreads();
         PH_T(ph3);
         PH_ADD(2, ph2, ph3);
@@ -708,6 +807,10 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         PH_ADD(4, ph0, ph4);
     }
 
+    if (a.tune & kTuneRowPrefetch) {  // no prefetch load may still be in flight when its landing register is released
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(pf_dummy));
+    }
     // ---- graph::search::Range second phase (range_search.rs:283-316, 424-470) -----------------------
     uint32_t range_written = 0, range_second = 0;
     // ---- inline filter search: matched_results sorted by distance (inline_filter_search.rs:279) ------------
@@ -994,7 +1097,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
 #ifdef DANN_PHASE_CYCLES
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[i], ph_acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.phase_cycles[i], ph_acc[i]);
 #endif
     if (spill) {  // hand the spill table back clean
         __syncthreads();
@@ -1091,10 +1194,16 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
         *regs_out = attr.numRegs;
         return DANN_OK;
     }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (lds > 64 * 1024) {  // raise the dynamic LDS limit of this instantiation once per device (160 KiB per CU)
+        static bool raised[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(a.nq), dim3(kWave), lds, stream, a);
     hipError_t e = hipGetLastError();

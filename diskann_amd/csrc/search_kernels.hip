@@ -71,7 +71,9 @@ uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids, uint32_t useful_wa
     const uint64_t granules = ((uint64_t)other + need * 4 + kLdsGranule - 1) / kLdsGranule;
     if (granules > kLdsGranules) return (uint32_t)need;
     const uint32_t waves = std::min<uint32_t>(kLdsGranules / (uint32_t)granules, useful_waves);
-    const int64_t top = ((int64_t)(kLdsGranules / waves) * kLdsGranule - other) / 4 / 64 * 64;
+    int64_t top = ((int64_t)(kLdsGranules / waves) * kLdsGranule - other) / 4 / 64 * 64;
+    // beyond ~8 slots per id the probe chains are already one step long; a larger table only costs its wipe
+    top = std::min<int64_t>(top, ((int64_t)cap_ids * 8 + 63) / 64 * 64);
     return (uint32_t)std::min<int64_t>(std::max<int64_t>(top, (int64_t)need), 32768);
 }
 
@@ -105,6 +107,12 @@ __global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uin
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kHistBins; i += blockDim.x)
         if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// development switches: DANN_TUNE_OFF=<bits> disables 1 = row prefetch in latency mode, 2 = latency-mode table sizing
+static bool tune_env(uint32_t bit) {
+    const char* e = getenv("DANN_TUNE_OFF");
+    return e && ((uint32_t)strtoul(e, nullptr, 0) & bit) != 0;
 }
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
@@ -144,16 +152,16 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
 static unsigned long long* g_phase_buf = nullptr;  // debug builds: per-phase cycle sums (SearchArgs::phase_cycles)
 unsigned long long* dann_phase_buffer() {
     if (!g_phase_buf) {
-        if (hipMalloc((void**)&g_phase_buf, 64) != hipSuccess) return nullptr;
-        (void)hipMemset(g_phase_buf, 0, 64);
+        if (hipMalloc((void**)&g_phase_buf, 128) != hipSuccess) return nullptr;
+        (void)hipMemset(g_phase_buf, 0, 128);
     }
     return g_phase_buf;
 }
 extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) try {
     unsigned long long* b = dann_phase_buffer();
     if (!b) return DANN_EHIP;
-    if (out) (void)hipMemcpy(out, b, 64, hipMemcpyDeviceToHost);
-    if (reset) (void)hipMemset(b, 0, 64);
+    if (out) (void)hipMemcpy(out, b, 128, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(b, 0, 128);
     return 0;
 } DANN_CATCH_ALL
 #endif
@@ -202,7 +210,11 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
             cal->waves = 4u * std::min<uint32_t>(std::max<uint32_t>(per_simd, 1u), 8u);
             if (getenv("DANN_DEBUG")) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal->waves);
         }
-        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->waves);
+        // a launch with fewer queries than the chip has wave slots leaves LDS idle: give each query the share of a CU
+        // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
+        const uint32_t per_cu = std::max<uint32_t>(1u, (a.nq + idx->num_cus - 1) / idx->num_cus);
+        const uint32_t waves = tune_env(2) ? cal->waves : std::min<uint32_t>(cal->waves, per_cu);
+        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), waves);
         if (getenv("DANN_DEBUG") && (cal->calls & (cal->calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u entries, %zu B LDS\n", a.l_value, a.beam_width,
                     cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->cap_ids ? "p90" : "prior", a.ht_entries,
@@ -220,6 +232,8 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
             return DANN_EINVAL;
         }
     }
+    // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
+    if (a.nq <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;
     a.fail_flag = idx->h_flag;
