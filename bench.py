@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
+    ap.add_argument("--only", default="", choices=["", "large", "large768", "gather", "sq8", "u8"],
+                    help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
+                         "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
+                         "u8 search kernel")
     ap.add_argument("--large", default="auto",
                     help="roofline_large workloads, comma-separated 'n:dim:dist:R:pruned:l_build', or 'none'")
     ap.add_argument("--steps", type=int, default=20)
@@ -143,6 +147,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.only in ("gather", "sq8", "u8"):
+        print(json.dumps({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)}), flush=True)
+        return
+    if args.only in ("large", "large768"):
+        args.only_large = True
+        if args.only == "large768":
+            specs = (LARGE_DEFAULT if args.large == "auto" else args.large).split(",")
+            args.large = specs[1] if len(specs) > 1 else specs[0]
     if args.only_large:
         rd = C.c_double(0.0)
         _ffi.lib().dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd))
@@ -658,10 +670,15 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     max_batch = 65536 if n >= 4_000_000 and dim <= 256 else 16384
     prov, base, queries, start, t_build = _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build, nq,
                                                         max_batch)
-    gt = ground_truth(torch, base, queries[:ngt], k)
     sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]
-    L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, sweep, args.target_recall)
-    reached = L is not None
+    if args.L:  # profiling passes: fixed L, no ground truth
+        gt = np.zeros((ngt, k), np.int64)
+        L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, [args.L], -1.0)
+        rec, reached = float("nan"), False
+    else:
+        gt = ground_truth(torch, base, queries[:ngt], k)
+        L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, sweep, args.target_recall)
+        reached = L is not None
     L = L or sweep[-1]
     run(L)
     prov.kernel_time_reset()
@@ -690,6 +707,9 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     if stream_read_gbps:
         res["measured_stream_read_GBps"] = stream_read_gbps
         res["frac_of_measured_stream_read"] = achieved / stream_read_gbps
+    if args.L:
+        prov.close()
+        return res
     # parity at this scale: a sample of the batch through the CPU oracle on the same rows and graph
     ms_n = 256
     adj = prov.download_graph()
@@ -714,6 +734,83 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
         pass
     prov.close()
     return res
+
+
+def only_variant(args, torch, da, lib, _ffi, dev, local):
+    """One secondary workload per process (so that a rocprofv3 pass sees only its kernel at full weight)."""
+    k, W = 10, args.beam_width
+    if args.only == "gather":
+        # ExpandBeam::expand_beam batched on a store far beyond the Infinity Cache: 10 M x 128 f32 rows (5.1 GB),
+        # 20 000 queries x 256 random row ids = 5.12 M evaluations x 512 B per launch
+        n, dim = 10_000_000, args.dim
+        base, queries = make_data(torch, dev, n, dim, 20000, "sift_like:1:2560", 0xD15CA11, 0xD15CA12)
+        prov = da.Provider(da.F32, da.L2, dim, n, 4, base[:1].cpu().numpy(), device=local)
+        for s0 in range(0, n, 1 << 21):
+            prov.set_elements(s0, base[s0:s0 + (1 << 21)].cpu().numpy())
+        gq, gl = 20000, 256
+        gids = np.random.default_rng(7).integers(0, n, gq * gl, dtype=np.uint32)
+        goff = np.arange(gq + 1, dtype=np.uint64) * gl
+        qh = queries.cpu().numpy()
+        prov.expand_beam_batch(qh, gids, goff)
+        prov.kernel_time_reset()
+        for _ in range(5):
+            prov.expand_beam_batch(qh, gids, goff)
+        ms, nl = prov.kernel_time(1)
+        alg = gq * gl * dim * 4
+        return {"kernel": "expand_beam_kernel", "workload": f"{gq} queries x {gl} random rows of a {n}x{dim} f32 store "
+                f"({n * dim * 4 / 1e9:.1f} GB)", "evals_per_launch": gq * gl, "algorithmic_bytes_per_launch": alg,
+                "avg_kernel_ms": ms / nl, "achieved_GBps": alg / (ms / nl * 1e-3) / 1e9,
+                "frac_of_hbm_peak": alg / (ms / nl * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # quantised / integer rows: the headline data as SQ-8 codes (dim + 4 bytes) or u8 rows (dim bytes)
+    base, queries = make_data(torch, dev, args.n, args.dim, args.nq, args.dist, 0xD15CA11, 0xD15CA12)
+    mean = base.double().mean(0).float()
+    medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
+    if args.only == "sq8":
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        sample = base[torch.randperm(args.n, generator=g, device=dev)[:min(args.n, 131072)]].cpu().numpy()
+        shift, scale, _ = da.sq8_train(sample, 2.0, device=local)
+        snorm = float(np.float32((shift ** 2).sum(dtype=np.float32)))
+        rows = da.sq8_compress(base.cpu().numpy(), shift, scale, device=local)
+        qrows = da.sq8_compress(queries.cpu().numpy(), shift, scale, device=local)
+        prov = da.Provider(da.SQ8, da.L2, args.dim, args.n, args.max_degree, rows[medoid:medoid + 1], device=local,
+                           sq_scale=scale, sq_shift_norm_sq=snorm)
+        row_bytes = args.dim + 4
+    else:
+        lo, hi = float(base.min()), float(base.max())
+        rows = ((base - lo) * (255.0 / (hi - lo))).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        qrows = ((queries - lo) * (255.0 / (hi - lo))).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        prov = da.Provider(da.U8, da.L2, args.dim, args.n, args.max_degree, rows[medoid:medoid + 1], device=local)
+        row_bytes = args.dim
+    prov.set_elements(0, rows)
+    prov.build(da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE),
+               0, args.n, args.growth, args.max_batch)
+    dq = torch.from_numpy(qrows).to(dev)
+    d_ids = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
+    d_d = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
+    d_st = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
+    L = args.L or 26
+
+    def run():
+        _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(dq.data_ptr()), args.nq, L, W, k,
+                                                C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_d.data_ptr()),
+                                                C.c_void_p(d_st.data_ptr())), "dann_search_batch_device")
+    for _ in range(3):
+        run()
+    prov.kernel_time_reset()
+    for _ in range(10):
+        run()
+    ms, nl = prov.kernel_time(0)
+    st = d_st.cpu().numpy().view(np.uint32)
+    alg = int(st[:, 0].sum()) * row_bytes + int(st[:, 1].sum()) * (args.max_degree + 1) * 4
+    # recall of the quantised search alone against the exact f32 ground truth (no rerank), for orientation
+    gt = ground_truth(torch, base, queries[:10000], k)
+    rec = recall_at_k(d_ids[:10000].cpu().numpy().view(np.uint32), gt, k)
+    return {"kernel": "beam_search_kernel", "rows": args.only, "row_bytes": row_bytes, "L": L, "nq": args.nq,
+            "recall_at_10_vs_exact_f32_no_rerank": round(rec, 4), "mean_cmps": float(st[:, 0].mean()),
+            "mean_hops": float(st[:, 1].mean()), "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": ms / nl,
+            "achieved_GBps": alg / (ms / nl * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms / nl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "qps": args.nq / (ms / nl * 1e-3)}
 
 
 def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):

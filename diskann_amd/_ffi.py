@@ -13,6 +13,7 @@ F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
+BUILD_MFMA_BACKEDGE = 1
 
 
 class Config(C.Structure):
@@ -90,6 +91,9 @@ SYMBOLS = {
     "dann_insert_batch_candidates": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _u32, _u32, _vp]),
     "dann_insert_batch_commit": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp]),
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
+    "dann_set_build_options": (_i32, [_vp, _u32]),
+    "dann_build_counters": (_i32, [_vp, _vp, _u32]),
+    "dann_debug_gram": (_i32, [_i32, _vp, _u32, _u32, _vp]),
     "dann_save_graph": (_i32, [_vp, C.c_char_p]),
     "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
     "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),

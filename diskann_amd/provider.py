@@ -357,6 +357,15 @@ class Provider:
         check(_ffi.lib().dann_insert_batch_commit(self._h, C.byref(cfg), _p(s), s.size, C.c_void_p(d_pending_all)),
               "dann_insert_batch_commit")
 
+    def set_build_options(self, flags):
+        """DANN_BUILD_* bits (dann.h): BUILD_MFMA_BACKEDGE = back-edge prunes through the Gram / MFMA path"""
+        check(_ffi.lib().dann_set_build_options(self._h, int(flags)), "dann_set_build_options")
+
+    def build_counters(self):
+        out = np.zeros(2, np.uint32)
+        check(_ffi.lib().dann_build_counters(self._h, _p(out), 2), "dann_build_counters")
+        return out
+
     def build(self, cfg, first, n, growth=0.02, max_batch=16384):
         return check(_ffi.lib().dann_build(self._h, C.byref(cfg), first, n, growth, max_batch), "dann_build")
 

@@ -355,6 +355,21 @@ int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t d
  * flight per lane), averaged over `reps` launches -- the achievable line to hold next to the 8 TB/s peak */
 int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps);
 
+/* build-path options (never change the resulting graph): DANN_BUILD_MFMA_BACKEDGE evaluates the pair similarities
+ * of every back-edge prune (add_edge_and_prune -> robust_prune_list, diskann/src/graph/index.rs:2264-2341,
+ * graph/internal/prune.rs:196-232) as one Gram matrix per candidate list on the matrix cores
+ * (v_mfma_f32_32x32x2_f32), with a bit-exact re-evaluation of every comparison the rounding-error interval of the
+ * Gram value does not decide.  f32 rows, L2 / inner product / cosine-normalized; other configurations ignore it. */
+enum { DANN_BUILD_MFMA_BACKEDGE = 1 };
+int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
+/* counters of the last dann_insert_batch / dann_build batch: out[0] = back-edge prunes through the MFMA path,
+ * out[1] = back-edge prunes of lists too long for it (lazy path inside the same kernel) */
+int32_t dann_build_counters(const dann_index* idx, uint32_t* out, uint32_t n);
+
+/* diagnostic: the Gram matrix of n <= 128 f32 rows exactly as the MFMA back-edge path computes it (f32 FMA chains of
+ * 32 terms in k order on v_mfma_f32_32x32x2_f32, block results summed in f64, one rounding to f32) */
+int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t dim, float* out);
+
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
 #define DANN_ABI_VERSION 2
 int32_t dann_abi_version(void);

@@ -154,6 +154,9 @@ void orc_paged_end(orc_paged* s);
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists);
 
+/* checker for the GPU build path's MFMA Gram (dann_debug_gram): blocked f32 fmaf chains, f64 block sum */
+void orc_gram_blocked(const float* rows, uint32_t n, uint32_t dim, float* out);
+
 /* ---- build ----------------------------------------------------------- */
 /* prune::robust_prune over a sorted pool (internal/prune.rs:106-259) + occlude_list
  * (index.rs:2565-2650).  pool_* is sorted here with the oracle's tie rule

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condense one profiles/run_only.sh pass (gpurun_out/<tag>_<workload>_*) into profiles/<name>_<workload>_summary.json
+(+ the kernel-trace CSV and the PMC rows of the dominant kernel).  For the large index it also refreshes
+profiles/pmc_large_latest.json, which bench.py reads for roofline_large.traffic.
+Usage: python profiles/condense_only.py <tag> <workload> <name>"""
+import csv, glob, json, os, shutil, sys
+
+tag, wl, name = sys.argv[1], sys.argv[2], sys.argv[3]
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = f"{R}/gpurun_out", f"{R}/profiles"
+flt = "expand_beam" if wl == "gather" else "beam_search"
+
+
+def last_json(path):
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+
+
+plain = list(last_json(f"{G}/{tag}_{wl}.json").values())[0]
+under = list(last_json(f"{G}/{tag}_{wl}_under_rocprof.json").values())[0]
+shutil.copy(f"{G}/{tag}_{wl}_kernel_trace.csv", f"{P}/{name}_{wl}_kernel_trace.csv")
+trace = None
+for row in csv.DictReader(open(f"{G}/{tag}_{wl}_kernel_trace.csv")):
+    # the timed launches are the longest ones of that kernel family (the index build launches many short ones)
+    if flt in row["kernel"] and (trace is None or float(row["avg_ms"]) > float(trace["avg_ms"])):
+        trace = row
+rows, vals, durs = [], {}, []
+for path in sorted(glob.glob(f"{G}/{tag}_{wl}_pmc_*.csv")):
+    best = {}
+    for row in csv.DictReader(open(path)):  # the timed launch = the longest dispatch group of that kernel
+        if flt in row["kernel"]:
+            c = row["counter"]
+            if c not in best or float(row["avg_duration_us"]) > float(best[c]["avg_duration_us"]):
+                best[c] = row
+    for c, row in best.items():
+        rows.append(row)
+        vals[c] = float(row["avg_value"])
+        durs.append(float(row["avg_duration_us"]))
+with open(f"{P}/{name}_{wl}_pmc.csv", "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    w.writerows(rows)
+hbm = (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024
+alg = plain["algorithmic_bytes_per_launch"]
+summary = {
+    "source": f"profiles/run_only.sh {tag} {wl}: plain run, then rocprofv3 --kernel-trace --stats, then one --pmc pass per "
+              "counter group over the same command (`python bench.py --only " + wl + " ...`)",
+    "plain_run": plain,
+    "under_kernel_trace": {k: under[k] for k in ("avg_kernel_ms",) if k in under},
+    "kernel_trace_dominant_kernel": trace,
+    "FETCH_SIZE_kb_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": vals["WRITE_SIZE"],
+    "fetch_correction": "x2 on gfx950 for 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
+    "hbm_bytes_per_launch_corrected": hbm,
+    "traffic_over_algorithmic": hbm / alg,
+    "TCC_HIT_sum": vals.get("TCC_HIT_sum"), "TCC_MISS_sum": vals.get("TCC_MISS_sum"),
+    "l2_hit_rate": (vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])) if "TCC_HIT_sum" in vals else None,
+    "avg_duration_us_under_pmc": sum(durs) / len(durs),
+}
+json.dump(summary, open(f"{P}/{name}_{wl}_summary.json", "w"), indent=1)
+if wl in ("large",):
+    spec = sys.argv[4] if len(sys.argv) > 4 else "10000000:128:sift_like:1:2560:32:28:100"
+    json.dump({"source": f"profiles/{name}_{wl}_summary.json", "workload": spec, "L": plain["L"],
+               "nq": int(plain["workload"].split(" queries/launch")[0].split()[-1]),
+               "hbm_bytes_per_launch_corrected": hbm}, open(f"{P}/pmc_large_latest.json", "w"), indent=1)
+print(json.dumps({k: summary[k] for k in ("hbm_bytes_per_launch_corrected", "traffic_over_algorithmic", "l2_hit_rate",
+                                          "avg_duration_us_under_pmc")}, indent=1), trace)

@@ -1,18 +1,36 @@
-import sys, os, time
+"""Phase split of the GPU index build (HIP-event clocks of the library: beam search with record, pool prune, back-edge
+prune; the rest is sorting / host orchestration).  usage: python scratch/build_phases.py [n dim R pruned l_build max_batch]"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+import torch
 import diskann_amd as da
-sys.argv=['x']; import bench
-n, dim = 1000000, 128
-dev=torch.device('cuda',0)
-base, q = bench.make_data(torch, dev, n, dim, 1000, 'sift_like', 0xD15CA11, 0xD15CA12)
-b=base.cpu().numpy()
-mean = base.double().mean(0).float(); medoid=int(torch.argmin(((base-mean[None,:])**2).sum(1)).item())
-for mb in (16384,):
-    p=da.Provider(da.F32,da.L2,dim,n,32,b[medoid:medoid+1]); p.set_elements(0,b)
-    p.kernel_time_reset(); torch.cuda.synchronize(); t=time.time()
-    nb=p.build(da.build_config(28,32,100,intra_batch_candidates=da.IBC_NONE),0,n,0.05,mb)
-    torch.cuda.synchronize(); dt=time.time()-t
-    ks=[p.kernel_time(i) for i in range(4)]
-    print(f"max_batch {mb}: build {dt:.3f}s batches {nb}; search {ks[0][0]:.0f} ms ({ks[0][1]}), gather {ks[1][0]:.0f}, prune {ks[2][0]:.0f} ms ({ks[2][1]}), backedge {ks[3][0]:.0f} ms ({ks[3][1]}); other {dt*1e3-sum(k[0] for k in ks):.0f} ms", flush=True)
-    del p
+from benchdata import make_data
+
+mfma = "--mfma" in sys.argv
+metric = da.INNER_PRODUCT if "--ip" in sys.argv else da.L2
+a = [int(x) for x in sys.argv[1:] if not x.startswith("--")]
+n, dim, R, pruned, lb, mb = (a + [1000000, 128, 32, 28, 100, 16384][len(a):])[:6]
+dev = torch.device('cuda', 0)
+base, q = make_data(torch, dev, n, dim, 1000, 'sift_like', 0xD15CA11, 0xD15CA12)
+mean = base.double().mean(0).float()
+medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
+p = da.Provider(da.F32, metric, dim, n, R, base[medoid:medoid + 1].cpu().numpy())
+if mfma:
+    p.set_build_options(da.BUILD_MFMA_BACKEDGE)
+for s0 in range(0, n, 1 << 20):
+    p.set_elements(s0, base[s0:s0 + (1 << 20)].cpu().numpy())
+p.kernel_time_reset()
+torch.cuda.synchronize()
+t = time.time()
+nb = p.build(da.build_config(pruned, R, lb, intra_batch_candidates=da.IBC_NONE), 0, n, 0.05, mb)
+torch.cuda.synchronize()
+dt = time.time() - t
+ks = [p.kernel_time(i) for i in range(4)]
+print(f"mfma={mfma} metric={metric} counters={p.build_counters().tolist()} ", end="")
+print(f"n={n} dim={dim} R={R}/{pruned} l_build={lb} max_batch={mb}: build {dt:.3f}s ({n / dt:,.0f} pts/s) batches {nb}; "
+      f"search {ks[0][0]:.0f} ms ({ks[0][1]}), prune {ks[2][0]:.0f} ms ({ks[2][1]}), backedge {ks[3][0]:.0f} ms ({ks[3][1]}); "
+      f"other {dt * 1e3 - sum(k[0] for k in ks):.0f} ms", flush=True)
