@@ -41,6 +41,9 @@ struct PruneCfg {
     uint32_t pruned_degree, max_degree, max_occlusion;
     float alpha;
     uint32_t saturate_after_prune;
+    // optional device counters (u64): [0] pair distances of the sweeps (row kernel), [1] list / extra distances
+    // d(location, c), [2] rows that went through an MFMA Gram, [3] sum of (Gram rows)^2 (x dim x 2 = MFMA flop)
+    unsigned long long* counters;
 };
 
 struct PoolLds {
@@ -142,7 +145,7 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     const float alpha = cfg.alpha;
     const float inc = alpha < 1.2f ? alpha : 1.2f;
     float cur_alpha = 1.0f;
-    uint32_t found = 0;
+    uint32_t found = 0, npairs = 0;
     const int g = lane / G, v = lane % G;
     if (N > 0) {
         while (found < degree) {
@@ -160,6 +163,7 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
                 bool rejected = false;
                 while (l != found && !rejected) {
                     const uint32_t cnt = (found - l) < (uint32_t)GROUPS ? (found - l) : (uint32_t)GROUPS;
+                    npairs += cnt;
                     // speculative distances for selected entries l .. l+cnt (one group each)
                     float d = 0.0f;
                     {
@@ -223,7 +227,10 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     }
     __syncthreads();
     for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
-    if (lane == 0) out[0] = nout;
+    if (lane == 0) {
+        out[0] = nout;
+        if (cfg.counters) atomicAdd(&cfg.counters[0], (unsigned long long)npairs);
+    }
 }
 
 // ---- kernel A: prune caller-provided pools (phase 2 of multi_insert, dann_prune_batch) -----
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(kWave) void backedge_kernel(BackArgs a) {
         return;
     }
     fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
+    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
     __syncthreads();
     // the list lives in LDS, so the result can go straight into the adjacency row (nobody
     // else reads this row during the back-edge phase)
@@ -682,7 +690,7 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     const float inc = alpha < 1.2f ? alpha : 1.2f;
     const float kMax = 3.402823466e+38f;
     float cur_alpha = 1.0f;
-    uint32_t found = 0;
+    uint32_t found = 0, nexact = 0;
     const int v = lane % G;
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     // first selected entry in sel[a..b) (pool order filter rp < i) whose pair distance with candidate i makes
@@ -724,6 +732,7 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                 const int f = __builtin_ctzll(tu);
                 if (__builtin_amdgcn_readlane(cls, f) == 1) return c0 + (uint32_t)f;
                 // bit-exact pair distance (every lane group evaluates the same pair)
+                ++nexact;
                 const uint32_t rpf = (uint32_t)__builtin_amdgcn_readlane((int)rp, f);
                 const uint8_t* y = ix.rows + (uint64_t)sid[rpf] * ix.row_stride;
                 const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(xi, y, (int)ix.dim, v), xi, y,
@@ -794,7 +803,14 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     }
     __syncthreads();
     for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
-    if (lane == 0) out[0] = nout;
+    if (lane == 0) {
+        out[0] = nout;
+        if (cfg.counters) {
+            atomicAdd(&cfg.counters[0], (unsigned long long)nexact);
+            atomicAdd(&cfg.counters[2], (unsigned long long)P);
+            atomicAdd(&cfg.counters[3], (unsigned long long)P * P);
+        }
+    }
 }
 
 // back-edges, one 4-wave workgroup per distinct target: list build (wave 0) -> Gram on the matrix cores (4 waves)
@@ -878,6 +894,7 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
     __syncthreads();
     if (wave != 0) return;  // ended waves leave the barrier count: wave 0 goes on alone
     fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
+    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
     __syncthreads();
     if (mode == 1) {
         prune_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow, GramCtx{gram, gld, ga.escale});
@@ -1043,6 +1060,7 @@ PruneCfg to_prune_cfg(const dann_build_config& c) {
     p.max_occlusion = c.max_occlusion_size ? c.max_occlusion_size : 750;
     p.alpha = c.alpha;
     p.saturate_after_prune = c.saturate_after_prune;
+    p.counters = nullptr;
     return p;
 }
 
@@ -1100,6 +1118,7 @@ struct BuildScratch {
     uint32_t batch_cap = 0, rec_stride = 0, pend_stride = 0, degree = 0;
     bool bootstrap_too_big = false;  // set when a batch needed the bootstrap with more members than its pool holds
     DevBuf slots, rec_ids, rec_d, rec_n, stats, pending, pending2, keys_in, keys_out, seg_start, seg_len, meta, sort_tmp;
+    DevBuf counters;  // 8 x u64, see PruneCfg::counters (accumulate until dann_build_counters_reset)
     size_t sort_tmp_bytes = 0;
 };
 
@@ -1121,6 +1140,10 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
     DANN_HIP(s.seg_start.alloc(nkeys * 4));
     DANN_HIP(s.seg_len.alloc(nkeys * 4 * 3));  // segment lengths | short worklist | long worklist
     DANN_HIP(s.meta.alloc(64));
+    if (!s.counters.p) {
+        DANN_HIP(s.counters.alloc(64));
+        DANN_HIP(hipMemset(s.counters.p, 0, 64));
+    }
     size_t tmp = 0;
     DANN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, s.keys_in.as<uint64_t>(), s.keys_out.as<uint64_t>(),
                                                (int)nkeys, 0, 64, nullptr));
@@ -1142,7 +1165,8 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
                                 const uint32_t* d_slots, uint32_t n, uint32_t lo, uint32_t hi,
                                 uint32_t* d_pending_out) {
     const IndexView ix = idx->view();
-    const PruneCfg pc = to_prune_cfg(cfg);
+    PruneCfg pc = to_prune_cfg(cfg);
+    pc.counters = s.counters.as<unsigned long long>();
     hipStream_t st = idx->stream;
     const uint32_t m = hi - lo;
     if (m == 0) return DANN_OK;
@@ -1217,6 +1241,10 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         set_error("candidate pool overflow in prune (pool cap %u)", pa.pcap);
         return DANN_EOVERFLOW;
     }
+    for (uint32_t i = 0; i < m; ++i) {
+        idx->build_counters[2] += hs[i].cmps;
+        idx->build_counters[3] += hs[i].hops;
+    }
     for (uint32_t i = 0; i < m; ++i)
         if (hs[i].status) {
             set_error("insert search %u: visited table or record buffer exhausted", lo + i);
@@ -1231,7 +1259,8 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
 static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, BuildScratch& s, const uint32_t* d_slots,
                             uint32_t n, const uint32_t* d_pending) {
     const IndexView ix = idx->view();
-    const PruneCfg pc = to_prune_cfg(cfg);
+    PruneCfg pc = to_prune_cfg(cfg);
+    pc.counters = s.counters.as<unsigned long long>();
     hipStream_t st = idx->stream;
     const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
     uint32_t* meta = s.meta.as<uint32_t>();
@@ -1505,10 +1534,21 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags) try {
     return DANN_OK;
 } DANN_CATCH_ALL
 
-int32_t dann_build_counters(const dann_index* idx, uint32_t* out, uint32_t n) try {
+int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n) try {
     if (!idx || (n && !out)) return DANN_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(idx->mu);
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 2 ? (uint32_t)std::min<uint64_t>(idx->build_counters[i], 0xFFFFFFFFull) : 0u;
+    uint64_t dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (idx->build_scratch) {
+        BuildScratch& s = *static_cast<BuildScratch*>(idx->build_scratch);
+        if (s.counters.p) {
+            DeviceGuard guard(idx->device);
+            DANN_HIP(hipStreamSynchronize(idx->stream));
+            DANN_HIP(hipMemcpy(dev, s.counters.p, 64, hipMemcpyDeviceToHost));
+        }
+    }
+    const uint64_t all[8] = {idx->build_counters[0], idx->build_counters[1], idx->build_counters[2], idx->build_counters[3],
+                             dev[0], dev[1], dev[2], dev[3]};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 8 ? all[i] : 0u;
     return DANN_OK;
 } DANN_CATCH_ALL
 

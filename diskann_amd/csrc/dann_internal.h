@@ -168,7 +168,9 @@ struct dann_index {
     uint32_t visited_bits = 0;
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
-    uint64_t build_counters[2] = {0, 0};  // back-edge prunes through the MFMA path / on the lazy path inside it
+    // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of
+    // the insert-time searches (host side; the device-side counters live in the build scratch)
+    uint64_t build_counters[4] = {0, 0, 0, 0};
     float* d_pq_pivots = nullptr;
     uint32_t* d_pq_offsets = nullptr;
     uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]

@@ -362,8 +362,8 @@ class Provider:
         check(_ffi.lib().dann_set_build_options(self._h, int(flags)), "dann_set_build_options")
 
     def build_counters(self):
-        out = np.zeros(2, np.uint32)
-        check(_ffi.lib().dann_build_counters(self._h, _p(out), 2), "dann_build_counters")
+        out = np.zeros(8, np.uint64)
+        check(_ffi.lib().dann_build_counters(self._h, _p(out), 8), "dann_build_counters")
         return out
 
     def build(self, cfg, first, n, growth=0.02, max_batch=16384):

@@ -69,7 +69,7 @@ def batch_schedule(first, n, growth, max_batch):
         done += b
 
 
-def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None):
+def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None, stats=None):
     """Multi-GPU index build over identical replicas (one `provider` per rank, rows already stored).
 
     Every batch is one multi_insert (diskann/src/graph/index.rs:815-1030): each rank generates the
@@ -113,6 +113,9 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
                 gathered = torch.empty(world * mine.numel(), dtype=torch.int32, device=dev)
                 dist.all_gather_into_tensor(gathered, mine.reshape(-1), group=group)
                 gathered = gathered.reshape(world, max(longest, 1), width)
+            if stats is not None:  # the build's only exchange: pending adjacency rows of the batch
+                stats["bytes_gathered"] = stats.get("bytes_gathered", 0) + world * max(longest, 1) * width * 4
+                stats["rounds"] = stats.get("rounds", 0) + 1
             parts = []
             for r in range(world):
                 a, z = partition(b, world, r)
@@ -132,3 +135,74 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
         done += b
         batches += 1
     return batches
+
+
+def rerank_sharded(shard, bounds, queries, cand_ids, k, rank=0, world=1, group=None, stats=None):
+    """Rerank (diskann-providers full_precision.rs:348-397) when the full-precision rows are PARTITIONED:
+    config 5's layout keeps a reduced-precision replica of every row on every GPU for the graph walk and
+    the f32 rows only on their owner (`bounds[r] <= id < bounds[r + 1]` lives on rank r as local slot
+    id - bounds[r] of `shard`).  Owner computes: every rank evaluates, with the bit-exact row kernel
+    (ExpandBeam), the candidates it owns for the queries of all ranks; the distances travel back and each
+    rank orders its own candidates exactly as the single-GPU Rerank does (distance, then candidate
+    position).  Only all_gather collectives (RCCL or gloo); `queries` are this rank's f32 queries,
+    `cand_ids` their candidate lists (global ids, 0xFFFFFFFF = padding).
+    Returns (ids[nq, k] uint32, dists[nq, k] float32); stats["bytes_gathered"] counts the exchange."""
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, shard.dim)
+    cand = np.ascontiguousarray(cand_ids, dtype=np.uint32).reshape(q.shape[0], -1)
+    nq, L = cand.shape
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        tdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+        def gather(arr, pad_rows):  # all ranks' arrays, each padded to pad_rows rows
+            a = np.zeros((pad_rows,) + arr.shape[1:], arr.dtype)
+            a[: arr.shape[0]] = arr
+            t = torch.from_numpy(a.view(np.int32).reshape(-1)).to(tdev)
+            out = torch.empty(world * t.numel(), dtype=torch.int32, device=tdev)
+            dist.all_gather_into_tensor(out, t, group=group)
+            if stats is not None:
+                stats["bytes_gathered"] = stats.get("bytes_gathered", 0) + out.numel() * 4
+            return out.cpu().numpy().view(arr.dtype).reshape((world, pad_rows) + arr.shape[1:])
+        counts = gather(np.array([[nq]], np.int32), 1).reshape(world)
+        rows = int(counts.max())
+        all_q = gather(q, rows)          # world x rows x dim
+        all_c = gather(cand, rows)       # world x rows x L
+    else:
+        counts, rows = np.array([nq]), nq
+        all_q, all_c = q[None], cand[None]
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    # the candidates this rank owns, as one ragged list per (rank, query)
+    dists_mine = np.full((world, rows, L), np.nan, np.float32)
+    for r in range(world):
+        c = all_c[r, : counts[r]]
+        own = (c >= lo) & (c < hi)
+        lens = own.sum(1)
+        if lens.sum() == 0:
+            continue
+        offsets = np.zeros(c.shape[0] + 1, np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        d = shard.expand_beam_batch(all_q[r, : counts[r]], (c[own] - lo).astype(np.uint32), offsets)
+        block = dists_mine[r, : counts[r]]
+        block[own] = d
+    if world > 1:
+        all_d = gather(dists_mine.reshape(world * rows, L), world * rows).reshape(world, world, rows, L)
+        mine = all_d[:, rank, :nq]       # owner x nq x L : NaN where that owner does not hold the candidate
+        owner = np.searchsorted(np.asarray(bounds[1:], dtype=np.uint64), cand.astype(np.uint64), side="right")
+        owner = np.minimum(owner, world - 1)
+        d = np.take_along_axis(mine, owner[None], 0)[0]
+    else:
+        d = dists_mine[0, :nq]
+    # Rerank's order: valid candidates in list order, sorted by (distance with -0 == +0, position), first k
+    out_i = np.full((nq, k), 0xFFFFFFFF, np.uint32)
+    out_d = np.full((nq, k), np.inf, np.float32)
+    valid = (cand != 0xFFFFFFFF) & (cand < np.uint64(bounds[-1]))
+    for i in range(nq):
+        ids = cand[i][valid[i]]
+        dd = d[i][valid[i]] + np.float32(0.0)
+        u = dd.view(np.uint32)
+        keys = np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64) << np.uint64(32) | np.arange(ids.size, dtype=np.uint64)
+        order = np.argsort(keys, kind="stable")[:k]
+        out_i[i, : order.size] = ids[order]
+        out_d[i, : order.size] = dd[order]
+    return out_i, out_d

@@ -362,9 +362,12 @@ int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t rep
  * Gram value does not decide.  f32 rows, L2 / inner product / cosine-normalized; other configurations ignore it. */
 enum { DANN_BUILD_MFMA_BACKEDGE = 1 };
 int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
-/* counters of the last dann_insert_batch / dann_build batch: out[0] = back-edge prunes through the MFMA path,
- * out[1] = back-edge prunes of lists too long for it (lazy path inside the same kernel) */
-int32_t dann_build_counters(const dann_index* idx, uint32_t* out, uint32_t n);
+/* work counters of the build path since index creation (the algorithmic-bytes model of profiles/): out[0] back-edge
+ * prunes through the MFMA path, [1] back-edge prunes of lists too long for it, [2] comparisons and [3] hops of the
+ * insert-time searches, [4] pair distances d(c_i, c_j) evaluated by the row kernel in the prune sweeps, [5] list /
+ * extra distances d(location, c), [6] candidate rows that went through an MFMA Gram, [7] sum of (Gram rows)^2
+ * (x dim x 2 = MFMA flop).  n <= 8 entries are written. */
+int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
 /* diagnostic: the Gram matrix of n <= 128 f32 rows exactly as the MFMA back-edge path computes it (f32 FMA chains of
  * 32 terms in k order on v_mfma_f32_32x32x2_f32, block results summed in f64, one rounding to f32) */

@@ -30,7 +30,17 @@ nb = p.build(da.build_config(pruned, R, lb, intra_batch_candidates=da.IBC_NONE),
 torch.cuda.synchronize()
 dt = time.time() - t
 ks = [p.kernel_time(i) for i in range(4)]
-print(f"mfma={mfma} metric={metric} counters={p.build_counters().tolist()} ", end="")
+import json
+c = [int(x) for x in p.build_counters()]
+row_b, adj_b = dim * 4, (R + 1) * 4
+print(json.dumps({"n": n, "dim": dim, "R": R, "pruned": pruned, "l_build": lb, "max_batch": mb, "mfma": mfma, "metric": int(metric),
+                  "build_seconds": dt, "batches": nb,
+                  "search": {"cmps": c[2], "hops": c[3], "algorithmic_bytes": c[2] * row_b + c[3] * adj_b},
+                  "prune_row_kernel": {"pair_distances": c[4], "list_distances": c[5],
+                                       "algorithmic_bytes": (2 * c[4] + c[5]) * row_b},
+                  "mfma": {"prunes": c[0], "too_long_for_gram": c[1], "gram_rows": c[6], "gram_rows_sq": c[7],
+                           "flop": 2 * c[7] * dim, "row_bytes_read": c[6] * row_b}}), flush=True)
+print(f"mfma={mfma} metric={metric} ", end="")
 print(f"n={n} dim={dim} R={R}/{pruned} l_build={lb} max_batch={mb}: build {dt:.3f}s ({n / dt:,.0f} pts/s) batches {nb}; "
       f"search {ks[0][0]:.0f} ms ({ks[0][1]}), prune {ks[2][0]:.0f} ms ({ks[2][1]}), backedge {ks[3][0]:.0f} ms ({ks[3][1]}); "
       f"other {dt * 1e3 - sum(k[0] for k in ks):.0f} ms", flush=True)

@@ -302,11 +302,14 @@ def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeyp
         gix.set_build_options(da.BUILD_MFMA_BACKEDGE)
         gix.build(gcfg, 0, n, growth, max_batch)
         assert np.array_equal(gix.download_graph(), oix.adj), (metric, dim, escale)
-        mfma, lazy = gix.build_counters()
+        cnt = gix.build_counters()
+        mfma, lazy = int(cnt[0]), int(cnt[1])
         assert mfma > 1000 and mfma > 20 * lazy, (mfma, lazy)   # the matrix-core path did the work
+        assert cnt[6] >= mfma * (maxdeg + 1) and cnt[7] > 0 and cnt[2] > 0 and cnt[3] > 0
     # and the lazy path (no option) gives the same graph
     plain = da.Provider(oracle.F32, metric, dim, n, maxdeg, start)
     plain.set_elements(0, data)
     plain.build(gcfg, 0, n, growth, max_batch)
     assert np.array_equal(plain.download_graph(), oix.adj)
-    assert plain.build_counters().sum() == 0
+    pc = plain.build_counters()
+    assert pc[0] == 0 and pc[1] == 0 and pc[6] == 0 and pc[4] > 0 and pc[5] > 0   # lazy path: row-kernel pairs only

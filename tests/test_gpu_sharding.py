@@ -58,6 +58,57 @@ print("rank", rank, "ok")
 """
 
 
+WORKER_CONFIG5 = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle, diskann_amd as da
+from diskann_amd.sharding import build_sharded, rerank_sharded, partition, batch_schedule
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+rng = np.random.default_rng(5)
+# config 5 in miniature: every rank holds an f16 replica of all rows + the whole graph, the f32 rows are partitioned
+n, dim, Rp, maxdeg, lb = 4000, 64, 12, 16, 32
+centers = rng.random((16, dim)).astype(np.float32)
+f32 = (centers[rng.integers(0, 16, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
+f16 = f32.astype(np.float16)
+start16 = f16.astype(np.float32).mean(0, keepdims=True).astype(np.float16)
+gcfg = da.build_config(Rp, maxdeg, lb, intra_batch_candidates=da.IBC_NONE)
+ocfg = oracle.build_config(Rp, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+rep = da.Provider(da.F16, da.L2, dim, n, maxdeg, start16)
+rep.set_elements(0, f16)
+st = {}
+nb = build_sharded(rep, gcfg, 0, n, 0.1, 512, rank, world, stats=st)
+o = oracle.Index(oracle.F16, oracle.L2, dim, n, maxdeg, start16)
+o.set_rows(0, f16)
+for s0, b in batch_schedule(0, n, 0.1, 512):
+    o.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+assert np.array_equal(rep.download_graph(), o.adj), "f16 replica build != oracle"
+assert st["rounds"] == nb and st["bytes_gathered"] > 0
+bounds = [partition(n, world, r)[0] for r in range(world)] + [n]
+lo, hi = bounds[rank], bounds[rank + 1]
+shard = da.Provider(da.F32, da.L2, dim, hi - lo, 1, f32[lo:lo + 1])     # the f32 rows this rank owns
+shard.set_elements(0, f32[lo:hi])
+queries = (centers[rng.integers(0, 16, 64)] + 0.2 * rng.standard_normal((64, dim))).astype(np.float32)
+qlo, qhi = partition(64, world, rank)
+myq = queries[qlo:qhi]
+L, k = 32, 10
+cand, _, _ = rep.search(da.Knn(L, 1), myq.astype(np.float16), L)        # graph walk on the replica
+rs = {}
+ids, d = rerank_sharded(shard, bounds, myq, cand, k, rank, world, stats=rs)
+full = da.Provider(da.F32, da.L2, dim, n, 1, f32[:1]); full.set_elements(0, f32)  # checker: un-partitioned f32 rows
+want_i, want_d = full.rerank(myq, cand, k)
+assert np.array_equal(ids, want_i) and np.array_equal(d.view(np.uint32), want_d.view(np.uint32)), "sharded rerank != Rerank"
+for qi in range(myq.shape[0]):
+    for j in range(k):
+        assert d[qi, j] == np.float32(oracle.query_distance(oracle.F32, oracle.L2, myq[qi], f32[ids[qi, j]]))
+assert rs["bytes_gathered"] > 0
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", st, rs)
+"""
+
+
 def _run(cmd, env, timeout=600):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -91,3 +142,15 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and "disagrees" in (r2.stdout + r2.stderr)
+
+
+def test_config5_layout_f16_replica_with_f32_owner_rerank(tmp_path):
+    """SURVEY.md 7, option (a) for 100 M x 768 at reduced scale: f16 replica + whole graph on every rank (built with
+    build_sharded, identical to the oracle's f16 build), f32 rows partitioned, Rerank computed by the owners."""
+    script = tmp_path / "worker5.py"
+    script.write_text(WORKER_CONFIG5)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", str(script), ROOT]
+    r = _run(cmd, env)
+    assert r.stdout.count("ok") == 2

@@ -74,3 +74,61 @@ def test_bench_launcher_rules(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE")
     bench.maybe_spawn(argparse.Namespace(gpus=1))
     bench.maybe_spawn(argparse.Namespace(gpus=None))
+
+
+WORKER_RERANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+import oracle
+from diskann_amd.sharding import rerank_sharded, partition
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(9)
+n, dim, L, k = 900, 20, 24, 7
+rows = rng.standard_normal((n, dim)).astype(np.float32)
+bounds = [partition(n, world, r)[0] for r in range(world)] + [n]
+
+
+class OracleShard:  # stands in for the HIP provider holding this rank's f32 rows (no GPU in this container)
+    def __init__(self, lo, hi):
+        self.dim = dim
+        self.ix = oracle.Index(oracle.F32, oracle.L2, dim, hi - lo, 1, rows[lo:lo + 1])
+        self.ix.set_rows(0, rows[lo:hi])
+
+    def expand_beam_batch(self, queries, ids, offsets):
+        out = np.empty(ids.size, np.float32)
+        for qi in range(len(offsets) - 1):
+            a, b = int(offsets[qi]), int(offsets[qi + 1])
+            if b > a:
+                out[a:b] = self.ix.expand_beam(queries[qi], ids[a:b])[1]
+        return out
+
+
+shard = OracleShard(bounds[rank], bounds[rank + 1])
+queries = rng.standard_normal((31, dim)).astype(np.float32)
+cand = rng.integers(0, n, (31, L)).astype(np.uint32)
+cand[:, -3:] = 0xFFFFFFFF                     # padding
+cand[5, :4] = cand[5, 4]                      # duplicates keep their list order
+qlo, qhi = partition(31, world, rank)
+ids, d = rerank_sharded(shard, bounds, queries[qlo:qhi], cand[qlo:qhi], k, rank, world)
+for qi in range(qlo, qhi):
+    c = cand[qi][cand[qi] != 0xFFFFFFFF]
+    dd = np.array([oracle.query_distance(oracle.F32, oracle.L2, queries[qi], rows[j]) for j in c], np.float32)
+    order = np.lexsort((np.arange(c.size), dd))[:k]
+    assert np.array_equal(ids[qi - qlo], c[order]) and np.array_equal(d[qi - qlo], dd[order]), qi
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_rerank_gloo_world2(tmp_path):
+    """owner-computes Rerank over partitioned f32 rows (config 5's layout), two ranks over gloo, oracle-backed shards"""
+    script = tmp_path / "worker_rerank.py"
+    script.write_text(WORKER_RERANK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29537", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
