@@ -557,59 +557,85 @@ constexpr float kGramC1 = 6.0e-6f, kGramC2 = 3.0e-6f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GramCtx {
-    const float* g;  // LDS: g[p * ld + q] = <row of pool position p, row of pool position q>
-    uint32_t ld;
-    float escale;    // 1.0; tests widen the error interval (DANN_GRAM_ESCALE) to drive every decision through the exact path
+    const float* g;      // LDS: g[p * ld + q] = <row p, row q>, p < nrows, q < ncols
+    const float* nrm;    // LDS: |row p|^2, p < nrows
+    uint32_t ld, nrows, ncols;
+    bool by_sorted;      // rows are indexed by sorted pool order (pool prune) or by pool position (back-edge lists)
+    float escale;        // 1.0; tests widen the error interval (DANN_GRAM_ESCALE) to drive every decision through the exact path
 };
 
-// all 4 waves of the workgroup: Gram of the rows pid[0..cnt) into g (ld = row stride), via K-slabs of 32 in LDS
-template <bool kUnused = false>
-__device__ void gram_mfma_f32(const IndexView& ix, const uint32_t* pid, uint32_t cnt, float* g, uint32_t ld, float* slab) {
+// All 4 waves of the workgroup: G[i][j] = <row ids[i], row ids[j]> for i < nrows, j < ncols (ncols <= nrows; the square
+// part uses the symmetry), and nrm[i] = |row ids[i]|^2.  K-slabs of 32 elements go through LDS (row stride 33 floats:
+// conflict-free operand reads); the next slab's global loads are issued before the current slab's MFMAs.
+constexpr int kGramMaxTiles = 3;   // 32x32 tiles per wave: 10 symmetric tiles of a 128 x 128 block over 4 waves
+constexpr int kGramMaxPasses = 4;  // 32-row fill passes: nrows <= 128
+__device__ void gram_mfma_f32(const IndexView& ix, const uint32_t* ids, uint32_t nrows, uint32_t ncols, float* g, uint32_t ld,
+                              float* nrm, float* slab) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t T = (cnt + 31u) >> 5;  // 32-row tiles
-    constexpr int kMaxTiles = 3;          // tiles per wave: T <= 4 -> 10 symmetric tiles over 4 waves
-    f32x16 acc[kMaxTiles];
-    double tot[kMaxTiles][16];
-    uint32_t trb[kMaxTiles], tcb[kMaxTiles];
+    const uint32_t TR = (nrows + 31u) >> 5, TC = (ncols + 31u) >> 5;
+    f32x16 acc[kGramMaxTiles];
+    double tot[kGramMaxTiles][16];
+    uint32_t trb[kGramMaxTiles], tcb[kGramMaxTiles];
     int nt = 0;
     {
         uint32_t m = 0;
-        for (uint32_t rb = 0; rb < T; ++rb)
-            for (uint32_t cb = 0; cb <= rb; ++cb, ++m)
-                if ((m & 3u) == wave && nt < kMaxTiles) {
+        for (uint32_t rb = 0; rb < TR; ++rb)
+            for (uint32_t cb = 0; cb <= rb && cb < TC; ++cb, ++m)
+                if ((m & 3u) == wave && nt < kGramMaxTiles) {
                     trb[nt] = rb;
                     tcb[nt] = cb;
                     ++nt;
                 }
     }
 #pragma unroll
-    for (int t = 0; t < kMaxTiles; ++t)
+    for (int t = 0; t < kGramMaxTiles; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot[t][r] = 0.0;
     const uint32_t dim = ix.dim;
     const uint32_t lr = tid >> 3, c4 = (tid & 7u) << 2;  // slab fill: 8 threads x 16 bytes per row, 32 rows per pass
-    for (uint32_t k0 = 0; k0 < dim; k0 += 32u) {
-        for (uint32_t pass = 0; pass < T; ++pass) {
-            const uint32_t r = (pass << 5) + lr;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-            if (r < cnt) {
-                const float* row = reinterpret_cast<const float*>(ix.rows + (uint64_t)pid[r] * ix.row_stride);
-                const uint32_t k = k0 + c4;
+    const float* rowp[kGramMaxPasses];
+    double nsq[kGramMaxPasses];
+#pragma unroll
+    for (int pass = 0; pass < kGramMaxPasses; ++pass) {
+        const uint32_t r = ((uint32_t)pass << 5) + lr;
+        rowp[pass] = (pass < (int)TR && r < nrows && ids[r] < ix.nslots)
+                         ? reinterpret_cast<const float*>(ix.rows + (uint64_t)ids[r] * ix.row_stride)
+                         : nullptr;  // rows of ids the sweep excludes anyway read as zero
+        nsq[pass] = 0.0;
+    }
+    float4 nxt[kGramMaxPasses];
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (int pass = 0; pass < kGramMaxPasses; ++pass) {
+            float4 q = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t k = k0 + c4;
+            if (rowp[pass] && k < dim) {
                 if (k + 3u < dim) {
-                    const float4 q = *reinterpret_cast<const float4*>(row + k);
-                    v0 = q.x, v1 = q.y, v2 = q.z, v3 = q.w;
+                    q = *reinterpret_cast<const float4*>(rowp[pass] + k);
                 } else {
-                    if (k < dim) v0 = row[k];
-                    if (k + 1u < dim) v1 = row[k + 1u];
-                    if (k + 2u < dim) v2 = row[k + 2u];
+                    q.x = rowp[pass][k];
+                    if (k + 1u < dim) q.y = rowp[pass][k + 1u];
+                    if (k + 2u < dim) q.z = rowp[pass][k + 2u];
                 }
             }
-            float* dst = slab + r * 33u + c4;
-            dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
+            nxt[pass] = q;
+        }
+    };
+    fetch(0);
+    for (uint32_t k0 = 0; k0 < dim; k0 += 32u) {
+#pragma unroll
+        for (int pass = 0; pass < kGramMaxPasses; ++pass) {
+            if (pass < (int)TR) {
+                const float4 q = nxt[pass];
+                float* dst = slab + (((uint32_t)pass << 5) + lr) * 33u + c4;
+                dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
+                nsq[pass] += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+            }
         }
         __syncthreads();
+        if (k0 + 32u < dim) fetch(k0 + 32u);  // in flight while the matrix cores work on this slab
 #pragma unroll
-        for (int t = 0; t < kMaxTiles; ++t) {
+        for (int t = 0; t < kGramMaxTiles; ++t) {
             if (t < nt) {
                 const float* pa = slab + ((trb[t] << 5) + (lane & 31u)) * 33u + (lane >> 5);
                 const float* pb = slab + ((tcb[t] << 5) + (lane & 31u)) * 33u + (lane >> 5);
@@ -625,30 +651,39 @@ __device__ void gram_mfma_f32(const IndexView& ix, const uint32_t* pid, uint32_t
     }
     (void)acc;
 #pragma unroll
-    for (int t = 0; t < kMaxTiles; ++t) {
+    for (int t = 0; t < kGramMaxTiles; ++t) {
         if (t < nt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t i = (trb[t] << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
                 const uint32_t j = (tcb[t] << 5) + (lane & 31u);
                 const float v = (float)tot[t][r];
-                g[i * ld + j] = v;
-                g[j * ld + i] = v;
+                g[i * ld + j] = v;             // i < 32 * TR, j < 32 * TC: inside the LDS block
+                if (trb[t] < TC) g[j * ld + i] = v;
             }
         }
+    }
+    // squared norms: the 8 threads of a row hold f64 partial sums (error far below the Gram's bound)
+#pragma unroll
+    for (int pass = 0; pass < kGramMaxPasses; ++pass) {
+        double v = nsq[pass];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const uint32_t r = ((uint32_t)pass << 5) + lr;
+        if (pass < (int)TR && (tid & 7u) == 0 && r < nrows) nrm[r] = (float)v;
     }
 }
 
 // prune_sorted_pool with the pair distances taken from the Gram matrix (exact re-check where the error interval
 // does not decide).  Single wave (lanes 0..63 of the workgroup); the other waves have exited.
-template <int OP, bool NORM>
-__device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t P,
-                                       uint32_t pcap, uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out,
-                                       const GramCtx gc) {
-    constexpr int DT = DT_F32;
-    using S = Scheme<DT, OP, true>;
-    constexpr int G = S::G;
-    const uint32_t lane = threadIdx.x;
+// one wave: LDS accesses of a single wave retire in program order; this is the compiler + counter fence between them
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// SortedNeighbors::new for one wave (the other waves of the workgroup may be waiting at a barrier): pid/pd[0..P) ->
+// sid/sd/occ/last[0..N), keys[i] keeps the pool position of sorted entry i.  Returns N.
+__device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pcap, uint8_t* smem, const PoolLds& L) {
+    const uint32_t lane = threadIdx.x & 63u;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem + L.keys_off);
     const uint32_t* pid = reinterpret_cast<const uint32_t*>(smem + L.pid_off);
     const float* pd = reinterpret_cast<const float*>(smem + L.pd_off);
@@ -656,10 +691,8 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     float* sd = reinterpret_cast<float*>(smem + L.sd_off);
     float* occ = reinterpret_cast<float*>(smem + L.occ_off);
     uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
-    uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
-    // ---- SortedNeighbors::new (as prune_sorted_pool) -----------------------------------------------------
     for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
-    __syncthreads();
+    wave_sync();
     for (uint32_t k = 2; k <= pcap; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
@@ -672,18 +705,39 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                     keys[p] = a;
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
     for (uint32_t i = lane; i < N; i += kWave) {
-        const uint32_t pos = (uint32_t)keys[i];  // pool position of sorted entry i: the Gram index (keys stay intact)
+        const uint32_t pos = (uint32_t)keys[i];
         sid[i] = pid[pos];
         sd[i] = pd[pos];
         occ[i] = 0.0f;
         last[i] = 0;
     }
-    __syncthreads();
+    wave_sync();
+    return N;
+}
+
+// The sweep of prune::robust_prune over a pool already sorted by sort_pool_wave, pair distances from the Gram matrix
+// where it covers the pair (exact re-check where the error interval does not decide, exact evaluation where it
+// does not cover it).  One wave (lanes 0..63 of the workgroup).
+template <int OP, bool NORM>
+__device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t N,
+                                       uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out,
+                                       const GramCtx gc) {
+    constexpr int DT = DT_F32;
+    using S = Scheme<DT, OP, true>;
+    constexpr int G = S::G;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(smem + L.keys_off);
+    const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
+    const float* sd = reinterpret_cast<const float*>(smem + L.sd_off);
+    float* occ = reinterpret_cast<float*>(smem + L.occ_off);
+    uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
+    const uint32_t P = N;
     const uint32_t degree = cfg.pruned_degree;
     const bool occluding = (ix.metric == M_IP);
     const float alpha = cfg.alpha;
@@ -696,8 +750,9 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     // first selected entry in sel[a..b) (pool order filter rp < i) whose pair distance with candidate i makes
     // update_occlude exceed `at`; returns its index in sel, or b when there is none
     auto first_exceed = [&](uint32_t i, uint32_t a, uint32_t b, float at) -> uint32_t {
-        const uint32_t pi = (uint32_t)keys[i];
-        const float gii = gc.g[pi * gc.ld + pi];
+        const uint32_t pi = gc.by_sorted ? i : (uint32_t)keys[i];
+        const bool irow = pi < gc.nrows;
+        const float gii = irow ? gc.nrm[pi] : 0.0f;
         const float di = sd[i];
         const uint8_t* xi = ix.rows + (uint64_t)sid[i] * ix.row_stride;
         const float thr = at * di;  // occluding rule: d_jk < alpha * d_ik (config/mod.rs:98)
@@ -708,15 +763,16 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
             if (c < b) {
                 rp = sel[c];
                 if (rp < i) {
-                    const uint32_t pj = (uint32_t)keys[rp];
-                    const float gij = gc.g[pi * gc.ld + pj], gjj = gc.g[pj * gc.ld + pj];
+                    const uint32_t pj = gc.by_sorted ? rp : (uint32_t)keys[rp];
+                    cls = 2;  // pairs the Gram does not cover are evaluated exactly
+                    if (irow && pj < gc.ncols) {
+                    const float gij = gc.g[pi * gc.ld + pj], gjj = gc.nrm[pj];
                     const float nsum = gii + gjj;
                     float dp;
                     if (OP == OP_L2) dp = nsum - 2.0f * gij;
                     else dp = NORM ? 1.0f - gij : -gij;
                     const float e = gc.escale * (kGramC1 * nsum + kGramC2 * __builtin_fabsf(dp));
                     const float lo = dp - e, hi = dp + e;
-                    cls = 2;
                     if (occluding) {
                         if (hi < thr) cls = 1;
                         else if (lo >= thr) cls = 0;
@@ -724,6 +780,7 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                         const float rmin = di / hi, rmax = di / lo;
                         if (rmin > at * 1.000001f) cls = 1;
                         else if (rmax < at * 0.999999f) cls = 0;
+                    }
                     }
                 }
             }
@@ -769,7 +826,7 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                         l = found;
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 if (lane == 0) {
                     last[i] = (uint16_t)l;
                     if (rejected) {
@@ -780,14 +837,14 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                     }
                 }
                 if (!rejected) ++found;
-                __syncthreads();
+                wave_sync();
             }
             if (cur_alpha == alpha) break;
             const float next = cur_alpha * inc;
             cur_alpha = next < alpha ? next : alpha;
         }
     }
-    __syncthreads();
+    wave_sync();
     uint32_t nout = found;
     if (force_saturate || (cfg.saturate_after_prune && alpha > 1.0f)) {
         for (uint32_t i = 0; i < N && nout < degree; ++i) {
@@ -798,10 +855,10 @@ __device__ void prune_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
             if (ballot64(dup)) continue;
             if (lane == 0) sel[nout] = i;
             ++nout;
-            __syncthreads();
+            wave_sync();
         }
     }
-    __syncthreads();
+    wave_sync();
     for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
     if (lane == 0) {
         out[0] = nout;
@@ -835,7 +892,8 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
     const uint32_t gld = ga.pg + 1u;
     float* gram = reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u));
     float* slab = gram + ga.pg * gld;
-    uint32_t* shared = reinterpret_cast<uint32_t*>(slab + ga.pg * 33u);  // [0] mode, [1] list length
+    float* gnrm = slab + ga.pg * 33u;
+    uint32_t* shared = reinterpret_cast<uint32_t*>(gnrm + ga.pg);  // [0] mode, [1] list length
     const uint32_t start = a.seg_start[seg];
     const uint32_t src = (uint32_t)(a.keys[start] >> 32);
     uint32_t* arow = a.ix.adj + (uint64_t)src * a.ix.adj_stride;
@@ -890,14 +948,16 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
     __syncthreads();
     const uint32_t mode = shared[0], cnt = shared[1];
     if (mode == 0) return;
-    if (mode == 1) gram_mfma_f32(a.ix, pid, cnt, gram, gld, slab);
+    if (mode == 1) gram_mfma_f32(a.ix, pid, cnt, cnt, gram, gld, gnrm, slab);
     __syncthreads();
     if (wave != 0) return;  // ended waves leave the barrier count: wave 0 goes on alone
     fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
     if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
     __syncthreads();
     if (mode == 1) {
-        prune_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow, GramCtx{gram, gld, ga.escale});
+        const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
+        sweep_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, src, N, smem, L, false, arow,
+                                         GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale});
     } else {
         prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
     }
@@ -909,7 +969,129 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
 
 inline size_t backedge_gram_lds(uint32_t pcap, uint32_t degree, uint32_t pg) {
     const size_t base = (pool_lds_layout(pcap, degree).total + 15u) & ~(size_t)15u;
-    return base + (size_t)pg * (pg + 1u) * 4u + (size_t)pg * 33u * 4u + 16u;
+    return base + (size_t)pg * (pg + 1u) * 4u + (size_t)pg * 33u * 4u + (size_t)pg * 4u + 16u;
+}
+
+// pool prune (phase 1 of multi_insert) with the matrix cores: wave 0 loads and sorts the pool, all 4 waves compute the
+// Gram of the first `ng` sorted candidates against the first `mg` (the selected ones come from the front of the sorted
+// pool), wave 0 sweeps.  Pairs outside that block are evaluated exactly by the row kernel.
+struct PoolGramArgs {
+    PoolArgs p;
+    uint32_t ng, mg;
+    float escale;
+};
+
+template <int OP, bool NORM>
+__global__ __launch_bounds__(256) void pool_prune_gram_kernel(PoolGramArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int DT = DT_F32;
+    using S = Scheme<DT, OP, true>;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    const PoolArgs& a = ga.p;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
+    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
+    const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
+    const uint32_t gld = ga.mg + 1u;
+    float* gram = reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u));
+    float* slab = gram + ga.ng * gld;
+    float* gnrm = slab + ga.ng * 33u;
+    uint32_t* shared = reinterpret_cast<uint32_t*>(gnrm + ga.ng);
+    const uint32_t loc = a.locs[item];
+    uint32_t* out = a.out + (uint64_t)wi * a.out_stride;
+    if (wave == 0) {
+        uint64_t lo;
+        uint32_t cnt;
+        if (a.offsets) {
+            lo = a.offsets[wi];
+            cnt = (uint32_t)(a.offsets[wi + 1] - lo);
+        } else {
+            lo = (uint64_t)wi * a.stride;
+            cnt = a.counts[wi];
+        }
+        uint32_t nex = 0;
+        if (a.cand != 0 && a.n > 1) nex = a.cand < a.n - 1 ? a.cand : a.n - 1;
+        uint32_t N = 0, mode = 0;
+        if (cnt + nex > a.pcap) {
+            if (lane == 0) {
+                *a.err = 1;
+                out[0] = 0;
+            }
+        } else {
+            for (uint32_t i = lane; i < cnt; i += kWave) {
+                pid[i] = a.pool_ids[lo + i];
+                pd[i] = a.pool_d[lo + i];
+            }
+            if (nex) {  // extras = around(ids, position, cand) (utils/async_tools.rs:51-131), as pool_prune_kernel
+                const uint32_t half = (nex + 1) / 2;
+                const uint32_t start = item >= half ? item - half : a.n - (half - item);
+                const uint8_t* x = a.ix.rows + (uint64_t)loc * a.ix.row_stride;
+                const int g = lane / G, v = lane % G;
+                for (uint32_t r0 = 0; r0 < nex; r0 += GROUPS) {
+                    const uint32_t r = r0 + g;
+                    if (r < nex) {
+                        uint32_t p = start + r;
+                        const uint32_t dist_to_item = item >= start ? item - start : item + a.n - start;
+                        if (r >= dist_to_item) p += 1;
+                        p %= a.n;
+                        const uint32_t id = a.locs[p];
+                        const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
+                        const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(x, y, (int)a.ix.dim, v), x, y,
+                                                                      a.ix.dim, SqParams{a.ix.sq_k, a.ix.sq_shift_norm_sq});
+                        if (v == 0) {
+                            pid[cnt + r] = id;
+                            pd[cnt + r] = d;
+                        }
+                    }
+                }
+                if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)nex);
+            }
+            wave_sync();
+            N = sort_pool_wave(a.cfg, cnt + nex, a.pcap, smem, L);
+            mode = 1;
+        }
+        if (lane == 0) {
+            shared[0] = mode;
+            shared[1] = N;
+        }
+    }
+    __syncthreads();
+    const uint32_t mode = shared[0], N = shared[1];
+    if (mode == 0) return;
+    const uint32_t nr = N < ga.ng ? N : ga.ng, nc = N < ga.mg ? N : ga.mg;
+    gram_mfma_f32(a.ix, sid, nr, nc, gram, gld, gnrm, slab);
+    __syncthreads();
+    if (wave != 0) return;
+    sweep_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, loc, N, smem, L, a.force_saturate != 0, out,
+                                     GramCtx{gram, gnrm, gld, nr, nc, true, ga.escale});
+}
+
+inline size_t pool_gram_lds(uint32_t pcap, uint32_t degree, uint32_t ng, uint32_t mg) {
+    const size_t base = (pool_lds_layout(pcap, degree).total + 15u) & ~(size_t)15u;
+    return base + (size_t)ng * (mg + 1u) * 4u + (size_t)ng * 33u * 4u + (size_t)ng * 4u + 16u;
+}
+
+int32_t launch_pool_gram(const IndexView& ix, const PoolGramArgs& ga, uint32_t grid, size_t lds, hipStream_t stream) {
+    int op;
+    bool norm;
+    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm) || ix.dtype != DT_F32 || op == OP_COS) return DANN_EUNSUPPORTED;
+    auto run = [&](auto kern) -> int32_t {
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, ga);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "pool_prune_gram_kernel launch");
+        return DANN_OK;
+    };
+    if (op == OP_L2) return run(pool_prune_gram_kernel<OP_L2, false>);
+    if (norm) return run(pool_prune_gram_kernel<OP_IP, true>);
+    return run(pool_prune_gram_kernel<OP_IP, false>);
 }
 
 __global__ __launch_bounds__(256) void gram_debug_kernel(IndexView ix, uint32_t cnt, float* out) {
@@ -918,9 +1100,10 @@ __global__ __launch_bounds__(256) void gram_debug_kernel(IndexView ix, uint32_t 
     uint32_t* pid = reinterpret_cast<uint32_t*>(smem);
     float* gram = reinterpret_cast<float*>(smem + pg * 4u);
     float* slab = gram + pg * ld;
+    float* gnrm = slab + pg * 33u;
     for (uint32_t i = threadIdx.x; i < pg; i += blockDim.x) pid[i] = i;
     __syncthreads();
-    gram_mfma_f32(ix, pid, cnt, gram, ld, slab);
+    gram_mfma_f32(ix, pid, cnt, cnt, gram, ld, gnrm, slab);
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < cnt * cnt; t += blockDim.x) out[t] = gram[(t / cnt) * ld + (t % cnt)];
 }
@@ -1230,8 +1413,27 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         return DANN_EUNSUPPORTED;
     }
     const size_t lds = pool_lds_layout(pa.pcap, pc.pruned_degree).total;
-    rc = dispatch<PoolLauncher>(ix, pa, m, lds, st);
-    if (rc != DANN_OK) return rc;
+    bool pool_gram = false;
+    if ((idx->build_flags & DANN_BUILD_MFMA_POOL) && ix.dtype == DT_F32 && ix.metric != M_COSINE) {
+        // Gram block: the first 128 sorted candidates against the first 96 (two workgroups per CU at a 256-entry pool)
+        const uint32_t ng = 128, mg = 96;
+        const size_t glds = pool_gram_lds(pa.pcap, pc.pruned_degree, ng, mg);
+        if (glds <= 160u * 1024u) {
+            PoolGramArgs ga;
+            ga.p = pa;
+            ga.ng = ng;
+            ga.mg = mg;
+            const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
+            ga.escale = es ? (float)atof(es) : 1.0f;
+            rc = launch_pool_gram(ix, ga, m, glds, st);
+            if (rc != DANN_OK) return rc;
+            pool_gram = true;
+        }
+    }
+    if (!pool_gram) {
+        rc = dispatch<PoolLauncher>(ix, pa, m, lds, st);
+        if (rc != DANN_OK) return rc;
+    }
     std::vector<dann_search_stats> hs(m);
     uint32_t h_err = 0;
     DANN_HIP(hipMemcpyAsync(hs.data(), s.stats.p, (size_t)m * sizeof(dann_search_stats), hipMemcpyDeviceToHost, st));
@@ -1339,7 +1541,11 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         //     to the short worklist (pool of 128 slots: full occupancy, and the MFMA path when it applies), the
         //     rare long ones (hubs hit by many back-edges in one batch) to a launch of their own whose LDS pool
         //     is sized by the longest of them -- one hub no longer sets the occupancy of the whole batch.
-        const bool want_gram = (idx->build_flags & DANN_BUILD_MFMA_BACKEDGE) && ix.dtype == DT_F32 && ix.metric != M_COSINE;
+        // default policy: rows of 1 KiB and more (where it is measured to win: 1 M x 768 build 3.50 -> 3.24 s) take the
+        // MFMA path unless DANN_BUILD_ROW_KERNEL_ONLY is set; DANN_BUILD_MFMA_BACKEDGE forces it for any row size
+        const bool want_gram = ix.dtype == DT_F32 && ix.metric != M_COSINE &&
+                               ((idx->build_flags & DANN_BUILD_MFMA_BACKEDGE) ||
+                                (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u));
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
@@ -1517,8 +1723,9 @@ int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t 
     ix.row_stride = stride;
     ix.dim = dim;
     ix.dtype = DT_F32;
+    ix.nslots = n;
     const uint32_t pg = (n + 31u) & ~31u;
-    const size_t lds = (size_t)pg * 4 + (size_t)pg * (pg + 1) * 4 + (size_t)pg * 33 * 4;
+    const size_t lds = (size_t)pg * 4 + (size_t)pg * (pg + 1) * 4 + (size_t)pg * 33 * 4 + (size_t)pg * 4;
     if (lds > 64 * 1024) DANN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_debug_kernel),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(gram_debug_kernel, dim3(1), dim3(256), lds, 0, ix, n, dout.as<float>());

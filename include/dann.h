@@ -360,7 +360,12 @@ int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t rep
  * graph/internal/prune.rs:196-232) as one Gram matrix per candidate list on the matrix cores
  * (v_mfma_f32_32x32x2_f32), with a bit-exact re-evaluation of every comparison the rounding-error interval of the
  * Gram value does not decide.  f32 rows, L2 / inner product / cosine-normalized; other configurations ignore it. */
-enum { DANN_BUILD_MFMA_BACKEDGE = 1 };
+enum { DANN_BUILD_MFMA_BACKEDGE = 1,
+       /* the same for the pool prune of every inserted point (robust_prune_with, index.rs:2476-2532): Gram of the
+        * first 128 candidates of the sorted pool against the first 96; pairs outside that block use the row kernel */
+       DANN_BUILD_MFMA_POOL = 2,
+       /* never use the matrix-core paths (by default back-edge prunes of f32 rows of 1 KiB and more use them) */
+       DANN_BUILD_ROW_KERNEL_ONLY = 4 };
 int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
 /* work counters of the build path since index creation (the algorithmic-bytes model of profiles/): out[0] back-edge
  * prunes through the MFMA path, [1] back-edge prunes of lists too long for it, [2] comparisons and [3] hops of the

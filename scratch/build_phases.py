@@ -19,8 +19,10 @@ base, q = make_data(torch, dev, n, dim, 1000, 'sift_like', 0xD15CA11, 0xD15CA12)
 mean = base.double().mean(0).float()
 medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
 p = da.Provider(da.F32, metric, dim, n, R, base[medoid:medoid + 1].cpu().numpy())
+if "--rowonly" in sys.argv:
+    p.set_build_options(da.BUILD_ROW_KERNEL_ONLY)
 if mfma:
-    p.set_build_options(da.BUILD_MFMA_BACKEDGE)
+    p.set_build_options(da.BUILD_MFMA_BACKEDGE | (0 if "--nopool" in sys.argv else da.BUILD_MFMA_POOL))
 for s0 in range(0, n, 1 << 20):
     p.set_elements(s0, base[s0:s0 + (1 << 20)].cpu().numpy())
 p.kernel_time_reset()

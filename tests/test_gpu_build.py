@@ -299,7 +299,7 @@ def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeyp
             monkeypatch.setenv("DANN_GRAM_ESCALE", escale)
         gix = da.Provider(oracle.F32, metric, dim, n, maxdeg, start)
         gix.set_elements(0, data)
-        gix.set_build_options(da.BUILD_MFMA_BACKEDGE)
+        gix.set_build_options(da.BUILD_MFMA_BACKEDGE | da.BUILD_MFMA_POOL)
         gix.build(gcfg, 0, n, growth, max_batch)
         assert np.array_equal(gix.download_graph(), oix.adj), (metric, dim, escale)
         cnt = gix.build_counters()
@@ -313,3 +313,28 @@ def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeyp
     assert np.array_equal(plain.download_graph(), oix.adj)
     pc = plain.build_counters()
     assert pc[0] == 0 and pc[1] == 0 and pc[6] == 0 and pc[4] > 0 and pc[5] > 0   # lazy path: row-kernel pairs only
+
+
+def test_mfma_pool_prune_with_intra_batch_candidates_and_big_pools():
+    """Pool prune on the matrix cores alone (no MFMA back-edges), with intra-batch candidates (the extras get their exact
+    distances before the sort) and l_build large enough that pools exceed the 128 x 96 Gram block: pairs outside the
+    block take the exact row kernel, the adjacency still equals the oracle's."""
+    from diskann_amd.sharding import batch_schedule
+    rng = np.random.default_rng(4321)
+    n, dim, R, maxdeg, lb = 5000, 48, 20, 24, 150
+    centers = rng.random((12, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 12, n)] + 0.2 * rng.standard_normal((n, dim))).astype(np.float32)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=6)
+    growth, max_batch = 0.2, 700
+    oix = oracle.Index(oracle.F32, oracle.L2, dim, n, maxdeg, start)
+    oix.set_rows(0, data)
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+    gix = da.Provider(oracle.F32, oracle.L2, dim, n, maxdeg, start)
+    gix.set_elements(0, data)
+    gix.set_build_options(da.BUILD_MFMA_POOL)
+    gix.build(gcfg, 0, n, growth, max_batch)
+    assert np.array_equal(gix.download_graph(), oix.adj)
+    cnt = gix.build_counters()
+    assert cnt[0] == 0 and cnt[6] > n * 20 and cnt[7] > 0     # Gram rows came from the pool prunes only
