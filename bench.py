@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--sharded-build", action="store_true",
                     help="N>1: build with diskann_amd.sharding.build_sharded (batch partitioned across ranks, RCCL "
                          "all-gather of the pending adjacency rows) instead of one independent build per rank")
+    ap.add_argument("--graph-cache", default="",
+                    help="file: load the built graph from it when present, else build and save it (profiling passes "
+                         "under rocprofv3 --pmc skip the thousands of build dispatches this way)")
     ap.add_argument("--visited-bits", type=int, default=0)
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
     if len(sys.argv) == 1 and os.environ.get("DANN_BENCH_ARGV"):  # a rank spawned by maybe_spawn()
@@ -178,11 +181,16 @@ def main():
     prov.set_elements(0, base_h)
     t1 = time.time()
     cfg = da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE)
-    if args.sharded_build and world > 1:
+    if args.graph_cache and os.path.exists(args.graph_cache):
+        prov.load_graph(args.graph_cache)
+        nb = 0
+    elif args.sharded_build and world > 1:
         from diskann_amd.sharding import build_sharded
         nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world)
     else:
         nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
+        if args.graph_cache and rank == 0:
+            prov.save_graph(args.graph_cache)
     torch.cuda.synchronize()
     t_build = time.time() - t1
     gt = ground_truth(torch, base, queries, 10)

@@ -437,6 +437,15 @@ __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
     uint32_t len = arow[0];
     len = len < a.ix.max_degree ? len : a.ix.max_degree;
     const uint32_t end = start + a.seg_len[start];
+    if (end - start > (uint32_t)kWave) {
+        // a hub hit by many back-edges: no serial scan here, the long-list kernel de-duplicates 64 sources at a time
+        // (len + #sources bounds its list; it also handles the case that everything still fits)
+        if (lane == 0) {
+            a.work_long[atomicAdd(&a.counts[1], 1u)] = seg;
+            atomicMax(&a.counts[2], len + (end - start));
+        }
+        return;
+    }
     // AdjacencyList::extend_from_slice: a source already in the list is skipped (sources of one target are distinct)
     uint32_t nnew = 0;
     const uint32_t mine = lane < len ? arow[1 + lane] : kEmpty;  // the first 64 entries stay in registers
@@ -1549,10 +1558,15 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
-        // small rows, no hub in this batch, no MFMA: the single-kernel form (list build + prune per target) is faster
-        // than scan + worklist (measured: 1 M x 128 build 0.68 s vs 0.78 s); everything else takes the split form
+        // small rows without the MFMA path: the single-kernel form (list build + prune per target, pool sized by the
+        // longest list of the batch) is faster than scan + worklists (measured: 1 M x 128 build 0.68 s vs 0.78 s);
+        // rows of 1 KiB and more take the split form (1 M x 768: 5.2 s -> 3.5 s, 3.25 s with the MFMA path)
         const uint32_t pcap_all = next_pow2(ix.max_degree + h_meta[2]);
-        if (!want_gram && pcap_all <= 128u && ix.layer_bytes < 1024u) {
+        if (!want_gram && ix.layer_bytes < 1024u) {
+            if (pcap_all > kMaxPool) {
+                set_error("a node received %u back-edges in one batch (cap %u): lower max_batch", h_meta[2], kMaxPool);
+                return DANN_EOVERFLOW;
+            }
             ba.pcap = pcap_all;
             rc = dispatch<BackLauncher>(ix, ba, ba.nseg, pool_lds_layout(ba.pcap, pc.pruned_degree).total, st);
             if (rc != DANN_OK) return rc;
