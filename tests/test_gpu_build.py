@@ -338,3 +338,30 @@ def test_mfma_pool_prune_with_intra_batch_candidates_and_big_pools():
     assert np.array_equal(gix.download_graph(), oix.adj)
     cnt = gix.build_counters()
     assert cnt[0] == 0 and cnt[6] > n * 20 and cnt[7] > 0     # Gram rows came from the pool prunes only
+
+
+@pytest.mark.parametrize("flags", [0, "row_only"])
+def test_large_rows_take_the_split_back_edge_path(flags):
+    """Rows of 1 KiB and more: back-edges go through scan/append + worklist prunes -- with the MFMA Gram by default, with
+    the row kernel under BUILD_ROW_KERNEL_ONLY (also the route of f16 / integer / cosine rows of that size).  Both equal
+    the oracle; a hub that receives hundreds of back-edges in one batch goes through the long-list launch."""
+    from diskann_amd.sharding import batch_schedule
+    rng = np.random.default_rng(260)
+    n, dim, R, maxdeg, lb = 3000, 260, 12, 16, 40
+    centers = rng.random((10, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 10, n)] + 0.1 * rng.standard_normal((n, dim))).astype(np.float32)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    growth, max_batch = 0.5, 1500      # big early batches: the start point's neighbourhood collects many back-edges at once
+    oix = oracle.Index(oracle.F32, oracle.L2, dim, n, maxdeg, start)
+    oix.set_rows(0, data)
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+    gix = da.Provider(oracle.F32, oracle.L2, dim, n, maxdeg, start)
+    gix.set_elements(0, data)
+    if flags:
+        gix.set_build_options(da.BUILD_ROW_KERNEL_ONLY)
+    gix.build(gcfg, 0, n, growth, max_batch)
+    assert np.array_equal(gix.download_graph(), oix.adj)
+    cnt = gix.build_counters()
+    assert (cnt[0] == 0) == bool(flags)
