@@ -267,7 +267,8 @@ def main():
     # ---- strong scaling: ONE shared query set, block-partitioned over the ranks (the reference's protocol:
     # diskann-benchmark-core/src/search/api.rs:399-436); the gathered g-rank output must equal the 1-rank output
     from diskann_amd.sharding import partition, search_sharded
-    nqs = args.nq_shared
+    # (skipped in single-rank --no-extras runs: under rocprofv3 every beam-search launch is then the timed workload)
+    nqs = args.nq_shared if (world > 1 or not args.no_extras or args.scaling == "strong") else 0
     _, shared = make_data(torch, dev, 0, args.dim, nqs, args.dist, 0xD15CA11, 0xD15CA20)  # same set on every rank
     lo, hi = partition(nqs, world, rank)
     s_ids = torch.empty((max(hi - lo, 1), k), dtype=torch.int32, device=dev)
@@ -292,11 +293,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         strong_elapsed = float(t.item())
     shared_h = shared.cpu().numpy()
-    g_ids, g_d = search_sharded(lambda qs: prov.search(da.Knn(chosen, W), qs, k)[:2] if len(qs) else
-                                (np.zeros((0, k), np.uint32), np.zeros((0, k), np.float32)), shared_h, k, rank, world)
-    strong = {"queries": nqs, "qps": nqs * args.steps / strong_elapsed, "ms_per_pass": strong_elapsed / args.steps * 1e3,
+    empty = (np.zeros((0, k), np.uint32), np.zeros((0, k), np.float32))
+    g_ids, g_d = empty if nqs == 0 else search_sharded(
+        lambda qs: prov.search(da.Knn(chosen, W), qs, k)[:2] if len(qs) else empty, shared_h, k, rank, world)
+    strong = {"queries": nqs, "qps": nqs * args.steps / max(strong_elapsed, 1e-9), "ms_per_pass": strong_elapsed / args.steps * 1e3,
               "ranks": world}
-    if rank == 0:
+    if rank == 0 and nqs:
         one_ids, one_d, _ = prov.search(da.Knn(chosen, W), shared_h, k)  # the same set through ONE rank
         strong["identical_to_single_rank"] = bool(np.array_equal(one_ids, g_ids) and
                                                   np.array_equal(one_d.view(np.uint32), g_d.view(np.uint32)))
