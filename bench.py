@@ -548,16 +548,18 @@ def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoi
 
 def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, full_prov):
     """PQ codes + the f32 index's graph, lookup-table beam search, Rerank on the f32 rows.  The codebook is
-    trained with dann_pq_lloyds (the reference's Lloyd iterations; random-sample seeding here instead of its
-    k-means++) on a 131 072-row sample and the rows are compressed with dann_pq_compress."""
+    trained with dann_pq_train (LightPQTrainingParameters::train: k-means++ seeding + 10 Lloyd iterations, the random
+    draws from numpy generators standing in for the reference's per-chunk StdRng) on a 131 072-row sample; the rows are
+    compressed with dann_pq_compress."""
     nch, dim = args.pq_chunks, args.dim
     bounds = np.linspace(0, dim, nch + 1).round().astype(np.uint32)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     sample = base[torch.randperm(args.n, generator=g, device=dev)[:min(args.n, 131072)]].cpu().numpy()
-    init = sample[np.random.default_rng(7).choice(sample.shape[0], 256, replace=False)]
+    gens = [np.random.default_rng(700 + c) for c in range(nch)]  # stand-ins for the per-chunk StdRng of the reference
     t_train = time.perf_counter()
-    pivots_h, _, _ = da.pq_lloyds(sample, bounds, init, 10, device=local)
+    pivots_h = da.pq_train(sample, bounds, 256, 10, lambda c, n: int(gens[c].integers(0, n)),
+                           lambda c, h: float(gens[c].random() * h), device=local)
     t_train = time.perf_counter() - t_train
     t_comp = time.perf_counter()
     codes_h = da.pq_compress(pivots_h, bounds, base.cpu().numpy(), device=local)
@@ -599,7 +601,7 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
     return {"chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
             "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()),
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
-            "train_seconds_lloyds_10_reps_131072_rows": round(t_train, 3),
+            "train_seconds_kmeanspp_plus_10_lloyds_131072_rows": round(t_train, 3),
             "compress_seconds_incl_pcie": round(t_comp, 3)}
 
 

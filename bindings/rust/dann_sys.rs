@@ -31,6 +31,12 @@ use std::ffi::{c_char, c_void};
     pub mode: u32, pub bits: *const u32, pub stride_words: u64,
     pub adaptive_samples: u32, pub adaptive_scale: f64, pub matched_cap: u32 }
 
+#[repr(C)] pub struct DannRng {              // include/dann.h: dann_rng -- closures over the per-chunk StdRng (train.rs:164-165)
+    pub ctx: *mut c_void,
+    pub uniform_index: extern "C" fn(ctx: *mut c_void, chunk: u32, n: u64) -> u64,     // Uniform::new(0, n).sample(rng)
+    pub uniform_f64: extern "C" fn(ctx: *mut c_void, chunk: u32, high: f64) -> f64,    // Uniform::<f64>::new(0.0, high).sample(rng)
+}
+
 // Every export of include/dann.h (generated from diskann_amd/_ffi.py::SYMBOLS, which tests/test_abi.py checks against
 // the header and the built library; argument meaning and const-ness: see the header).
 #[link(name = "dann_hip")]
@@ -92,6 +98,8 @@ extern "C" {
     pub fn dann_pq_compress(a0: i32, a1: *mut c_void, a2: u32, a3: *mut c_void, a4: u32, a5: u32, a6: *mut c_void, a7: u64, a8: *mut c_void) -> i32;
     pub fn dann_pq_lloyds(a0: i32, a1: *mut c_void, a2: u64, a3: u32, a4: *mut c_void, a5: u32, a6: u32, a7: *mut c_void, a8: u32, a9: *mut c_void, a10: *mut c_void) -> i32;
     pub fn dann_pq_scan(a0: i32, a1: *mut c_void, a2: u32, a3: u32, a4: *mut c_void, a5: u64, a6: *mut c_void, a7: *mut c_void, a8: *mut c_void) -> i32;
+    pub fn dann_pq_kmeanspp(a0: i32, a1: *mut c_void, a2: u64, a3: u32, a4: *mut c_void, a5: u32, a6: u32, a7: *const DannRng, a8: *mut c_void, a9: *mut c_void) -> i32;
+    pub fn dann_pq_train(a0: i32, a1: *mut c_void, a2: u64, a3: u32, a4: *mut c_void, a5: u32, a6: u32, a7: u32, a8: *const DannRng, a9: *mut c_void) -> i32;
     pub fn dann_abi_version() -> i32;
     pub fn dann_debug_stream_read_gbps(a0: i32, a1: u64, a2: u32, a3: *mut f64) -> i32;
     pub fn dann_last_error(a0: *mut c_char, a1: u64) -> i32;

@@ -37,6 +37,15 @@ class Filter(C.Structure):
                 ("adaptive_samples", C.c_uint32), ("adaptive_scale", C.c_double), ("matched_cap", C.c_uint32)]
 
 
+RNG_INDEX_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64)
+RNG_F64_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint32, C.c_double)
+
+
+class Rng(C.Structure):
+    """dann_rng: the caller's generator for the two random draws of k-means++ (plusplus.rs:417, 440-444)."""
+    _fields_ = [("ctx", C.c_void_p), ("uniform_index", RNG_INDEX_FN), ("uniform_f64", RNG_F64_FN)]
+
+
 class SearchStats(C.Structure):
     _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32),
                 ("written", C.c_uint32)]
@@ -105,6 +114,8 @@ SYMBOLS = {
     "dann_pq_compress": (_i32, [_i32, _vp, _u32, _vp, _u32, _u32, _vp, _u64, _vp]),
     "dann_pq_lloyds": (_i32, [_i32, _vp, _u64, _u32, _vp, _u32, _u32, _vp, _u32, _vp, _vp]),
     "dann_pq_scan": (_i32, [_i32, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "dann_pq_kmeanspp": (_i32, [_i32, _vp, _u64, _u32, _vp, _u32, _u32, _P(Rng), _vp, _vp]),
+    "dann_pq_train": (_i32, [_i32, _vp, _u64, _u32, _vp, _u32, _u32, _u32, _P(Rng), _vp]),
     "dann_abi_version": (_i32, []),
     "dann_debug_stream_read_gbps": (_i32, [_i32, _u64, _u32, _P(C.c_double)]),
     "dann_last_error": (_i32, [C.c_char_p, _u64]),

@@ -184,6 +184,91 @@ __global__ __launch_bounds__(256) void pq_compress_kernel(const float* pivots, u
     codes[r * nchunks + c] = (uint8_t)mi;
 }
 
+// ---- k-means++ seeding of the PQ trainer (kmeans::plusplus::kmeans_plusplus_into_inner, plusplus.rs:366-497) --------
+// update_distances (:239-311) with the BlockTransposed<f32, 16> micro-kernel (:87-237): one thread per row evaluates
+// the reference's per-row chain (fma over the chunk's columns in order, * -2, (norm + |centre|^2) + that, strict-<
+// minimum); the 16 rows of a block fold their minima in the reference's order (lane k with lane k + 8, the 8 pair sums
+// left to right, in f64).  A second kernel adds the block sums sequentially (the reference's rolling f64 sum).
+__global__ __launch_bounds__(256) void kpp_update_kernel(const float* data, uint64_t n, uint32_t dim, const uint32_t* offsets,
+                                                         const float* norms, const float* last, const float* last_norm,
+                                                         float* mins, double* block_sums, uint64_t nblocks) {
+    __shared__ float cur[256];
+    const uint32_t c = blockIdx.y;
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t s0 = offsets[c], len = offsets[c + 1] - s0;
+    float v = 0.0f;  // lanes past the end hold 0 and stay 0 (finish_last)
+    if (row < n) {
+        const float* x = data + row * dim + s0;
+        const float* l = last + (uint64_t)c * dim + s0;
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < len; ++k) acc = __builtin_fmaf(x[k], l[k], acc);
+        acc = acc * -2.0f;
+        const float d = (norms[(uint64_t)c * n + row] + last_norm[c]) + acc;
+        float m = mins[(uint64_t)c * n + row];
+        if (d < m) {
+            m = d;
+            mins[(uint64_t)c * n + row] = m;
+        }
+        v = m;
+    }
+    cur[threadIdx.x] = v;
+    __syncthreads();
+    if ((threadIdx.x & 15u) == 0) {
+        const uint64_t b = row >> 4;
+        if (b < nblocks) {
+            double blk = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) blk += (double)cur[threadIdx.x + k] + (double)cur[threadIdx.x + k + 8];
+            block_sums[(uint64_t)c * nblocks + b] = blk;
+        }
+    }
+}
+__global__ void kpp_total_kernel(const double* block_sums, uint64_t nblocks, double* totals) {
+    const uint32_t c = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (uint64_t b = 0; b < nblocks; ++b) s += block_sums[(uint64_t)c * nblocks + b];
+    totals[c] = s;
+}
+// the D^2 draw (plusplus.rs:446-462): first row whose running f64 sum reaches the threshold, with a positive minimum,
+// not picked before.  Sequential by definition; one thread per chunk, chunks in parallel.
+__global__ void kpp_select_kernel(const float* mins, uint64_t n, const double* thresholds, const uint8_t* active,
+                                  uint8_t* picked, int64_t* chosen) {
+    const uint32_t c = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    chosen[c] = -1;
+    if (!active[c]) return;
+    const double t = thresholds[c];
+    double acc = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const float m = mins[(uint64_t)c * n + i];
+        acc += (double)m;
+        if (acc >= t && m > 0.0f && !picked[(uint64_t)c * n + i]) {
+            picked[(uint64_t)c * n + i] = 1;
+            chosen[c] = (int64_t)i;
+            return;
+        }
+    }
+}
+// copy the chosen rows' chunk columns into centre `cur` and publish them as the next `last` (+ their norms)
+__global__ void kpp_commit_kernel(const float* data, uint64_t n, uint32_t dim, const uint32_t* offsets, const float* norms,
+                                  const int64_t* chosen, uint32_t cur, float* centers, float* last, float* last_norm) {
+    const uint32_t c = blockIdx.x;
+    const int64_t i = chosen[c];
+    if (i < 0) return;
+    const uint32_t s0 = offsets[c], len = offsets[c + 1] - s0;
+    for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) {
+        const float v = data[(uint64_t)i * dim + s0 + k];
+        centers[(uint64_t)cur * dim + s0 + k] = v;
+        last[(uint64_t)c * dim + s0 + k] = v;
+    }
+    if (threadIdx.x == 0) last_norm[c] = norms[(uint64_t)c * n + (uint64_t)i];
+}
+__global__ void kpp_fill_kernel(float* v, uint64_t n, float x) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = x;
+}
+
 // ---- Lloyd iterations of the PQ trainer (product/train.rs:96-226, kmeans/lloyds.rs:23-438) ----------------
 // |x|^2 of every (row, chunk): kmeans::square_norm
 __global__ __launch_bounds__(256) void pq_data_norms_kernel(const float* data, uint64_t n, uint32_t dim,
@@ -642,4 +727,124 @@ extern "C" int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n,
     DANN_HIP(hipGetLastError());
     DANN_HIP(hipMemcpy(out, dout.p, (size_t)n * (dim + 4), hipMemcpyDeviceToHost));
     return DANN_OK;
+} DANN_CATCH_ALL
+
+// k-means++ for every chunk in lockstep: per centre one update launch over all (row, chunk) pairs, the sequential f64
+// totals, one host round trip for the caller's threshold draws, the sequential selection, the commit.
+extern "C" int32_t dann_pq_kmeanspp(int32_t device, const float* data, uint64_t n, uint32_t dim,
+                                    const uint32_t* chunk_offsets, uint32_t nchunks, uint32_t ncenters, const dann_rng* rng,
+                                    float* centers, uint32_t* selected) try {
+    using namespace dann;
+    if (!data || !chunk_offsets || !centers || !rng || !rng->uniform_index || !rng->uniform_f64 || nchunks == 0 || dim == 0)
+        return DANN_EINVAL;
+    if (n > 0xFFFFFFFFull) return DANN_EINVAL;
+    if (chunk_offsets[0] != 0 || chunk_offsets[nchunks] != dim) {
+        set_error("chunk offsets must start at 0 and end at dim");
+        return DANN_EINVAL;
+    }
+    for (uint32_t c = 0; c < nchunks; ++c)
+        if (chunk_offsets[c + 1] <= chunk_offsets[c]) return DANN_EINVAL;
+    memset(centers, 0, (size_t)ncenters * dim * 4);
+    if (selected) memset(selected, 0, (size_t)nchunks * 4);
+    if (n == 0 || ncenters == 0) return DANN_OK;  // DatasetTooSmall is recoverable: all centres stay zero
+    if (device >= 0) DANN_HIP(hipSetDevice(device));
+    const uint64_t nblocks = (n + 15) / 16;
+    Buf dx, doff, dcen, dnorm, dmins, dbs, dtot, dthr, dact, dpicked, dchosen, dlast, dlastn;
+    DANN_HIP(hipMalloc(&dx.p, n * dim * 4));
+    DANN_HIP(hipMalloc(&doff.p, (size_t)(nchunks + 1) * 4));
+    DANN_HIP(hipMalloc(&dcen.p, (size_t)ncenters * dim * 4));
+    DANN_HIP(hipMalloc(&dnorm.p, (size_t)nchunks * n * 4));
+    DANN_HIP(hipMalloc(&dmins.p, (size_t)nchunks * n * 4));
+    DANN_HIP(hipMalloc(&dbs.p, (size_t)nchunks * nblocks * 8));
+    DANN_HIP(hipMalloc(&dtot.p, (size_t)nchunks * 8));
+    DANN_HIP(hipMalloc(&dthr.p, (size_t)nchunks * 8));
+    DANN_HIP(hipMalloc(&dact.p, nchunks));
+    DANN_HIP(hipMalloc(&dpicked.p, (size_t)nchunks * n));
+    DANN_HIP(hipMalloc(&dchosen.p, (size_t)nchunks * 8));
+    DANN_HIP(hipMalloc(&dlast.p, (size_t)nchunks * dim * 4));
+    DANN_HIP(hipMalloc(&dlastn.p, (size_t)nchunks * 4));
+    DANN_HIP(hipMemcpy(dx.p, data, n * dim * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemcpy(doff.p, chunk_offsets, (size_t)(nchunks + 1) * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemset(dcen.p, 0, (size_t)ncenters * dim * 4));
+    DANN_HIP(hipMemset(dpicked.p, 0, (size_t)nchunks * n));
+    const dim3 rows_grid((uint32_t)((n + 255) / 256), nchunks);
+    hipLaunchKernelGGL(pq_data_norms_kernel, rows_grid, dim3(256), 0, 0, (const float*)dx.p, n, dim,
+                       (const uint32_t*)doff.p, (float*)dnorm.p);
+    {
+        const uint64_t tot = (uint64_t)nchunks * n;
+        hipLaunchKernelGGL(kpp_fill_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, 0, (float*)dmins.p, tot,
+                           __builtin_inff());
+    }
+    // first centre of every chunk: Uniform::new(0, n).sample(rng)
+    std::vector<int64_t> h_chosen(nchunks);
+    std::vector<uint8_t> h_pick1(1, 1), h_active(nchunks, 1);
+    std::vector<uint32_t> sel(nchunks, 0);
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint64_t i = rng->uniform_index(rng->ctx, c, n);
+        if (i >= n) {
+            set_error("uniform_index callback returned %llu for n = %llu", (unsigned long long)i, (unsigned long long)n);
+            return DANN_EINVAL;
+        }
+        h_chosen[c] = (int64_t)i;
+        DANN_HIP(hipMemcpy((uint8_t*)dpicked.p + (size_t)c * n + i, h_pick1.data(), 1, hipMemcpyHostToDevice));
+        sel[c] = 1;
+    }
+    DANN_HIP(hipMemcpy(dchosen.p, h_chosen.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kpp_commit_kernel, dim3(nchunks), dim3(64), 0, 0, (const float*)dx.p, n, dim, (const uint32_t*)doff.p,
+                       (const float*)dnorm.p, (const int64_t*)dchosen.p, 0u, (float*)dcen.p, (float*)dlast.p,
+                       (float*)dlastn.p);
+    const uint64_t limit = std::min<uint64_t>(ncenters, n);
+    std::vector<double> h_tot(nchunks), h_thr(nchunks);
+    int32_t status = DANN_OK;
+    for (uint64_t cur = 1; cur < limit; ++cur) {
+        bool any = false;
+        for (uint32_t c = 0; c < nchunks; ++c) any |= h_active[c] != 0;
+        if (!any) break;
+        hipLaunchKernelGGL(kpp_update_kernel, rows_grid, dim3(256), 0, 0, (const float*)dx.p, n, dim, (const uint32_t*)doff.p,
+                           (const float*)dnorm.p, (const float*)dlast.p, (const float*)dlastn.p, (float*)dmins.p,
+                           (double*)dbs.p, nblocks);
+        hipLaunchKernelGGL(kpp_total_kernel, dim3(nchunks), dim3(64), 0, 0, (const double*)dbs.p, nblocks, (double*)dtot.p);
+        DANN_HIP(hipMemcpy(h_tot.data(), dtot.p, (size_t)nchunks * 8, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            if (!h_active[c]) continue;
+            const double s = h_tot[c];
+            if (!(0.0 < s)) {  // Uniform::<f64>::new(0.0, s) -> EmptyRange: no pick -> InsufficientDiversity
+                h_active[c] = 0;
+                continue;
+            }
+            if (!std::isfinite(s)) {  // NonFinite -> FailureReason::SawInfinity (not recoverable)
+                set_error("k-means++ (chunk %u): a value of infinity or NaN was observed", c);
+                status = DANN_EINVAL;
+                h_active[c] = 0;
+                continue;
+            }
+            h_thr[c] = rng->uniform_f64(rng->ctx, c, s);
+        }
+        if (status != DANN_OK) break;
+        DANN_HIP(hipMemcpy(dthr.p, h_thr.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
+        DANN_HIP(hipMemcpy(dact.p, h_active.data(), nchunks, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(kpp_select_kernel, dim3(nchunks), dim3(64), 0, 0, (const float*)dmins.p, n, (const double*)dthr.p,
+                           (const uint8_t*)dact.p, (uint8_t*)dpicked.p, (int64_t*)dchosen.p);
+        hipLaunchKernelGGL(kpp_commit_kernel, dim3(nchunks), dim3(64), 0, 0, (const float*)dx.p, n, dim,
+                           (const uint32_t*)doff.p, (const float*)dnorm.p, (const int64_t*)dchosen.p, (uint32_t)cur,
+                           (float*)dcen.p, (float*)dlast.p, (float*)dlastn.p);
+        DANN_HIP(hipMemcpy(h_chosen.data(), dchosen.p, (size_t)nchunks * 8, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            if (!h_active[c]) continue;
+            if (h_chosen[c] < 0) h_active[c] = 0;  // InsufficientDiversity: this chunk stops, its remaining centres stay zero
+            else sel[c] = (uint32_t)cur + 1;
+        }
+    }
+    DANN_HIP(hipMemcpy(centers, dcen.p, (size_t)ncenters * dim * 4, hipMemcpyDeviceToHost));
+    if (selected) memcpy(selected, sel.data(), (size_t)nchunks * 4);
+    return status;
+} DANN_CATCH_ALL
+
+// LightPQTrainingParameters::train (product/train.rs:96-226): k-means++ seeding then the Lloyd iterations, per chunk
+extern "C" int32_t dann_pq_train(int32_t device, const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets,
+                                 uint32_t nchunks, uint32_t ncenters, uint32_t lloyds_reps, const dann_rng* rng,
+                                 float* pivots) try {
+    int32_t rc = dann_pq_kmeanspp(device, data, n, dim, chunk_offsets, nchunks, ncenters, rng, pivots, nullptr);
+    if (rc != DANN_OK) return rc;
+    return dann_pq_lloyds(device, data, n, dim, chunk_offsets, nchunks, ncenters, pivots, lloyds_reps, nullptr, nullptr);
 } DANN_CATCH_ALL

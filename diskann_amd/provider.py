@@ -467,6 +467,35 @@ def pq_lloyds(data, chunk_offsets, centers, max_reps, device=-1):
     return cen, assign, res
 
 
+def _rng(uniform_index, uniform_f64):
+    return _ffi.Rng(None, _ffi.RNG_INDEX_FN(lambda ctx, c, n: int(uniform_index(c, n))),
+                    _ffi.RNG_F64_FN(lambda ctx, c, h: float(uniform_f64(c, h))))
+
+
+def pq_kmeanspp(data, chunk_offsets, ncenters, uniform_index, uniform_f64, device=-1):
+    """k-means++ seeding of the PQ trainer on the GPU with the caller's random draws (uniform_index(chunk, n),
+    uniform_f64(chunk, high)); returns (centers[ncenters, dim], selected[nchunks])."""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    cen = np.zeros((ncenters, x.shape[1]), np.float32)
+    sel = np.zeros(off.size - 1, np.uint32)
+    rng = _rng(uniform_index, uniform_f64)
+    check(_ffi.lib().dann_pq_kmeanspp(device, _p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, ncenters, C.byref(rng),
+                                      _p(cen), _p(sel)), "dann_pq_kmeanspp")
+    return cen, sel
+
+
+def pq_train(data, chunk_offsets, ncenters, lloyds_reps, uniform_index, uniform_f64, device=-1):
+    """LightPQTrainingParameters::train on the GPU: k-means++ then the Lloyd iterations; returns pivots[ncenters, dim]."""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    piv = np.zeros((ncenters, x.shape[1]), np.float32)
+    rng = _rng(uniform_index, uniform_f64)
+    check(_ffi.lib().dann_pq_train(device, _p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, ncenters, lloyds_reps,
+                                   C.byref(rng), _p(piv)), "dann_pq_train")
+    return piv
+
+
 def sq8_train(data, standard_deviations=2.0, device=-1):
     """ScalarQuantizationParameters::train on the GPU: (shift[dim] f32, scale, mean_norm)."""
     x = np.ascontiguousarray(data, dtype=np.float32)

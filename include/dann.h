@@ -321,6 +321,27 @@ int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n, uint32_t d
                        uint32_t nchunks, uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments,
                        float* residuals);
 
+/* the caller's random generator for the two draws of k-means++: on the Rust side closures over the
+ * `rng_builder.build_boxed_rng(chunk)` generators of LightPQTrainingParameters::train (train.rs:164-165,
+ * diskann-quantization/src/random.rs:33-44), so that the GPU consumes exactly the reference's stream:
+ *   uniform_index(ctx, chunk, n)   == Uniform::new(0, n).unwrap().sample(rng_chunk)              (plusplus.rs:417)
+ *   uniform_f64(ctx, chunk, high)  == Uniform::<f64>::new(0.0, high).unwrap().sample(rng_chunk)  (plusplus.rs:440-444)
+ * Called from the calling thread only, chunk by chunk, in the reference's order within a chunk. */
+typedef struct {
+    void* ctx;
+    uint64_t (*uniform_index)(void* ctx, uint32_t chunk, uint64_t n);
+    double (*uniform_f64)(void* ctx, uint32_t chunk, double high);
+} dann_rng;
+/* kmeans::plusplus::kmeans_plusplus_into_inner (algorithms/kmeans/plusplus.rs:366-497) for every chunk.  centers:
+ * ncenters x dim out (the chunk columns of centres that could not be selected stay zero); selected: nchunks out or NULL
+ * (fewer than ncenters = the reference's recoverable DatasetTooSmall / InsufficientDiversity).  DANN_EINVAL when a
+ * non-finite distance total appears (SawInfinity). */
+int32_t dann_pq_kmeanspp(int32_t device, const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets,
+                         uint32_t nchunks, uint32_t ncenters, const dann_rng* rng, float* centers, uint32_t* selected);
+/* LightPQTrainingParameters::train (product/train.rs:96-226): dann_pq_kmeanspp + dann_pq_lloyds; pivots: ncenters x dim */
+int32_t dann_pq_train(int32_t device, const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets,
+                      uint32_t nchunks, uint32_t ncenters, uint32_t lloyds_reps, const dann_rng* rng, float* pivots);
+
 /* ---- on-disk formats of the reference (so a GPU-built index loads in the reference and vice versa)
  * graph: diskann-providers/src/storage/bin.rs:234-380 -- 24-byte header {u64 file_size, u32 max_degree,
  *        u32 start_point, u64 num_start_points} then per node {u32 len, len x u32}, nodes in slot order

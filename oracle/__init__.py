@@ -63,6 +63,14 @@ class OrcBuildConfig(C.Structure):
     ]
 
 
+RNG_INDEX_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64)
+RNG_F64_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint32, C.c_double)
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("uniform_index", RNG_INDEX_FN), ("uniform_f64", RNG_F64_FN)]
+
+
 _lib = None
 
 
@@ -121,6 +129,8 @@ def lib():
     L.orc_pq_compress.argtypes = [vp, u32, vp, u32, u32, vp, u64, vp]
     L.orc_pq_square_norms.restype = i32
     L.orc_pq_square_norms.argtypes = [vp, u32, vp, u32, u32, vp]
+    L.orc_pq_kmeanspp.restype = i32
+    L.orc_pq_kmeanspp.argtypes = [vp, u64, u32, vp, u32, u32, P(OrcRng), vp, vp]
     L.orc_pq_lloyds.restype = i32
     L.orc_pq_lloyds.argtypes = [vp, u64, u32, vp, u32, u32, vp, u32, vp, vp]
     L.orc_sq8_train.restype = None
@@ -432,6 +442,19 @@ def pq_compress(pivots, chunk_offsets, rows):
     codes = np.zeros((x.shape[0], off.size - 1), np.uint8)
     rc = lib().orc_pq_compress(_p(piv), piv.shape[0], _p(off), off.size - 1, piv.shape[1], _p(x), x.shape[0], _p(codes))
     return int(rc), codes
+
+
+def pq_kmeanspp(data, chunk_offsets, ncenters, uniform_index, uniform_f64):
+    """kmeans_plusplus_into_inner per chunk; uniform_index(chunk, n) -> int, uniform_f64(chunk, high) -> float are the
+    caller's random draws.  Returns (status, centers[ncenters, dim], selected[nchunks])."""
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    off = np.ascontiguousarray(chunk_offsets, dtype=np.uint32)
+    cen = np.zeros((ncenters, x.shape[1]), np.float32)
+    sel = np.zeros(off.size - 1, np.uint32)
+    rng = OrcRng(None, RNG_INDEX_FN(lambda ctx, c, n: int(uniform_index(c, n))),
+                 RNG_F64_FN(lambda ctx, c, h: float(uniform_f64(c, h))))
+    rc = lib().orc_pq_kmeanspp(_p(x), x.shape[0], x.shape[1], _p(off), off.size - 1, ncenters, C.byref(rng), _p(cen), _p(sel))
+    return int(rc), cen, sel
 
 
 def pq_lloyds(data, chunk_offsets, centers, max_reps):

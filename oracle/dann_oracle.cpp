@@ -1724,6 +1724,88 @@ int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* 
  * (:273-296).  Norms of the centres are refreshed between iterations only (:334-350).
  * centers: ncenters x dim (chunk columns concatenated), assignments: nchunks x n (last assignment step),
  * residuals: nchunks. */
+/* ---- k-means++ seeding of the PQ trainer: kmeans::plusplus::kmeans_plusplus_into_inner
+ * (diskann-quantization/src/algorithms/kmeans/plusplus.rs:366-497) for every chunk, as LightPQTrainingParameters::train
+ * calls it (product/train.rs:164-197).  The two random draws of the algorithm come from the caller's generator
+ * (the reference seeds rand's StdRng per chunk, random.rs:33-44; that generator is not part of the reference tree):
+ *   uniform_index(ctx, chunk, n)   == Uniform::new(0, n).sample(rng)           first centre
+ *   uniform_f64(ctx, chunk, high)  == Uniform::<f64>::new(0.0, high).sample(rng)  D^2 threshold
+ * update_distances (:239-311) with the BlockTransposed<f32, 16> micro-kernel (:87-237): per row one fma chain over
+ * the chunk's columns in order, times -2, distance = (norm + |centre|^2) + that, minimum with strict <, and the sum of
+ * the minima accumulated in f64 block by block (16 rows: lanes k and k + 8 paired, the 8 pair sums folded in order).
+ * Returns 0, or -2 when a non-finite total appears (FailureReason::SawInfinity); selected[c] < ncenters reports the
+ * recoverable failures (DatasetTooSmall / InsufficientDiversity: remaining centres stay zero). */
+int32_t orc_pq_kmeanspp(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
+                        uint32_t ncenters, const orc_rng* rng, float* centers, uint32_t* selected) {
+    if (!data || !chunk_offsets || !centers || !rng || !rng->uniform_index || !rng->uniform_f64) return -1;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t s0 = chunk_offsets[c], len = chunk_offsets[c + 1] - s0;
+        for (uint32_t j = 0; j < ncenters; ++j) std::fill(centers + (size_t)j * dim + s0, centers + (size_t)j * dim + s0 + len, 0.0f);
+        uint32_t sel = 0;
+        if (selected) selected[c] = 0;
+        if (n == 0 || ncenters == 0) continue; /* DatasetTooSmall / nothing to do */
+        std::vector<float> norms(n), mins(n, std::numeric_limits<float>::infinity());
+        for (uint64_t r = 0; r < n; ++r) norms[r] = pq_square_norm(data + r * dim + s0, len);
+        std::vector<uint8_t> picked(n, 0);
+        uint64_t first = rng->uniform_index(rng->ctx, c, n);
+        if (first >= n) return -1;
+        std::copy(data + first * dim + s0, data + first * dim + s0 + len, centers + s0);
+        picked[first] = 1;
+        float prev_norm = norms[first];
+        sel = 1;
+        const uint64_t limit = std::min<uint64_t>(ncenters, n);
+        for (uint64_t cur = 1; cur < limit; ++cur) {
+            const float* last = centers + (cur - 1) * dim + s0;
+            /* update_distances */
+            double rolling = 0.0;
+            for (uint64_t b0 = 0; b0 < n; b0 += 16) {
+                float curd[16];
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t row = b0 + r;
+                    if (row >= n) { /* finish_last: lanes past the end hold 0 and stay 0 */
+                        curd[r] = 0.0f;
+                        continue;
+                    }
+                    const float* x = data + row * dim + s0;
+                    float acc = 0.0f;
+                    for (uint32_t k = 0; k < len; ++k) acc = std::fma(x[k], last[k], acc);
+                    acc = acc * -2.0f;
+                    const float d = (norms[row] + prev_norm) + acc;
+                    if (d < mins[row]) mins[row] = d;
+                    curd[r] = mins[row];
+                }
+                double blk = 0.0;
+                for (int k = 0; k < 8; ++k) blk += (double)curd[k] + (double)curd[k + 8];
+                rolling += blk;
+            }
+            const double s = rolling;
+            bool got = false;
+            if (0.0 < s) { /* Uniform::<f64>::new(0.0, s): EmptyRange unless 0 < s */
+                if (!std::isfinite(s)) {
+                    if (selected) selected[c] = sel;
+                    return -2; /* NonFinite -> SawInfinity */
+                }
+                const double threshold = rng->uniform_f64(rng->ctx, c, s);
+                double acc = 0.0;
+                for (uint64_t i = 0; i < n; ++i) {
+                    acc += (double)mins[i];
+                    if (acc >= threshold && mins[i] > 0.0f && !picked[i]) {
+                        std::copy(data + i * dim + s0, data + i * dim + s0 + len, centers + cur * dim + s0);
+                        picked[i] = 1;
+                        prev_norm = norms[i];
+                        sel = (uint32_t)cur + 1;
+                        got = true;
+                        break;
+                    }
+                }
+            }
+            if (!got) break; /* InsufficientDiversity */
+        }
+        if (selected) selected[c] = sel;
+    }
+    return 0;
+}
+
 int32_t orc_pq_lloyds(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
                       uint32_t ncenters, float* centers, uint32_t max_reps, uint32_t* assignments, float* residuals) {
     if (!data || !chunk_offsets || !centers || ncenters == 0 || n == 0) return -1;

@@ -188,6 +188,15 @@ int32_t orc_pq_square_norms(const float* pivots, uint32_t ncenters, const uint32
                             uint32_t dim, float* norms);
 int64_t orc_pq_compress(const float* pivots, uint32_t ncenters, const uint32_t* chunk_offsets, uint32_t nchunks,
                         uint32_t dim, const float* rows, uint64_t n, uint8_t* codes);
+/* k-means++ seeding (kmeans_plusplus_into_inner, algorithms/kmeans/plusplus.rs:366-497) per chunk with the caller's
+ * random draws; centers: ncenters x dim (chunk columns of unselected centres are zero); selected: nchunks. */
+typedef struct {
+    void* ctx;
+    uint64_t (*uniform_index)(void* ctx, uint32_t chunk, uint64_t n);
+    double (*uniform_f64)(void* ctx, uint32_t chunk, double high);
+} orc_rng;
+int32_t orc_pq_kmeanspp(const float* data, uint64_t n, uint32_t dim, const uint32_t* chunk_offsets, uint32_t nchunks,
+                        uint32_t ncenters, const orc_rng* rng, float* centers, uint32_t* selected);
 /* PQ training minus the seeding: the Lloyd iterations of LightPQTrainingParameters::train
  * (product/train.rs:96-226, algorithms/kmeans/lloyds.rs:23-438) for every chunk; `centers` (ncenters x dim)
  * carries the initial centres in and the trained pivots out.  assignments: nchunks x n (optional), residuals:

@@ -277,3 +277,45 @@ def test_sq8_train_vs_oracle(n, dim):
         assert np.float32(gc) == wc and np.float32(gm) == wm
     with pytest.raises(da.DannError):
         da.sq8_train(x, 0.0)
+
+
+class _Draws:
+    def __init__(self, seed, nchunks):
+        self.g = [np.random.default_rng(seed + c) for c in range(nchunks)]
+
+    def index(self, c, n):
+        return int(self.g[c].integers(0, n))
+
+    def f64(self, c, high):
+        return float(self.g[c].random() * high)
+
+
+@pytest.mark.parametrize("n,dim,off,k", [(3000, 24, [0, 8, 16, 24], 64), (1000, 17, [0, 5, 17], 16), (777, 9, [0, 9], 256)])
+def test_pq_kmeanspp_and_train_vs_oracle(n, dim, off, k):
+    """k-means++ seeding and the whole LightPQTrainingParameters::train on the GPU, bit-identical to the oracle given the
+    same random draws (n not a multiple of 16: the partial block of update_distances; k = 256: the PQ default)."""
+    rng = np.random.default_rng(n + dim)
+    x = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 3.0, (1, dim))).astype(np.float32)
+    d1, d2 = _Draws(77, len(off) - 1), _Draws(77, len(off) - 1)
+    rc, ocen, osel = oracle.pq_kmeanspp(x, off, k, d1.index, d1.f64)
+    gcen, gsel = da.pq_kmeanspp(x, off, k, d2.index, d2.f64)
+    assert rc == 0 and np.array_equal(osel, gsel) and np.array_equal(bits(ocen), bits(gcen))
+    d3 = _Draws(78, len(off) - 1)
+    piv = da.pq_train(x, off, k, 6, d3.index, d3.f64)
+    d4 = _Draws(78, len(off) - 1)
+    _, seed_c, _ = oracle.pq_kmeanspp(x, off, k, d4.index, d4.f64)
+    want, _, _ = oracle.pq_lloyds(x, off, seed_c, 6)
+    assert np.array_equal(bits(piv), bits(want))
+
+
+def test_pq_kmeanspp_degenerate_inputs():
+    rng = np.random.default_rng(3)
+    few = np.repeat(rng.integers(-3, 4, (4, 6)).astype(np.float32), 30, axis=0)   # 4 distinct rows (exact arithmetic), 10 centres wanted
+    d1, d2 = _Draws(1, 1), _Draws(1, 1)
+    rc, ocen, osel = oracle.pq_kmeanspp(few, [0, 6], 10, d1.index, d1.f64)
+    gcen, gsel = da.pq_kmeanspp(few, [0, 6], 10, d2.index, d2.f64)
+    assert rc == 0 and osel[0] == 4 and np.array_equal(osel, gsel) and np.array_equal(bits(ocen), bits(gcen))
+    bad = rng.standard_normal((40, 6)).astype(np.float32)
+    bad[3, 2] = np.inf
+    with pytest.raises(da.DannError):
+        da.pq_kmeanspp(bad, [0, 6], 5, _Draws(2, 1).index, _Draws(2, 1).f64)

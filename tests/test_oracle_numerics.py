@@ -254,3 +254,68 @@ def test_unreadable_slots_equal_a_graph_without_them():
     plain.adj[:] = adj
     a, b = tagged.search_batch(q, 40, 2, 10), plain.search_batch(q, 40, 2, 10)
     assert all(np.array_equal(x, y) for x, y in zip(a[::2], b[::2]))
+
+
+class _Draws:
+    """deterministic stand-in for the per-chunk StdRng of the PQ trainer (the same draws go to the oracle and the GPU)"""
+
+    def __init__(self, seed, nchunks):
+        self.g = [np.random.default_rng(seed + c) for c in range(nchunks)]
+        self.log = []
+
+    def index(self, c, n):
+        v = int(self.g[c].integers(0, n))
+        self.log.append(("i", c, n, v))
+        return v
+
+    def f64(self, c, high):
+        v = float(self.g[c].random() * high)
+        self.log.append(("f", c, high, v))
+        return v
+
+
+def test_kmeanspp_post_conditions_and_d2_sampling():
+    """kmeans_plusplus_into_inner (plusplus.rs:366-497) as the reference's own tests state it: every selected centre is a
+    dataset row, no row twice; fewer distinct rows than centres -> the remaining centres stay zero (recoverable
+    InsufficientDiversity / DatasetTooSmall); and the D^2 rule itself, checked against a straight numpy re-derivation of
+    the running sums (same draws)."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((700, 20)).astype(np.float32)
+    off = [0, 7, 12, 20]
+    d = _Draws(5, 3)
+    rc, cen, sel = oracle.pq_kmeanspp(x, off, 32, d.index, d.f64)
+    assert rc == 0 and sel.tolist() == [32, 32, 32]
+    for c in range(3):
+        a, b = off[c], off[c + 1]
+        rows = {v.tobytes() for v in x[:, a:b]}
+        got = [v.tobytes() for v in cen[:, a:b]]
+        assert all(g in rows for g in got) and len(set(got)) == 32
+    # D^2 sampling re-derived: exact squared distances in f64 differ from the kernel's f32 values only in the last
+    # bits, so the pick is the same except when the threshold falls within rounding of a running sum (not the case here)
+    c, (a, b) = 0, (off[0], off[1])
+    xs = x[:, a:b].astype(np.float64)
+    draws = [e for e in d.log if e[1] == c]
+    first = draws[0][3]
+    assert np.array_equal(cen[0, a:b], x[first, a:b])
+    mins = ((xs - xs[first]) ** 2).sum(1)
+    picked = {first}
+    for k in range(1, 6):
+        thr = draws[k][3]
+        run = np.cumsum(mins)
+        cand = [i for i in range(x.shape[0]) if run[i] >= thr and mins[i] > 0 and i not in picked]
+        assert np.array_equal(cen[k, a:b], x[cand[0], a:b]), k
+        picked.add(cand[0])
+        mins = np.minimum(mins, ((xs - xs[cand[0]]) ** 2).sum(1))
+    # too few distinct rows
+    few = np.repeat(rng.integers(-3, 4, (5, 8)).astype(np.float32), 20, axis=0)  # integer entries: duplicate rows are at distance exactly 0
+    d2 = _Draws(9, 1)
+    rc, cen, sel = oracle.pq_kmeanspp(few, [0, 8], 12, d2.index, d2.f64)
+    assert rc == 0 and sel[0] == 5 and not cen[5:].any() and len({v.tobytes() for v in cen[:5]}) == 5
+    # fewer rows than centres
+    rc, cen, sel = oracle.pq_kmeanspp(x[:6], off, 9, _Draws(1, 3).index, _Draws(1, 3).f64)
+    assert rc == 0 and (sel == 6).all() and not cen[6:].any()
+    # a non-finite total is the unrecoverable SawInfinity
+    bad = x[:50].copy()
+    bad[7, 3] = np.inf
+    rc, _, _ = oracle.pq_kmeanspp(bad, off, 4, _Draws(2, 3).index, _Draws(2, 3).f64)
+    assert rc == -2
