@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # working sets far beyond the 256 MiB Infinity Cache, "n:dim:dist:R:pruned:l_build": the headline's row shape at 10 M
 # points (6.4 GB; the generator's per-blob density kept: 2 560 blobs) and config 5's row shape (1 M x 768, 3.3 GB)
-LARGE_DEFAULT = "10000000:128:sift_like:1:2560:32:28:100,1000000:768:sift_like:64:56:128"
+LARGE_DEFAULT = ("10000000:128:sift_like:1:2560:32:28:100,1000000:768:sift_like:64:56:128,"
+                 "1000000:768:sift_like:64:56:128:f16")
 
 
 def parse():
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
-    ap.add_argument("--only", default="", choices=["", "large", "large768", "gather", "sq8", "u8"],
+    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
                          "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
                          "u8 search kernel")
@@ -153,11 +154,13 @@ def main():
     if args.only in ("gather", "sq8", "u8"):
         print(json.dumps({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)}), flush=True)
         return
-    if args.only in ("large", "large768"):
+    if args.only in ("large", "large768", "large768f16"):
         args.only_large = True
         if args.only == "large768":
             specs = (LARGE_DEFAULT if args.large == "auto" else args.large).split(",")
             args.large = specs[1] if len(specs) > 1 else specs[0]
+        if args.only == "large768f16":  # config 5's replica: the same rows stored as f16 (Full<f16>)
+            args.large = "1000000:768:sift_like:64:56:128:f16"
     if args.only_large:
         rd = C.c_double(0.0)
         _ffi.lib().dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd))
@@ -464,7 +467,7 @@ def main():
             torch.cuda.empty_cache()
             specs = LARGE_DEFAULT if args.large == "auto" else args.large
             for i, spec in enumerate(specs.split(",")):
-                key = "roofline_large" if i == 0 else f"roofline_large_d{spec.split(':')[1]}"
+                key = "roofline_large" if i == 0 else f"roofline_large_d{spec.split(':')[1]}" + ("_f16" if spec.endswith(":f16") else "")
                 try:
                     out[key] = large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W,
                                              out["roofline"].get("measured_stream_read_GBps"))
@@ -605,14 +608,23 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
             "compress_seconds_incl_pcie": round(t_comp, 3)}
 
 
-def _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build, nq, max_batch):
+def _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build, nq, max_batch, f16=False):
     base, queries = make_data(torch, dev, n, dim, nq, dist, 0xD15CA11, 0xD15CA12)
     mean = base.double().mean(0).float()
     medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
-    start = base[medoid:medoid + 1].cpu().numpy()
-    prov = da.Provider(da.F32, da.L2, dim, n, R, start, device=local)
+    if f16:  # the reference's Full<f16> provider: rows and queries stored as f16 (ground truth stays on the f32 data)
+        rows = base.half()
+        start = rows[medoid:medoid + 1].cpu().numpy()
+        prov = da.Provider(da.F16, da.L2, dim, n, R, start, device=local)
+    else:
+        rows = base
+        start = base[medoid:medoid + 1].cpu().numpy()
+        prov = da.Provider(da.F32, da.L2, dim, n, R, start, device=local)
     for s0 in range(0, n, 1 << 21):
-        prov.set_elements(s0, base[s0:s0 + (1 << 21)].cpu().numpy())
+        prov.set_elements(s0, rows[s0:s0 + (1 << 21)].cpu().numpy())
+    if f16:
+        base = (base, rows)  # (f32 for the ground truth, f16 as stored)
+        queries = (queries, queries.half().contiguous())
     t0 = time.time()
     cfg = da.build_config(pruned, R, l_build, intra_batch_candidates=da.IBC_NONE)
     prov.build(cfg, 0, n, args.growth, max_batch)
@@ -675,20 +687,29 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     whole batch, and a sample of the queries is re-run through the CPU oracle on the same graph bytes."""
     import oracle
     f = spec.split(":")
+    f16 = f[-1] == "f16"
+    if f16:
+        f = f[:-1]
     n, dim = int(f[0]), int(f[1])
     dist = ":".join(f[2:-3])
     R, pruned, l_build = int(f[-3]), int(f[-2]), int(f[-1])
     nq, ngt = args.nq, min(args.nq, 10000)
     max_batch = 65536 if n >= 4_000_000 and dim <= 256 else 16384
     prov, base, queries, start, t_build = _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build, nq,
-                                                        max_batch)
+                                                        max_batch, f16=f16)
+    stored = base
+    if f16:
+        (base, stored), (queries32, queries) = base, queries
+    else:
+        queries32 = queries
+    esz, tname, odt = (2, "f16", oracle.F16) if f16 else (4, "f32", oracle.F32)
     sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]
     if args.L:  # profiling passes: fixed L, no ground truth
         gt = np.zeros((ngt, k), np.int64)
         L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, [args.L], -1.0)
         rec, reached = float("nan"), False
     else:
-        gt = ground_truth(torch, base, queries[:ngt], k)
+        gt = ground_truth(torch, base, queries32[:ngt], k)
         L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, sweep, args.target_recall)
         reached = L is not None
     L = L or sweep[-1]
@@ -702,11 +723,11 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     dt = (time.perf_counter() - t0) / 5
     ms, launches = prov.kernel_time(0)
     avg_ms = ms / max(launches, 1)
-    row_bytes, adj_bytes = dim * 4, (R + 1) * 4
+    row_bytes, adj_bytes = dim * esz, (R + 1) * 4
     alg = int(st[:, 0].sum()) * row_bytes + int(st[:, 1].sum()) * adj_bytes
     achieved = alg / (avg_ms * 1e-3) / 1e9
     res = {
-        "workload": f"batched beam search over a {n}x{dim} f32 index ({dist}; {n * row_bytes / 1e9:.1f} GB rows + "
+        "workload": f"batched beam search over a {n}x{dim} {tname} index ({dist}; {n * row_bytes / 1e9:.1f} GB rows + "
                     f"{(n + 1) * adj_bytes / 1e9:.1f} GB adjacency resident in HBM), {nq} queries/launch, k=10, L={L}, "
                     f"beam_width={W}; Vamana R={R} (pruned {pruned}), l_build={l_build}, built on the GPU in "
                     f"{t_build:.1f} s",
@@ -725,9 +746,9 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     # parity at this scale: a sample of the batch through the CPU oracle on the same rows and graph
     ms_n = 256
     adj = prov.download_graph()
-    oix = oracle.Index(oracle.F32, oracle.L2, dim, n, R, start)
+    oix = oracle.Index(odt, oracle.L2, dim, n, R, start)
     for s0 in range(0, n, 1 << 21):
-        blk = base[s0:s0 + (1 << 21)].cpu().numpy()
+        blk = stored[s0:s0 + (1 << 21)].cpu().numpy()
         oix.rows[s0:s0 + blk.shape[0], :] = blk.view(np.uint8).reshape(blk.shape[0], -1)
     oix.adj[:] = adj
     qh = queries[:ms_n].cpu().numpy()

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdann_hip.so")
+# DANN_LIB_PATH: developer hook for A/B builds of the library (scratch/); the default is the in-tree build
+LIB_PATH = os.environ.get("DANN_LIB_PATH") or os.path.join(_HERE, "libdann_hip.so")
 
 F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3

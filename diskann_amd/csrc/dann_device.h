@@ -196,6 +196,14 @@ __device__ __forceinline__ float group_distance_raw(const QT* __restrict__ q, co
         }
     }
     const int rem = dim & 7;
+    RT ty[4];
+    if (rem) {  // all four requests issued together (index clamped into the block)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * (v & 1) + i;
+            ty[i] = row[full_end + (l < rem ? l : 0)];
+        }
+    }
     // partial block: zero-padded masked load accumulated into the *combined* vector
     // (simd.rs:735-745, SIMDSchema::epilogue :545-563)
     auto partial = [&](float(&a)[4], int which) {
@@ -206,7 +214,7 @@ __device__ __forceinline__ float group_distance_raw(const QT* __restrict__ q, co
             float x = 0.0f, y = 0.0f;
             if (l < rem) {
                 x = load1(q + full_end + l);
-                y = load1(row + full_end + l);
+                y = to_f32(ty[i]);
             }
             if (OP == OP_L2) {
                 float c = x - y;
@@ -244,11 +252,9 @@ __device__ __forceinline__ float group_distance_pair(const RT* __restrict__ x, c
     if (rem) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int l = 4 * (v & 1) + i;
-            if (l < rem) {
-                tx[i] = x[full_end + l];
-                ty[i] = y[full_end + l];
-            }
+            const int l = 4 * (v & 1) + i, lc = l < rem ? l : 0;  // clamped, unconditional: no branch, no wait
+            tx[i] = x[full_end + lc];
+            ty[i] = y[full_end + lc];
         }
     }
     constexpr int T = 4;
@@ -352,8 +358,7 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
         for (int i = 0; i < 4; ++i) {
             const int l = 4 * (v & 1) + i;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (l < rem && active[u]) ty[u][i] = rows[u][full_end + l];
+            for (int u = 0; u < U; ++u) ty[u][i] = rows[u][full_end + (l < rem ? l : 0)];  // unconditional: no branch, no wait
         }
     }
     // T trips of loads are issued before the first FMA: U*T 16-byte requests in flight per lane
@@ -480,6 +485,10 @@ __device__ __forceinline__ float finish_wide(float (&a)[8], const float (&px)[8]
     return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
 }
 
+#ifndef DANN_WIDE_TRIPS
+#define DANN_WIDE_TRIPS 4
+#endif
+constexpr int kWideTrips = DANN_WIDE_TRIPS;
 template <int NACC, int OP, int U, typename QT, typename RT>
 __device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, const RT* const (&rows)[U],
                                                     const bool (&active)[U], int dim, int w, float (&out)[U]) {
@@ -490,15 +499,30 @@ __device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, co
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[u][i] = nx[u][i] = ny[u][i] = 0.0f;
-    constexpr int T = 4;
+    // the partial block (dim % 8 != 0) is requested first, unconditionally (index clamped into the block), so
+    // it travels with the main loads instead of costing `rem` dependent round trips after them
+    const int rem = dim & 7;
+    RT ry[U][8];
+    if (rem) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ry[u][i] = rows[u][full_end + (i < rem ? i : 0)];
+    }
+    constexpr int T = kWideTrips;
     for (int e0 = 8 * w; e0 < full_end; e0 += TRIP * T) {
+        // All T*U 16-byte requests of a trip are issued back to back, unconditionally: a load under a per-lane
+        // condition is compiled as a branch with its own s_waitcnt vmcnt(0), which leaves ONE request in
+        // flight per wave (measured: 1 M x 768 f16 at 3.65 TB/s, the same time as the f32 rows).  Out-of-range
+        // trips re-read the trip's first block and inactive rows point at row 0 (the caller's contract), so
+        // every address is valid; their values are never used.
         uint4 raw[T][U];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int e = e0 + t * TRIP;
+            const int el = e < full_end ? e : e0;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (e < full_end && active[u]) raw[t][u] = *reinterpret_cast<const uint4*>(rows[u] + e);
+            for (int u = 0; u < U; ++u) raw[t][u] = *reinterpret_cast<const uint4*>(rows[u] + el);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -507,8 +531,7 @@ __device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, co
             const F8v x = load8(q + e);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (!active[u]) continue;
-                const F8v y = cvt8<RT>(raw[t][u]);
+                const F8v y = cvt8<RT>(raw[t][u]);  // inactive rows: computed and discarded
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (OP == OP_L2) {
@@ -525,7 +548,6 @@ __device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, co
             }
         }
     }
-    const int rem = dim & 7;
     float px[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) px[i] = (rem && i < rem) ? load1(q + full_end + i) : 0.0f;
@@ -533,7 +555,7 @@ __device__ __forceinline__ void group_distance_wide(const QT* __restrict__ q, co
     for (int u = 0; u < U; ++u) {
         float py[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) py[i] = (rem && active[u] && i < rem) ? load1(rows[u] + full_end + i) : 0.0f;
+        for (int i = 0; i < 8; ++i) py[i] = (rem && i < rem) ? to_f32(ry[u][i]) : 0.0f;
         float r = finish_wide<NACC>(s[u], px, py, rem, OP == OP_L2 ? 0 : 1);
         if (OP == OP_COS) {
             float a = finish_wide<NACC>(nx[u], px, py, rem, 2);
@@ -712,7 +734,10 @@ __device__ __forceinline__ float group_distance_rows(const uint8_t* x, const uin
     }
 }
 
-template <int DT, int OP, bool PAIR, int U, typename QT>
+// U rows per lane group at once.  Contract: rows[u] is a readable row address even when !active[u] (callers pass
+// row 0): the loads are issued unconditionally so that none of them sits behind a branch with its own wait.
+// WIDE = false keeps the G-lane layout for 2-byte rows (kernels whose lane groups are Scheme::G wide).
+template <int DT, int OP, bool PAIR, int U, bool WIDE = true, typename QT>
 __device__ __forceinline__ void group_distance_many(const QT* q, const uint8_t* const (&rows)[U],
                                                     const bool (&active)[U], int dim, int v, float (&out)[U]) {
     if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {
@@ -722,7 +747,7 @@ __device__ __forceinline__ void group_distance_many(const QT* q, const uint8_t* 
         const RT* typed[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) typed[u] = reinterpret_cast<const RT*>(rows[u]);
-        if constexpr (Scheme<DT, OP, PAIR>::kWide)
+        if constexpr (Scheme<DT, OP, PAIR>::kWide && WIDE)
             group_distance_wide<Scheme<DT, OP, PAIR>::NACC, OP, U>(q, typed, active, dim, v, out);
         else
             group_distance_multi<Scheme<DT, OP, PAIR>::NACC, OP, U>(q, typed, active, dim, v, out);

@@ -125,12 +125,8 @@ __global__ __launch_bounds__(kWave) void rerank_kernel(IndexView ix, const void*
             act[u] = c < n;
             rows[u] = ix.rows + (uint64_t)(act[u] ? cid[c] : 0u) * ix.row_stride;
         }
-        if constexpr (S::kWide) {  // wide groups are a search-kernel layout; here G = S::G lanes per row
-            for (int u = 0; u < U; ++u)
-                o[u] = act[u] ? group_distance<DT, OP, false, 0>(qs, rows[u], (int)ix.dim, v) : 0.0f;
-        } else {
-            group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, o);
-        }
+        // (wide groups are a search-kernel layout; here G = S::G lanes per row for every row type)
+        group_distance_many<DT, OP, false, U, false>(qs, rows, act, (int)ix.dim, v, o);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t c = c0 + u * GROUPS + g;

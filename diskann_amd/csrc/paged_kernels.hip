@@ -138,12 +138,7 @@ __global__ __launch_bounds__(kWave) void paged_kernel(PagedArgs a) {
                 act[u] = c < nc;
                 rows[u] = ix.rows + (uint64_t)(act[u] ? cand_id[c] : 0u) * ix.row_stride;
             }
-            if constexpr (S::kWide) {
-                for (int u = 0; u < U; ++u)
-                    o[u] = act[u] ? group_distance<DT, OP, false, 0>(qs, rows[u], (int)ix.dim, v) : 0.0f;
-            } else {
-                group_distance_many<DT, OP, false, U>(qs, rows, act, (int)ix.dim, v, o);
-            }
+            group_distance_many<DT, OP, false, U, false>(qs, rows, act, (int)ix.dim, v, o);  // G-lane groups
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t c = c0 + u * GROUPS + g;

@@ -16,6 +16,10 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxBeam = 16;
 constexpr int kGatherRows = 4;
+#ifndef DANN_WIDE_ROWS
+#define DANN_WIDE_ROWS 2
+#endif
+constexpr int kWideRows = DANN_WIDE_ROWS;  // rows per lane group and trip in the wide (f16) gather
 constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
 constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
 constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                 if (tg < kTagPublished) cand_id[c] = kEmpty;
             }
         } else {
-            constexpr int U = S::kWide ? 2 : kGatherRows;
+            constexpr int U = S::kWide ? kWideRows : kGatherRows;
             for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
                 const uint8_t* rows[U];
                 bool act[U];
