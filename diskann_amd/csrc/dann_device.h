@@ -318,9 +318,7 @@ __device__ __forceinline__ void group_distance_pre(const F4 (&xs)[DIM / (8 * NAC
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (active[u]) ys[u][t].load(rows[u] + t * TRIP + 4 * v);
-        }
+        for (int t = 0; t < NT; ++t) ys[u][t].load(rows[u] + t * TRIP + 4 * v);  // unconditional (see group_distance_many)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -368,9 +366,9 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int e = e0 + t * TRIP;
+            const int el = e < full_end ? e : e0;  // clamped: every request is issued, none behind a branch
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (e < full_end && active[u]) ys[t][u].load(rows[u] + e);
+            for (int u = 0; u < U; ++u) ys[t][u].load(rows[u] + el);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -378,8 +376,7 @@ __device__ __forceinline__ void group_distance_multi(const QT* __restrict__ q, c
             if (e < full_end) {
                 const F4 x = load4(q + e);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (active[u]) acc[u].step(x, ys[t][u].get());
+                for (int u = 0; u < U; ++u) acc[u].step(x, ys[t][u].get());  // inactive rows: computed, discarded
             }
         }
     }
@@ -628,13 +625,11 @@ __device__ __forceinline__ void group_distance_int_multi(const uint8_t* __restri
     for (int e = 16 * v; e < vec_end; e += 128) {
         uint4 ys[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (active[u]) ys[u] = *reinterpret_cast<const uint4*>(rows[u] + e);
+        for (int u = 0; u < U; ++u) ys[u] = *reinterpret_cast<const uint4*>(rows[u] + e);  // unconditional
         const uint4 x = *reinterpret_cast<const uint4*>(q + e);
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!active[u]) continue;
             const uint32_t yw[4] = {ys[u].x, ys[u].y, ys[u].z, ys[u].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
