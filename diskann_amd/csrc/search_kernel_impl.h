@@ -173,10 +173,18 @@ __device__ __forceinline__ float f32_load(const float* p) {
                                                        __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// FILT = false compiles every filtered-search branch out (the plain Knn / Range / record kernels keep their
-// register budget); filtered launches use the generic-length instantiations.
-template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
+// MODE selects what is compiled in (every switch below is wave-uniform at run time; as a run-time switch each one
+// costs scalar compares, branches and live SGPRs in every hop -- the hop is issue-bound, §3.2 of DESIGN.md):
+//   kModePlain    beam_width == 1, no inline tags, max_degree <= 64, no filter: the Knn / Range / record search of
+//                 a published store (every benchmark configuration).  Same-box A/B against kModeGeneral on the
+//                 same launch: single query L = 64 235 -> 217 us, 1024 concurrent queries +8 %.
+//   kModeGeneral  any beam width, inline tags, any degree; no filter
+//   kModeFiltered the filtered searches (inline / multihop / AdaptiveL); generic-length instantiations only
+enum : int { kModePlain = 0, kModeGeneral = 1, kModeFiltered = 2 };
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE>
 __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
+    constexpr bool FILT = MODE == kModeFiltered;
+    constexpr bool PLAIN = MODE == kModePlain;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using S = Scheme<DT, OP, false>;
     constexpr int G = (DIM > 0) ? S::G : S::GS;  // fixed-length path: narrow groups, query slice in registers
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t qi = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;
     const uint32_t R = ix.max_degree;
-    const uint32_t W = a.beam_width;
+    const uint32_t W = PLAIN ? 1u : a.beam_width;
     uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207); AdaptiveL may grow it
     const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
                                                                               : ((ix.nstart + 63u) & ~63u);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     // the tag byte of each row is requested together with the row (no extra round trip), an unreadable slot
     // (tag < PUBLISHED) is marked kEmpty and compacted away afterwards -- expand_beam_inner skips it after the
     // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
-    const uint32_t tag_off = ix.tag_off;
+    const uint32_t tag_off = PLAIN ? 0u : ix.tag_off;
     auto gather = [&](uint32_t nc) -> uint32_t {
         if constexpr (DIM > 0 && !kInt) {
             constexpr int U = kGatherRows;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         // adjacency row of the best unexpanded entry of the *current* queue; if no new
         // candidate beats it, the next hop starts without a dependent HBM round trip.
         pf_node = kEmpty;
-        if (W == 1 && R <= (uint32_t)kWave) {
+        if (PLAIN || (W == 1 && R <= (uint32_t)kWave)) {
             pf_node = pf_next;
             if (pf_node != kEmpty) {
                 const uint32_t* prow = ix.adj + (uint64_t)pf_node * ix.adj_stride;
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             for (uint32_t m0 = 0; m0 < nc; m0 += kWave) merge(m0, (nc - m0) < (uint32_t)kWave ? (nc - m0) : (uint32_t)kWave);
             // AdaptiveL (inline_filter_search.rs:262-277): one resize, decided from the hit rate so far; the new
             // L comes from a table the host filled with compute_adaptive_l (f64 log10 / powf of the host libm)
-            if (a.ad_samples && !l_adjusted && sample_visited >= a.ad_samples) {
+            if (FILT && a.ad_samples && !l_adjusted && sample_visited >= a.ad_samples) {
                 l_adjusted = true;
                 const uint32_t new_l = a.ad_table[(uint64_t)(sample_visited - a.ad_samples) * a.ad_stride + sample_matched];
                 if (new_l > a.l_value) {  // NeighborPriorityQueue::reconfigure (queue.rs:339-353)
@@ -1188,9 +1196,9 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     }
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM, bool FILT>
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, FILT>;
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE>;
     if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
         hipFuncAttributes attr;
         hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
@@ -1215,21 +1223,23 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
     return DANN_OK;
 }
 
-template <int DT, int OP, bool NORM, int DIM, bool FILT>
+template <int DT, int OP, bool NORM, int DIM, int MODE>
 int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, FILT>(a, lds, stream, regs_out);
-    if (qcap <= 1024) return launch_one<DT, OP, NORM, 16, DIM, FILT>(a, lds, stream, regs_out);
+    if (qcap <= 64) return launch_one<DT, OP, NORM, 1, DIM, MODE>(a, lds, stream, regs_out);
+    if (qcap <= 128) return launch_one<DT, OP, NORM, 2, DIM, MODE>(a, lds, stream, regs_out);
+    if (qcap <= 256) return launch_one<DT, OP, NORM, 4, DIM, MODE>(a, lds, stream, regs_out);
+    if (qcap <= 512) return launch_one<DT, OP, NORM, 8, DIM, MODE>(a, lds, stream, regs_out);
+    if (qcap <= 1024) return launch_one<DT, OP, NORM, 16, DIM, MODE>(a, lds, stream, regs_out);
     set_error("search list size L + start points = %u exceeds the supported maximum of 1024", qcap);
     return DANN_EUNSUPPORTED;
 }
 
 template <int DT, int OP, bool NORM, int DIM>
 int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, true>(a, qcap, lds, stream, regs_out);
-    return launch_qs2<DT, OP, NORM, DIM, false>(a, qcap, lds, stream, regs_out);
+    if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, kModeFiltered>(a, qcap, lds, stream, regs_out);
+    if (a.beam_width == 1 && a.ix.tag_off == 0 && a.ix.max_degree <= (uint32_t)kWave)
+        return launch_qs2<DT, OP, NORM, DIM, kModePlain>(a, qcap, lds, stream, regs_out);
+    return launch_qs2<DT, OP, NORM, DIM, kModeGeneral>(a, qcap, lds, stream, regs_out);
 }
 
 template <int DT>

@@ -47,7 +47,7 @@ summary = {
               f"launch (grid {nq} workgroups x 64)",
     "workload": {"nq": nq, "L": bench["config"]["L"], "beam_width": bench["config"]["beam_width"], "n": 1000000,
                  "dim": 128},
-    "kernel": "beam_search_kernel<F32, L2, QS=1, DIM=128, FILT=0>",
+    "kernel": "beam_search_kernel<F32, L2, QS=1, DIM=128, MODE=plain>",
     "FETCH_SIZE_kb_per_launch": fetch_kb,
     "WRITE_SIZE_kb_per_launch": write_kb,
     "fetch_correction": "x2 on gfx950 for 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
