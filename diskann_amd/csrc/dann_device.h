@@ -662,6 +662,44 @@ __device__ __forceinline__ void group_distance_int_multi(const uint8_t* __restri
     }
 }
 
+// Fixed 128-byte integer rows: the lane's 16 query bytes (`x`) and the query's squared norm (`xx`, the same for
+// every row, summed once per search) stay in registers; per row only xy and yy are accumulated.  Integer sums:
+// any order is bit-identical.  Valid in lane v == 0; rows[] must all be readable (see group_distance_many).
+template <int OP, bool SIGNED, int U>
+__device__ __forceinline__ void group_distance_int_pre(const uint4& x, int xx, const uint8_t* const (&rows)[U], int v,
+                                                       float (&out)[U]) {
+    uint4 ys[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ys[u] = *reinterpret_cast<const uint4*>(rows[u] + 16 * v);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t yw[4] = {ys[u].x, ys[u].y, ys[u].z, ys[u].w};
+        int xy = 0, yy = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xy = dot4<SIGNED>(xs[i], yw[i], xy);
+            if (OP != OP_IP) yy = dot4<SIGNED>(yw[i], yw[i], yy);
+        }
+        const int sxy = group8_sum(xy);
+        if (OP == OP_IP) {
+            out[u] = (float)sxy;
+            continue;
+        }
+        const int syy = group8_sum(yy);
+        if (OP == OP_L2) out[u] = (float)(int)((uint32_t)xx + (uint32_t)syy - 2u * (uint32_t)sxy);
+        else out[u] = cosine_finish((float)xx, (float)syy, (float)sxy);
+    }
+}
+template <bool SIGNED>
+__device__ __forceinline__ int group_norm_int_pre(const uint4& x) {
+    int xx = dot4<SIGNED>(x.x, x.x, 0);
+    xx = dot4<SIGNED>(x.y, x.y, xx);
+    xx = dot4<SIGNED>(x.z, x.z, xx);
+    xx = dot4<SIGNED>(x.w, x.w, xx);
+    return group8_sum(xx);
+}
+
 // ---- dtype dispatch ------------------------------------------------------------------
 // Query-side staging type and group width for the *search* path
 // (Full<T>::query_distance, diskann-inmem/src/layers/full.rs:351-504):

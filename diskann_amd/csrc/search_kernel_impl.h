@@ -256,6 +256,15 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
         for (int t = 0; t < NTQ; ++t) xq[t] = load4(reinterpret_cast<const float*>(qs) + t * 4 * G + 4 * v);
     }
 
+    // 128-byte integer rows: the lane's 16 query bytes and the query's squared norm in registers
+    uint4 xqi = {0u, 0u, 0u, 0u};
+    int xx_pre = 0;
+    if constexpr (DIM > 0 && kInt) {
+        static_assert(!kInt || DIM == 0 || DIM == 128, "integer rows: only the 128-byte length is specialised");
+        xqi = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(qs) + 16 * v);
+        xx_pre = group_norm_int_pre<DT == DT_I8>(xqi);
+    }
+
     // ---- queue state: entry p at lane p % 64, slot p / 64 ------------------------------
     uint32_t qid[QS];
     float qd[QS];
@@ -334,6 +343,35 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
                     uint32_t c = c0 + u * GROUPS + g;
                     if (act[u] && v == 0) {
                         cand_d[c] = post_op<OP, NORM>(out[u]);  // float rows only
+                        if (tag_off && tg[u] < kTagPublished) cand_id[c] = kEmpty;
+                    }
+                }
+            }
+        } else if constexpr (DIM > 0 && kInt) {
+            constexpr int U = kGatherRows;
+            for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
+                const uint8_t* rows[U];
+                bool act[U];
+                float out[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    act[u] = c < nc;
+                    uint32_t id = act[u] ? cand_id[c] : 0u;
+                    rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
+                }
+                uint8_t tg[U];
+                if (tag_off) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) tg[u] = (act[u] && v == 0) ? rows[u][tag_off] : (uint8_t)255;
+                }
+                group_distance_int_pre<OP, DT == DT_I8, U>(xqi, xx_pre, rows, v, out);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t c = c0 + u * GROUPS + g;
+                    if (act[u] && v == 0) {
+                        cand_d[c] = finish_distance<DT, OP, NORM>(out[u], reinterpret_cast<const uint8_t*>(qs), rows[u],
+                                                                  ix.dim, sqp);
                         if (tag_off && tg[u] < kTagPublished) cand_id[c] = kEmpty;
                     }
                 }
@@ -1255,7 +1293,13 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
             if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream, regs_out);
         }
         if constexpr (DT == DT_SQ8) {
-            if (norm) return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream, regs_out);
+            if (norm) {
+                if (a.ix.dim == 128) return launch_qs<DT, OP_L2, true, 128>(a, qcap, lds, stream, regs_out);
+                return launch_qs<DT, OP_L2, true, 0>(a, qcap, lds, stream, regs_out);
+            }
+        }
+        if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {  // 128-byte integer rows (C-int8)
+            if (a.ix.dim == 128) return launch_qs<DT, OP_L2, false, 128>(a, qcap, lds, stream, regs_out);
         }
         return launch_qs<DT, OP_L2, false, 0>(a, qcap, lds, stream, regs_out);
     }
@@ -1263,7 +1307,13 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
         if constexpr (DT == DT_F32 || DT == DT_F16) {
             if (norm) return launch_qs<DT, OP_IP, true, 0>(a, qcap, lds, stream, regs_out);
         }
+        if constexpr (DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8) {
+            if (a.ix.dim == 128) return launch_qs<DT, OP_IP, false, 128>(a, qcap, lds, stream, regs_out);
+        }
         return launch_qs<DT, OP_IP, false, 0>(a, qcap, lds, stream, regs_out);
+    }
+    if constexpr (DT == DT_U8 || DT == DT_I8) {
+        if (a.ix.dim == 128) return launch_qs<DT, OP_COS, false, 128>(a, qcap, lds, stream, regs_out);
     }
     if constexpr (DT != DT_SQ8 && DT != DT_PQ) return launch_qs<DT, OP_COS, false, 0>(a, qcap, lds, stream, regs_out);
     return DANN_EUNSUPPORTED;

@@ -1,9 +1,5 @@
 #!/bin/sh
-# A/B: scratch/bin/libdann_base.so vs the in-tree library: latency lab (tune 0), u8 / sq8 search-only; then the parity tests
-for v in ${VARIANTS:-base new base new}; do
-  if [ $v = new ]; then unset DANN_LIB_PATH; else export DANN_LIB_PATH=$PWD/scratch/bin/libdann_$v.so; fi
-  echo "=== $v"; timeout 200 python scratch/latency_lab.py --tunes 0 2>&1 | grep -v "amdgpu.ids\|DANN_TUNE"
-done
+# A/B: scratch/bin/libdann_base.so vs the in-tree library on the u8 / sq8 search-only workloads; then the parity tests
 for v in ${VARIANTS:-base new base new}; do
   if [ $v = new ]; then unset DANN_LIB_PATH; else export DANN_LIB_PATH=$PWD/scratch/bin/libdann_$v.so; fi
   for w in u8 sq8; do

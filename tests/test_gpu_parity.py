@@ -136,6 +136,9 @@ SEARCH_CASES = [
     (oracle.F16, oracle.COSINE_NORMALIZED, 72, 20, 0),
     (oracle.U8, oracle.L2, 128, 32, 0),
     (oracle.I8, oracle.COSINE, 100, 16, 0),
+    (oracle.I8, oracle.L2, 128, 32, 0),          # 128-byte integer rows: query slice and norm in registers
+    (oracle.I8, oracle.INNER_PRODUCT, 128, 24, 0),
+    (oracle.U8, oracle.COSINE, 128, 16, 0),
 ]
 
 
