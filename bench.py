@@ -382,6 +382,19 @@ def main():
             lat = timed_small(1, 64, 200)
             t1024 = timed_small(1024, chosen, 50)
             t10k = timed_small(10000, chosen, 20)
+            # configs[2] as a server sees it: 1024 searches kept in flight (dann_set_max_concurrency: 1024 persistent
+            # wavefronts share the queries of a call; a finished search is replaced at once, not at the batch's end)
+            prov.set_max_concurrency(1024)
+            nsus = min(20480, args.nq)
+            tsus = timed_small(nsus, chosen, 20)
+            tsus64 = timed_small(nsus, 64, 10)
+            prov.set_max_concurrency(0)
+            out["other_configs"].update({
+                "sustained_1024_in_flight_qps_at_L": nsus / tsus,
+                "sustained_1024_in_flight_mean_latency_us_at_L": 1024 * tsus / nsus * 1e6,
+                "sustained_1024_in_flight_qps_L64": nsus / tsus64,
+                "sustained_1024_in_flight_queries_per_call": nsus,
+            })
             out["other_configs"].update({
                 "single_query_L64_latency_us": lat * 1e6,
                 "single_query_L64_qps": 1.0 / lat,

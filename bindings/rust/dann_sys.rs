@@ -106,6 +106,7 @@ extern "C" {
     pub fn dann_kernel_time(a0: *mut c_void, a1: i32, a2: *mut f64, a3: *mut u64) -> i32;
     pub fn dann_kernel_time_reset(a0: *mut c_void) -> i32;
     pub fn dann_set_visited_bits(a0: *mut c_void, a1: u32) -> i32;
+    pub fn dann_set_max_concurrency(a0: *mut c_void, a1: u32) -> i32;
 }
 
 fn check(status: i32) -> diskann::ANNResult<i32> {

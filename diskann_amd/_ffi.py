@@ -123,6 +123,7 @@ SYMBOLS = {
     "dann_kernel_time": (_i32, [_vp, _i32, _P(C.c_double), _P(_u64)]),
     "dann_kernel_time_reset": (_i32, [_vp]),
     "dann_set_visited_bits": (_i32, [_vp, _u32]),
+    "dann_set_max_concurrency": (_i32, [_vp, _u32]),
 }
 
 _lib = None

@@ -1376,4 +1376,10 @@ int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) try {
     return DANN_OK;
 } DANN_CATCH_ALL
 
+int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight) try {
+    if (!idx) return DANN_EINVAL;
+    idx->max_concurrency = max_queries_in_flight;
+    return DANN_OK;
+} DANN_CATCH_ALL
+
 }  // extern "C"

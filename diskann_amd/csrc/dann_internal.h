@@ -118,6 +118,8 @@ struct SearchArgs {
     unsigned long long* phase_cycles = nullptr;  // -DDANN_PHASE_CYCLES builds only
     uint32_t qcap_max = 0;           // largest queue capacity an adaptive resize can ask for (0 = l_value + nstart)
     uint32_t tune = 0;               // kTune* bits, chosen per launch by search_with_retry (never affect results)
+    uint32_t grid = 0;               // 0: one wave per query; else `grid` persistent waves share the nq queries through
+    uint32_t* work_next = nullptr;   //    this counter (zeroed before the launch): dann_set_max_concurrency
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out = nullptr);
@@ -166,6 +168,7 @@ struct dann_index {
     uint32_t layer_bytes = 0;
     uint32_t nslots = 0;
     uint32_t visited_bits = 0;
+    uint32_t max_concurrency = 0;  // dann_set_max_concurrency: queries in flight per search call (0 = all of them)
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
     // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of

@@ -182,10 +182,9 @@ __device__ __forceinline__ float f32_load(const float* p) {
 //   kModeFiltered the filtered searches (inline / multihop / AdaptiveL); generic-length instantiations only
 enum : int { kModePlain = 0, kModeGeneral = 1, kModeFiltered = 2 };
 template <int DT, int OP, bool NORM, int QS, int DIM, int MODE>
-__global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
+__device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint32_t slot, uint8_t* smem) {
     constexpr bool FILT = MODE == kModeFiltered;
     constexpr bool PLAIN = MODE == kModePlain;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using S = Scheme<DT, OP, false>;
     constexpr int G = (DIM > 0) ? S::G : S::GS;  // fixed-length path: narrow groups, query slice in registers
     constexpr int GROUPS = kWave / G;
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
     const IndexView& ix = a.ix;
     const uint32_t lane = threadIdx.x;
-    const uint32_t qi = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;
+    const uint32_t qi = a.qmap ? a.qmap[slot] : slot;
     const uint32_t R = ix.max_degree;
     const uint32_t W = PLAIN ? 1u : a.beam_width;
     uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207); AdaptiveL may grow it
@@ -1234,9 +1233,40 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     }
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE>
+// One wave per query (grid = nq) or, PERSIST -- dann_set_max_concurrency -- `grid` persistent waves that take the
+// launch's queries one after the other from a shared counter: a server that keeps N queries in flight is not held
+// up by the slowest query of each batch of N (the tail is 2.3x the mean search at N = 1024).  Results do not depend
+// on it.  A separate instantiation (plain mode only): the loop around the body costs the one-wave-per-query
+// launch 3-5 % when it is compiled into the same kernel.
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, bool PERSIST>
+__global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if constexpr (!PERSIST) {
+        beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, blockIdx.x, smem);
+    } else {
+        uint32_t slot = blockIdx.x;
+        for (;;) {
+            uint32_t nxt = 0;  // the ticket for the search after this one is drawn now: its round trip hides behind the search
+            if (threadIdx.x == 0) nxt = atomicAdd(a.work_next, 1u);
+            beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, slot, smem);
+            __syncthreads();  // the next query reuses this wave's LDS
+            slot = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+            if (slot >= a.nq) break;
+        }
+    }
+}
+
+// what kModePlain assumes (checked by the host for every launch)
+inline bool plain_mode(const SearchArgs& a) {
+    return !a.filter_mode && a.beam_width == 1 && a.ix.tag_off == 0 && a.ix.max_degree <= (uint32_t)kWave;
+}
+
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, bool PERSIST = false>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE>;
+    if constexpr (MODE == kModePlain && !PERSIST) {
+        if (a.grid && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, true>(a, lds, stream, regs_out);
+    }
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, PERSIST>;
     if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
         hipFuncAttributes attr;
         hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
@@ -1255,7 +1285,7 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(kWave), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(PERSIST ? a.grid : a.nq), dim3(kWave), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
     return DANN_OK;
@@ -1275,7 +1305,7 @@ int32_t launch_qs2(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t s
 template <int DT, int OP, bool NORM, int DIM>
 int32_t launch_qs(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
     if (a.filter_mode) return launch_qs2<DT, OP, NORM, 0, kModeFiltered>(a, qcap, lds, stream, regs_out);
-    if (a.beam_width == 1 && a.ix.tag_off == 0 && a.ix.max_degree <= (uint32_t)kWave)
+    if (plain_mode(a))
         return launch_qs2<DT, OP, NORM, DIM, kModePlain>(a, qcap, lds, stream, regs_out);
     return launch_qs2<DT, OP, NORM, DIM, kModeGeneral>(a, qcap, lds, stream, regs_out);
 }

@@ -194,6 +194,14 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     a.spill_bits = idx->spill_bits;
     a.spill_next = idx->d_spill + ((size_t)idx->spill_slices << idx->spill_bits);
     DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
+    // dann_set_max_concurrency: `grid` persistent waves share the queries (counter in the zeroed pad words above)
+    auto cap_grid = [&](SearchArgs& x) {
+        const bool capped = idx->max_concurrency && x.nq > idx->max_concurrency && plain_mode(x);
+        x.grid = capped ? idx->max_concurrency : 0u;
+        x.work_next = capped ? x.spill_next + 8 : nullptr;
+    };
+    cap_grid(a);
+    const uint32_t inflight = a.grid ? a.grid : a.nq;
     // automatic table size: calibrated 90th percentile for this (L, beam, mode), else the prior
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = ((uint64_t)a.l_value << 32) | ((uint64_t)a.beam_width << 8) | (a.rec_ids ? 1u : 0u) |
@@ -212,7 +220,7 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         }
         // a launch with fewer queries than the chip has wave slots leaves LDS idle: give each query the share of a CU
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
-        const uint32_t per_cu = std::max<uint32_t>(1u, (a.nq + idx->num_cus - 1) / idx->num_cus);
+        const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
         const uint32_t waves = tune_env(2) ? cal->waves : std::min<uint32_t>(cal->waves, per_cu);
         a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), waves);
         if (getenv("DANN_DEBUG") && (cal->calls & (cal->calls - 1)) == 0)
@@ -233,7 +241,7 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         }
     }
     // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
-    if (a.nq <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
+    if (inflight <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
     volatile uint32_t* hflag = idx->h_flag;
     *hflag = 0;
     a.fail_flag = idx->h_flag;
@@ -295,6 +303,7 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
         a.qmap = qmap = lists[round & 1];
         a.nq = n = h;
+        cap_grid(a);
         if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
         DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
         *hflag = 0;

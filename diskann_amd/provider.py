@@ -411,6 +411,10 @@ class Provider:
     def set_visited_bits(self, bits):
         check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")
 
+    def set_max_concurrency(self, n):
+        """Queries in flight per search call (0 = all): n persistent wavefronts share the call's queries."""
+        check(_ffi.lib().dann_set_max_concurrency(self._h, n), "dann_set_max_concurrency")
+
 
 def sq8_compress(x, shift, scale, device=-1):
     """ScalarQuantizer::compress_into (8 bits) on the GPU: rows of dim code bytes + f32 compensation."""

@@ -414,6 +414,13 @@ int32_t dann_kernel_time_reset(dann_index* idx);
 /* tuning knob: per-query LDS visited-table size. 0 = auto from L and degree; 6..15 = log2(entries);
  * 64..32768 = explicit entry count (rounded up to a multiple of 64). Never affects results. */
 int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
+/* queries in flight per search call.  0 (default) = every query of the call gets its own wavefront at once;
+ * N > 0 = N persistent wavefronts take the call's queries one after the other from a shared counter -- what a
+ * server does that keeps N searches in flight (the reference: N tokio workers calling DiskANNIndex::search on a
+ * shared index, SURVEY 8(b) "Threading"): a finished search is replaced at once instead of waiting for the slowest
+ * of its batch.  Applies to the plain searches (beam width 1, no filter, no inline tags, degree <= 64: Knn, Range,
+ * the insert search); the other modes keep one wavefront per query.  Never affects results. */
+int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,13 @@ if [ ! -f /tmp/prof_$TAG/graph.bin ]; then  # the PMC passes load the graph: no 
     python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --L $L --graph-cache /tmp/prof_$TAG/graph.bin > /dev/null 2>&1
 fi
 if [ -n "${SKIP_PMC:-}" ]; then exit 0; fi
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE"; do
+# PMC_SHORT=1: the traffic counters and the instruction mix only (4 passes instead of 6)
+if [ -n "${PMC_SHORT:-}" ]; then
+  set -- FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
+else
+  set -- FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE"
+fi
+for C in "$@"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-40)
     rocprofv3 --pmc $C --kernel-trace -d /tmp/prof_$TAG/pmc_$N -o p -- python $R/bench.py --steps 3 --warmup 1 \
         --no-cpu-baseline --no-extras --L $L --graph-cache /tmp/prof_$TAG/graph.bin > /dev/null 2> /tmp/prof_$TAG/pmc_$N.err

@@ -87,3 +87,10 @@ for tune in [int(x) for x in args.tunes.split(",")]:
     if not args.prof:
         timed(100000, 26, 10)
         timed(100000, 64, 5)
+    for cap in (1024, 256):  # sustained rate with `cap` queries in flight (persistent waves, dann_set_max_concurrency)
+        prov.set_max_concurrency(cap)
+        print(f"  max_concurrency {cap}:", end=" ")
+        timed(20 * cap, 26, 20)
+        print(f"  max_concurrency {cap}:", end=" ")
+        timed(20 * cap, 64, 10)
+    prov.set_max_concurrency(0)

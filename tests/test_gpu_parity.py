@@ -162,6 +162,35 @@ def test_search_parity_random_graph(dtype, metric, dim, R, stride):
         assert np.array_equal(ost[:, 2], gst["result_count"]), (L, W)  # Translate's count (provider.rs:933-944)
 
 
+def test_max_concurrency_does_not_change_results():
+    """dann_set_max_concurrency: N persistent waves share the queries of a call through a counter; ids, distances
+    and statistics are those of the one-wave-per-query launch (and the oracle's), in record mode too."""
+    rng = np.random.default_rng(4242)
+    n, dim, R, nq = 6000, 128, 32, 333
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    queries = rand_vectors(rng, oracle.F32, nq, dim)
+    oi, od, oc, ost = oix.search_batch(queries, 40, 1, 10)
+    slots = rng.choice(n, 150, replace=False).astype(np.uint32)
+    ref_rec = gix.search_record(slots, 30)
+    for cap in (0, 1, 7, 64, 332, 333, 5000):
+        gix.set_max_concurrency(cap)
+        for W in (1, 3):
+            gi, gd, gst = gix.search(da.Knn(40, W), queries, 10)
+            if W == 1:
+                assert np.array_equal(oi, gi) and np.array_equal(bits(od), bits(gd)), cap
+                assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"]), cap
+            else:
+                o3 = oix.search_batch(queries, 40, W, 10)
+                assert np.array_equal(o3[0], gi) and np.array_equal(bits(o3[1]), bits(gd)), cap
+        rid, rd, rn, st = gix.search_record(slots, 30)
+        assert np.array_equal(rn, ref_rec[2]), cap
+        for i in range(slots.size):  # entries past the record length are unspecified
+            assert np.array_equal(rid[i, :rn[i]], ref_rec[0][i, :rn[i]]) and np.array_equal(bits(rd[i, :rn[i]]), bits(ref_rec[1][i, :rn[i]])), cap
+    gix.set_max_concurrency(0)
+
+
 def test_search_multiple_start_points_and_short_lists():
     rng = np.random.default_rng(77)
     n, dim, R = 2000, 32, 8
