@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--prof", action="store_true")
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--tunes", default="3,2,1,0")
+ap.add_argument("--points", default="", help="comma list nq:L[:reps] run instead of the standard set")
 args = ap.parse_args()
 import diskann_amd._ffi as ffi
 if args.prof:
@@ -79,6 +80,11 @@ def timed(nq, L, reps):
 for tune in [int(x) for x in args.tunes.split(",")]:
     os.environ["DANN_TUNE_OFF"] = str(tune)
     print(f"---- DANN_TUNE_OFF={tune} (1: no row prefetch, 2: no latency-mode table sizing)", flush=True)
+    if args.points:
+        for pt in args.points.split(","):
+            f = [int(x) for x in pt.split(":")]
+            timed(f[0], f[1], f[2] if len(f) > 2 else 100)
+        continue
     timed(1, 64, 300)
     timed(1, 26, 300)
     timed(1024, 26, 100)
