@@ -633,6 +633,8 @@ def _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build,
         rows = base
         start = base[medoid:medoid + 1].cpu().numpy()
         prov = da.Provider(da.F32, da.L2, dim, n, R, start, device=local)
+    if args.visited_bits:  # experiment knob: explicit LDS visited-table size (never affects results)
+        prov.set_visited_bits(args.visited_bits)
     for s0 in range(0, n, 1 << 21):
         prov.set_elements(s0, rows[s0:s0 + (1 << 21)].cpu().numpy())
     if f16:
