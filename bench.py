@@ -94,6 +94,17 @@ def log(*a):
 from benchdata import ground_truth, make_data, recall_at_k  # noqa: E402  (synthetic data + exact ground truth)
 
 
+def _strict(o):
+    """NaN / inf -> null so that the printed line is strict JSON (e.g. recall when --L skips the ground truth)."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _strict(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_strict(v) for v in o]
+    return o
+
+
 def maybe_spawn(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: re-exec N ranks, one per GPU, under
     torch.distributed.run on 127.0.0.1.  Under a launcher (WORLD_SIZE set) --gpus must agree with it."""
@@ -152,7 +163,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.only in ("gather", "sq8", "u8"):
-        print(json.dumps({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)}), flush=True)
+        print(json.dumps(_strict({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
     if args.only in ("large", "large768", "large768f16"):
         args.only_large = True
@@ -165,8 +176,8 @@ def main():
         rd = C.c_double(0.0)
         _ffi.lib().dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd))
         spec = (LARGE_DEFAULT if args.large == "auto" else args.large).split(",")[0]
-        print(json.dumps({"roofline_large": large_variant(args, spec, torch, da, _ffi.lib(), _ffi, dev, local, 10,
-                                                          args.beam_width, rd.value or None)}), flush=True)
+        print(json.dumps(_strict({"roofline_large": large_variant(args, spec, torch, da, _ffi.lib(), _ffi, dev, local, 10,
+                                                                  args.beam_width, rd.value or None)})), flush=True)
         return
 
     # ---- setup (untimed): data, index build on the GPU, ground truth ---------------------
@@ -487,7 +498,7 @@ def main():
                 except Exception as e:
                     out[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(_strict(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
