@@ -46,14 +46,15 @@ __host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
     return ix.dim * 4u;
 }
 
+// The visited table comes last: every other region then sits at an offset that depends only on (cmax, queue slots,
+// query bytes) -- compile-time constants in the plain fixed-length instantiations, where the region pointers cost no
+// SGPRs and the LDS instructions carry immediate offsets.
 __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
                                                        uint32_t qbytes) {
     SearchLds l;
     uint32_t off = 0;
     l.q_off = off;
     off += round16(qbytes);
-    l.ht_off = off;
-    off += ht_entries * 4u;  // any multiple of 64
     l.cand_id_off = off;
     off += round16(cmax * 4u);
     l.cand_d_off = off;
@@ -66,6 +67,8 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     off += 64u * 4u;
     l.beam_off = off;
     off += round16(kMaxBeam * 4u);
+    l.ht_off = off;        // 16-byte aligned (wiped with 16-byte stores)
+    off += ht_entries * 4u;  // any multiple of 64
     l.total = off;
     return l;
 }
@@ -198,9 +201,13 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t R = ix.max_degree;
     const uint32_t W = PLAIN ? 1u : a.beam_width;
     uint32_t qcap = a.l_value + ix.nstart;  // queue capacity == search_l (scratch.rs:199-207); AdaptiveL may grow it
-    const uint32_t cmax = ((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
-                                                                              : ((ix.nstart + 63u) & ~63u);
-    const uint32_t qbytes = query_lds_bytes(ix);
+    // plain mode: W = 1, R <= 64 and at most 64 start points (plain_mode) -> one 64-entry candidate block
+    const uint32_t cmax = PLAIN ? (uint32_t)kWave
+                                : (((W * R + 63u) & ~63u) > ((ix.nstart + 63u) & ~63u) ? ((W * R + 63u) & ~63u)
+                                                                                       : ((ix.nstart + 63u) & ~63u));
+    // fixed-length instantiations know the staged query's size (f32 vector, raw bytes, SQ-8: bytes + compensation)
+    const uint32_t qbytes = DIM > 0 ? (kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u)
+                                    : query_lds_bytes(ix);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
@@ -1258,7 +1265,8 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
 
 // what kModePlain assumes (checked by the host for every launch)
 inline bool plain_mode(const SearchArgs& a) {
-    return !a.filter_mode && a.beam_width == 1 && a.ix.tag_off == 0 && a.ix.max_degree <= (uint32_t)kWave;
+    return !a.filter_mode && a.beam_width == 1 && a.ix.tag_off == 0 && a.ix.max_degree <= (uint32_t)kWave &&
+           a.ix.nstart <= (uint32_t)kWave;
 }
 
 template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, bool PERSIST = false>
