@@ -83,6 +83,8 @@ extern "C" {
     pub fn dann_insert_batch(a0: *mut c_void, a1: *const DannBuildConfig, a2: *mut c_void, a3: u32) -> i32;
     pub fn dann_insert_batch_candidates(a0: *mut c_void, a1: *const DannBuildConfig, a2: *mut c_void, a3: u32, a4: u32, a5: u32, a6: *mut c_void) -> i32;
     pub fn dann_insert_batch_commit(a0: *mut c_void, a1: *const DannBuildConfig, a2: *mut c_void, a3: u32, a4: *mut c_void) -> i32;
+    pub fn dann_insert_batch_commit_part(a0: *mut c_void, a1: *const DannBuildConfig, a2: *const c_void, a3: u32, a4: *const c_void, a5: u32, a6: u32, a7: *mut c_void, a8: u32, a9: *mut u32) -> i32;
+    pub fn dann_apply_neighbor_rows_device(a0: *mut c_void, a1: *const c_void, a2: u32) -> i32;
     pub fn dann_build(a0: *mut c_void, a1: *const DannBuildConfig, a2: u32, a3: u32, a4: f32, a5: u32) -> i32;
     pub fn dann_set_build_options(a0: *mut c_void, a1: u32) -> i32;
     pub fn dann_build_counters(a0: *mut c_void, a1: *mut c_void, a2: u32) -> i32;

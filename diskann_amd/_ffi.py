@@ -100,6 +100,8 @@ SYMBOLS = {
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
     "dann_insert_batch_candidates": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _u32, _u32, _vp]),
     "dann_insert_batch_commit": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp]),
+    "dann_insert_batch_commit_part": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _u32, _u32, _vp, _u32, _P(_u32)]),
+    "dann_apply_neighbor_rows_device": (_i32, [_vp, _vp, _u32]),
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
     "dann_set_build_options": (_i32, [_vp, _u32]),
     "dann_build_counters": (_i32, [_vp, _vp, _u32]),

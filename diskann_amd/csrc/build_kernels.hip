@@ -426,7 +426,33 @@ struct ScanArgs {
     uint32_t* work_long;
     uint32_t* counts;          // [0] #short [1] #long [2] longest list among the long ones
     uint32_t* counters;        // [0] appends
+    uint32_t rank = 0, world = 1;  // owner-partitioned commit: only targets with id % world == rank are queued here
 };
+
+// Partitioned commit (multi-GPU build): lists that fit are appended by every replica (cheap, deterministic); a list
+// that has to be pruned -- the expensive part -- is queued only on the rank that owns the target.  The owners export
+// the resulting rows, the others apply them (dann_insert_batch_commit_part / dann_apply_neighbor_rows_device).
+__global__ void export_rows_kernel(IndexView ix, const uint64_t* keys, const uint32_t* seg_start, const uint32_t* work_short,
+                                   uint32_t nshort, const uint32_t* work_long, uint32_t nlong, uint32_t* out) {
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    if (i >= nshort + nlong) return;
+    const uint32_t seg = i < nshort ? work_short[i] : work_long[i - nshort];
+    const uint32_t tgt = (uint32_t)(keys[seg_start[seg]] >> 32);
+    const uint32_t* arow = ix.adj + (uint64_t)tgt * ix.adj_stride;
+    uint32_t* o = out + (uint64_t)i * (ix.max_degree + 2u);
+    if (lane == 0) o[0] = tgt;
+    for (uint32_t e = lane; e < ix.max_degree + 1u; e += blockDim.x) o[1 + e] = arow[e];
+}
+
+__global__ void apply_rows_kernel(IndexView ix, const uint32_t* rows, uint32_t count) {
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    if (i >= count) return;
+    const uint32_t* r = rows + (uint64_t)i * (ix.max_degree + 2u);
+    const uint32_t tgt = r[0];
+    if (tgt >= ix.nslots) return;
+    uint32_t* arow = ix.adj + (uint64_t)tgt * ix.adj_stride;
+    for (uint32_t e = lane; e < ix.max_degree + 1u; e += blockDim.x) arow[e] = e == 0 ? (r[1] < ix.max_degree ? r[1] : ix.max_degree) : r[1 + e];
+}
 
 __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
     __shared__ uint32_t newid[256];
@@ -437,10 +463,11 @@ __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
     uint32_t len = arow[0];
     len = len < a.ix.max_degree ? len : a.ix.max_degree;
     const uint32_t end = start + a.seg_len[start];
+    const bool owned = a.world <= 1u || src % a.world == a.rank;
     if (end - start > (uint32_t)kWave) {
         // a hub hit by many back-edges: no serial scan here, the long-list kernel de-duplicates 64 sources at a time
         // (len + #sources bounds its list; it also handles the case that everything still fits)
-        if (lane == 0) {
+        if (lane == 0 && owned) {
             a.work_long[atomicAdd(&a.counts[1], 1u)] = seg;
             atomicMax(&a.counts[2], len + (end - start));
         }
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
         }
         return;
     }
-    if (lane == 0) {
+    if (lane == 0 && owned) {
         if (cnt <= a.short_cap && cnt > a.cfg_max_degree) {
             a.work_short[atomicAdd(&a.counts[0], 1u)] = seg;
         } else {
@@ -1468,7 +1495,9 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
 // nearly empty, set_neighbors_bulk, add_edge_and_prune per distinct target.  Deterministic given the
 // pending rows of the *whole* batch, so identical replicas stay identical.
 static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, BuildScratch& s, const uint32_t* d_slots,
-                            uint32_t n, const uint32_t* d_pending) {
+                            uint32_t n, const uint32_t* d_pending, uint32_t rank = 0, uint32_t world = 1,
+                            uint32_t* d_rows_out = nullptr, uint32_t rows_cap = 0, uint32_t* count_out = nullptr) {
+    if (count_out) *count_out = 0;
     const IndexView ix = idx->view();
     PruneCfg pc = to_prune_cfg(cfg);
     pc.counters = s.counters.as<unsigned long long>();
@@ -1562,7 +1591,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         // longest list of the batch) is faster than scan + worklists (measured: 1 M x 128 build 0.68 s vs 0.78 s);
         // rows of 1 KiB and more take the split form (1 M x 768: 5.2 s -> 3.5 s, 3.25 s with the MFMA path)
         const uint32_t pcap_all = next_pow2(ix.max_degree + h_meta[2]);
-        if (!want_gram && ix.layer_bytes < 1024u) {
+        if (!want_gram && ix.layer_bytes < 1024u && world <= 1u) {
             if (pcap_all > kMaxPool) {
                 set_error("a node received %u back-edges in one batch (cap %u): lower max_batch", h_meta[2], kMaxPool);
                 return DANN_EOVERFLOW;
@@ -1584,6 +1613,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         sa.work_long = work + ba.nseg;
         sa.counts = meta + 10;
         sa.counters = meta + 4;
+        sa.rank = rank;
+        sa.world = world;
         hipLaunchKernelGGL(backedge_scan_kernel, dim3(ba.nseg), dim3(kWave), 0, st, sa);
         uint32_t h_counts[3] = {0, 0, 0};
         DANN_HIP(hipMemcpyAsync(h_counts, meta + 10, 12, hipMemcpyDeviceToHost, st));
@@ -1624,6 +1655,17 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
             }
             rc = dispatch<BackLauncher>(ix, bl, bl.nseg, pool_lds_layout(bl.pcap, pc.pruned_degree).total, st);
             if (rc != DANN_OK) return rc;
+        }
+        if (world > 1u) {  // the rows this rank owns and has just rewritten, for the other replicas
+            const uint32_t cnt = h_counts[0] + h_counts[1];
+            if (cnt > rows_cap || (cnt && !d_rows_out)) {
+                set_error("partitioned commit: %u rewritten rows exceed the export buffer (%u)", cnt, rows_cap);
+                return DANN_EOVERFLOW;
+            }
+            if (cnt)
+                hipLaunchKernelGGL(export_rows_kernel, dim3(cnt), dim3(kWave), 0, st, ix, ba.keys, ba.seg_start, work,
+                                   h_counts[0], work + ba.nseg, h_counts[1], d_rows_out);
+            if (count_out) *count_out = cnt;
         }
         }
     }
@@ -1721,6 +1763,41 @@ int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, 
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
     return batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all);
+} DANN_CATCH_ALL
+
+int32_t dann_insert_batch_commit_part(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                      const uint32_t* d_pending_all, uint32_t rank, uint32_t world, uint32_t* d_rows_out,
+                                      uint32_t rows_cap, uint32_t* count_out) try {
+    if (!idx || !count_out || world == 0 || rank >= world) return DANN_EINVAL;
+    *count_out = 0;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (n == 0) return DANN_OK;
+    if (!slots || !d_pending_all) return DANN_EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] >= idx->cfg.capacity) return DANN_EBOUNDS;
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    rc = batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all, rank, world, d_rows_out, rows_cap, count_out);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipStreamSynchronize(idx->stream));  // the exported rows are read by the caller's collective next
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows, uint32_t count) try {
+    if (!idx || (count && !d_rows)) return DANN_EINVAL;
+    if (count == 0) return DANN_OK;
+    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    hipLaunchKernelGGL(apply_rows_kernel, dim3(count), dim3(kWave), 0, idx->stream, idx->view(), d_rows, count);
+    DANN_HIP(hipGetLastError());
+    DANN_HIP(hipStreamSynchronize(idx->stream));
+    return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t dim, float* out) try {

@@ -357,6 +357,21 @@ class Provider:
         check(_ffi.lib().dann_insert_batch_commit(self._h, C.byref(cfg), _p(s), s.size, C.c_void_p(d_pending_all)),
               "dann_insert_batch_commit")
 
+    def insert_batch_commit_part(self, cfg, slots, d_pending_all, rank, world, d_rows_out, rows_cap):
+        """phase 2 with the prunes partitioned by target owner (id % world == rank); returns the number of rows this
+        rank rewrote and exported to the device buffer `d_rows_out` (rows of max_degree + 2 u32)."""
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        cnt = C.c_uint32(0)
+        check(_ffi.lib().dann_insert_batch_commit_part(self._h, C.byref(cfg), _p(s), s.size, C.c_void_p(d_pending_all),
+                                                       rank, world, C.c_void_p(d_rows_out), rows_cap, C.byref(cnt)),
+              "dann_insert_batch_commit_part")
+        return cnt.value
+
+    def apply_neighbor_rows(self, d_rows, count):
+        """adjacency rows exported by other replicas' insert_batch_commit_part (device pointer)"""
+        check(_ffi.lib().dann_apply_neighbor_rows_device(self._h, C.c_void_p(d_rows), count),
+              "dann_apply_neighbor_rows_device")
+
     def set_build_options(self, flags):
         """DANN_BUILD_* bits (dann.h): BUILD_MFMA_BACKEDGE = back-edge prunes through the Gram / MFMA path"""
         check(_ffi.lib().dann_set_build_options(self._h, int(flags)), "dann_set_build_options")

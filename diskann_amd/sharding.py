@@ -69,7 +69,8 @@ def batch_schedule(first, n, growth, max_batch):
         done += b
 
 
-def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None, stats=None):
+def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None, stats=None,
+                  owner_prunes=True):
     """Multi-GPU index build over identical replicas (one `provider` per rank, rows already stored).
 
     Every batch is one multi_insert (diskann/src/graph/index.rs:815-1030): each rank generates the
@@ -79,7 +80,10 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
     stay byte-identical to a single-GPU dann_build.  The batch schedule is dann_build's, including its
     fallback: a batch whose bootstrap (index.rs:926-938) would not fit one prune pool leaves the graph
     untouched and is re-inserted as smaller batches -- the test runs in the commit phase on identical
-    data, so every rank takes the same decision.  Returns the number of batches."""
+    data, so every rank takes the same decision.  With `owner_prunes` (default) the expensive part of that
+    update is partitioned too: a back-edge target whose list must be pruned is handled only by the rank that
+    owns it (id % world), the rewritten rows are all-gathered (second, small exchange) and applied by the
+    others -- the replicas still end every batch byte-identical.  Returns the number of batches."""
     import math
 
     import torch
@@ -124,13 +128,45 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
         else:
             pending = mine[:b].contiguous()
         torch.cuda.synchronize(dev)
+        part = owner_prunes and world > 1
         try:
-            provider.insert_batch_commit(cfg, slots, pending.data_ptr())
+            if part:
+                rw = provider.max_degree + 2
+                cap = b * cfg.pruned_degree + 1  # one row per distinct back-edge target at most
+                mine_rows = torch.zeros((cap, rw), dtype=torch.int32, device=dev)
+                torch.cuda.synchronize(dev)
+                cnt = provider.insert_batch_commit_part(cfg, slots, pending.data_ptr(), rank, world,
+                                                        mine_rows.data_ptr(), cap)
+            else:
+                provider.insert_batch_commit(cfg, slots, pending.data_ptr())
         except DannError as e:
             if e.status == EUNSUPPORTED and b > 1:
                 limit = max(1, b // 2)
                 continue
             raise
+        if part:  # second exchange: the rows each owner rewrote (counts first, then rows padded to the longest list)
+            import torch.distributed as dist
+            cpu = dist.get_backend(group) == "gloo"
+            cdev = torch.device("cpu") if cpu else dev
+            counts = torch.empty(world, dtype=torch.int32, device=cdev)
+            dist.all_gather_into_tensor(counts, torch.tensor([cnt], dtype=torch.int32, device=cdev), group=group)
+            counts = counts.cpu().tolist()
+            longest_rows = max(counts)
+            if longest_rows:
+                send = mine_rows[:longest_rows].reshape(-1)
+                send = send.cpu() if cpu else send.contiguous()
+                got = torch.empty(world * send.numel(), dtype=torch.int32, device=cdev)
+                dist.all_gather_into_tensor(got, send, group=group)
+                got = got.to(dev).reshape(world, longest_rows, rw)
+                torch.cuda.synchronize(dev)
+                for r in range(world):
+                    if r != rank and counts[r]:
+                        rows_r = got[r, : counts[r]].contiguous()
+                        torch.cuda.synchronize(dev)
+                        provider.apply_neighbor_rows(rows_r.data_ptr(), counts[r])
+                if stats is not None:
+                    stats["bytes_gathered_rows"] = stats.get("bytes_gathered_rows", 0) + world * longest_rows * rw * 4
+                    stats["rows_rewritten"] = stats.get("rows_rewritten", 0) + sum(counts)
         limit = min(max_batch, limit * 2)
         done += b
         batches += 1

@@ -284,6 +284,16 @@ int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* c
                                      uint32_t lo, uint32_t hi, uint32_t* d_pending_out);
 int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
                                  const uint32_t* d_pending_all);
+/* phase 2 with the expensive part partitioned (multi-GPU build): every replica applies the new rows and the
+ * back-edges whose target list still fits; a target whose list must be pruned (robust_prune of add_edge_and_prune,
+ * index.rs:2264-2341) is handled only by the rank that owns it (id % world == rank).  The rows rewritten by this rank
+ * are exported to d_rows_out (DEVICE, rows of max_degree + 2 u32: [target id, len, ids...], at most rows_cap of
+ * them, *count_out on return) -- all-gather them and hand the other ranks' rows to dann_apply_neighbor_rows_device;
+ * after that every replica equals the result of dann_insert_batch_commit.  world = 1 is dann_insert_batch_commit. */
+int32_t dann_insert_batch_commit_part(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
+                                      const uint32_t* d_pending_all, uint32_t rank, uint32_t world,
+                                      uint32_t* d_rows_out, uint32_t rows_cap, uint32_t* count_out);
+int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows, uint32_t count);
 /* insert every slot in [first, first+n) in id order with a geometric batch schedule
  * (batch = clamp(ceil(inserted * growth), 1, max_batch)); returns the number of batches */
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,

@@ -39,20 +39,23 @@ assert np.array_equal(ids, ref_ids) and np.array_equal(d.view(np.uint32), ref_d.
 n, dim, Rp, maxdeg, lb = 2500, 24, 8, 10, 24
 data = rand_vectors(rng, oracle.F32, n, dim)
 start = data.mean(0, keepdims=True).astype(np.float32)
-for ibc in (da.IBC_NONE, 4):
+for ibc, owner_prunes in ((da.IBC_NONE, True), (4, True), (da.IBC_NONE, False)):
     gcfg = da.build_config(Rp, maxdeg, lb, intra_batch_candidates=ibc)
     ocfg = oracle.build_config(Rp, maxdeg, lb, intra_batch_candidates=ibc)
     p = da.Provider(da.F32, da.L2, dim, n, maxdeg, start)
     p.set_elements(0, data)
     growth, max_batch = 0.1, 300
-    nb = build_sharded(p, gcfg, 0, n, growth, max_batch, rank, world)
+    st = {}
+    # owner_prunes: prunes of back-edge targets partitioned by id % world, rewritten rows all-gathered and applied
+    nb = build_sharded(p, gcfg, 0, n, growth, max_batch, rank, world, stats=st, owner_prunes=owner_prunes)
+    assert (st.get("rows_rewritten", 0) > 0) == owner_prunes, st
     got = p.download_graph()
     o = oracle.Index(oracle.F32, oracle.L2, dim, n, maxdeg, start)
     o.set_rows(0, data)
     nb_o = 0
     for s0, b in batch_schedule(0, n, growth, max_batch):
         o.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32)); nb_o += 1
-    assert nb == nb_o and np.array_equal(got, o.adj), f"rank {rank}: sharded build != oracle multi_insert (ibc {ibc})"
+    assert nb == nb_o and np.array_equal(got, o.adj), f"rank {rank}: sharded build != oracle multi_insert (ibc {ibc}, owner_prunes {owner_prunes})"
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
