@@ -193,6 +193,7 @@ def main():
     lib = _ffi.lib()
     base_h = base.cpu().numpy()
     prov.set_elements(0, base_h)
+    build_stats = None
     t1 = time.time()
     cfg = da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE)
     if args.graph_cache and os.path.exists(args.graph_cache):
@@ -200,7 +201,17 @@ def main():
         nb = 0
     elif args.sharded_build and world > 1:
         from diskann_amd.sharding import build_sharded
-        nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world)
+        build_stats = {}
+        nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world, stats=build_stats)
+        # the replicas must be byte-identical: compare a digest of every rank's adjacency
+        import hashlib
+        dig = np.frombuffer(hashlib.sha256(prov.download_graph().tobytes()).digest()[:8], dtype=np.int64).copy()
+        mine_d = torch.from_numpy(dig).to(torch.device("cpu") if one_dev else dev)
+        all_d = torch.empty(world, dtype=torch.int64, device=mine_d.device)
+        dist.all_gather_into_tensor(all_d, mine_d)
+        if len(set(all_d.cpu().tolist())) != 1:
+            raise SystemExit("sharded build: the replicas' graphs differ")
+        build_stats["replicas_identical"] = True
     else:
         nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
         if args.graph_cache and rank == 0:
@@ -343,13 +354,16 @@ def main():
                 "workload": f"batched beam search over a {args.n}x{args.dim} f32 index resident in HBM, "
                             f"{args.nq} queries/step/GPU, k=10, L={chosen}, beam_width={W}",
                 "index": f"Vamana R={args.max_degree} (pruned {args.pruned_degree}), l_build={args.l_build}, "
-                         f"alpha=1.2, built on GPU by dann_build (growth {args.growth}, max_batch {args.max_batch})",
+                         f"alpha=1.2, built on GPU by " + (f"sharding.build_sharded over {world} ranks" if build_stats
+                                                           is not None else "dann_build") +
+                         f" (growth {args.growth}, max_batch {args.max_batch})",
                 "recall_at_10": round(rec, 4),
                 "L": chosen,
                 "beam_width": W,
                 "mean_cmps": cmps_sum / args.nq,
                 "mean_hops": hops_sum / args.nq,
                 "build_seconds": round(t_build, 2),
+                **({"build_exchange": build_stats} if build_stats is not None else {}),
                 "parallelism": f"replicated index x{world}, query streams sharded, no collective",
             },
             "roofline": {
