@@ -81,6 +81,9 @@ def parse():
                     help="file: load the built graph from it when present, else build and save it (profiling passes "
                          "under rocprofv3 --pmc skip the thousands of build dispatches this way)")
     ap.add_argument("--visited-bits", type=int, default=0)
+    ap.add_argument("--sq8-stride", type=int, default=256,
+                    help="row stride of the SQ-8 store: 256 keeps the 128 code bytes of a row in one 128-byte line (the "
+                         "L2 kernel never reads the compensation); 0 = payload rounded to 16 B (144: rows straddle lines)")
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
     if len(sys.argv) == 1 and os.environ.get("DANN_BENCH_ARGV"):  # a rank spawned by maybe_spawn()
         return ap.parse_args(json.loads(os.environ["DANN_BENCH_ARGV"]))
@@ -529,7 +532,7 @@ def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoi
     codes = da.sq8_compress(base.cpu().numpy(), shift, scale, device=local)
     qcodes = da.sq8_compress(queries.cpu().numpy(), shift, scale, device=local)
     prov = da.Provider(da.SQ8, da.L2, args.dim, args.n, args.max_degree, codes[medoid:medoid + 1], device=local,
-                       sq_scale=scale, sq_shift_norm_sq=snorm)
+                       sq_scale=scale, sq_shift_norm_sq=snorm, row_stride=args.sq8_stride)
     prov.set_elements(0, codes)
     t0 = time.time()
     cfg = da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE)
@@ -847,7 +850,7 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
         rows = da.sq8_compress(base.cpu().numpy(), shift, scale, device=local)
         qrows = da.sq8_compress(queries.cpu().numpy(), shift, scale, device=local)
         prov = da.Provider(da.SQ8, da.L2, args.dim, args.n, args.max_degree, rows[medoid:medoid + 1], device=local,
-                           sq_scale=scale, sq_shift_norm_sq=snorm)
+                           sq_scale=scale, sq_shift_norm_sq=snorm, row_stride=args.sq8_stride)
         row_bytes = args.dim + 4
     else:
         lo, hi = float(base.min()), float(base.max())

@@ -42,8 +42,10 @@ def test_sq8_compress_matches_oracle():
         assert np.array_equal(got, want), dim
 
 
-@pytest.mark.parametrize("metric", [oracle.L2, oracle.INNER_PRODUCT, oracle.COSINE_NORMALIZED])
-def test_sq8_search_and_distances(metric):
+@pytest.mark.parametrize("metric,stride", [(oracle.L2, 0), (oracle.INNER_PRODUCT, 0), (oracle.COSINE_NORMALIZED, 0),
+                                           (oracle.L2, 256), (oracle.INNER_PRODUCT, 256)])
+def test_sq8_search_and_distances(metric, stride):
+    """stride 256: the line-aligned SQ-8 store bench.py uses (code bytes of a row in one 128-byte line)"""
     rng = np.random.default_rng(32 + metric)
     n, dim, R = 4000, 128, 24
     data, shift, scale = _sq_setup(rng, n, dim)
@@ -53,7 +55,7 @@ def test_sq8_search_and_distances(metric):
     oix = oracle.Index(oracle.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
     oix.set_rows(0, codes)
     oix.adj[:] = adj
-    gix = da.Provider(da.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
+    gix = da.Provider(da.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm, row_stride=stride)
     gix.set_elements(0, codes)
     gix.upload_graph(adj)
     queries = da.sq8_compress(rng.normal(0.3, 0.5, (40, dim)).astype(np.float32), shift, scale)
