@@ -89,7 +89,13 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
     import torch
 
     from ._ffi import DannError, EUNSUPPORTED
-    dev = torch.device("cuda", provider.device)
+    # (a provider on device -1 is a host-memory stand-in: the CPU tests drive this exchange protocol over gloo)
+    dev = torch.device("cuda", provider.device) if provider.device >= 0 else torch.device("cpu")
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
     width = cfg.pruned_degree + 1
     g = float(np.float32(growth))
     done, batches, limit = 0, 0, max_batch
@@ -103,7 +109,7 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
         longest = partition(b, world, 0)[1]
         mine = torch.zeros((max(longest, 1), width), dtype=torch.int32, device=dev)
         # the fill above runs on torch's stream, the library writes `mine` from the index's own stream
-        torch.cuda.synchronize(dev)
+        sync()
         provider.insert_batch_candidates(cfg, slots, lo, hi, mine.data_ptr())
         if world > 1:
             import torch.distributed as dist
@@ -127,14 +133,14 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
             pending = torch.cat(parts).contiguous()
         else:
             pending = mine[:b].contiguous()
-        torch.cuda.synchronize(dev)
+        sync()
         part = owner_prunes and world > 1
         try:
             if part:
                 rw = provider.max_degree + 2
                 cap = b * cfg.pruned_degree + 1  # one row per distinct back-edge target at most
                 mine_rows = torch.zeros((cap, rw), dtype=torch.int32, device=dev)
-                torch.cuda.synchronize(dev)
+                sync()
                 cnt = provider.insert_batch_commit_part(cfg, slots, pending.data_ptr(), rank, world,
                                                         mine_rows.data_ptr(), cap)
             else:
@@ -158,11 +164,11 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
                 got = torch.empty(world * send.numel(), dtype=torch.int32, device=cdev)
                 dist.all_gather_into_tensor(got, send, group=group)
                 got = got.to(dev).reshape(world, longest_rows, rw)
-                torch.cuda.synchronize(dev)
+                sync()
                 for r in range(world):
                     if r != rank and counts[r]:
                         rows_r = got[r, : counts[r]].contiguous()
-                        torch.cuda.synchronize(dev)
+                        sync()
                         provider.apply_neighbor_rows(rows_r.data_ptr(), counts[r])
                 if stats is not None:
                     stats["bytes_gathered_rows"] = stats.get("bytes_gathered_rows", 0) + world * longest_rows * rw * 4
