@@ -47,6 +47,12 @@ class Rng(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("uniform_index", RNG_INDEX_FN), ("uniform_f64", RNG_F64_FN)]
 
 
+class ServerConfig(C.Structure):
+    """dann_server_config: the resident search server (dann_server_start)."""
+    _fields_ = [("l_value", C.c_uint32), ("k", C.c_uint32), ("workers", C.c_uint32), ("ring", C.c_uint32),
+                ("idle_timeout_us", C.c_uint32)]
+
+
 class SearchStats(C.Structure):
     _fields_ = [("cmps", C.c_uint32), ("hops", C.c_uint32), ("result_count", C.c_uint32), ("status", C.c_uint32),
                 ("written", C.c_uint32)]
@@ -106,6 +112,7 @@ SYMBOLS = {
     "dann_set_build_options": (_i32, [_vp, _u32]),
     "dann_build_counters": (_i32, [_vp, _vp, _u32]),
     "dann_debug_gram": (_i32, [_i32, _vp, _u32, _u32, _vp]),
+    "dann_debug_gram_tiles": (_i32, [_i32, _i32, _vp, _u32, _u32, _u32, _vp, _vp]),
     "dann_save_graph": (_i32, [_vp, C.c_char_p]),
     "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
     "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),
@@ -126,6 +133,14 @@ SYMBOLS = {
     "dann_kernel_time_reset": (_i32, [_vp]),
     "dann_set_visited_bits": (_i32, [_vp, _u32]),
     "dann_set_max_concurrency": (_i32, [_vp, _u32]),
+    "dann_server_start": (_i32, [_vp, _vp]),
+    "dann_server_stop": (_i32, [_vp]),
+    "dann_search_submit": (_i32, [_vp, _vp, _P(_u64)]),
+    "dann_search_poll": (_i32, [_vp, _u64]),
+    "dann_search_wait": (_i32, [_vp, _u64, _vp, _vp, _vp]),
+    "dann_server_stats": (_i32, [_vp, _P(_u64), _P(_u64)]),
+    "dann_debug_concurrent_callers": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp,
+                                             _P(C.c_double)]),
 }
 
 _lib = None

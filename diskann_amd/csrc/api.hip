@@ -64,16 +64,83 @@ struct DeviceGuard {
 // time one launch on the index stream with HIP events (the stream the kernel runs on)
 template <class F>
 static int32_t timed(dann_index* idx, int which, F&& f) {
-    DANN_HIP(hipEventRecord(idx->ev0, idx->stream));
+    DANN_HIP(hipEventRecord(idx->main.ev0, idx->main.stream));
     int32_t rc = f();
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipEventRecord(idx->ev1, idx->stream));
-    DANN_HIP(hipEventSynchronize(idx->ev1));
+    DANN_HIP(hipEventRecord(idx->main.ev1, idx->main.stream));
+    DANN_HIP(hipEventSynchronize(idx->main.ev1));
     float ms = 0.f;
-    DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+    DANN_HIP(hipEventElapsedTime(&ms, idx->main.ev0, idx->main.ev1));
+    std::lock_guard<std::mutex> lk(idx->stat_mu);
     idx->clocks[which].total_ms += ms;
     idx->clocks[which].launches += 1;
     return DANN_OK;
+}
+
+int32_t SearchCtx::init() {
+    DANN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DANN_HIP(hipEventCreate(&ev0));
+    DANN_HIP(hipEventCreate(&ev1));
+    DANN_HIP(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));
+    *h_flag = 0;
+    return DANN_OK;
+}
+
+void SearchCtx::destroy() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+    if (d_fail) (void)hipFree(d_fail);
+    if (h_flag) (void)hipHostFree(h_flag);
+    if (d_spill) (void)hipFree(d_spill);
+    for (void* p : stage)
+        if (p) (void)hipFree(p);
+    if (h_stage) (void)hipHostFree(h_stage);
+    for (hipEvent_t e : chunk_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (stream) (void)hipStreamDestroy(stream);
+    *this = SearchCtx();
+}
+
+CtxLease::CtxLease(dann_index* i) : idx(i) {
+    std::unique_lock<std::mutex> lk(idx->ctx_mu);
+    for (;;) {
+        if (!idx->ctx_free.empty()) {
+            ctx = idx->ctx_free.back();
+            idx->ctx_free.pop_back();
+            return;
+        }
+        if (idx->ctx_created < kMaxSearchCtx) {
+            ++idx->ctx_created;
+            lk.unlock();
+            SearchCtx* c = new (std::nothrow) SearchCtx();
+            status = c ? c->init() : DANN_ENOMEM;
+            if (status != DANN_OK) {
+                if (c) {
+                    c->destroy();
+                    delete c;
+                }
+                lk.lock();
+                --idx->ctx_created;
+                idx->ctx_cv.notify_one();
+                return;
+            }
+            ctx = c;
+            return;
+        }
+        idx->ctx_cv.wait(lk);
+    }
+}
+
+CtxLease::~CtxLease() {
+    if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(idx->ctx_mu);
+        idx->ctx_free.push_back(ctx);
+    }
+    idx->ctx_cv.notify_one();
 }
 
 uint32_t auto_visited_entries(const dann_index* idx, uint32_t, uint32_t) {
@@ -216,19 +283,19 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             idx->num_cus = (uint32_t)cus;
     }
-    if ((e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    if ((e = hipEventCreate(&idx->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
-    if ((e = hipEventCreate(&idx->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+    if (int32_t irc = idx->main.init()) {
+        dann_index_destroy(idx);
+        return irc;
+    }
     const size_t rows_bytes = (size_t)idx->nslots * idx->cfg.row_stride + 256;
     const size_t adj_bytes = (size_t)idx->nslots * (cfg->max_degree + 1) * 4;
-    if ((e = hipHostMalloc((void**)&idx->h_flag, 64, hipHostMallocMapped)) != hipSuccess) return fail(e, "hipHostMalloc");
     if ((e = hipMalloc((void**)&idx->d_rows, rows_bytes)) != hipSuccess) return fail(e, "hipMalloc(rows)");
     if ((e = hipMalloc((void**)&idx->d_adj, adj_bytes)) != hipSuccess) return fail(e, "hipMalloc(adjacency)");
-    if ((e = hipMemsetAsync(idx->d_rows, 0, rows_bytes, idx->stream)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMemsetAsync(idx->d_adj, 0, adj_bytes, idx->stream)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemsetAsync(idx->d_rows, 0, rows_bytes, idx->main.stream)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemsetAsync(idx->d_adj, 0, adj_bytes, idx->main.stream)) != hipSuccess) return fail(e, "hipMemset");
     if (cfg->num_start_points) {
         e = hipMemcpy2DAsync(idx->d_rows + (size_t)cfg->capacity * idx->cfg.row_stride, idx->cfg.row_stride, start_rows,
-                             lb, lb, cfg->num_start_points, hipMemcpyHostToDevice, idx->stream);
+                             lb, lb, cfg->num_start_points, hipMemcpyHostToDevice, idx->main.stream);
         if (e != hipSuccess) return fail(e, "hipMemcpy2D(start rows)");
     }
     if (idx->cfg.inline_tags) {  // dynamic slots AVAILABLE (0, the memset above), start points FROZEN (store.rs:766-772)
@@ -236,11 +303,11 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
         if (cfg->num_start_points) {
             std::fill(idx->h_tags.begin() + cfg->capacity, idx->h_tags.end(), (uint8_t)255);
             e = hipMemset2DAsync(idx->d_rows + (size_t)cfg->capacity * idx->cfg.row_stride + lb, idx->cfg.row_stride, 255, 1,
-                                 cfg->num_start_points, idx->stream);
+                                 cfg->num_start_points, idx->main.stream);
             if (e != hipSuccess) return fail(e, "hipMemset2D(start tags)");
         }
     }
-    if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    if ((e = hipStreamSynchronize(idx->main.stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
     *out = idx;
     return DANN_OK;
 } DANN_CATCH_ALL
@@ -248,21 +315,18 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
 int32_t dann_index_destroy(dann_index* idx) try {
     if (!idx) return DANN_OK;
     DeviceGuard guard(idx->device);
-    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    if (idx->server) (void)dann_server_stop(idx);
+    idx->main.destroy();
+    for (SearchCtx* c : idx->ctx_free) {
+        c->destroy();
+        delete c;
+    }
+    idx->ctx_free.clear();
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_adj) (void)hipFree(idx->d_adj);
-    if (idx->d_fail) (void)hipFree(idx->d_fail);
-    if (idx->h_flag) (void)hipHostFree(idx->h_flag);
-    if (idx->d_spill) (void)hipFree(idx->d_spill);
-    for (void* p : idx->stage)
-        if (p) (void)hipFree(p);
-    if (idx->h_stage) (void)hipHostFree(idx->h_stage);
     if (idx->d_pq_pivots) (void)hipFree(idx->d_pq_pivots);
     if (idx->d_pq_offsets) (void)hipFree(idx->d_pq_offsets);
     if (idx->build_scratch && idx->build_scratch_free) idx->build_scratch_free(idx->build_scratch);
-    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
-    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
-    if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
     return DANN_OK;
 } DANN_CATCH_ALL
@@ -280,7 +344,7 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out) try {
         set_error("null index");                        \
         return DANN_EINVAL;                             \
     }                                                   \
-    std::lock_guard<std::recursive_mutex> _lock((idx)->mu); \
+    ::dann::ExclusiveGuard _lock(idx); \
     DeviceGuard _guard((idx)->device)
 
 int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) try {
@@ -298,13 +362,13 @@ int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, cons
         return DANN_EBOUNDS;
     }
     DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride, idx->cfg.row_stride, rows,
-                              idx->layer_bytes, idx->layer_bytes, n, hipMemcpyHostToDevice, idx->stream));
+                              idx->layer_bytes, idx->layer_bytes, n, hipMemcpyHostToDevice, idx->main.stream));
     if (idx->cfg.inline_tags) {  // Slot::publish (store.rs:776-782)
         DANN_HIP(hipMemset2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride + idx->layer_bytes,
-                                  idx->cfg.row_stride, 254, 1, n, idx->stream));
+                                  idx->cfg.row_stride, 254, 1, n, idx->main.stream));
         std::fill(idx->h_tags.begin() + first_slot, idx->h_tags.begin() + first_slot + n, (uint8_t)254);
     }
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -317,16 +381,23 @@ int32_t dann_set_tags(dann_index* idx, uint32_t first_slot, uint32_t n, const ui
         return DANN_EUNSUPPORTED;
     }
     if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
+    // start points are FROZEN for the lifetime of the store (store.rs:766-772); a search that cannot read one fails
+    // ("could not retrieve start point", provider.rs:408-431) -- refuse the state instead of producing it
+    for (uint32_t i = 0; i < n; ++i)
+        if (first_slot + i >= idx->cfg.capacity && tags[i] < 254) {
+            set_error("dann_set_tags: start point slot %u must stay readable (tag >= 254), got %u", first_slot + i, tags[i]);
+            return DANN_EINVAL;
+        }
     DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride + idx->layer_bytes,
-                              idx->cfg.row_stride, tags, 1, 1, n, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                              idx->cfg.row_stride, tags, 1, 1, n, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     memcpy(idx->h_tags.data() + first_slot, tags, n);
     return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_get_tags(const dann_index* idx, uint32_t first_slot, uint32_t n, uint8_t* tags) try {
     if (!idx || (n && !tags)) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     if ((uint64_t)first_slot + n > idx->nslots) return DANN_EBOUNDS;
     if (!idx->cfg.inline_tags) memset(tags, 254, n);  // a store without tags: every slot readable
     else memcpy(tags, idx->h_tags.data() + first_slot, n);
@@ -346,8 +417,8 @@ int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint
     }
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     DANN_HIP(hipMemcpyAsync(bytes, idx->d_rows + (size_t)slot * idx->cfg.row_stride, len, hipMemcpyDeviceToHost,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -362,9 +433,17 @@ int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, ui
         set_error("dann_upload_store: inline_tags needs a source stride > %u payload bytes", idx->layer_bytes);
         return DANN_ELENGTH;
     }
+    if (tags) {  // as dann_set_tags: a start point must stay readable
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(base) + idx->layer_bytes;
+        for (uint32_t i = idx->cfg.capacity; i < nrows; ++i)
+            if (b[(size_t)i * stride] < 254) {
+                set_error("dann_upload_store: start point slot %u must be readable (tag >= 254), got %u", i, b[(size_t)i * stride]);
+                return DANN_EINVAL;
+            }
+    }
     DANN_HIP(hipMemcpy2DAsync(idx->d_rows, idx->cfg.row_stride, base, stride, idx->layer_bytes + (tags ? 1u : 0u), nrows,
-                              hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                              hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     if (tags) {
         const uint8_t* b = reinterpret_cast<const uint8_t*>(base) + idx->layer_bytes;
         for (uint32_t i = 0; i < nrows; ++i) idx->h_tags[i] = b[(size_t)i * stride];
@@ -391,16 +470,16 @@ int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* 
         }
     if (!idx->d_pq_pivots) DANN_HIP(hipMalloc((void**)&idx->d_pq_pivots, (size_t)256 * dim * 4));
     if (!idx->d_pq_offsets) DANN_HIP(hipMalloc((void**)&idx->d_pq_offsets, (size_t)(nc + 1) * 4));
-    DANN_HIP(hipMemcpyAsync(idx->d_pq_pivots, pivots, (size_t)256 * dim * 4, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(idx->d_pq_offsets, chunk_offsets, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(idx->d_pq_pivots, pivots, (size_t)256 * dim * 4, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(idx->d_pq_offsets, chunk_offsets, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
 // ---- external ids ------------------------------------------------------------------------
 int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, const uint64_t* ext_ids) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     if (n == 0) return DANN_OK;
     if (!ext_ids) return DANN_EINVAL;
     if ((uint64_t)first_slot + n > idx->cfg.capacity) return DANN_EBOUNDS;
@@ -411,7 +490,7 @@ int32_t dann_set_external_ids(dann_index* idx, uint32_t first_slot, uint32_t n, 
 
 int32_t dann_to_external(const dann_index* idx, const uint32_t* slot_ids, uint64_t n, uint64_t* out_ext) try {
     if (!idx || (n && (!slot_ids || !out_ext))) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     for (uint64_t i = 0; i < n; ++i) {
         const uint32_t s = slot_ids[i];
         if (s >= idx->cfg.capacity) out_ext[i] = ~0ull;  // start points / padding have no mapping
@@ -430,8 +509,8 @@ int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, 
     }
     std::vector<uint32_t> row(idx->cfg.max_degree + 1);
     DANN_HIP(hipMemcpyAsync(row.data(), idx->d_adj + (size_t)slot * row.size(), row.size() * 4, hipMemcpyDeviceToHost,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     uint32_t len = std::min(row[0], idx->cfg.max_degree);
     *out_len = len;
     if (len > cap || (len && !out)) return DANN_ETOOLONG;
@@ -451,8 +530,8 @@ int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, 
     row[0] = n;
     if (n) memcpy(row.data() + 1, ids, (size_t)n * 4);
     DANN_HIP(hipMemcpyAsync(idx->d_adj + (size_t)slot * (idx->cfg.max_degree + 1), row.data(), row.size() * 4,
-                            hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -481,9 +560,9 @@ int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t
     }
     for (uint32_t i = 0; i < n; ++i) {
         DANN_HIP(hipMemcpyAsync(idx->d_adj + (size_t)slots[i] * w, lists + (size_t)i * w, (size_t)w * 4,
-                                hipMemcpyHostToDevice, idx->stream));
+                                hipMemcpyHostToDevice, idx->main.stream));
     }
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -492,8 +571,8 @@ int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) 
     if (!adj) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
     DANN_HIP(hipMemcpyAsync(idx->d_adj, adj, (size_t)nrows * (idx->cfg.max_degree + 1) * 4, hipMemcpyHostToDevice,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -502,8 +581,8 @@ int32_t dann_download_graph(const dann_index* idx, uint32_t* adj, uint64_t nrows
     if (!adj) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
     DANN_HIP(hipMemcpyAsync(adj, idx->d_adj, (size_t)nrows * (idx->cfg.max_degree + 1) * 4, hipMemcpyDeviceToHost,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -520,13 +599,13 @@ int32_t dann_distance(const dann_index* idx, const void* x, uint64_t xlen, const
     DevBuf buf;
     DANN_HIP(buf.alloc(2 * stride + 16));
     uint8_t* d = buf.as<uint8_t>();
-    DANN_HIP(hipMemcpyAsync(d, x, xlen, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(d + stride, y, ylen, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(d, x, xlen, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(d + stride, y, ylen, hipMemcpyHostToDevice, idx->main.stream));
     float* d_out = reinterpret_cast<float*>(d + 2 * stride);
-    int32_t rc = launch_distance_raw(idx->view(), d, d + stride, stride, 1, d_out, idx->stream);
+    int32_t rc = launch_distance_raw(idx->view(), d, d + stride, stride, 1, d_out, idx->main.stream);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(out, d_out, 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(out, d_out, 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -541,12 +620,12 @@ int32_t dann_distance_pairs(const dann_index* idx, const uint32_t* a, const uint
     uint32_t* da = buf.as<uint32_t>();
     uint32_t* db = da + n;
     float* dout = reinterpret_cast<float*>(db + n);
-    DANN_HIP(hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(db, b, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
-    int32_t rc = launch_distance_pairs(idx->view(), da, db, n, dout, idx->stream);
+    DANN_HIP(hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(db, b, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
+    int32_t rc = launch_distance_pairs(idx->view(), da, db, n, dout, idx->main.stream);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -566,8 +645,8 @@ int32_t dann_query_create(const dann_index* idx, const void* query, uint64_t len
         delete q;
         return hip_fail(e, "hipMalloc(query)");
     }
-    e = hipMemcpyAsync(q->d_query, query, len, hipMemcpyHostToDevice, idx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(idx->stream);
+    e = hipMemcpyAsync(q->d_query, query, len, hipMemcpyHostToDevice, idx->main.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->main.stream);
     if (e != hipSuccess) {
         (void)hipFree(q->d_query);
         delete q;
@@ -595,18 +674,19 @@ static int32_t expand_on_device(const dann_index* idx, const IndexView& view, co
     uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_off + 2);
     float* d_out = reinterpret_cast<float*>(d_ids + n);
     uint64_t off[2] = {0, n};
-    DANN_HIP(hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
-    int32_t rc = launch_expand_beam(view, d_query, 1, d_ids, d_off, n, d_out, idx->stream);
+    DANN_HIP(hipMemcpyAsync(d_off, off, 16, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
+    int32_t rc = launch_expand_beam(view, d_query, 1, d_ids, d_off, n, d_out, idx->main.stream);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 }
 
 int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, float* out) try {
     if (!q || !row || !out) return DANN_EINVAL;
     const dann_index* idx = q->idx;
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     if (len != idx->layer_bytes) {
         set_error("expected slice of length %u - instead got %llu", idx->layer_bytes, (unsigned long long)len);
@@ -614,7 +694,7 @@ int32_t dann_query_distance(const dann_query* q, const void* row, uint64_t len, 
     }
     DevBuf rowbuf;
     DANN_HIP(rowbuf.alloc((len + 15) & ~15ull));
-    DANN_HIP(hipMemcpyAsync(rowbuf.p, row, len, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(rowbuf.p, row, len, hipMemcpyHostToDevice, idx->main.stream));
     IndexView v = idx->view();
     v.rows = rowbuf.as<uint8_t>();
     v.nslots = 1;
@@ -626,6 +706,7 @@ int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, u
                          uint32_t* out_n) try {
     if (!q || !out_n) return DANN_EINVAL;
     const dann_index* idx = q->idx;
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     *out_n = 0;
     if (n == 0) return DANN_OK;
@@ -634,11 +715,8 @@ int32_t dann_expand_beam(const dann_query* q, const uint32_t* ids, uint32_t n, u
         if (ids[i] >= idx->nslots) return DANN_EBOUNDS;
     // read_in_bounds(i) -> None for a slot whose tag is not readable: skipped, not counted (provider.rs:681-686)
     uint32_t m = 0;
-    {
-        std::lock_guard<std::recursive_mutex> lock(idx->mu);
-        for (uint32_t i = 0; i < n; ++i)
-            if (!idx->cfg.inline_tags || idx->h_tags[ids[i]] >= 254) out_ids[m++] = ids[i];
-    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (!idx->cfg.inline_tags || idx->h_tags[ids[i]] >= 254) out_ids[m++] = ids[i];
     *out_n = m;
     if (m == 0) return DANN_OK;
     return expand_on_device(idx, idx->view(), q->d_query, out_ids, m, out_dists);
@@ -664,16 +742,16 @@ int32_t dann_expand_beam_batch(const dann_index* cidx, const void* queries, uint
     DANN_HIP(bo.alloc((size_t)(nq + 1) * 8));
     DANN_HIP(bi.alloc(total * 4));
     DANN_HIP(bd.alloc(total * 4));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(bo.p, offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(bi.p, ids, total * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(bo.p, offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(bi.p, ids, total * 4, hipMemcpyHostToDevice, idx->main.stream));
     int32_t rc = timed(idx, 1, [&] {
         return launch_expand_beam(idx->view(), bq.p, nq, bi.as<uint32_t>(), bo.as<uint64_t>(), max_len, bd.as<float>(),
-                                  idx->stream);
+                                  idx->main.stream);
     });
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, total * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, total * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     if (idx->cfg.inline_tags)  // the positional batch form cannot drop entries: unreadable slots report NaN
         for (uint64_t i = 0; i < total; ++i)
             if (idx->h_tags[ids[i]] < 254) out_dists[i] = __builtin_nanf("");
@@ -689,7 +767,7 @@ static int32_t pq_ready(const dann_index* idx) {
     return DANN_OK;
 }
 
-static int32_t search_device(dann_index* idx, const void* d_queries, const uint32_t* d_qslots, uint32_t nq,
+static int32_t search_device(dann_index* idx, SearchCtx& ctx, const void* d_queries, const uint32_t* d_qslots, uint32_t nq,
                              uint32_t l_value, uint32_t beam, uint32_t k, uint32_t* d_ids, float* d_dists,
                              dann_search_stats* d_stats, uint32_t* d_rec_ids, float* d_rec_d, uint32_t rec_stride,
                              uint32_t* d_rec_n) {
@@ -724,94 +802,181 @@ static int32_t search_device(dann_index* idx, const void* d_queries, const uint3
     a.spill = nullptr;
     a.spill_next = nullptr;
     a.spill_slices = a.spill_bits = 0;
-    return search_with_retry(idx, a);
+    return search_with_retry(idx, ctx, a);
+}
+
+// shared access for the Knn search entry points: the index is read-only here, every call runs on its own context
+#define CHECK_IDX_SHARED(idx)                               \
+    if (!(idx)) {                                           \
+        set_error("null index");                            \
+        return DANN_EINVAL;                                 \
+    }                                                       \
+    std::shared_lock<std::shared_mutex> _rd((idx)->rw);     \
+    DeviceGuard _guard((idx)->device);                      \
+    CtxLease _lease(idx);                                   \
+    if (_lease.status != DANN_OK) return _lease.status;     \
+    SearchCtx& ctx = *_lease.ctx
+
+static int32_t grow_stage(SearchCtx& ctx, int i, size_t need) {
+    if (ctx.stage_bytes[i] >= need) return DANN_OK;
+    if (ctx.stage[i]) (void)hipFree(ctx.stage[i]);
+    ctx.stage[i] = nullptr;
+    ctx.stage_bytes[i] = 0;
+    const size_t sz = need + need / 4;
+    DANN_HIP(hipMalloc(&ctx.stage[i], sz));
+    ctx.stage_bytes[i] = sz;
+    return DANN_OK;
 }
 
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
                                  dann_search_stats* d_out_stats) try {
-    CHECK_IDX(idx);
+    CHECK_IDX_SHARED(idx);
     if (nq == 0) return DANN_OK;
     if (!d_queries || !d_out_ids || !d_out_dists) return DANN_EINVAL;
-    if (!d_out_stats) {  // the overflow retry needs per-query status: index-owned stats when the caller passes none
-        const size_t need = (size_t)nq * sizeof(dann_search_stats);
-        if (idx->stage_bytes[2] < need) {
-            if (idx->stage[2]) (void)hipFree(idx->stage[2]);
-            idx->stage[2] = nullptr;
-            idx->stage_bytes[2] = 0;
-            DANN_HIP(hipMalloc(&idx->stage[2], need + need / 4));
-            idx->stage_bytes[2] = need + need / 4;
-        }
-        d_out_stats = reinterpret_cast<dann_search_stats*>(idx->stage[2]);
+    if (!d_out_stats) {  // the overflow retry needs per-query status: context-owned stats when the caller passes none
+        if (int32_t rc = grow_stage(ctx, 2, (size_t)nq * sizeof(dann_search_stats))) return rc;
+        d_out_stats = reinterpret_cast<dann_search_stats*>(ctx.stage[2]);
     }
-    return search_device(idx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
+    return search_device(idx, ctx, d_queries, nullptr, nq, l_value, beam_width, k, d_out_ids, d_out_dists, d_out_stats,
                          nullptr, nullptr, 0, nullptr);
 } DANN_CATCH_ALL
 
-int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
-                          uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
-    CHECK_IDX(idx);
-    if (nq == 0) return DANN_OK;
-    if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
-    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
-    // device staging owned by the index (grow-only): [0] queries, [1] ids | dists | stats in one block
-    const size_t ids_b = ((size_t)nq * k * 4 + 15) & ~(size_t)15, st_b = (size_t)nq * sizeof(dann_search_stats);
-    const size_t need[2] = {(size_t)nq * qb + 16, 2 * ids_b + st_b + 16};
-    for (int i = 0; i < 2; ++i)
-        if (idx->stage_bytes[i] < need[i]) {
-            if (idx->stage[i]) (void)hipFree(idx->stage[i]);
-            idx->stage[i] = nullptr;
-            idx->stage_bytes[i] = 0;
-            const size_t sz = need[i] + need[i] / 4;
-            DANN_HIP(hipMalloc(&idx->stage[i], sz));
-            idx->stage_bytes[i] = sz;
-        }
-    void* bq = idx->stage[0];
-    uint8_t* ob = reinterpret_cast<uint8_t*>(idx->stage[1]);
-    uint32_t* bi = reinterpret_cast<uint32_t*>(ob);
-    float* bd = reinterpret_cast<float*>(ob + ids_b);
-    dann_search_stats* bs = reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b);
-    // small batches go through pinned host memory: one H2D and one D2H, both truly asynchronous (copies from / to
-    // pageable memory cost tens of microseconds each on ROCm 7.2, which is the latency regime's whole budget)
-    const size_t in_b = (size_t)nq * qb, out_b = 2 * ids_b + st_b;
-    const bool pinned = in_b + out_b <= (1u << 20);
-    if (pinned && idx->h_stage_bytes < in_b + out_b) {
-        if (idx->h_stage) (void)hipHostFree(idx->h_stage);
-        idx->h_stage = nullptr;
-        idx->h_stage_bytes = 0;
-        DANN_HIP(hipHostMalloc(&idx->h_stage, 1u << 20, hipHostMallocDefault));
-        idx->h_stage_bytes = 1u << 20;
-    }
-    std::vector<dann_search_stats> stats(nq);
-    if (pinned) {
-        uint8_t* hs = reinterpret_cast<uint8_t*>(idx->h_stage);
-        memcpy(hs, queries, in_b);
-        DANN_HIP(hipMemcpyAsync(bq, hs, in_b, hipMemcpyHostToDevice, idx->stream));
-        int32_t rc = search_device(idx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
-        if (rc != DANN_OK) return rc;
-        DANN_HIP(hipMemcpyAsync(hs + in_b, ob, out_b, hipMemcpyDeviceToHost, idx->stream));
-        DANN_HIP(hipStreamSynchronize(idx->stream));
-        memcpy(out_ids, hs + in_b, (size_t)nq * k * 4);
-        memcpy(out_dists, hs + in_b + ids_b, (size_t)nq * k * 4);
-        memcpy(stats.data(), hs + in_b + 2 * ids_b, st_b);
-    } else {
-        DANN_HIP(hipMemcpyAsync(bq, queries, in_b, hipMemcpyHostToDevice, idx->stream));
-        int32_t rc = search_device(idx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
-        if (rc != DANN_OK) return rc;
-        DANN_HIP(hipMemcpyAsync(out_ids, bi, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-        DANN_HIP(hipMemcpyAsync(out_dists, bd, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-        DANN_HIP(hipMemcpyAsync(stats.data(), bs, st_b, hipMemcpyDeviceToHost, idx->stream));
-        DANN_HIP(hipStreamSynchronize(idx->stream));
-    }
-    if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+static int32_t first_failed_query(const dann_search_stats* stats, uint32_t nq, uint32_t base) {
     for (uint32_t i = 0; i < nq; ++i) {
+        if (stats[i].status == (uint32_t)(-DANN_EINVAL)) {
+            set_error("query %u: could not retrieve start point (a start slot is not readable)", base + i);
+            return DANN_EINVAL;
+        }
         if (stats[i].status) {
             set_error("query %u: per-query scratch exhausted (visited table and spill pool); raise the table "
-                      "size with dann_set_visited_bits", i);
+                      "size with dann_set_visited_bits", base + i);
             return DANN_EOVERFLOW;
         }
     }
     return DANN_OK;
+}
+
+// queries per chunk of the host-pointer pipeline, and the batch size from which it is used
+constexpr uint32_t kHostChunk = 32768;
+
+int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
+                          uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
+    CHECK_IDX_SHARED(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
+    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
+    static const bool pipeline_off = [] {
+        const char* e = getenv("DANN_HOST_PIPELINE");
+        return e && atoi(e) == 0;
+    }();
+    const bool chunked = nq >= 2 * kHostChunk && !pipeline_off;
+    const uint32_t cq = chunked ? kHostChunk : nq;  // queries per device pass
+    // device staging owned by the context (grow-only): [0] queries, [1] ids | dists | stats in one block; the
+    // chunked form keeps two of each ([0]/[3] hold the two query buffers, [1] both output blocks)
+    const size_t ids_b = ((size_t)cq * k * 4 + 15) & ~(size_t)15, st_b = ((size_t)cq * sizeof(dann_search_stats) + 15) & ~(size_t)15;
+    const size_t in_b = (size_t)cq * qb, out_b = 2 * ids_b + st_b;
+    if (int32_t rc = grow_stage(ctx, 0, in_b + 16)) return rc;
+    if (int32_t rc = grow_stage(ctx, 1, (chunked ? 2 : 1) * out_b + 16)) return rc;
+    if (chunked)
+        if (int32_t rc = grow_stage(ctx, 3, in_b + 16)) return rc;
+    // pinned host staging: copies from / to pageable memory are neither asynchronous nor fast on ROCm 7.2
+    const bool pinned = chunked || in_b + out_b <= (1u << 20);
+    const size_t h_need = chunked ? 2 * (in_b + out_b) : (size_t)1 << 20;
+    if (pinned && ctx.h_stage_bytes < h_need) {
+        if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
+        ctx.h_stage = nullptr;
+        ctx.h_stage_bytes = 0;
+        DANN_HIP(hipHostMalloc(&ctx.h_stage, h_need, hipHostMallocDefault));
+        ctx.h_stage_bytes = h_need;
+    }
+    if (!chunked) {
+        void* bq = ctx.stage[0];
+        uint8_t* ob = reinterpret_cast<uint8_t*>(ctx.stage[1]);
+        uint32_t* bi = reinterpret_cast<uint32_t*>(ob);
+        float* bd = reinterpret_cast<float*>(ob + ids_b);
+        dann_search_stats* bs = reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b);
+        std::vector<dann_search_stats> stats(nq);
+        if (pinned) {
+            uint8_t* hs = reinterpret_cast<uint8_t*>(ctx.h_stage);
+            memcpy(hs, queries, in_b);
+            DANN_HIP(hipMemcpyAsync(bq, hs, in_b, hipMemcpyHostToDevice, ctx.stream));
+            int32_t rc = search_device(idx, ctx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
+            if (rc != DANN_OK) return rc;
+            DANN_HIP(hipMemcpyAsync(hs + in_b, ob, out_b, hipMemcpyDeviceToHost, ctx.stream));
+            DANN_HIP(hipStreamSynchronize(ctx.stream));
+            memcpy(out_ids, hs + in_b, (size_t)nq * k * 4);
+            memcpy(out_dists, hs + in_b + ids_b, (size_t)nq * k * 4);
+            memcpy(stats.data(), hs + in_b + 2 * ids_b, (size_t)nq * sizeof(dann_search_stats));
+        } else {
+            DANN_HIP(hipMemcpyAsync(bq, queries, in_b, hipMemcpyHostToDevice, ctx.stream));
+            int32_t rc = search_device(idx, ctx, bq, nullptr, nq, l_value, beam_width, k, bi, bd, bs, nullptr, nullptr, 0, nullptr);
+            if (rc != DANN_OK) return rc;
+            DANN_HIP(hipMemcpyAsync(out_ids, bi, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx.stream));
+            DANN_HIP(hipMemcpyAsync(out_dists, bd, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx.stream));
+            DANN_HIP(hipMemcpyAsync(stats.data(), bs, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost, ctx.stream));
+            DANN_HIP(hipStreamSynchronize(ctx.stream));
+        }
+        if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+        return first_failed_query(stats.data(), nq, 0);
+    }
+    // ---- chunked pipeline: while the kernel of chunk i runs on the context's stream, the copy stream carries chunk
+    // i + 1's queries up and chunk i - 1's results down, and the host moves them between the caller's (pageable)
+    // buffers and the pinned ring.  The kernel call itself blocks (it waits on its own HIP events), so everything
+    // that should overlap with it is enqueued before it.
+    if (!ctx.copy_stream) DANN_HIP(hipStreamCreateWithFlags(&ctx.copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx.chunk_ev)
+        if (!e) DANN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    uint8_t* hs = reinterpret_cast<uint8_t*>(ctx.h_stage);
+    uint8_t* h_in[2] = {hs, hs + in_b};
+    uint8_t* h_out[2] = {hs + 2 * in_b, hs + 2 * in_b + out_b};
+    void* d_in[2] = {ctx.stage[0], ctx.stage[3]};
+    uint8_t* d_out[2] = {reinterpret_cast<uint8_t*>(ctx.stage[1]), reinterpret_cast<uint8_t*>(ctx.stage[1]) + out_b};
+    hipEvent_t up_done[2] = {ctx.chunk_ev[0], ctx.chunk_ev[1]}, down_done[2] = {ctx.chunk_ev[2], ctx.chunk_ev[3]};
+    const uint32_t nchunks = (nq + cq - 1) / cq;
+    auto chunk_len = [&](uint32_t c) { return std::min(cq, nq - c * cq); };
+    auto upload = [&](uint32_t c) -> int32_t {
+        const uint32_t n = chunk_len(c);
+        memcpy(h_in[c & 1], reinterpret_cast<const uint8_t*>(queries) + (size_t)c * cq * qb, (size_t)n * qb);
+        DANN_HIP(hipMemcpyAsync(d_in[c & 1], h_in[c & 1], (size_t)n * qb, hipMemcpyHostToDevice, ctx.copy_stream));
+        DANN_HIP(hipEventRecord(up_done[c & 1], ctx.copy_stream));
+        return DANN_OK;
+    };
+    int32_t failed = DANN_OK;
+    auto drain = [&](uint32_t c) -> int32_t {  // results of chunk c: pinned ring -> the caller's buffers
+        const uint32_t n = chunk_len(c);
+        DANN_HIP(hipEventSynchronize(down_done[c & 1]));
+        const uint8_t* o = h_out[c & 1];
+        memcpy(out_ids + (size_t)c * cq * k, o, (size_t)n * k * 4);
+        memcpy(out_dists + (size_t)c * cq * k, o + ids_b, (size_t)n * k * 4);
+        const dann_search_stats* st = reinterpret_cast<const dann_search_stats*>(o + 2 * ids_b);
+        if (out_stats) memcpy(out_stats + (size_t)c * cq, st, (size_t)n * sizeof(dann_search_stats));
+        if (failed == DANN_OK) failed = first_failed_query(st, n, c * cq);
+        return DANN_OK;
+    };
+    if (int32_t rc = upload(0)) return rc;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t n = chunk_len(c);
+        if (c + 1 < nchunks)
+            if (int32_t rc = upload(c + 1)) return rc;  // chunk c - 1's kernel finished before: its query buffer is free
+        DANN_HIP(hipStreamWaitEvent(ctx.stream, up_done[c & 1], 0));
+        uint8_t* ob = d_out[c & 1];
+        int32_t rc = search_device(idx, ctx, d_in[c & 1], nullptr, n, l_value, beam_width, k, reinterpret_cast<uint32_t*>(ob),
+                                   reinterpret_cast<float*>(ob + ids_b), reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b),
+                                   nullptr, nullptr, 0, nullptr);
+        if (rc != DANN_OK) {
+            (void)hipStreamSynchronize(ctx.copy_stream);
+            return rc;
+        }
+        // (the search call returned: the kernel is complete, its output block can travel)
+        if (c >= 2) DANN_HIP(hipEventSynchronize(down_done[c & 1]));  // ring slot of chunk c - 2 (drained below, in order)
+        DANN_HIP(hipMemcpyAsync(h_out[c & 1], ob, out_b, hipMemcpyDeviceToHost, ctx.copy_stream));
+        DANN_HIP(hipEventRecord(down_done[c & 1], ctx.copy_stream));
+        if (c >= 1)
+            if (int32_t drc = drain(c - 1)) return drc;
+    }
+    if (int32_t drc = drain(nchunks - 1)) return drc;
+    return failed;
 } DANN_CATCH_ALL
 
 int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
@@ -856,7 +1021,7 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     DANN_HIP(bri.alloc((size_t)nq * cap * 4));
     DANN_HIP(brd.alloc((size_t)nq * cap * 4));
     DANN_HIP(bsec.alloc((size_t)nq * 4));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->main.stream));
     SearchArgs a;
     a.ix = idx->view();
     a.queries = bq.p;
@@ -888,16 +1053,16 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     a.spill = nullptr;
     a.spill_next = nullptr;
     a.spill_slices = a.spill_bits = 0;
-    int32_t rc = search_with_retry(idx, a);
+    int32_t rc = search_with_retry(idx, idx->main, a);
     if (rc != DANN_OK) return rc;
     std::vector<dann_search_stats> stats(nq);
-    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->main.stream));
     DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
-                            idx->stream));
+                            idx->main.stream));
     if (out_second_round)
-        DANN_HIP(hipMemcpyAsync(out_second_round, bsec.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+        DANN_HIP(hipMemcpyAsync(out_second_round, bsec.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i)
         if (stats[i].status) {
@@ -968,7 +1133,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
                   (unsigned long long)f->stride_words, (unsigned long long)words);
         return DANN_EINVAL;
     }
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->main.stream;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
     const bool inl = f->mode == DANN_FILTER_INLINE;
     SearchArgs a;
@@ -1065,7 +1230,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
         DANN_HIP(hipMemcpyAsync(bq.p, (const uint8_t*)c.queries + (size_t)off * qb, (size_t)n * qb, hipMemcpyHostToDevice, st));
         a.nq = n;
         a.filter = bf.as<uint32_t>() + (size_t)off * f->stride_words;
-        int32_t rc = search_with_retry(idx, a);
+        int32_t rc = search_with_retry(idx, idx->main, a);
         if (rc != DANN_OK) return rc;
         DANN_HIP(hipMemcpyAsync(c.out_ids + (size_t)off * c.k, bi.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
         DANN_HIP(hipMemcpyAsync(c.out_dists + (size_t)off * c.k, bd.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
@@ -1143,7 +1308,7 @@ int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_
     if (!d_queries || !d_cand_ids || !d_out_ids || !d_out_dists || k == 0) return DANN_EINVAL;
     int32_t rc = timed(idx, 1, [&] {
         return launch_rerank(idx->view(), d_queries, nq, d_cand_ids, cand_stride, k, d_out_ids, d_out_dists,
-                             idx->stream);
+                             idx->main.stream);
     });
     return rc;
 } DANN_CATCH_ALL
@@ -1158,14 +1323,14 @@ int32_t dann_rerank_batch(dann_index* idx, const void* queries, uint32_t nq, con
     DANN_HIP(bc.alloc((size_t)nq * cand_stride * 4));
     DANN_HIP(bi.alloc((size_t)nq * k * 4));
     DANN_HIP(bd.alloc((size_t)nq * k * 4));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->stream));
-    DANN_HIP(hipMemcpyAsync(bc.p, cand_ids, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * idx->layer_bytes, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(bc.p, cand_ids, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, idx->main.stream));
     int32_t rc = launch_rerank(idx->view(), bq.p, nq, bc.as<uint32_t>(), cand_stride, k, bi.as<uint32_t>(),
-                               bd.as<float>(), idx->stream);
+                               bd.as<float>(), idx->main.stream);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -1183,18 +1348,18 @@ int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_
     DANN_HIP(brd.alloc((size_t)nq * rec_stride * 4));
     DANN_HIP(brn.alloc((size_t)nq * 4));
     DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
-    DANN_HIP(hipMemcpyAsync(bsl.p, slots, (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
-    int32_t rc = search_device(idx, nullptr, bsl.as<uint32_t>(), nq, l_value, 1, 0, nullptr, nullptr,
+    DANN_HIP(hipMemcpyAsync(bsl.p, slots, (size_t)nq * 4, hipMemcpyHostToDevice, idx->main.stream));
+    int32_t rc = search_device(idx, idx->main, nullptr, bsl.as<uint32_t>(), nq, l_value, 1, 0, nullptr, nullptr,
                                bs.as<dann_search_stats>(), bri.as<uint32_t>(), brd.as<float>(), rec_stride,
                                brn.as<uint32_t>());
     if (rc != DANN_OK) return rc;
     std::vector<dann_search_stats> stats(nq);
-    DANN_HIP(hipMemcpyAsync(rec_ids, bri.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(rec_dists, brd.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->stream));
-    DANN_HIP(hipMemcpyAsync(rec_n, brn.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    DANN_HIP(hipMemcpyAsync(rec_ids, bri.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(rec_dists, brd.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(rec_n, brn.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->main.stream));
     DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
-                            idx->stream));
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i)
         if (stats[i].status) {
@@ -1307,8 +1472,8 @@ int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t 
     std::vector<uint8_t> rows((size_t)n * idx->layer_bytes);
     if (n) {
         DANN_HIP(hipMemcpy2DAsync(rows.data(), idx->layer_bytes, idx->d_rows + (size_t)first_slot * idx->cfg.row_stride,
-                                  idx->cfg.row_stride, idx->layer_bytes, n, hipMemcpyDeviceToHost, idx->stream));
-        DANN_HIP(hipStreamSynchronize(idx->stream));
+                                  idx->cfg.row_stride, idx->layer_bytes, n, hipMemcpyDeviceToHost, idx->main.stream));
+        DANN_HIP(hipStreamSynchronize(idx->main.stream));
     }
     File out;
     out.f = fopen(path, "wb");
@@ -1358,6 +1523,7 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
 int32_t dann_abi_version(void) { return DANN_ABI_VERSION; }
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) try {
     if (!idx || which < 0 || which > 4) return DANN_EINVAL;
+    std::lock_guard<std::mutex> lk(idx->stat_mu);
     if (total_ms) *total_ms = idx->clocks[which].total_ms;
     if (launches) *launches = idx->clocks[which].launches;
     return DANN_OK;
@@ -1365,6 +1531,7 @@ int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms,
 
 int32_t dann_kernel_time_reset(dann_index* idx) try {
     if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::mutex> lk(idx->stat_mu);
     for (auto& c : idx->clocks) c = KernelClock();
     return DANN_OK;
 } DANN_CATCH_ALL

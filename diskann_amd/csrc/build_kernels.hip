@@ -42,7 +42,8 @@ struct PruneCfg {
     float alpha;
     uint32_t saturate_after_prune;
     // optional device counters (u64): [0] pair distances of the sweeps (row kernel), [1] list / extra distances
-    // d(location, c), [2] rows that went through an MFMA Gram, [3] sum of (Gram rows)^2 (x dim x 2 = MFMA flop)
+    // d(location, c), [2] rows that went through an MFMA Gram, [3] Gram entries computed (x dim x 2 = MFMA flop),
+    // [4] pair distances the lazy scans of the Gram sweeps asked for, [5] those answered by an exact re-evaluation
     unsigned long long* counters;
 };
 
@@ -589,15 +590,32 @@ __global__ __launch_bounds__(kWave) void backedge_kernel(BackArgs a) {
 // does not decide it, the pair is re-evaluated with the bit-exact row kernel.  The adjacency lists are therefore
 // identical to the lazy path's (and the oracle's) by construction; tests/test_gpu_build.py checks it.
 // ======================================================================================================
+// Two Gram arithmetics exist, each with its own C1 (relative to |x|^2 + |y|^2):
+//   blocked (backedge_gram_kernel, gram_mfma_f32): chains of 32 terms summed in f64 -> 3 gamma_32 = 6e-6;
+//   chained (gram_tiles_kernel): one f32 FMA chain over the whole row, K = dim rounded up to 32 terms:
+//       |G_ij - <x,y>| <= gamma_K sum|x_e y_e| <= K u (|x|^2 + |y|^2) / 2, u = 2^-24;  d' = (|x|^2 + |y|^2) - 2 G_ij
+//       with the norms accumulated in f64 -> (K + 4) u (|x|^2 + |y|^2) covers G, the norms' rounding and the two f32
+//       operations on terms of that size (5 % slack on top).
+// C2 (relative to |d'|) covers the final subtraction and the reference's own f32 rounding, which grows with the row
+// length: its L2 / IP kernels run dim / (8 NACC) terms per chain plus the combine and sum_tree adds and round x - y
+// before squaring -> (dim / 8 + 16) u bounds every row type and strategy (never below the 3e-6 of the 128-d analysis).
 constexpr float kGramC1 = 6.0e-6f, kGramC2 = 3.0e-6f;
+constexpr float kUnitRoundoff = 5.9604645e-8f;  // 2^-24
+inline float gram_c2_for_dim(uint32_t dim) {
+    const float c = ((float)(dim / 8u) + 16.0f) * kUnitRoundoff;
+    return c > kGramC2 ? c : kGramC2;
+}
+inline float gram_c1_chained(uint32_t dim) { return 1.05f * ((float)((dim + 31u) & ~31u) + 4.0f) * kUnitRoundoff; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GramCtx {
-    const float* g;      // LDS: g[p * ld + q] = <row p, row q>, p < nrows, q < ncols
-    const float* nrm;    // LDS: |row p|^2, p < nrows
+    const float* g;      // LDS or global: g[p * ld + q] = <row p, row q>, p < nrows, q < ncols
+    const float* nrm;    // |row p|^2, p < nrows
     uint32_t ld, nrows, ncols;
     bool by_sorted;      // rows are indexed by sorted pool order (pool prune) or by pool position (back-edge lists)
     float escale;        // 1.0; tests widen the error interval (DANN_GRAM_ESCALE) to drive every decision through the exact path
+    float c1, c2;        // error interval E = c1 (|x|^2 + |y|^2) + c2 |d'| of this Gram's arithmetic
+    bool count_rows;     // add this list to the Gram row / flop counters (the tiles kernel counts its own)
 };
 
 // All 4 waves of the workgroup: G[i][j] = <row ids[i], row ids[j]> for i < nrows, j < ncols (ncols <= nrows; the square
@@ -759,11 +777,10 @@ __device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pca
 // The sweep of prune::robust_prune over a pool already sorted by sort_pool_wave, pair distances from the Gram matrix
 // where it covers the pair (exact re-check where the error interval does not decide, exact evaluation where it
 // does not cover it).  One wave (lanes 0..63 of the workgroup).
-template <int OP, bool NORM>
+template <int DT, int OP, bool NORM>
 __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t N,
                                        uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out,
                                        const GramCtx gc) {
-    constexpr int DT = DT_F32;
     using S = Scheme<DT, OP, true>;
     constexpr int G = S::G;
     const uint32_t lane = threadIdx.x & 63u;
@@ -780,7 +797,7 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     const float inc = alpha < 1.2f ? alpha : 1.2f;
     const float kMax = 3.402823466e+38f;
     float cur_alpha = 1.0f;
-    uint32_t found = 0, nexact = 0;
+    uint32_t found = 0, nexact = 0, nasked = 0;  // nasked: pair distances the reference's lazy scan asks for
     const int v = lane % G;
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     // first selected entry in sel[a..b) (pool order filter rp < i) whose pair distance with candidate i makes
@@ -807,7 +824,7 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                     float dp;
                     if (OP == OP_L2) dp = nsum - 2.0f * gij;
                     else dp = NORM ? 1.0f - gij : -gij;
-                    const float e = gc.escale * (kGramC1 * nsum + kGramC2 * __builtin_fabsf(dp));
+                    const float e = gc.escale * (gc.c1 * nsum + gc.c2 * __builtin_fabsf(dp));
                     const float lo = dp - e, hi = dp + e;
                     if (occluding) {
                         if (hi < thr) cls = 1;
@@ -821,9 +838,15 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                 }
             }
             uint64_t tu = ballot64(cls != 0);
+            const uint64_t valid = ballot64(c < b && rp < i);  // the pairs of this block the lazy scan would evaluate
+            auto asked_upto = [&](int f) { nasked += (uint32_t)__popcll(valid & (f >= 63 ? ~0ull : ((2ull << f) - 1ull))); };
+            if (!tu) asked_upto(63);
             while (tu) {
                 const int f = __builtin_ctzll(tu);
-                if (__builtin_amdgcn_readlane(cls, f) == 1) return c0 + (uint32_t)f;
+                if (__builtin_amdgcn_readlane(cls, f) == 1) {
+                    asked_upto(f);
+                    return c0 + (uint32_t)f;
+                }
                 // bit-exact pair distance (every lane group evaluates the same pair)
                 ++nexact;
                 const uint32_t rpf = (uint32_t)__builtin_amdgcn_readlane((int)rp, f);
@@ -831,8 +854,12 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
                 const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(xi, y, (int)ix.dim, v), xi, y,
                                                               ix.dim, sqp);
                 const float dg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 0));
-                if (update_occlude<OP>(di, dg, 0.0f, at, occluding) > at) return c0 + (uint32_t)f;
+                if (update_occlude<OP>(di, dg, 0.0f, at, occluding) > at) {
+                    asked_upto(f);
+                    return c0 + (uint32_t)f;
+                }
                 tu &= tu - 1;
+                if (!tu) asked_upto(63);
             }
         }
         return b;
@@ -900,8 +927,12 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
         out[0] = nout;
         if (cfg.counters) {
             atomicAdd(&cfg.counters[0], (unsigned long long)nexact);
-            atomicAdd(&cfg.counters[2], (unsigned long long)P);
-            atomicAdd(&cfg.counters[3], (unsigned long long)P * P);
+            if (gc.count_rows) {
+                atomicAdd(&cfg.counters[2], (unsigned long long)P);
+                atomicAdd(&cfg.counters[3], (unsigned long long)P * P);
+            }
+            atomicAdd(&cfg.counters[4], (unsigned long long)nasked);
+            atomicAdd(&cfg.counters[5], (unsigned long long)nexact);
         }
     }
 }
@@ -912,6 +943,7 @@ struct BackGramArgs {
     BackArgs b;
     uint32_t pg;       // Gram rows available in LDS (multiple of 32, <= 128)
     float escale;      // error-interval scale (1.0)
+    float c2;          // gram_c2_for_dim(dim)
     uint32_t* stats;   // optional: [0] MFMA prunes [1] lazy prunes (list too long)
 };
 
@@ -992,8 +1024,8 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
     __syncthreads();
     if (mode == 1) {
         const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
-        sweep_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, src, N, smem, L, false, arow,
-                                         GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale});
+        sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, src, N, smem, L, false, arow,
+                                             GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale, kGramC1, ga.c2, true});
     } else {
         prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
     }
@@ -1008,126 +1040,328 @@ inline size_t backedge_gram_lds(uint32_t pcap, uint32_t degree, uint32_t pg) {
     return base + (size_t)pg * (pg + 1u) * 4u + (size_t)pg * 33u * 4u + (size_t)pg * 4u + 16u;
 }
 
-// pool prune (phase 1 of multi_insert) with the matrix cores: wave 0 loads and sorts the pool, all 4 waves compute the
-// Gram of the first `ng` sorted candidates against the first `mg` (the selected ones come from the front of the sorted
-// pool), wave 0 sweeps.  Pairs outside that block are evaluated exactly by the row kernel.
-struct PoolGramArgs {
+// ======================================================================================================
+// Pool prune (phase 1 of multi_insert: robust_prune_with, index.rs:2476-2532) on the matrix cores, three kernels:
+//   pool_sort_kernel   one wave per inserted point: pool + intra-batch extras -> SortedNeighbors::new, the sorted
+//                      (id, distance) list goes to global memory;
+//   gram_tiles_kernel  one 4-wave workgroup per point: the lower-triangular 32 x 32 tiles of
+//                      G = C[0..ng) x C[0..mg)^T (the selected candidates come from the front of the sorted pool, and the
+//                      sweep only ever asks for pairs (i, j) with j < i) with v_mfma_f32_32x32x2_f32, rows streamed
+//                      through 32-column LDS slabs, the next slab's global loads in flight under the MFMAs; nothing
+//                      else lives in this kernel, so several workgroups per CU keep the matrix pipes fed;
+//   pool_sweep_kernel  one wave per point at full occupancy: the sweep of prune::robust_prune with look-ups in G
+//                      (global memory, L2 / Infinity-Cache resident) and the bit-exact row kernel where the error
+//                      interval does not decide or the pair lies outside the block.
+// The fused form (sort + Gram + sweep in one 4-wave workgroup, 75 KB of LDS) ran two sweeps per CU and lost to the row
+// kernel (1 M x 768: 4.84 s vs 3.24 s); here the serial sweep and the Gram no longer share a workgroup.
+// f16 rows are widened exactly while a slab is filled (the reference's f16 kernels widen to f32 and run f32 FMAs).
+// ======================================================================================================
+struct SortArgs {
     PoolArgs p;
-    uint32_t ng, mg;
-    float escale;
+    uint32_t* sid;   // n x pcap: ids in sorted pool order
+    float* sd;       // n x pcap: their distances to the location
+    uint32_t* sn;    // n: sorted pool length after the max_occlusion cut (0 = the pool overflowed)
 };
 
-template <int OP, bool NORM>
-__global__ __launch_bounds__(256) void pool_prune_gram_kernel(PoolGramArgs ga) {
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void pool_sort_kernel(SortArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int DT = DT_F32;
     using S = Scheme<DT, OP, true>;
     constexpr int G = S::G, GROUPS = kWave / G;
-    const PoolArgs& a = ga.p;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
+    const PoolArgs& a = sa.p;
+    const uint32_t lane = threadIdx.x, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
     const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
     uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
     float* pd = reinterpret_cast<float*>(smem + L.pd_off);
     const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
-    const uint32_t gld = ga.mg + 1u;
-    float* gram = reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u));
-    float* slab = gram + ga.ng * gld;
-    float* gnrm = slab + ga.ng * 33u;
-    uint32_t* shared = reinterpret_cast<uint32_t*>(gnrm + ga.ng);
+    const float* sd = reinterpret_cast<const float*>(smem + L.sd_off);
     const uint32_t loc = a.locs[item];
-    uint32_t* out = a.out + (uint64_t)wi * a.out_stride;
-    if (wave == 0) {
-        uint64_t lo;
-        uint32_t cnt;
-        if (a.offsets) {
-            lo = a.offsets[wi];
-            cnt = (uint32_t)(a.offsets[wi + 1] - lo);
-        } else {
-            lo = (uint64_t)wi * a.stride;
-            cnt = a.counts[wi];
-        }
-        uint32_t nex = 0;
-        if (a.cand != 0 && a.n > 1) nex = a.cand < a.n - 1 ? a.cand : a.n - 1;
-        uint32_t N = 0, mode = 0;
-        if (cnt + nex > a.pcap) {
-            if (lane == 0) {
-                *a.err = 1;
-                out[0] = 0;
-            }
-        } else {
-            for (uint32_t i = lane; i < cnt; i += kWave) {
-                pid[i] = a.pool_ids[lo + i];
-                pd[i] = a.pool_d[lo + i];
-            }
-            if (nex) {  // extras = around(ids, position, cand) (utils/async_tools.rs:51-131), as pool_prune_kernel
-                const uint32_t half = (nex + 1) / 2;
-                const uint32_t start = item >= half ? item - half : a.n - (half - item);
-                const uint8_t* x = a.ix.rows + (uint64_t)loc * a.ix.row_stride;
-                const int g = lane / G, v = lane % G;
-                for (uint32_t r0 = 0; r0 < nex; r0 += GROUPS) {
-                    const uint32_t r = r0 + g;
-                    if (r < nex) {
-                        uint32_t p = start + r;
-                        const uint32_t dist_to_item = item >= start ? item - start : item + a.n - start;
-                        if (r >= dist_to_item) p += 1;
-                        p %= a.n;
-                        const uint32_t id = a.locs[p];
-                        const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
-                        const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(x, y, (int)a.ix.dim, v), x, y,
-                                                                      a.ix.dim, SqParams{a.ix.sq_k, a.ix.sq_shift_norm_sq});
-                        if (v == 0) {
-                            pid[cnt + r] = id;
-                            pd[cnt + r] = d;
-                        }
-                    }
-                }
-                if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)nex);
-            }
-            wave_sync();
-            N = sort_pool_wave(a.cfg, cnt + nex, a.pcap, smem, L);
-            mode = 1;
-        }
+    uint64_t lo;
+    uint32_t cnt;
+    if (a.offsets) {
+        lo = a.offsets[wi];
+        cnt = (uint32_t)(a.offsets[wi + 1] - lo);
+    } else {
+        lo = (uint64_t)wi * a.stride;
+        cnt = a.counts[wi];
+    }
+    uint32_t nex = 0;
+    if (a.cand != 0 && a.n > 1) nex = a.cand < a.n - 1 ? a.cand : a.n - 1;
+    if (cnt + nex > a.pcap) {
         if (lane == 0) {
-            shared[0] = mode;
-            shared[1] = N;
+            *a.err = 1;
+            a.out[(uint64_t)wi * a.out_stride] = 0;
+            sa.sn[wi] = 0;
+        }
+        return;
+    }
+    for (uint32_t i = lane; i < cnt; i += kWave) {
+        pid[i] = a.pool_ids[lo + i];
+        pd[i] = a.pool_d[lo + i];
+    }
+    if (nex) {  // extras = around(ids, position, cand) (utils/async_tools.rs:51-131), as pool_prune_kernel
+        const uint32_t half = (nex + 1) / 2;
+        const uint32_t start = item >= half ? item - half : a.n - (half - item);
+        const uint8_t* x = a.ix.rows + (uint64_t)loc * a.ix.row_stride;
+        const int g = lane / G, v = lane % G;
+        for (uint32_t r0 = 0; r0 < nex; r0 += GROUPS) {
+            const uint32_t r = r0 + g;
+            if (r < nex) {
+                uint32_t p = start + r;
+                const uint32_t dist_to_item = item >= start ? item - start : item + a.n - start;
+                if (r >= dist_to_item) p += 1;
+                p %= a.n;
+                const uint32_t id = a.locs[p];
+                const uint8_t* y = a.ix.rows + (uint64_t)id * a.ix.row_stride;
+                const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(x, y, (int)a.ix.dim, v), x, y,
+                                                              a.ix.dim, SqParams{a.ix.sq_k, a.ix.sq_shift_norm_sq});
+                if (v == 0) {
+                    pid[cnt + r] = id;
+                    pd[cnt + r] = d;
+                }
+            }
+        }
+        if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)nex);
+    }
+    wave_sync();
+    const uint32_t N = sort_pool_wave(a.cfg, cnt + nex, a.pcap, smem, L);
+    uint32_t* gs = sa.sid + (uint64_t)wi * a.pcap;
+    float* gd = sa.sd + (uint64_t)wi * a.pcap;
+    for (uint32_t i = lane; i < N; i += kWave) {
+        gs[i] = sid[i];
+        gd[i] = sd[i];
+    }
+    if (lane == 0) sa.sn[wi] = N;
+}
+
+struct TileArgs {
+    IndexView ix;
+    const uint32_t* sid;  // n x pcap sorted candidate ids (pool_sort_kernel)
+    const uint32_t* sn;   // n
+    uint32_t pcap;
+    uint32_t ng, mg;      // Gram rows / columns per item: multiples of 32, ng <= 256, mg <= 96
+    float* gram;          // n x ng x mg, entry (p, q) valid for q < p (and on the diagonal blocks)
+    float* nrm;           // n x ng
+    unsigned long long* counters;  // PruneCfg::counters: [2] += rows, [3] += tiles * 1024 (x dim x 2 = MFMA flop)
+};
+
+constexpr int kTileRowBlocks = 8;  // ng <= 256: wave w of the 8-wave workgroup owns row block w
+constexpr int kTileColBlocks = 3;  // mg <= 96
+constexpr int kTilePasses = kTileRowBlocks / 2;  // slab fill: 64 rows per pass
+
+template <typename RT>
+__device__ __forceinline__ float4 tile_load4(const uint8_t* p);  // 4 consecutive elements, widened exactly
+template <>
+__device__ __forceinline__ float4 tile_load4<float>(const uint8_t* p) {
+    return *reinterpret_cast<const float4*>(p);
+}
+template <>
+__device__ __forceinline__ float4 tile_load4<__half>(const uint8_t* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const float2 a = __half22float2(__builtin_bit_cast(__half2, t.x)), b = __half22float2(__builtin_bit_cast(__half2, t.y));
+    return float4{a.x, a.y, b.x, b.y};
+}
+template <typename RT>
+__device__ __forceinline__ float4 tile_fetch4(const uint8_t* row, uint32_t k, uint32_t dim);
+template <>
+__device__ __forceinline__ float4 tile_fetch4<float>(const uint8_t* row, uint32_t k, uint32_t dim) {
+    const float* r = reinterpret_cast<const float*>(row);
+    float4 q = {0.f, 0.f, 0.f, 0.f};
+    if (k + 3u < dim) {
+        q = *reinterpret_cast<const float4*>(r + k);
+    } else if (k < dim) {
+        q.x = r[k];
+        if (k + 1u < dim) q.y = r[k + 1u];
+        if (k + 2u < dim) q.z = r[k + 2u];
+    }
+    return q;
+}
+template <>
+__device__ __forceinline__ float4 tile_fetch4<__half>(const uint8_t* row, uint32_t k, uint32_t dim) {
+    const __half* r = reinterpret_cast<const __half*>(row);
+    float4 q = {0.f, 0.f, 0.f, 0.f};
+    if (k + 3u < dim) {
+        const uint2 t = *reinterpret_cast<const uint2*>(r + k);
+        const float2 a = __half22float2(__builtin_bit_cast(__half2, t.x)), b = __half22float2(__builtin_bit_cast(__half2, t.y));
+        q = {a.x, a.y, b.x, b.y};
+    } else if (k < dim) {
+        q.x = __half2float(r[k]);
+        if (k + 1u < dim) q.y = __half2float(r[k + 1u]);
+        if (k + 2u < dim) q.z = __half2float(r[k + 2u]);
+    }
+    return q;
+}
+
+// one 32-column slab of NT tiles that share the row-block operand: every operand of the slab is read from LDS up front
+// (the compiler is free to interleave), then 16 NT independent-accumulator MFMAs stream into the matrix pipe
+template <int NT>
+__device__ __forceinline__ void tile_slab(const float* pa, const float* pc, f32x16 (&acc)[kTileColBlocks]) {
+    float av[16], bv[NT][16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        av[kk] = pa[2 * kk];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t][kk] = pc[t * 32 * 33 + 2 * kk];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+}
+
+template <typename RT>
+__global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* slab = reinterpret_cast<float*>(smem);  // ng rows x 33 floats
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, item = blockIdx.x;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform for the compiler too
+    const uint32_t N = a.sn[item];
+    const uint32_t nrows = N < a.ng ? N : a.ng, ncols = N < a.mg ? N : a.mg;
+    if (nrows == 0) return;
+    const uint32_t TR = (nrows + 31u) >> 5, TC = (ncols + 31u) >> 5;
+    const uint32_t* ids = a.sid + (uint64_t)item * a.pcap;
+    const uint32_t dim = a.ix.dim;
+    // slab fill: 8 threads x 4 elements per row, 64 rows per pass.  Every request of the steady state is unconditional
+    // (a load under a per-lane condition gets its own s_waitcnt and the prefetch degenerates to one request in flight):
+    // rows that do not exist or cannot be retrieved point at row 0 and are zeroed when the slab is written.
+    const uint32_t lr = tid >> 3, c4 = (tid & 7u) << 2;
+    const uint8_t* rowp[kTilePasses];
+    bool rowok[kTilePasses];
+    double nsq[kTilePasses];
+#pragma unroll
+    for (int p = 0; p < kTilePasses; ++p) {
+        const uint32_t r = ((uint32_t)p << 6) + lr;
+        const uint32_t id = r < nrows ? ids[r] : kEmpty;
+        rowok[p] = id < a.ix.nslots;  // ids the sweep excludes anyway (not retrievable) read as zero rows
+        rowp[p] = a.ix.rows + (uint64_t)(rowok[p] ? id : 0u) * a.ix.row_stride + (size_t)c4 * sizeof(RT);
+        nsq[p] = 0.0;
+    }
+    float4 nxt[kTilePasses];
+    const uint32_t dim_full = dim & ~31u;  // slabs below this are complete: one 4-element request per thread and row
+    // tiles of this wave: row block `wave`, column blocks 0 .. min(wave, TC - 1)
+    const uint32_t nt = wave < TR ? ((wave < TC ? wave : TC - 1u) + 1u) : 0u;
+    f32x16 acc[kTileColBlocks];
+#pragma unroll
+    for (int t = 0; t < kTileColBlocks; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const uint32_t l31 = lane & 31u, hi = lane >> 5;
+    const uint32_t fill_rows = TR << 5;
+    const float* pa = slab + ((wave << 5) + l31) * 33u + hi;
+    const float* pc = slab + l31 * 33u + hi;
+    auto write_slab = [&]() {
+#pragma unroll
+        for (int p = 0; p < kTilePasses; ++p) {
+            const uint32_t r = ((uint32_t)p << 6) + lr;
+            if (r < fill_rows) {
+                float4 q = nxt[p];
+                if (!rowok[p]) q = float4{0.f, 0.f, 0.f, 0.f};
+                float* dst = slab + r * 33u + c4;
+                dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
+                nsq[p] += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+            }
+        }
+    };
+    auto mfma_slab = [&]() {
+        if (nt == 3u) tile_slab<3>(pa, pc, acc);
+        else if (nt == 2u) tile_slab<2>(pa, pc, acc);
+        else if (nt == 1u) tile_slab<1>(pa, pc, acc);
+    };
+    if (dim_full) {
+        // steady state: one basic block of requests per slab -- all kTilePasses of them, unconditionally (passes beyond
+        // the item's rows re-read row 0 from cache): a request under a branch, even a uniform one, is fenced by its own
+        // s_waitcnt.  The last iteration re-requests its own slab instead of branching around the prefetch.
+#pragma unroll
+        for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p]);
+        for (uint32_t k0 = 0; k0 < dim_full; k0 += 32u) {
+            write_slab();
+            __syncthreads();
+            const uint32_t kn = k0 + 32u < dim_full ? k0 + 32u : k0;
+#pragma unroll
+            for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p] + (size_t)kn * sizeof(RT));
+            mfma_slab();
+            __syncthreads();
         }
     }
-    __syncthreads();
-    const uint32_t mode = shared[0], N = shared[1];
-    if (mode == 0) return;
-    const uint32_t nr = N < ga.ng ? N : ga.ng, nc = N < ga.mg ? N : ga.mg;
-    gram_mfma_f32(a.ix, sid, nr, nc, gram, gld, gnrm, slab);
-    __syncthreads();
-    if (wave != 0) return;
-    sweep_sorted_pool_gram<OP, NORM>(a.ix, a.cfg, loc, N, smem, L, a.force_saturate != 0, out,
-                                     GramCtx{gram, gnrm, gld, nr, nc, true, ga.escale});
-}
-
-inline size_t pool_gram_lds(uint32_t pcap, uint32_t degree, uint32_t ng, uint32_t mg) {
-    const size_t base = (pool_lds_layout(pcap, degree).total + 15u) & ~(size_t)15u;
-    return base + (size_t)ng * (mg + 1u) * 4u + (size_t)ng * 33u * 4u + (size_t)ng * 4u + 16u;
-}
-
-int32_t launch_pool_gram(const IndexView& ix, const PoolGramArgs& ga, uint32_t grid, size_t lds, hipStream_t stream) {
-    int op;
-    bool norm;
-    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm) || ix.dtype != DT_F32 || op == OP_COS) return DANN_EUNSUPPORTED;
-    auto run = [&](auto kern) -> int32_t {
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-            raised = true;
+    if (dim_full < dim) {  // the last, partial slab (dim % 32 != 0): element-wise requests, once per item
+#pragma unroll
+        for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_fetch4<RT>(rowp[p] - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
+        write_slab();
+        __syncthreads();
+        mfma_slab();
+        __syncthreads();
+    }
+    // C layout of v_mfma_f32_32x32x2_f32: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+    float* g = a.gram + (uint64_t)item * a.ng * a.mg;
+#pragma unroll
+    for (int t = 0; t < kTileColBlocks; ++t) {
+        if ((uint32_t)t < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t i = (wave << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
+                g[(uint64_t)i * a.mg + ((uint32_t)t << 5) + l31] = acc[t][r];  // i < 32 TR <= ng, column < 32 TC <= mg
+            }
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, ga);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "pool_prune_gram_kernel launch");
-        return DANN_OK;
-    };
-    if (op == OP_L2) return run(pool_prune_gram_kernel<OP_L2, false>);
-    if (norm) return run(pool_prune_gram_kernel<OP_IP, true>);
-    return run(pool_prune_gram_kernel<OP_IP, false>);
+    }
+    // squared norms: the 8 threads of a row hold f64 partial sums
+    float* nr = a.nrm + (uint64_t)item * a.ng;
+#pragma unroll
+    for (int p = 0; p < kTilePasses; ++p) {
+        double v = nsq[p];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const uint32_t r = ((uint32_t)p << 6) + lr;
+        if ((tid & 7u) == 0 && r < nrows) nr[r] = (float)v;
+    }
+    if (tid == 0 && a.counters) {
+        uint32_t tiles = 0;
+        for (uint32_t rb = 0; rb < TR; ++rb) tiles += (rb < TC ? rb : TC - 1u) + 1u;
+        atomicAdd(&a.counters[2], (unsigned long long)nrows);
+        atomicAdd(&a.counters[3], (unsigned long long)tiles * 1024ull);
+    }
+}
+
+struct SweepArgs {
+    PoolArgs p;
+    const uint32_t* sid;
+    const float* sd;
+    const uint32_t* sn;
+    const float* gram;
+    const float* nrm;
+    uint32_t ng, mg;
+    float escale, c1, c2;
+};
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const PoolArgs& a = sa.p;
+    const uint32_t lane = threadIdx.x, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
+    const uint32_t N = sa.sn[wi];
+    if (N == 0) {  // overflow (reported by pool_sort_kernel) or an empty pool
+        if (lane == 0) a.out[(uint64_t)wi * a.out_stride] = 0;
+        return;
+    }
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* sid = reinterpret_cast<uint32_t*>(smem + L.sid_off);
+    float* sd = reinterpret_cast<float*>(smem + L.sd_off);
+    float* occ = reinterpret_cast<float*>(smem + L.occ_off);
+    uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
+    const uint32_t* gs = sa.sid + (uint64_t)wi * a.pcap;
+    const float* gd = sa.sd + (uint64_t)wi * a.pcap;
+    for (uint32_t i = lane; i < N; i += kWave) {
+        sid[i] = gs[i];
+        sd[i] = gd[i];
+        occ[i] = 0.0f;
+        last[i] = 0;
+    }
+    wave_sync();
+    const uint32_t nr = N < sa.ng ? N : sa.ng, nc = N < sa.mg ? N : sa.mg;
+    sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, a.locs[item], N, smem, L, a.force_saturate != 0,
+                                         a.out + (uint64_t)wi * a.out_stride,
+                                         GramCtx{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
+                                                 nr, nc, true, sa.escale, sa.c1, sa.c2, false});
 }
 
 __global__ __launch_bounds__(256) void gram_debug_kernel(IndexView ix, uint32_t cnt, float* out) {
@@ -1266,10 +1500,43 @@ DANN_LAUNCHER(PoolLauncher, pool_prune_kernel, PoolArgs)
 DANN_LAUNCHER(BootLauncher, bootstrap_kernel, ListArgs)
 DANN_LAUNCHER(BackLauncher, backedge_kernel, BackArgs)
 
+// the three kernels of the MFMA pool prune: float rows (f32 / f16), L2 / inner product / cosine-normalized
+template <template <int, int, bool> class K, class Args>
+int32_t dispatch_float(const IndexView& ix, const Args& a, uint32_t grid, size_t lds, hipStream_t stream) {
+    int op;
+    bool norm;
+    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm) || op == OP_COS || (ix.dtype != DT_F32 && ix.dtype != DT_F16))
+        return DANN_EUNSUPPORTED;
+    if (ix.dtype == DT_F32) {
+        if (op == OP_L2) return K<DT_F32, OP_L2, false>::run(a, grid, lds, stream);
+        return norm ? K<DT_F32, OP_IP, true>::run(a, grid, lds, stream) : K<DT_F32, OP_IP, false>::run(a, grid, lds, stream);
+    }
+    if (op == OP_L2) return K<DT_F16, OP_L2, false>::run(a, grid, lds, stream);
+    return norm ? K<DT_F16, OP_IP, true>::run(a, grid, lds, stream) : K<DT_F16, OP_IP, false>::run(a, grid, lds, stream);
+}
+DANN_LAUNCHER(SortLauncher, pool_sort_kernel, SortArgs)
+DANN_LAUNCHER(SweepLauncher, pool_sweep_kernel, SweepArgs)
+
+int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) {
+    const size_t lds = (size_t)a.ng * 33u * 4u;
+    if (a.ix.dtype == DT_F32) hipLaunchKernelGGL(gram_tiles_kernel<float>, dim3(grid), dim3(512), lds, stream, a);
+    else if (a.ix.dtype == DT_F16) hipLaunchKernelGGL(gram_tiles_kernel<__half>, dim3(grid), dim3(512), lds, stream, a);
+    else return DANN_EUNSUPPORTED;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gram_tiles_kernel launch");
+    return DANN_OK;
+}
+
 uint32_t next_pow2(uint32_t x) {
     uint32_t p = 64;
     while (p < x) p <<= 1;
     return p;
+}
+
+// development switch: DANN_POOL_GRAM=0 keeps the row kernel for the pool prune of large rows (A/B runs)
+bool pool_gram_default() {
+    const char* e = getenv("DANN_POOL_GRAM");
+    return !e || atoi(e) != 0;
 }
 
 PruneCfg to_prune_cfg(const dann_build_config& c) {
@@ -1339,6 +1606,9 @@ struct BuildScratch {
     DevBuf slots, rec_ids, rec_d, rec_n, stats, pending, pending2, keys_in, keys_out, seg_start, seg_len, meta, sort_tmp;
     DevBuf counters;  // 8 x u64, see PruneCfg::counters (accumulate until dann_build_counters_reset)
     size_t sort_tmp_bytes = 0;
+    // MFMA pool prune: sorted pools, Gram blocks and norms of one batch slice (grow-only)
+    DevBuf g_sid, g_sd, g_sn, g_gram, g_nrm;
+    size_t g_sorted_elems = 0, g_items = 0, g_gram_elems = 0, g_nrm_elems = 0;
 };
 
 int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uint32_t degree) {
@@ -1359,6 +1629,7 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
     DANN_HIP(s.seg_start.alloc(nkeys * 4));
     DANN_HIP(s.seg_len.alloc(nkeys * 4 * 3));  // segment lengths | short worklist | long worklist
     DANN_HIP(s.meta.alloc(64));
+    DANN_HIP(hipMemset(s.meta.p, 0, 64));  // the commit phase may run first on this handle (sharded build: empty slice)
     if (!s.counters.p) {
         DANN_HIP(s.counters.alloc(64));
         DANN_HIP(hipMemset(s.counters.p, 0, 64));
@@ -1386,7 +1657,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     const IndexView ix = idx->view();
     PruneCfg pc = to_prune_cfg(cfg);
     pc.counters = s.counters.as<unsigned long long>();
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->main.stream;
     const uint32_t m = hi - lo;
     if (m == 0) return DANN_OK;
     const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
@@ -1420,7 +1691,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     uint32_t* meta = s.meta.as<uint32_t>();  // [0] nseg [1] nkeys [2] maxseg [3] err [4] appends [5] prunes [6] max record
     DANN_HIP(hipMemsetAsync(meta, 0, 64, st));
     sa.rec_max = meta + 6;
-    int32_t rc = search_with_retry(idx, sa);
+    int32_t rc = search_with_retry(idx, idx->main, sa);
     if (rc != DANN_OK) return rc;
     // the pool's LDS footprint follows the longest record of this batch, not the worst-case bound
     uint32_t h_recmax = 0;
@@ -1450,21 +1721,74 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     }
     const size_t lds = pool_lds_layout(pa.pcap, pc.pruned_degree).total;
     bool pool_gram = false;
-    if ((idx->build_flags & DANN_BUILD_MFMA_POOL) && ix.dtype == DT_F32 && ix.metric != M_COSINE) {
-        // Gram block: the first 128 sorted candidates against the first 96 (two workgroups per CU at a 256-entry pool)
-        const uint32_t ng = 128, mg = 96;
-        const size_t glds = pool_gram_lds(pa.pcap, pc.pruned_degree, ng, mg);
-        if (glds <= 160u * 1024u) {
-            PoolGramArgs ga;
-            ga.p = pa;
-            ga.ng = ng;
-            ga.mg = mg;
-            const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
-            ga.escale = es ? (float)atof(es) : 1.0f;
-            rc = launch_pool_gram(ix, ga, m, glds, st);
-            if (rc != DANN_OK) return rc;
-            pool_gram = true;
+    // matrix-core path (three kernels: sort, Gram tiles, sweep).  Default for float rows of 1 KiB and more unless
+    // DANN_BUILD_ROW_KERNEL_ONLY is set; DANN_BUILD_MFMA_POOL forces it for any row size.
+    const bool floatrows = (ix.dtype == DT_F32 || ix.dtype == DT_F16) && ix.metric != M_COSINE;
+    const bool want_pool_gram = floatrows && ((idx->build_flags & DANN_BUILD_MFMA_POOL) ||
+                                              (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u &&
+                                               pool_gram_default()));
+    if (want_pool_gram) {
+        const char* ce = getenv("DANN_GRAM_COLS");  // tuning hook: columns of the Gram block (32 / 64 / 96)
+        uint32_t mg = ce ? (uint32_t)atoi(ce) : 96u;
+        mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
+        const uint32_t ng = std::max<uint32_t>(mg, std::min<uint32_t>(32u * kTileRowBlocks, (h_recmax + nex + 31u) & ~31u));
+        const size_t sorted_elems = (size_t)m * pa.pcap, gram_elems = (size_t)m * ng * mg, nrm_elems = (size_t)m * ng;
+        if (s.g_sorted_elems < sorted_elems) {
+            s.g_sorted_elems = 0;
+            DANN_HIP(s.g_sid.alloc(sorted_elems * 4));
+            DANN_HIP(s.g_sd.alloc(sorted_elems * 4));
+            s.g_sorted_elems = sorted_elems;
         }
+        if (s.g_items < m) {
+            s.g_items = 0;
+            DANN_HIP(s.g_sn.alloc((size_t)m * 4));
+            s.g_items = m;
+        }
+        if (s.g_gram_elems < gram_elems) {
+            s.g_gram_elems = 0;
+            DANN_HIP(s.g_gram.alloc(gram_elems * 4));
+            s.g_gram_elems = gram_elems;
+        }
+        if (s.g_nrm_elems < nrm_elems) {
+            s.g_nrm_elems = 0;
+            DANN_HIP(s.g_nrm.alloc(nrm_elems * 4));
+            s.g_nrm_elems = nrm_elems;
+        }
+        SortArgs so;
+        so.p = pa;
+        so.sid = s.g_sid.as<uint32_t>();
+        so.sd = s.g_sd.as<float>();
+        so.sn = s.g_sn.as<uint32_t>();
+        rc = dispatch_float<SortLauncher>(ix, so, m, lds, st);
+        if (rc != DANN_OK) return rc;
+        TileArgs ta;
+        ta.ix = ix;
+        ta.sid = so.sid;
+        ta.sn = so.sn;
+        ta.pcap = pa.pcap;
+        ta.ng = ng;
+        ta.mg = mg;
+        ta.gram = s.g_gram.as<float>();
+        ta.nrm = s.g_nrm.as<float>();
+        ta.counters = pc.counters;
+        rc = launch_gram_tiles(ta, m, st);
+        if (rc != DANN_OK) return rc;
+        SweepArgs sw;
+        sw.p = pa;
+        sw.sid = so.sid;
+        sw.sd = so.sd;
+        sw.sn = so.sn;
+        sw.gram = ta.gram;
+        sw.nrm = ta.nrm;
+        sw.ng = ng;
+        sw.mg = mg;
+        const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
+        sw.escale = es ? (float)atof(es) : 1.0f;
+        sw.c1 = gram_c1_chained(ix.dim);
+        sw.c2 = gram_c2_for_dim(ix.dim);
+        rc = dispatch_float<SweepLauncher>(ix, sw, m, lds, st);
+        if (rc != DANN_OK) return rc;
+        pool_gram = true;
     }
     if (!pool_gram) {
         rc = dispatch<PoolLauncher>(ix, pa, m, lds, st);
@@ -1501,7 +1825,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
     const IndexView ix = idx->view();
     PruneCfg pc = to_prune_cfg(cfg);
     pc.counters = s.counters.as<unsigned long long>();
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->main.stream;
     const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
     uint32_t* meta = s.meta.as<uint32_t>();
     const uint32_t* pending = d_pending;
@@ -1523,6 +1847,9 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         return DANN_OK;
     };
     uint32_t h_meta[4] = {0, 0, 0, 0};
+    // err, appends, prunes, longest record, pad: a commit does not inherit the error word of an earlier call on this
+    // handle (phase 1 reports its own errors before it returns); within the commit the word stays sticky
+    DANN_HIP(hipMemsetAsync(meta + 3, 0, 20, st));
     rc = aggregate(h_meta);
     if (rc != DANN_OK) return rc;
 
@@ -1633,6 +1960,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 ga.stats = meta + 8;
                 const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
                 ga.escale = es ? (float)atof(es) : 1.0f;
+                ga.c2 = gram_c2_for_dim(ix.dim);
                 rc = launch_backedge_gram(ix, ga, backedge_gram_lds(bs.pcap, pc.pruned_degree, pg), st);
                 if (rc != DANN_OK) return rc;
                 gram = true;
@@ -1704,7 +2032,7 @@ extern "C" {
 
 int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1719,7 +2047,7 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
     const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
     rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
     return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), n);
 } DANN_CATCH_ALL
 
@@ -1729,7 +2057,7 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
 int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
                                      uint32_t lo, uint32_t hi, uint32_t* d_pending_out) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1742,14 +2070,14 @@ int32_t dann_insert_batch_candidates(dann_index* idx, const dann_build_config* c
     const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
     rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
     return batch_candidates(idx, *cfg, s, s.slots.as<uint32_t>(), n, lo, hi, d_pending_out);
 } DANN_CATCH_ALL
 
 int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n,
                                  const uint32_t* d_pending_all) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1761,7 +2089,7 @@ int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, 
     const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
     rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
     return batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all);
 } DANN_CATCH_ALL
 
@@ -1770,7 +2098,7 @@ int32_t dann_insert_batch_commit_part(dann_index* idx, const dann_build_config* 
                                       uint32_t rows_cap, uint32_t* count_out) try {
     if (!idx || !count_out || world == 0 || rank >= world) return DANN_EINVAL;
     *count_out = 0;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1782,21 +2110,21 @@ int32_t dann_insert_batch_commit_part(dann_index* idx, const dann_build_config* 
     const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
     rc = ensure_scratch(s, n, rec_stride, cfg->pruned_degree);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream));
+    DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
     rc = batch_commit(idx, *cfg, s, s.slots.as<uint32_t>(), n, d_pending_all, rank, world, d_rows_out, rows_cap, count_out);
     if (rc != DANN_OK) return rc;
-    DANN_HIP(hipStreamSynchronize(idx->stream));  // the exported rows are read by the caller's collective next
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));  // the exported rows are read by the caller's collective next
     return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows, uint32_t count) try {
     if (!idx || (count && !d_rows)) return DANN_EINVAL;
     if (count == 0) return DANN_OK;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
-    hipLaunchKernelGGL(apply_rows_kernel, dim3(count), dim3(kWave), 0, idx->stream, idx->view(), d_rows, count);
+    hipLaunchKernelGGL(apply_rows_kernel, dim3(count), dim3(kWave), 0, idx->main.stream, idx->view(), d_rows, count);
     DANN_HIP(hipGetLastError());
-    DANN_HIP(hipStreamSynchronize(idx->stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -1825,35 +2153,84 @@ int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t 
     return DANN_OK;
 } DANN_CATCH_ALL
 
+int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
+                              float* out_gram, float* out_nrm) try {
+    if (!rows || !out_gram || !out_nrm || n == 0 || n > 32u * kTileRowBlocks || dim == 0 || (dtype != DT_F32 && dtype != DT_F16))
+        return DANN_EINVAL;
+    mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
+    DeviceGuard guard(device < 0 ? 0 : device);
+    const size_t esz = dtype == DT_F32 ? 4 : 2;
+    const size_t stride = ((size_t)dim * esz + 15) & ~(size_t)15;
+    const uint32_t ng = (n + 31u) & ~31u;
+    DevBuf dr, dids, dsn, dg, dn;
+    DANN_HIP(dr.alloc(stride * n + 256));
+    DANN_HIP(dids.alloc((size_t)ng * 4));
+    DANN_HIP(dsn.alloc(4));
+    DANN_HIP(dg.alloc((size_t)ng * mg * 4));
+    DANN_HIP(dn.alloc((size_t)ng * 4));
+    DANN_HIP(hipMemset(dr.p, 0, stride * n + 256));
+    DANN_HIP(hipMemset(dg.p, 0, (size_t)ng * mg * 4));
+    DANN_HIP(hipMemset(dn.p, 0, (size_t)ng * 4));
+    DANN_HIP(hipMemcpy2D(dr.p, stride, rows, (size_t)dim * esz, (size_t)dim * esz, n, hipMemcpyHostToDevice));
+    std::vector<uint32_t> ids(ng);
+    for (uint32_t i = 0; i < ng; ++i) ids[i] = i;
+    DANN_HIP(hipMemcpy(dids.p, ids.data(), (size_t)ng * 4, hipMemcpyHostToDevice));
+    DANN_HIP(hipMemcpy(dsn.p, &n, 4, hipMemcpyHostToDevice));
+    TileArgs ta{};
+    ta.ix.rows = dr.as<uint8_t>();
+    ta.ix.row_stride = stride;
+    ta.ix.dim = dim;
+    ta.ix.dtype = dtype;
+    ta.ix.nslots = n;
+    ta.sid = dids.as<uint32_t>();
+    ta.sn = dsn.as<uint32_t>();
+    ta.pcap = ng;
+    ta.ng = ng;
+    ta.mg = std::min(mg, ng);
+    ta.gram = dg.as<float>();
+    ta.nrm = dn.as<float>();
+    ta.counters = nullptr;
+    int32_t rc = launch_gram_tiles(ta, 1, 0);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipDeviceSynchronize());
+    // out_gram: n x mg (row stride mg as passed, entries beyond the computed block are zero)
+    std::vector<float> g((size_t)ng * ta.mg);
+    DANN_HIP(hipMemcpy(g.data(), dg.p, g.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < mg; ++j) out_gram[(size_t)i * mg + j] = j < ta.mg ? g[(size_t)i * ta.mg + j] : 0.0f;
+    DANN_HIP(hipMemcpy(out_nrm, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DANN_OK;
+} DANN_CATCH_ALL
+
 int32_t dann_set_build_options(dann_index* idx, uint32_t flags) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     idx->build_flags = flags;
     return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n) try {
     if (!idx || (n && !out)) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     uint64_t dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (idx->build_scratch) {
         BuildScratch& s = *static_cast<BuildScratch*>(idx->build_scratch);
         if (s.counters.p) {
             DeviceGuard guard(idx->device);
-            DANN_HIP(hipStreamSynchronize(idx->stream));
+            DANN_HIP(hipStreamSynchronize(idx->main.stream));
             DANN_HIP(hipMemcpy(dev, s.counters.p, 64, hipMemcpyDeviceToHost));
         }
     }
-    const uint64_t all[8] = {idx->build_counters[0], idx->build_counters[1], idx->build_counters[2], idx->build_counters[3],
-                             dev[0], dev[1], dev[2], dev[3]};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 8 ? all[i] : 0u;
+    const uint64_t all[10] = {idx->build_counters[0], idx->build_counters[1], idx->build_counters[2], idx->build_counters[3],
+                              dev[0], dev[1], dev[2], dev[3], dev[4], dev[5]};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? all[i] : 0u;
     return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
                    uint32_t max_batch) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1874,8 +2251,8 @@ int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first
         b = std::min(b, n - done);
         ids.resize(b);
         for (uint32_t i = 0; i < b; ++i) ids[i] = first + done + i;
-        DANN_HIP(hipMemcpyAsync(s.slots.p, ids.data(), (size_t)b * 4, hipMemcpyHostToDevice, idx->stream));
-        DANN_HIP(hipStreamSynchronize(idx->stream));
+        DANN_HIP(hipMemcpyAsync(s.slots.p, ids.data(), (size_t)b * 4, hipMemcpyHostToDevice, idx->main.stream));
+        DANN_HIP(hipStreamSynchronize(idx->main.stream));
         s.bootstrap_too_big = false;
         rc = insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), b);
         if (rc == DANN_EUNSUPPORTED && s.bootstrap_too_big && b > 1) {
@@ -1896,7 +2273,7 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
                          const uint32_t* pool_ids, const float* pool_dists, const uint64_t* offsets,
                          int32_t force_saturate, uint32_t* out_adj) try {
     if (!idx) return DANN_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock(idx->mu);
+    ::dann::ExclusiveGuard lock(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -1922,7 +2299,7 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
     DANN_HIP(doff.alloc((size_t)(n + 1) * 8));
     DANN_HIP(dout.alloc((size_t)n * ostride * 4));
     DANN_HIP(derr.alloc(4));
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->main.stream;
     DANN_HIP(hipMemcpyAsync(dl.p, locs, (size_t)n * 4, hipMemcpyHostToDevice, st));
     DANN_HIP(hipMemcpyAsync(di.p, pool_ids, total * 4, hipMemcpyHostToDevice, st));
     DANN_HIP(hipMemcpyAsync(dd.p, pool_dists, total * 4, hipMemcpyHostToDevice, st));

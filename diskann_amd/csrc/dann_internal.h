@@ -3,9 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -70,6 +73,34 @@ struct IndexView {
     uint32_t tag_off;
 };
 
+// Persistent search server (dann_server_start): device view of the submission ring.  The ring lives in host-mapped,
+// fine-grained memory: a caller copies its query into slot (ticket % ring) and publishes it by storing the slot's lap
+// number; wave 0 of the kernel (the dispatcher) polls the publication words over PCIe, 64 at a time, and advances
+// `avail` in device memory; the worker waves draw tickets from `head`, wait for avail > ticket, stage the query into
+// device memory, run the ordinary beam search and write the result plus a completion word back to the host ring.
+struct ServerView {
+    const uint8_t* h_queries = nullptr;  // host ring: ring x qstride bytes
+    const uint32_t* h_pub = nullptr;     // host: ring publication words ((ticket / ring) + 1 once slot is filled)
+    uint32_t* h_res_ids = nullptr;       // host: ring x k
+    float* h_res_d = nullptr;            // host: ring x k
+    dann_search_stats* h_res_stats = nullptr;  // host: ring
+    uint32_t* h_done = nullptr;          // host: ring completion words ((ticket / ring) + 1 once the result is written)
+    uint32_t* h_ctl = nullptr;           // host: [0] stop request (host -> GPU), [1] the dispatcher has decided to exit
+    unsigned long long* d_head = nullptr;   // device: next ticket a worker draws
+    unsigned long long* d_avail = nullptr;  // device: tickets below this are published
+    uint32_t* d_stop = nullptr;          // device: workers leave when they see it
+    uint8_t* d_q = nullptr;              // device: workers x qstride (staged queries)
+    uint32_t ring = 0;                   // entries, a power of two
+    uint32_t ring_shift = 0;             // log2(ring)
+    uint32_t qstride = 0;                // bytes per query slot (multiple of 16)
+    uint32_t qbytes = 0;                 // bytes of one query
+    uint32_t workers = 0;
+    uint32_t ticks_per_us = 100;         // wall_clock64 rate (hipDeviceAttributeWallClockRate)
+    uint32_t idle_timeout_us = 100000;   // the kernel leaves after this long without a new submission (a later submit
+                                         // relaunches it): a device-wide synchronisation elsewhere in the process must
+                                         // not wait for ever on an idle server
+};
+
 struct SearchArgs {
     IndexView ix;
     const void* queries = nullptr;     // nq rows of layer bytes, or nullptr when `qslots` is used
@@ -120,6 +151,31 @@ struct SearchArgs {
     uint32_t tune = 0;               // kTune* bits, chosen per launch by search_with_retry (never affect results)
     uint32_t grid = 0;               // 0: one wave per query; else `grid` persistent waves share the nq queries through
     uint32_t* work_next = nullptr;   //    this counter (zeroed before the launch): dann_set_max_concurrency
+    ServerView srv;                  // srv.ring != 0: the launch is the persistent server (grid = workers + 1 waves)
+};
+
+// Everything one in-flight search call needs besides the (read-only) index: its own stream and events, the retry
+// scratch, a pool of global-memory visited tables, the failure flag and staging buffers.  The index owns one
+// (`main`, also the stream of every mutation) plus a pool of further ones handed to concurrent searches -- the
+// reference's model is N workers calling `search` on one shared `&DiskANNIndex`
+// (diskann-benchmark-core/src/search/api.rs:409-425); here N callers' launches run side by side on N streams.
+struct SearchCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
+    size_t fail_cap = 0;
+    uint32_t* d_spill = nullptr;  // spill tables | counter (+pad) | busy flags | cmps histogram
+    uint32_t spill_slices = 0, spill_bits = 0;
+    uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
+    // grow-only device staging for the host-pointer search entry (no hipMalloc / hipFree per call)
+    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    void* h_stage = nullptr;     // pinned host staging (small batches: one H2D + one D2H per call; large: chunk ring)
+    size_t h_stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;  // second stream of the chunked host-pointer pipeline
+    hipEvent_t chunk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t init();   // stream, events, failure flag (device already current)
+    void destroy();
 };
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out = nullptr);
@@ -134,7 +190,9 @@ DANN_DECL_LAUNCH(sq8);
 DANN_DECL_LAUNCH(pq);
 #undef DANN_DECL_LAUNCH
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
-int32_t search_with_retry(dann_index* idx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
+int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a);
+// enqueue the persistent server kernel (a.srv filled in) on ctx.stream; returns without waiting
+int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);
 // explicit table size set with dann_set_visited_bits, or 0 = let search_with_retry size it
 uint32_t auto_visited_entries(const dann_index* idx, uint32_t l_value, uint32_t beam);
@@ -158,11 +216,12 @@ int32_t launch_distance_raw(const IndexView& ix, const void* d_x, const void* d_
 
 }  // namespace dann
 
+struct dann_server;  // persistent search server (server.hip)
+
 struct dann_index {
     dann_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    dann::SearchCtx main;  // stream of every mutation and of the non-concurrent entry points
     uint8_t* d_rows = nullptr;
     uint32_t* d_adj = nullptr;
     uint32_t layer_bytes = 0;
@@ -176,27 +235,57 @@ struct dann_index {
     uint64_t build_counters[4] = {0, 0, 0, 0};
     float* d_pq_pivots = nullptr;
     uint32_t* d_pq_offsets = nullptr;
-    uint32_t* d_fail = nullptr;  // retry scratch: [count, pad, list A (cap), list B (cap)]
-    size_t fail_cap = 0;
-    uint32_t* d_spill = nullptr;   // spill tables | counter (+pad) | busy flags | cmps histogram
-    std::unordered_map<uint64_t, dann::VisitedCalib> calib;
-    uint32_t spill_slices = 0, spill_bits = 0;
+    std::unordered_map<uint64_t, dann::VisitedCalib> calib;  // guarded by stat_mu
     void* build_scratch = nullptr;            // owned by build_kernels.hip
     void (*build_scratch_free)(void*) = nullptr;
-    uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
-    // grow-only device staging for the host-pointer search entry (no hipMalloc / hipFree per call)
-    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[4] = {0, 0, 0, 0};
-    void* h_stage = nullptr;     // pinned host staging for small batches (one H2D + one D2H per call)
-    size_t h_stage_bytes = 0;
-    dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries)
+    dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries); stat_mu
     std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
     std::vector<uint8_t> h_tags;    // inline_tags: host mirror of the tag bytes (the reference's Store::tags, store.rs:150)
-    // one stream, one pair of events and one set of scratch buffers per index: calls that launch
-    // work are serialised per handle (they would serialise on the stream anyway)
+    // Locking.  `rw` is the index: shared by the Knn search entry points (dann_search_batch(_device), the server),
+    // exclusive for everything that mutates the index or uses the `main` context.  Exclusive calls may nest
+    // (dann_append_neighbors -> dann_get_neighbors): `mu` serialises them among themselves and `excl_depth` takes /
+    // drops `rw` at the outermost level only.  std::shared_mutex does not promise writer priority: a mutation waits
+    // for the searches in flight (the reference's writers go through EBR / tags instead; out of scope).
     mutable std::recursive_mutex mu;
+    mutable std::shared_mutex rw;
+    mutable uint32_t excl_depth = 0;
+    mutable std::mutex stat_mu;   // calib, clocks
+    // pool of further search contexts for concurrent callers
+    std::mutex ctx_mu;
+    std::condition_variable ctx_cv;
+    std::vector<dann::SearchCtx*> ctx_free;
+    uint32_t ctx_created = 0;
+    dann_server* server = nullptr;  // dann_server_start / dann_search_submit
     dann::IndexView view() const;
 };
+
+namespace dann {
+// exclusive access (mutations, every entry point that runs on idx->main)
+struct ExclusiveGuard {
+    const dann_index* i;
+    explicit ExclusiveGuard(const dann_index* idx) : i(idx) {
+        i->mu.lock();
+        if (i->excl_depth++ == 0) i->rw.lock();
+    }
+    ~ExclusiveGuard() {
+        if (--i->excl_depth == 0) i->rw.unlock();
+        i->mu.unlock();
+    }
+    ExclusiveGuard(const ExclusiveGuard&) = delete;
+    ExclusiveGuard& operator=(const ExclusiveGuard&) = delete;
+};
+constexpr uint32_t kMaxSearchCtx = 16;
+// a search context for one concurrent call: from the pool, created on demand (at most kMaxSearchCtx), else waits
+struct CtxLease {
+    dann_index* idx;
+    SearchCtx* ctx = nullptr;
+    int32_t status = DANN_OK;
+    explicit CtxLease(dann_index* idx);
+    ~CtxLease();
+    CtxLease(const CtxLease&) = delete;
+    CtxLease& operator=(const CtxLease&) = delete;
+};
+}  // namespace dann
 
 struct dann_query {
     const dann_index* idx;

@@ -658,12 +658,15 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         }
         ht_count = ns;
         __syncthreads();
-        gather(ns);  // start points are FROZEN slots: always readable (store.rs:766-772)
+        // start points are created FROZEN (store.rs:766-772) and the host refuses to unpublish them; should one be
+        // unreadable all the same, the search fails as the reference's does
+        const uint32_t nsk = gather(ns);
+        if (nsk != ns) status = (uint32_t)(-DANN_EINVAL);  // "could not retrieve start point" (provider.rs:408-431)
         __syncthreads();
         // the filtered searches do not count the start points as comparisons (inline_filter_search.rs:186-197)
-        cmps = fmode ? 0u : ns;
-        if (fmode == DANN_FILTER_INLINE) append_matched(ns);
-        for (uint32_t m0 = 0; m0 < ns; m0 += kWave) merge(m0, (ns - m0) < (uint32_t)kWave ? (ns - m0) : (uint32_t)kWave);
+        cmps = fmode ? 0u : nsk;
+        if (fmode == DANN_FILTER_INLINE) append_matched(nsk);
+        for (uint32_t m0 = 0; m0 < nsk; m0 += kWave) merge(m0, (nsk - m0) < (uint32_t)kWave ? (nsk - m0) : (uint32_t)kWave);
     }
 
     uint32_t* const rec_i = a.rec_ids ? a.rec_ids + (uint64_t)qi * a.rec_stride : nullptr;  // wave-uniform
@@ -1240,17 +1243,65 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     }
 }
 
-// One wave per query (grid = nq) or, PERSIST -- dann_set_max_concurrency -- `grid` persistent waves that take the
-// launch's queries one after the other from a shared counter: a server that keeps N queries in flight is not held
-// up by the slowest query of each batch of N (the tail is 2.3x the mean search at N = 1024).  Results do not depend
-// on it.  A separate instantiation (plain mode only): the loop around the body costs the one-wave-per-query
-// launch 3-5 % when it is compiled into the same kernel.
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, bool PERSIST>
+// ---- persistent server (dann_server_start / dann_search_submit / dann_search_wait) ----------------------------------
+__device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store_u32(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wave 0: turns the host's publication words into the device-side `avail` counter; leaves on a stop request or
+// after idle_timeout_us without a new submission
+__device__ void server_dispatch(const ServerView& sv) {
+    const uint32_t lane = threadIdx.x;
+    unsigned long long avail = __hip_atomic_load(sv.d_avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long last = wall_clock64();
+    const long long idle_ticks = (long long)sv.idle_timeout_us * (long long)sv.ticks_per_us;
+    uint32_t backoff = 1;
+    // second bound, should the wall clock not advance: an idle iteration costs at least a PCIe round trip (~1 us)
+    uint32_t idle_iters = 0;
+    const uint32_t max_idle_iters = sv.idle_timeout_us * 4u + 1024u;
+    for (;;) {
+        const unsigned long long t = avail + lane;
+        const uint32_t expect = (uint32_t)(t >> sv.ring_shift) + 1u;
+        const bool ready = sys_load_u32(sv.h_pub + (uint32_t)(t & (sv.ring - 1u))) == expect;
+        const uint64_t m = ballot64(ready);
+        const uint32_t n = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);  // published tickets form a prefix
+        if (n) {
+            avail += n;
+            if (lane == 0) __hip_atomic_store(sv.d_avail, avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = wall_clock64();
+            backoff = 1;
+            idle_iters = 0;
+            continue;
+        }
+        const bool stop = sys_load_u32(sv.h_ctl) != 0u;
+        const bool idle = wall_clock64() - last > idle_ticks || ++idle_iters > max_idle_iters;
+        if (stop || idle) {
+            if (lane == 0) {
+                sys_store_u32(sv.h_ctl + 1, 1u);  // tells the host to relaunch on the next submission
+                __hip_atomic_store(sv.d_stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_sleep(16);
+        if (backoff < 8u) ++backoff;
+        for (uint32_t b = 1; b < backoff; ++b) __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+// One wave per query (grid = nq); LOOP = 1 (PERSIST, dann_set_max_concurrency): `grid` persistent waves take the
+// launch's queries one after the other from a shared counter -- a server that keeps N queries in flight is not held
+// up by the slowest query of each batch of N (the tail is 2.3x the mean search at N = 1024); LOOP = 2: the waves
+// serve the submission ring of dann_server_start until told to stop.  Results do not depend on it.  Separate
+// instantiations (plain mode only): the loop around the body costs the one-wave-per-query launch 3-5 % when it is
+// compiled into the same kernel.
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP>
 __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if constexpr (!PERSIST) {
+    if constexpr (LOOP == 0) {
         beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, blockIdx.x, smem);
-    } else {
+    } else if constexpr (LOOP == 1) {
         uint32_t slot = blockIdx.x;
         for (;;) {
             uint32_t nxt = 0;  // the ticket for the search after this one is drawn now: its round trip hides behind the search
@@ -1259,6 +1310,74 @@ __global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
             __syncthreads();  // the next query reuses this wave's LDS
             slot = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
             if (slot >= a.nq) break;
+        }
+    } else {
+        const ServerView& sv = a.srv;
+        if (blockIdx.x == 0) {
+            server_dispatch(sv);
+            return;
+        }
+        const uint32_t lane = threadIdx.x, w = blockIdx.x - 1u;
+        uint8_t* myq = sv.d_q + (size_t)w * sv.qstride;
+        for (;;) {
+            // ---- draw a ticket, wait until the host has published it
+            uint32_t tlo = 0, thi = 0;
+            if (lane == 0) {
+                const unsigned long long t0 = atomicAdd(sv.d_head, 1ull);
+                tlo = (uint32_t)t0;
+                thi = (uint32_t)(t0 >> 32);
+            }
+            tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)tlo);
+            thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)thi);
+            const unsigned long long t = ((unsigned long long)thi << 32) | tlo;
+            bool leave = false;
+            uint32_t naps = 0;
+            for (;;) {
+                if (__hip_atomic_load(sv.d_avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) break;
+                if (__hip_atomic_load(sv.d_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    leave = true;  // the ticket stays unserved: the host resets head to avail before it relaunches
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                if (naps < 16u) ++naps;
+                for (uint32_t b = 0; b < naps; ++b) __builtin_amdgcn_s_sleep(32);
+            }
+            if (leave) break;
+            const uint32_t slot = (uint32_t)(t & (sv.ring - 1u));
+            // ---- stage the query: host ring -> this worker's device buffer (system-scope 16-byte loads)
+            {
+                const uint8_t* src = sv.h_queries + (size_t)slot * sv.qstride;
+                for (uint32_t o = lane * 16u; o < sv.qbytes; o += kWave * 16u) {
+                    u32x4 v;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src + o) : "memory");
+                    *reinterpret_cast<u32x4*>(myq + o) = v;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the search reads the staged query back with plain loads: drop this CU's (stale) L1 copy of the buffer
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, w, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- result: this worker's device rows -> the host ring, then the completion word
+            {
+                const uint32_t* oi = a.out_ids + (size_t)w * a.k;
+                const float* od = a.out_dists + (size_t)w * a.k;
+                for (uint32_t r = lane; r < a.k; r += kWave) {
+                    sys_store_u32(sv.h_res_ids + (size_t)slot * a.k + r, u32_load(oi + r));
+                    sys_store_u32(reinterpret_cast<uint32_t*>(sv.h_res_d) + (size_t)slot * a.k + r,
+                                  __builtin_bit_cast(uint32_t, f32_load(od + r)));
+                }
+                if (lane < 5u) {
+                    const uint32_t* st = reinterpret_cast<const uint32_t*>(a.stats + w);
+                    sys_store_u32(reinterpret_cast<uint32_t*>(sv.h_res_stats + slot) + lane, u32_load(st + lane));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the result words before the completion word
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) sys_store_u32(sv.h_done + slot, (uint32_t)(t >> sv.ring_shift) + 1u);
+            }
+            __syncthreads();  // the next query reuses this wave's LDS
         }
     }
 }
@@ -1269,12 +1388,17 @@ inline bool plain_mode(const SearchArgs& a) {
            a.ix.nstart <= (uint32_t)kWave;
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, bool PERSIST = false>
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
-    if constexpr (MODE == kModePlain && !PERSIST) {
-        if (a.grid && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, true>(a, lds, stream, regs_out);
+    if constexpr (MODE == kModePlain && LOOP == 0) {
+        if (a.srv.ring && !regs_out) {
+            if constexpr (QS <= 4) return launch_one<DT, OP, NORM, QS, DIM, MODE, 2>(a, lds, stream, regs_out);
+            set_error("the search server supports L + start points <= 256");
+            return DANN_EUNSUPPORTED;
+        }
+        if (a.grid && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, 1>(a, lds, stream, regs_out);
     }
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, PERSIST>;
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, LOOP>;
     if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
         hipFuncAttributes attr;
         hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
@@ -1293,7 +1417,8 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(PERSIST ? a.grid : a.nq), dim3(kWave), lds, stream, a);
+    const uint32_t grid = LOOP == 2 ? a.srv.workers + 1u : LOOP == 1 ? a.grid : a.nq;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
     return DANN_OK;

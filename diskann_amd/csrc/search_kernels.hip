@@ -166,66 +166,62 @@ extern "C" int32_t dann_debug_phase_cycles(unsigned long long* out, int reset) t
 } DANN_CATCH_ALL
 #endif
 
-int32_t search_with_retry(dann_index* idx, SearchArgs a) {
-    hipStream_t st = idx->stream;
-    if (a.nq == 0) return DANN_OK;
-    if (idx->fail_cap < a.nq || !idx->d_fail) {
-        if (idx->d_fail) (void)hipFree(idx->d_fail);
-        idx->d_fail = nullptr;
-        idx->fail_cap = 0;
-        DANN_HIP(hipMalloc((void**)&idx->d_fail, (2 * (size_t)a.nq + 4) * 4));
-        idx->fail_cap = a.nq;
-    }
-    uint32_t* count = idx->d_fail;
-    uint32_t* lists[2] = {idx->d_fail + 4, idx->d_fail + 4 + idx->fail_cap};
+static uint64_t calib_key(const SearchArgs& a) {
+    return ((uint64_t)a.l_value << 32) | ((uint64_t)a.beam_width << 8) | (a.rec_ids ? 1u : 0u) | (a.range_ids ? 2u : 0u) |
+           (a.filter_mode << 2);
+}
+
+// everything a beam-search launch needs besides its arguments: the context's spill pool (zeroed counters), the size of
+// the LDS visited table (calibrated per (L, beam, mode), never affects results) and the tuning bits.  `inflight` is the
+// number of wavefronts the launch keeps resident.
+static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, uint32_t inflight) {
+    hipStream_t st = ctx.stream;
     // failure flag in pinned host memory: written over the fabric only by a query that
     // overflows (rare), read by the host after the stream sync -- no memset / D2H copy
-    if (!idx->d_spill) {  // 512 spill tables of 2^14 ids (32 MiB), cleaned and released by their users
+    if (!ctx.d_spill) {  // 512 spill tables of 2^14 ids (32 MiB), cleaned and released by their users
         const uint32_t slices = 512, sbits = 14;
         // tables | counter (+pad) | busy flags | cmps histogram
         const size_t words = ((size_t)slices << sbits) + 16 + slices + kHistBins;
-        DANN_HIP(hipMalloc((void**)&idx->d_spill, words * 4));
-        DANN_HIP(hipMemsetAsync(idx->d_spill, 0xFF, words * 4, st));
-        idx->spill_slices = slices;
-        idx->spill_bits = sbits;
+        DANN_HIP(hipMalloc((void**)&ctx.d_spill, words * 4));
+        DANN_HIP(hipMemsetAsync(ctx.d_spill, 0xFF, words * 4, st));
+        ctx.spill_slices = slices;
+        ctx.spill_bits = sbits;
     }
-    a.spill = idx->d_spill;
-    a.spill_slices = idx->spill_slices;
-    a.spill_bits = idx->spill_bits;
-    a.spill_next = idx->d_spill + ((size_t)idx->spill_slices << idx->spill_bits);
-    DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
-    // dann_set_max_concurrency: `grid` persistent waves share the queries (counter in the zeroed pad words above)
-    auto cap_grid = [&](SearchArgs& x) {
-        const bool capped = idx->max_concurrency && x.nq > idx->max_concurrency && plain_mode(x);
-        x.grid = capped ? idx->max_concurrency : 0u;
-        x.work_next = capped ? x.spill_next + 8 : nullptr;
-    };
-    cap_grid(a);
-    const uint32_t inflight = a.grid ? a.grid : a.nq;
-    // automatic table size: calibrated 90th percentile for this (L, beam, mode), else the prior
+    a.spill = ctx.d_spill;
+    a.spill_slices = ctx.spill_slices;
+    a.spill_bits = ctx.spill_bits;
+    a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
+    DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     const bool autosize = a.ht_entries == 0;
-    const uint64_t key = ((uint64_t)a.l_value << 32) | ((uint64_t)a.beam_width << 8) | (a.rec_ids ? 1u : 0u) |
-                         (a.range_ids ? 2u : 0u) | (a.filter_mode << 2);
-    VisitedCalib* cal = nullptr;
+    const uint64_t key = calib_key(a);
+    // calibration state of this (L, beam, mode) -- shared by concurrent callers: read and written under stat_mu
+    VisitedCalib cal;
     if (autosize) {
-        cal = &idx->calib[key];
-        if (!cal->waves) {  // queries per CU the registers of this instantiation allow (512 VGPRs per SIMD lane)
+        {
+            std::lock_guard<std::mutex> lk(idx->stat_mu);
+            cal = idx->calib[key];
+        }
+        if (!cal.waves) {  // queries per CU the registers of this instantiation allow (512 VGPRs per SIMD lane)
             int regs = 0;
             a.ht_entries = 256;
             int32_t qrc = launch_search(a, st, &regs);
             if (qrc != DANN_OK) return qrc;
             const uint32_t per_simd = regs > 0 ? 512u / (((uint32_t)regs + 7u) & ~7u) : 4u;
-            cal->waves = 4u * std::min<uint32_t>(std::max<uint32_t>(per_simd, 1u), 8u);
-            if (getenv("DANN_DEBUG")) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal->waves);
+            cal.waves = 4u * std::min<uint32_t>(std::max<uint32_t>(per_simd, 1u), 8u);
+            {
+                std::lock_guard<std::mutex> lk(idx->stat_mu);
+                idx->calib[key].waves = cal.waves;
+            }
+            if (getenv("DANN_DEBUG")) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal.waves);
         }
         // a launch with fewer queries than the chip has wave slots leaves LDS idle: give each query the share of a CU
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
         const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
-        const uint32_t waves = tune_env(2) ? cal->waves : std::min<uint32_t>(cal->waves, per_cu);
-        a.ht_entries = snap_visited_entries(a, cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), waves);
-        if (getenv("DANN_DEBUG") && (cal->calls & (cal->calls - 1)) == 0)
+        const uint32_t waves = tune_env(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
+        a.ht_entries = snap_visited_entries(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves);
+        if (getenv("DANN_DEBUG") && (cal.calls & (cal.calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u entries, %zu B LDS\n", a.l_value, a.beam_width,
-                    cal->cap_ids ? cal->cap_ids : prior_visited_cap(a), cal->cap_ids ? "p90" : "prior", a.ht_entries,
+                    cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior", a.ht_entries,
                     search_lds_bytes(a));
     }
     // the start points are inserted unconditionally and the first hop needs room before the freeze test can
@@ -242,34 +238,86 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
     }
     // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
     if (inflight <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
-    volatile uint32_t* hflag = idx->h_flag;
+    return DANN_OK;
+}
+
+// the persistent server of dann_server_start: sized like a launch that keeps `workers` searches in flight, enqueued on
+// the context's stream, not waited for
+int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
+    if (!plain_mode(a)) {
+        set_error("the search server runs the plain Knn search (beam width 1, no inline tags, degree <= 64)");
+        return DANN_EUNSUPPORTED;
+    }
+    a.nq = a.srv.workers;
+    int32_t rc = prepare_launch(idx, ctx, a, a.srv.workers);
+    if (rc != DANN_OK) return rc;
+    a.fail_flag = nullptr;
+    a.ht_prime = largest_prime_leq(a.ht_entries);
+    return launch_search(a, ctx.stream);
+}
+
+int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
+    hipStream_t st = ctx.stream;
+    if (a.nq == 0) return DANN_OK;
+    if (ctx.fail_cap < a.nq || !ctx.d_fail) {
+        if (ctx.d_fail) (void)hipFree(ctx.d_fail);
+        ctx.d_fail = nullptr;
+        ctx.fail_cap = 0;
+        DANN_HIP(hipMalloc((void**)&ctx.d_fail, (2 * (size_t)a.nq + 4) * 4));
+        ctx.fail_cap = a.nq;
+    }
+    uint32_t* count = ctx.d_fail;
+    uint32_t* lists[2] = {ctx.d_fail + 4, ctx.d_fail + 4 + ctx.fail_cap};
+    // dann_set_max_concurrency: `grid` persistent waves share the queries (counter in the zeroed pad words above)
+    auto cap_grid = [&](SearchArgs& x) {
+        const bool capped = idx->max_concurrency && x.nq > idx->max_concurrency && plain_mode(x);
+        x.grid = capped ? idx->max_concurrency : 0u;
+        x.work_next = capped ? x.spill_next + 8 : nullptr;
+    };
+    const bool capped0 = idx->max_concurrency && a.nq > idx->max_concurrency && plain_mode(a);
+    const uint32_t inflight = capped0 ? idx->max_concurrency : a.nq;
+    const bool autosize = a.ht_entries == 0;
+    const uint64_t key = calib_key(a);
+    if (int32_t prc = prepare_launch(idx, ctx, a, inflight)) return prc;
+    cap_grid(a);  // (the counter lives behind the spill pool prepare_launch has just attached)
+    volatile uint32_t* hflag = ctx.h_flag;
     *hflag = 0;
-    a.fail_flag = idx->h_flag;
+    a.fail_flag = ctx.h_flag;
     // HIP events bracket exactly the beam-search launches, on the stream they run on
+    float last_ms = 0.f;
     auto timed_launch = [&](SearchArgs& args) -> int32_t {
         args.ht_prime = largest_prime_leq(args.ht_entries);
 #ifdef DANN_PHASE_CYCLES
         args.phase_cycles = dann_phase_buffer();
 #endif
-        DANN_HIP(hipEventRecord(idx->ev0, st));
+        DANN_HIP(hipEventRecord(ctx.ev0, st));
         int32_t r = launch_search(args, st);
         if (r != DANN_OK) return r;
-        DANN_HIP(hipEventRecord(idx->ev1, st));
-        DANN_HIP(hipEventSynchronize(idx->ev1));
+        DANN_HIP(hipEventRecord(ctx.ev1, st));
+        DANN_HIP(hipEventSynchronize(ctx.ev1));
         float ms = 0.f;
-        DANN_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+        DANN_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        last_ms = ms;
+        std::lock_guard<std::mutex> lk(idx->stat_mu);
         idx->clocks[0].total_ms += ms;
         return DANN_OK;
     };
     int32_t rc = timed_launch(a);
     if (rc != DANN_OK) return rc;
-    idx->clocks[0].launches += 1;  // one logical search = one "launch" (+ rare retry launches, time included)
+    {
+        std::lock_guard<std::mutex> lk(idx->stat_mu);
+        idx->clocks[0].launches += 1;  // one logical search = one "launch" (+ rare retry launches, time included)
+    }
     // recalibrate on calls 1, 2, 4, 8, ... of this key (a 512-bin histogram of cmps, 2 KiB D2H)
-    if (cal && a.stats && !a.qmap && !a.range_ids && a.nq >= 256) {
-        cal->calls += 1;
+    if (autosize && a.stats && !a.qmap && !a.range_ids && a.nq >= 256) {
+        uint64_t calls;
+        {
+            std::lock_guard<std::mutex> lk(idx->stat_mu);
+            calls = ++idx->calib[key].calls;
+        }
         // insert-time searches run on a growing graph (comparisons grow with it): recalibrate on every batch
-        if ((cal->calls & (cal->calls - 1)) == 0 || a.rec_ids) {
-            uint32_t* d_hist = a.spill_next + 16 + idx->spill_slices;
+        if ((calls & (calls - 1)) == 0 || a.rec_ids) {
+            uint32_t* d_hist = a.spill_next + 16 + ctx.spill_slices;
             DANN_HIP(hipMemsetAsync(d_hist, 0, kHistBins * 4, st));
             hipLaunchKernelGGL(cmps_hist_kernel, dim3(std::min<uint32_t>((a.nq + 255) / 256, 256)), dim3(256), 0, st,
                                a.stats, a.nq, d_hist);
@@ -281,7 +329,8 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
             for (uint32_t b = 0; b < kHistBins && total; ++b) {
                 acc += hist[b];
                 if (acc * 10 >= total * 9) {
-                    cal->cap_ids = (b + 1) * 64;
+                    std::lock_guard<std::mutex> lk(idx->stat_mu);
+                    idx->calib[key].cap_ids = (b + 1) * 64;
                     break;
                 }
             }
@@ -305,12 +354,12 @@ int32_t search_with_retry(dann_index* idx, SearchArgs a) {
         a.nq = n = h;
         cap_grid(a);
         if (search_lds_bytes(a) > 160 * 1024) return DANN_OK;
-        DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)idx->spill_slices) * 4, st));
+        DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
         *hflag = 0;
-        const double before = idx->clocks[0].total_ms;
         rc = timed_launch(a);
         if (rc != DANN_OK) return rc;
-        idx->clocks[4].total_ms += idx->clocks[0].total_ms - before;
+        std::lock_guard<std::mutex> lk(idx->stat_mu);
+        idx->clocks[4].total_ms += last_ms;
         idx->clocks[4].launches += h;
     }
 }

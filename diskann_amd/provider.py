@@ -377,8 +377,8 @@ class Provider:
         check(_ffi.lib().dann_set_build_options(self._h, int(flags)), "dann_set_build_options")
 
     def build_counters(self):
-        out = np.zeros(8, np.uint64)
-        check(_ffi.lib().dann_build_counters(self._h, _p(out), 8), "dann_build_counters")
+        out = np.zeros(10, np.uint64)
+        check(_ffi.lib().dann_build_counters(self._h, _p(out), 10), "dann_build_counters")
         return out
 
     def build(self, cfg, first, n, growth=0.02, max_batch=16384):
@@ -429,6 +429,54 @@ class Provider:
     def set_max_concurrency(self, n):
         """Queries in flight per search call (0 = all): n persistent wavefronts share the call's queries."""
         check(_ffi.lib().dann_set_max_concurrency(self._h, n), "dann_set_max_concurrency")
+
+    # -- search server: N callers on one shared index, one query per call, no kernel launch per call ----------
+    def server_start(self, l_value, k=10, workers=1024, ring=0, idle_timeout_us=0):
+        cfg = _ffi.ServerConfig(int(l_value), int(k), int(workers), int(ring), int(idle_timeout_us))
+        check(_ffi.lib().dann_server_start(self._h, C.byref(cfg)), "dann_server_start")
+        self._server_k = int(k)
+
+    def server_stop(self):
+        check(_ffi.lib().dann_server_stop(self._h), "dann_server_stop")
+
+    def submit(self, query):
+        """one query (row of query_dtype) -> ticket"""
+        q = np.ascontiguousarray(query, dtype=self.query_dtype).reshape(self.query_elems)
+        t = C.c_uint64(0)
+        check(_ffi.lib().dann_search_submit(self._h, _p(q), C.byref(t)), "dann_search_submit")
+        return t.value
+
+    def poll(self, ticket):
+        return check(_ffi.lib().dann_search_poll(self._h, C.c_uint64(ticket)), "dann_search_poll") == 1
+
+    def wait(self, ticket):
+        """(ids[k], dists[k], stats) of the query behind `ticket` (every ticket exactly once)"""
+        k = self._server_k
+        ids = np.empty(k, np.uint32)
+        dists = np.empty(k, np.float32)
+        st = np.zeros(1, STATS_DTYPE)
+        check(_ffi.lib().dann_search_wait(self._h, C.c_uint64(ticket), _p(ids), _p(dists), _p(st)), "dann_search_wait")
+        return ids, dists, st[0]
+
+    def server_stats(self):
+        sub, rel = C.c_uint64(0), C.c_uint64(0)
+        check(_ffi.lib().dann_server_stats(self._h, C.byref(sub), C.byref(rel)), "dann_server_stats")
+        return sub.value, rel.value
+
+    def concurrent_callers(self, queries, l_value, k=10, threads=16, mode=0, depth=1):
+        """`threads` native host threads issue single-query calls on this index (dann_debug_concurrent_callers):
+        mode 0 = dann_search_batch(nq = 1) per call, mode 1 = submit / wait with `depth` tickets outstanding per
+        thread.  Returns (ids, dists, latency_us[nq], seconds)."""
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        lat = np.zeros(nq, np.float32)
+        secs = C.c_double(0.0)
+        check(_ffi.lib().dann_debug_concurrent_callers(self._h, _p(q), nq, int(l_value), int(k), int(threads), int(mode),
+                                                       int(depth), _p(ids), _p(dists), _p(lat), C.byref(secs)),
+              "dann_debug_concurrent_callers")
+        return ids, dists, lat, secs.value
 
 
 def sq8_compress(x, shift, scale, device=-1):

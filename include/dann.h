@@ -12,9 +12,12 @@
  * 682-756): opaque handles, caller-owned buffers passed as pointer + length, `int32_t`
  * status (>= 0 ok, < 0 one of DANN_E*), no exceptions or aborts cross the boundary,
  * a thread-local message is available from dann_last_error().  Entry points are
- * thread-safe for distinct handles; search entry points may be called concurrently on
- * a shared index as long as no mutation is in flight (the GPU index is an immutable
- * snapshot between mutations; the reference's EBR/tag machinery stays on the host).
+ * thread-safe.  Threading model (the reference: N workers on one shared `&DiskANNIndex`): dann_search_batch,
+ * dann_search_batch_device and the server entry points (dann_search_submit / wait) take the index shared -- calls
+ * from different threads run side by side on the device, each on its own stream; everything that mutates the
+ * index, and the remaining search entry points (range / filtered / paged / record / rerank, the fine-grained seam),
+ * take it exclusively and wait for the searches in flight (the GPU index is an immutable snapshot between mutations;
+ * the reference's EBR / tag machinery stays on the host).
  *
  * All "host" pointers are plain host memory; `_device` variants take HIP device
  * pointers that live on the index's device.
@@ -392,22 +395,31 @@ int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t rep
  * (v_mfma_f32_32x32x2_f32), with a bit-exact re-evaluation of every comparison the rounding-error interval of the
  * Gram value does not decide.  f32 rows, L2 / inner product / cosine-normalized; other configurations ignore it. */
 enum { DANN_BUILD_MFMA_BACKEDGE = 1,
-       /* the same for the pool prune of every inserted point (robust_prune_with, index.rs:2476-2532): Gram of the
-        * first 128 candidates of the sorted pool against the first 96; pairs outside that block use the row kernel */
+       /* the same for the pool prune of every inserted point (robust_prune_with, index.rs:2476-2532), f32 and f16 rows:
+        * three kernels -- sort, Gram tiles of the first <= 256 sorted candidates against the first 96 on the matrix
+        * cores (lower triangle only), sweep; pairs outside that block use the row kernel */
        DANN_BUILD_MFMA_POOL = 2,
-       /* never use the matrix-core paths (by default back-edge prunes of f32 rows of 1 KiB and more use them) */
+       /* never use the matrix-core paths (by default float rows of 1 KiB and more use them: back-edge prunes of f32
+        * rows, pool prunes of f32 and f16 rows) */
        DANN_BUILD_ROW_KERNEL_ONLY = 4 };
 int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
 /* work counters of the build path since index creation (the algorithmic-bytes model of profiles/): out[0] back-edge
  * prunes through the MFMA path, [1] back-edge prunes of lists too long for it, [2] comparisons and [3] hops of the
  * insert-time searches, [4] pair distances d(c_i, c_j) evaluated by the row kernel in the prune sweeps, [5] list /
- * extra distances d(location, c), [6] candidate rows that went through an MFMA Gram, [7] sum of (Gram rows)^2
- * (x dim x 2 = MFMA flop).  n <= 8 entries are written. */
+ * extra distances d(location, c), [6] candidate rows that went through an MFMA Gram, [7] Gram entries computed
+ * (x dim x 2 = MFMA flop), [8] pair distances the lazy scans of the MFMA sweeps asked for, [9] those of [8] that needed
+ * an exact re-evaluation by the row kernel (the rest were answered from a Gram).  n <= 10 entries are written. */
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
 /* diagnostic: the Gram matrix of n <= 128 f32 rows exactly as the MFMA back-edge path computes it (f32 FMA chains of
  * 32 terms in k order on v_mfma_f32_32x32x2_f32, block results summed in f64, one rounding to f32) */
 int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t dim, float* out);
+
+/* diagnostic: the Gram block of the three-kernel MFMA pool prune (gram_tiles_kernel) for n <= 256 rows of dtype
+ * DANN_F32 / DANN_F16: out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain
+ * over k = 0 .. dim-1 of row_i[k] * row_j[k] (f16 rows widened exactly); out_nrm[i] = |row_i|^2 accumulated in f64 */
+int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
+                              float* out_gram, float* out_nrm);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
 #define DANN_ABI_VERSION 2
@@ -431,6 +443,41 @@ int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
  * of its batch.  Applies to the plain searches (beam width 1, no filter, no inline tags, degree <= 64: Knn, Range,
  * the insert search); the other modes keep one wavefront per query.  Never affects results. */
 int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight);
+
+/* ---- search server: the reference's serving model -- N workers calling DiskANNIndex::search on one shared index,
+ * one query per call (diskann-benchmark-core/src/search/api.rs:399-436, tokio.rs:10-14) -- without a kernel launch
+ * per call.  dann_server_start keeps `workers` wavefronts resident on the device (Knn search, beam width 1, L =
+ * l_value, k results); dann_search_submit copies one query (host pointer, layer bytes) into a ring in host-mapped
+ * memory and returns a ticket; dann_search_wait blocks until that query's result has arrived and copies it out
+ * (ids are slot ids, unwritten entries 0xFFFFFFFF / +inf, as dann_search_batch).  Every ticket must be waited for
+ * exactly once; a slot of the ring is reused `ring` tickets later, so at most `ring` tickets can be outstanding.
+ * Submit / wait / poll may be called from any number of threads concurrently and take no lock on the index; results are
+ * identical to dann_search_batch.  Mutations of the index (set / insert / build) must not run while tickets are
+ * outstanding.  The resident kernel leaves after idle_timeout_us without a submission (default 100 ms) and is
+ * relaunched by the next submission: a device-wide synchronisation elsewhere in the process waits at most that
+ * long on an idle server.  Row lengths must be a multiple of 16 bytes; L + start points <= 256. */
+typedef struct {
+    uint32_t l_value;
+    uint32_t k;
+    uint32_t workers;          /* searches in flight on the device (wavefronts), e.g. 1024 */
+    uint32_t ring;             /* ring entries (rounded up to a power of two); 0 = 4 * workers */
+    uint32_t idle_timeout_us;  /* 0 = 100000 */
+} dann_server_config;
+int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg);
+int32_t dann_server_stop(dann_index* idx);  /* also called by dann_index_destroy */
+int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket);
+/* 1 = the result of `ticket` has arrived (dann_search_wait will not block), 0 = not yet */
+int32_t dann_search_poll(dann_index* idx, uint64_t ticket);
+int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, float* out_dists,
+                         dann_search_stats* out_stats);
+/* tickets issued so far, relaunches of the resident kernel after an idle exit */
+int32_t dann_server_stats(dann_index* idx, uint64_t* submitted, uint64_t* relaunches);
+/* measurement harness: `threads` host threads issue single-query calls on the shared index, thread t serving queries
+ * t, t + threads, ...: mode 0 = dann_search_batch(nq = 1) per call, mode 1 = submit / wait with up to `depth` tickets
+ * outstanding per thread (1 = synchronous).  out_latency_us (nq, optional): submit -> result, host clock. */
+int32_t dann_debug_concurrent_callers(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t k,
+                                      uint32_t threads, uint32_t mode, uint32_t depth, uint32_t* out_ids,
+                                      float* out_dists, float* out_latency_us, double* out_seconds);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,8 @@ def lib():
     L.orc_expand_beam.argtypes = [P(OrcIndex), vp, vp, u32, vp, vp]
     L.orc_gram_blocked.restype = None
     L.orc_gram_blocked.argtypes = [vp, u32, u32, vp]
+    L.orc_gram_chain.restype = None
+    L.orc_gram_chain.argtypes = [vp, u32, u32, vp]
     L.orc_prune_pool.restype = i32
     L.orc_prune_pool.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp, vp, u32, i32, vp, vp]
     L.orc_insert.restype = i32
@@ -405,6 +407,14 @@ def gram_blocked(rows):
     r = np.ascontiguousarray(rows, dtype=np.float32)
     out = np.empty((r.shape[0], r.shape[0]), np.float32)
     lib().orc_gram_blocked(_p(r), r.shape[0], r.shape[1], _p(out))
+    return out
+
+
+def gram_chain(rows):
+    """checker of dann_debug_gram_tiles: one f32 fmaf chain over the whole row per entry"""
+    r = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.empty((r.shape[0], r.shape[0]), np.float32)
+    lib().orc_gram_chain(_p(r), r.shape[0], r.shape[1], _p(out))
     return out
 
 

@@ -1455,6 +1455,17 @@ void orc_gram_blocked(const float* rows, uint32_t n, uint32_t dim, float* out) {
         }
 }
 
+/* checker for gram_tiles_kernel (dann_debug_gram_tiles): one f32 fmaf chain over k = 0 .. dim-1 per entry (what
+ * v_mfma_f32_32x32x2_f32 computes when its accumulator runs through the whole row; zero padding adds nothing) */
+void orc_gram_chain(const float* rows, uint32_t n, uint32_t dim, float* out) {
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            float acc = 0.0f;
+            for (uint32_t k = 0; k < dim; ++k) acc = std::fmaf(rows[(size_t)i * dim + k], rows[(size_t)j * dim + k], acc);
+            out[(size_t)i * n + j] = acc;
+        }
+}
+
 int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_t location, uint32_t* pool_ids,
                        float* pool_dists, uint32_t pool_n, int32_t force_saturate, uint32_t* out_neighbors,
                        uint64_t* pair_evals) {

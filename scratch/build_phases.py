@@ -18,13 +18,15 @@ dev = torch.device('cuda', 0)
 base, q = make_data(torch, dev, n, dim, 1000, 'sift_like', 0xD15CA11, 0xD15CA12)
 mean = base.double().mean(0).float()
 medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
-p = da.Provider(da.F32, metric, dim, n, R, base[medoid:medoid + 1].cpu().numpy())
+f16 = "--f16" in sys.argv
+rows = base.half() if f16 else base
+p = da.Provider(da.F16 if f16 else da.F32, metric, dim, n, R, rows[medoid:medoid + 1].cpu().numpy())
 if "--rowonly" in sys.argv:
     p.set_build_options(da.BUILD_ROW_KERNEL_ONLY)
 if mfma:
     p.set_build_options(da.BUILD_MFMA_BACKEDGE | (0 if "--nopool" in sys.argv else da.BUILD_MFMA_POOL))
 for s0 in range(0, n, 1 << 20):
-    p.set_elements(s0, base[s0:s0 + (1 << 20)].cpu().numpy())
+    p.set_elements(s0, rows[s0:s0 + (1 << 20)].cpu().numpy())
 p.kernel_time_reset()
 torch.cuda.synchronize()
 t = time.time()
@@ -34,14 +36,17 @@ dt = time.time() - t
 ks = [p.kernel_time(i) for i in range(4)]
 import json
 c = [int(x) for x in p.build_counters()]
-row_b, adj_b = dim * 4, (R + 1) * 4
+row_b, adj_b = dim * (2 if f16 else 4), (R + 1) * 4
 print(json.dumps({"n": n, "dim": dim, "R": R, "pruned": pruned, "l_build": lb, "max_batch": mb, "mfma": mfma, "metric": int(metric),
                   "build_seconds": dt, "batches": nb,
                   "search": {"cmps": c[2], "hops": c[3], "algorithmic_bytes": c[2] * row_b + c[3] * adj_b},
                   "prune_row_kernel": {"pair_distances": c[4], "list_distances": c[5],
                                        "algorithmic_bytes": (2 * c[4] + c[5]) * row_b},
-                  "mfma": {"prunes": c[0], "too_long_for_gram": c[1], "gram_rows": c[6], "gram_rows_sq": c[7],
-                           "flop": 2 * c[7] * dim, "row_bytes_read": c[6] * row_b}}), flush=True)
+                  "mfma": {"prunes": c[0], "too_long_for_gram": c[1], "gram_rows": c[6], "gram_entries": c[7],
+                           "flop": 2 * c[7] * dim, "row_bytes_read": c[6] * row_b,
+                           "pairs_asked_by_gram_sweeps": c[8], "of_those_exact_rechecks": c[9],
+                           "mfma_share_of_all_prune_pair_distances": (c[8] - c[9]) / max(1, c[8] - c[9] + c[4])},
+                  "f16": f16, "env": {k: os.environ[k] for k in os.environ if k.startswith("DANN_")}}), flush=True)
 print(f"mfma={mfma} metric={metric} ", end="")
 print(f"n={n} dim={dim} R={R}/{pruned} l_build={lb} max_batch={mb}: build {dt:.3f}s ({n / dt:,.0f} pts/s) batches {nb}; "
       f"search {ks[0][0]:.0f} ms ({ks[0][1]}), prune {ks[2][0]:.0f} ms ({ks[2][1]}), backedge {ks[3][0]:.0f} ms ({ks[3][1]}); "

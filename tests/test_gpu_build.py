@@ -340,6 +340,68 @@ def test_mfma_pool_prune_with_intra_batch_candidates_and_big_pools():
     assert cnt[0] == 0 and cnt[6] > n * 20 and cnt[7] > 0     # Gram rows came from the pool prunes only
 
 
+@pytest.mark.parametrize("dtype", [oracle.F32, oracle.F16])
+def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
+    """gram_tiles_kernel (the Gram of the three-kernel MFMA pool prune): v_mfma_f32_32x32x2_f32 with the accumulator
+    running through the whole row is one k-ordered f32 FMA chain per entry -- bit-identical to orc_gram_chain on the
+    lower triangle of the block (the sweep only asks for j < i), for sizes that exercise 1..8 row blocks, partial
+    blocks, the partial K slab and rows narrower than a slab; f16 rows are widened exactly.  Norms: f64 sums."""
+    import ctypes as C
+    rng = np.random.default_rng(55)
+    lib = da._ffi.lib()
+    npdt = np.float32 if dtype == oracle.F32 else np.float16
+    for n, dim, mg in ((1, 8, 32), (7, 33, 32), (33, 100, 64), (70, 768, 96), (96, 96, 96), (130, 260, 96), (200, 128, 96),
+                       (256, 64, 96), (160, 1536, 96)):
+        rows = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 8.0, (n, 1))).astype(npdt)
+        got = np.empty((n, mg), np.float32)
+        nrm = np.empty(n, np.float32)
+        da._ffi.check(lib.dann_debug_gram_tiles(-1, dtype, rows.ctypes.data_as(C.c_void_p), n, dim, mg,
+                                                got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
+                      "dann_debug_gram_tiles")
+        wide = rows.astype(np.float32)
+        want = oracle.gram_chain(wide)
+        for i in range(n):
+            m = min(i + 1, mg)  # columns j <= i inside the block
+            assert np.array_equal(bits(got[i, :m]), bits(want[i, :m])), (n, dim, i)
+        exact = (wide.astype(np.float64) ** 2).sum(1)
+        assert np.all(np.abs(nrm.astype(np.float64) - exact) <= np.spacing(exact.astype(np.float32)).astype(np.float64)), (n, dim)
+
+
+@pytest.mark.parametrize("dtype,metric,dim", [(oracle.F16, oracle.L2, 96), (oracle.F16, oracle.INNER_PRODUCT, 100),
+                                              (oracle.F32, oracle.L2, 260)])
+def test_mfma_pool_prune_f16_and_default_policy_identical_to_oracle(dtype, metric, dim, monkeypatch):
+    """The three-kernel pool prune on f16 rows (widened exactly while the Gram slabs are filled; exact re-checks by the
+    reference's f16 x f16 pair kernel) and as the default policy for rows of 1 KiB and more (dim 260 f32): adjacency ==
+    the oracle's multi_insert, also with every decision forced through the exact path, and most pair distances the
+    lazy scan asks for are answered from the Gram."""
+    from diskann_amd.sharding import batch_schedule
+    rng = np.random.default_rng(3000 + dim)
+    n, R, maxdeg, lb = 5000, 24, 32, 64
+    npdt = np.float32 if dtype == oracle.F32 else np.float16
+    centers = rng.random((16, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 16, n)] + 0.15 * rng.standard_normal((n, dim))).astype(npdt)
+    start = data.astype(np.float32).mean(0, keepdims=True).astype(npdt)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    growth, max_batch = 0.1, 1024
+    oix = oracle.Index(dtype, metric, dim, n, maxdeg, start)
+    oix.set_rows(0, data)
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+    for escale in (None, "1e6"):
+        if escale:
+            monkeypatch.setenv("DANN_GRAM_ESCALE", escale)
+        gix = da.Provider(dtype, metric, dim, n, maxdeg, start)
+        gix.set_elements(0, data)
+        if dim * data.itemsize < 1024:
+            gix.set_build_options(da.BUILD_MFMA_POOL)   # small rows: opt in; rows >= 1 KiB take the path by default
+        gix.build(gcfg, 0, n, growth, max_batch)
+        assert np.array_equal(gix.download_graph(), oix.adj), (dtype, metric, dim, escale)
+        cnt = gix.build_counters()
+        assert cnt[6] > n * 20 and cnt[7] > 0 and cnt[8] > 0
+        if not escale:  # the Gram answered nearly everything the lazy scan asked for
+            assert cnt[9] < 0.1 * cnt[8], (int(cnt[9]), int(cnt[8]))
+
+
 @pytest.mark.parametrize("flags", [0, "row_only"])
 def test_large_rows_take_the_split_back_edge_path(flags):
     """Rows of 1 KiB and more: back-edges go through scan/append + worklist prunes -- with the MFMA Gram by default, with

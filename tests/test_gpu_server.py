@@ -1,0 +1,147 @@
+"""Concurrent callers on one shared index (the reference's model: N workers calling DiskANNIndex::search on a shared
+&DiskANNIndex, diskann-benchmark-core/src/search/api.rs:399-436): the launch path on the context pool, and the resident
+search server (dann_server_start / dann_search_submit / dann_search_wait).  Every result must equal the oracle's."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import bits, make_pair, rand_vectors, random_graph
+
+pytestmark = pytest.mark.gpu
+da = pytest.importorskip("diskann_amd")
+
+
+def _index(dtype, metric, n, dim, R, seed, nstart=1):
+    rng = np.random.default_rng(seed)
+    data = rand_vectors(rng, dtype, n, dim)
+    adj = random_graph(rng, n, R, nstart=nstart)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:nstart], R)
+    return rng, oix, gix
+
+
+def test_single_query_calls_from_many_threads_overlap():
+    """16 native threads x single-query dann_search_batch calls: same results as the oracle, and the calls overlap on
+    the device (each on its own stream) instead of queueing behind a per-index lock."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 20000, 128, 32, 41)
+    q = rand_vectors(rng, oracle.F32, 2048, 128)
+    L, k = 64, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    gix.concurrent_callers(q[:64], L, k, threads=4, mode=0)  # warm: contexts, calibration
+    ids1, d1, lat1, t1 = gix.concurrent_callers(q, L, k, threads=1, mode=0)
+    ids16, d16, lat16, t16 = gix.concurrent_callers(q, L, k, threads=16, mode=0)
+    for ids, d in ((ids1, d1), (ids16, d16)):
+        assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od))
+    # 16 callers must finish the same work in well under the serial time (the reference's workers do not serialise)
+    assert t16 < 0.5 * t1, (t1, t16)
+
+
+@pytest.mark.parametrize("dtype,metric,dim,R,L,k", [
+    (oracle.F32, oracle.L2, 128, 32, 64, 10),
+    (oracle.F32, oracle.INNER_PRODUCT, 100, 24, 40, 5),
+    (oracle.F16, oracle.L2, 128, 32, 26, 10),
+    (oracle.U8, oracle.L2, 128, 32, 100, 20),
+    (oracle.I8, oracle.COSINE, 64, 16, 30, 10),
+])
+def test_server_results_equal_the_oracle(dtype, metric, dim, R, L, k):
+    """submit / wait from several Python threads, tickets waited for out of order, ring wrap-around (the ring is far
+    smaller than the number of queries): ids, distances and stats identical to the oracle's single-query searches."""
+    rng, oix, gix = _index(dtype, metric, 8000, dim, R, 77 + dim + L)
+    q = rand_vectors(rng, dtype, 3000, dim)
+    oi, od, oc, ost = oix.search_batch(q, L, 1, k)
+    gix.server_start(L, k, workers=96, ring=256)
+    try:
+        got_i = np.zeros_like(oi)
+        got_d = np.zeros_like(od)
+        got_c = np.zeros(len(q), np.uint32)
+        err = []
+
+        def work(t, nthreads, depth):
+            try:
+                mine = list(range(t, len(q), nthreads))
+                for s0 in range(0, len(mine), depth):
+                    chunk = mine[s0:s0 + depth]
+                    tickets = [(i, gix.submit(q[i])) for i in chunk]
+                    for i, tk in reversed(tickets):      # out of submission order
+                        ids, dists, st = gix.wait(tk)
+                        got_i[i], got_d[i], got_c[i] = ids, dists, st["cmps"]
+                        assert st["status"] == 0
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=work, args=(t, 6, 8)) for t in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not err, err
+        assert np.array_equal(got_i, oi)
+        assert np.array_equal(bits(got_d), bits(od))
+        assert np.array_equal(got_c, ost[:, 0])
+        sub, _ = gix.server_stats()
+        assert sub == len(q)
+    finally:
+        gix.server_stop()
+
+
+def test_server_survives_idle_exit_and_interleaves_with_batches():
+    """The resident kernel leaves after idle_timeout_us without a submission and the next submit relaunches it; searches
+    through the launch path keep working while the server is up; stop / start again on the same index."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 6000, 128, 32, 5)
+    q = rand_vectors(rng, oracle.F32, 400, 128)
+    L, k = 32, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    gix.server_start(L, k, workers=64, ring=128, idle_timeout_us=20000)
+    try:
+        for rnd in range(3):
+            ids, d, lat, _ = gix.concurrent_callers(q, L, k, threads=4, mode=1, depth=8)
+            assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od)), rnd
+            bi, bd, _ = gix.search(da.Knn(L), q[:50], k)      # the launch path, server resident or not
+            assert np.array_equal(bi, oi[:50])
+            time.sleep(0.08)                                   # > idle timeout: the kernel has left by now
+        _, rel = gix.server_stats()
+        assert rel >= 2, rel
+    finally:
+        gix.server_stop()
+    gix.server_start(L, k, workers=32)
+    try:
+        t = gix.submit(q[7])
+        while not gix.poll(t):
+            time.sleep(0.0005)
+        ids, d, st = gix.wait(t)
+        assert np.array_equal(ids, oi[7]) and np.array_equal(bits(d), bits(od[7]))
+        with pytest.raises(da.DannError):
+            gix.wait(t)                                        # a ticket is waited for exactly once
+    finally:
+        gix.server_stop()
+
+
+def test_server_overflowing_query_falls_back_to_the_launch_path():
+    """A tiny explicit visited table makes resident searches exhaust their scratch; dann_search_wait re-runs those
+    queries through the launch path (which retries with larger tables): results still equal the oracle's."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 30000, 128, 32, 13)
+    q = rand_vectors(rng, oracle.F32, 300, 128)
+    L, k = 200, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    gix.set_visited_bits(8)   # 256 entries
+    gix.server_start(L, k, workers=48)
+    try:
+        ids, d, _, _ = gix.concurrent_callers(q, L, k, threads=3, mode=1, depth=4)
+        assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od))
+    finally:
+        gix.server_stop()
+        gix.set_visited_bits(0)
+
+
+def test_host_pointer_search_pipeline_equals_one_pass():
+    """dann_search_batch with a batch large enough for the chunked H2D / kernel / D2H pipeline returns exactly what the
+    same queries return in small calls."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 5000, 64, 16, 3)
+    q = rand_vectors(rng, oracle.F32, 70000, 64)
+    L, k = 20, 10
+    ids, d, st = gix.search(da.Knn(L), q, k)
+    for s0 in (0, 32768 - 100, 65536 - 50):
+        si, sd, sst = gix.search(da.Knn(L), q[s0:s0 + 300], k)
+        assert np.array_equal(ids[s0:s0 + 300], si) and np.array_equal(bits(d[s0:s0 + 300]), bits(sd))
+        assert np.array_equal(st["cmps"][s0:s0 + 300], sst["cmps"])
+    oi, od, _, _ = oix.search_batch(q[:500], L, 1, k)
+    assert np.array_equal(ids[:500], oi)
