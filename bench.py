@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
-    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8"],
+    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8", "build768"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
                          "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
                          "u8 search kernel")
@@ -85,6 +85,8 @@ def parse():
                     help="row stride of the SQ-8 store: 256 keeps the 128 code bytes of a row in one 128-byte line (the "
                          "L2 kernel never reads the compensation); 0 = payload rounded to 16 B (144: rows straddle lines)")
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
+    ap.add_argument("--query-sets", type=int, default=4,
+                    help="distinct query sets of --nq queries each; timed step i searches set i %% query_sets")
     if len(sys.argv) == 1 and os.environ.get("DANN_BENCH_ARGV"):  # a rank spawned by maybe_spawn()
         return ap.parse_args(json.loads(os.environ["DANN_BENCH_ARGV"]))
     return ap.parse_args()
@@ -186,6 +188,11 @@ def main():
     # ---- setup (untimed): data, index build on the GPU, ground truth ---------------------
     t0 = time.time()
     base, queries = make_data(torch, dev, args.n, args.dim, args.nq, args.dist, 0xD15CA11, 0xD15CA12 + rank)
+    # the timed steps rotate through several distinct query sets (set 0 is the one the recall sweep uses): no two
+    # consecutive steps replay the same address stream
+    nsets = max(1, args.query_sets)
+    qsets = [queries] + [make_data(torch, dev, 0, args.dim, args.nq, args.dist, 0xD15CA11, 0xD15CB00 + 97 * i + rank)[1]
+                         for i in range(1, nsets)]
     # medoid start point (diskann-utils/src/sampling/medoid.rs:15-48): f64 mean, nearest row
     mean = base.double().mean(0).float()
     medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
@@ -231,8 +238,8 @@ def main():
     d_dists = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
     d_stats = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
 
-    def run_search(L, W):
-        _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), args.nq, L, W, k,
+    def run_search(L, W, qset=0):
+        _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(qsets[qset].data_ptr()), args.nq, L, W, k,
                                                 C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dists.data_ptr()),
                                                 C.c_void_p(d_stats.data_ptr())), "dann_search_batch_device")
 
@@ -274,16 +281,27 @@ def main():
         if int(t.item()) != chosen:
             chosen = int(t.item())
             rec, st = evaluate(chosen, W)
-    cmps_sum, hops_sum = int(st[:, 0].sum()), int(st[:, 1].sum())
+    # algorithmic bytes of a launch: the mean over the query sets the timed steps cycle through
+    set_cmps, set_hops = [int(st[:, 0].sum())], [int(st[:, 1].sum())]
+    for i in range(1, nsets):
+        run_search(chosen, W, i)
+        sti = d_stats.cpu().numpy().view(np.uint32)
+        if sti[:, 3].any():
+            raise RuntimeError(f"per-query scratch overflow at L={chosen} (query set {i})")
+        set_cmps.append(int(sti[:, 0].sum()))
+        set_hops.append(int(sti[:, 1].sum()))
+    used = [i % nsets for i in range(args.steps)] or [0]
+    cmps_sum = sum(set_cmps[i] for i in used) / len(used)
+    hops_sum = sum(set_hops[i] for i in used) / len(used)
 
     # ---- timed region ------------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        run_search(chosen, W)
+    for w_ in range(args.warmup):
+        run_search(chosen, W, w_ % nsets)
     prov.kernel_time_reset()
     barrier()
     tstart = time.perf_counter()
-    for _ in range(args.steps):
-        run_search(chosen, W)
+    for i in range(args.steps):
+        run_search(chosen, W, i % nsets)
     barrier()
     elapsed = time.perf_counter() - tstart
     kernel_ms, launches = prov.kernel_time(0)
@@ -365,13 +383,16 @@ def main():
                 "beam_width": W,
                 "mean_cmps": cmps_sum / args.nq,
                 "mean_hops": hops_sum / args.nq,
+                "query_sets_rotated": nsets,
                 "build_seconds": round(t_build, 2),
                 **({"build_exchange": build_stats} if build_stats is not None else {}),
                 "parallelism": f"replicated index x{world}, query streams sharded, no collective",
             },
             "roofline": {
                 "kernel": "beam_search_kernel",
-                "bound": "hbm",
+                # a 644 MB working set against a 256 MiB Infinity Cache: the rate below is what the fabric delivers
+                # (HBM + cache hits); the HBM-side fraction of the same kernel is `hbm_side_frac` (the 6.4 GB index)
+                "bound": "fabric (HBM + Infinity Cache)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -406,6 +427,27 @@ def main():
             out["config"]["workload"] = (f"batched beam search over a {args.n}x{args.dim} f32 index resident in HBM, ONE "
                                          f"shared set of {nqs} queries per step block-partitioned over {world} GPU(s), "
                                          f"k=10, L={chosen}, beam_width={W}")
+        oix_head, qh_all, ref_small = None, None, None
+        if not args.no_cpu_baseline and world == 1:
+            import oracle
+            oix_head = oracle.Index(oracle.F32, oracle.L2, args.dim, args.n, args.max_degree, start)
+            oix_head.rows[:args.n, :] = base_h.view(np.uint8).reshape(args.n, -1)
+            oix_head.adj[:] = prov.download_graph()
+            qh_all = queries.cpu().numpy()
+            # the oracle's answer for the first 2048 queries at the chosen L and at L = 64: every secondary leg is
+            # checked against it (ids and distance bits)
+            ref_small = {L_: oix_head.search_batch(qh_all[:2048], L_, W, k, threads=host_cores()[0], fast=True)[:2]
+                         for L_ in {chosen, 64}}
+
+        def same_as_oracle(ids, dists, L_, nfirst):
+            if ref_small is None:
+                return None
+            m = min(nfirst, 2048)
+            return bool(np.array_equal(ids[:m], ref_small[L_][0][:m]) and
+                        np.array_equal(dists[:m].view(np.uint32), ref_small[L_][1][:m].view(np.uint32)))
+
+        def out_small(nq_small):
+            return (d_ids[:nq_small].cpu().numpy().view(np.uint32), d_dists[:nq_small].cpu().numpy())
         if not args.no_extras:
             lat = timed_small(1, 64, 200)
             t1024 = timed_small(1024, chosen, 50)
@@ -416,8 +458,12 @@ def main():
             nsus = min(20480, args.nq)
             tsus = timed_small(nsus, chosen, 20)
             tsus64 = timed_small(nsus, 64, 10)
+            timed_small(nsus, chosen, 1)
+            i_, d_ = out_small(2048)
+            sus_same = same_as_oracle(i_, d_, chosen, 2048)
             prov.set_max_concurrency(0)
             out["other_configs"].update({
+                "sustained_1024_in_flight_identical_to_oracle": sus_same,
                 "sustained_1024_in_flight_qps_at_L": nsus / tsus,
                 "sustained_1024_in_flight_mean_latency_us_at_L": 1024 * tsus / nsus * 1e6,
                 "sustained_1024_in_flight_qps_L64": nsus / tsus64,
@@ -430,6 +476,59 @@ def main():
                 # the survey's protocol size (SIFT's query set): one launch of 10 000 queries
                 "protocol_nq10000_qps_at_L": 10000 / t10k,
             })
+            # per-call latency distribution of the single-query launch (what SearchResults reports per query:
+            # mean / p90 / p99, diskann-benchmark-core/src/search/graph/knn.rs:300-330), device-resident buffers
+            one = []
+            for r in range(300):
+                qptr = queries.data_ptr() + (r % 256) * args.dim * 4
+                t_0 = time.perf_counter()
+                lib.dann_search_batch_device(prov._h, C.c_void_p(qptr), 1, 64, W, k, C.c_void_p(d_ids.data_ptr()),
+                                             C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_stats.data_ptr()))
+                one.append((time.perf_counter() - t_0) * 1e6)
+            out["other_configs"]["single_query_L64_latency"] = pct(one[20:])
+            # parity of the small-batch regimes (teams of wavefronts per query): 1024 queries as one batch, a single query
+            timed_small(1024, chosen, 1)
+            i_, d_ = out_small(1024)
+            out["other_configs"]["concurrent_1024_identical_to_oracle"] = same_as_oracle(i_, d_, chosen, 1024)
+            lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), 1, 64, W, k, C.c_void_p(d_ids.data_ptr()),
+                                         C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_stats.data_ptr()))
+            i_, d_ = out_small(1)
+            out["other_configs"]["single_query_L64_identical_to_oracle"] = same_as_oracle(i_, d_, 64, 1)
+            # the whole 100 000-query batch at L = 64 (BASELINE config 2's L on the throughput workload)
+            prov.kernel_time_reset()
+            t64 = timed_small(args.nq, 64, 5)
+            ms64, n64 = prov.kernel_time(0)
+            st64 = d_stats.cpu().numpy().view(np.uint32)
+            alg64 = int(st64[:, 0].sum()) * row_bytes + int(st64[:, 1].sum()) * adj_bytes
+            i_, d_ = out_small(2048)
+            out["other_configs"]["batch_L64"] = {
+                "queries": args.nq, "qps": args.nq / t64, "avg_kernel_ms": ms64 / max(n64, 1),
+                "algorithmic_GBps": alg64 / (ms64 / max(n64, 1) * 1e-3) / 1e9,
+                "frac_of_hbm_peak": alg64 / (ms64 / max(n64, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ids_identical_to_oracle": same_as_oracle(i_, d_, 64, 2048)}
+            # the drop-in call of a host that holds its queries in host memory: dann_search_batch with host pointers
+            # (H2D, kernel, D2H; batches of 2 x 32768 queries and more go through the chunked two-stream pipeline)
+            qh_host = qsets[0].cpu().numpy()
+            h_ids = np.empty((args.nq, k), np.uint32)
+            h_d = np.empty((args.nq, k), np.float32)
+
+            def host_call():
+                _ffi.check(lib.dann_search_batch(prov._h, qh_host.ctypes.data, args.nq, chosen, W, k, h_ids.ctypes.data,
+                                                 h_d.ctypes.data, None), "dann_search_batch")
+            host_call()
+            t_0 = time.perf_counter()
+            for _ in range(5):
+                host_call()
+            th = (time.perf_counter() - t_0) / 5
+            out["other_configs"]["host_pointer_search_batch"] = {
+                "queries_per_call": args.nq, "qps_pcie_inclusive": args.nq / th, "ms_per_call": th * 1e3,
+                "ids_identical_to_device_path": bool(np.array_equal(h_ids, evaluate.last_ids)),
+                "note": "host (pageable) buffers in and out; never the reported `value`"}
+            # the reference's serving model on one shared index: 16 host threads, one query per call
+            try:
+                out["other_configs"]["concurrent_callers"] = callers_variant(prov, qh_host, chosen, k, same_as_oracle)
+            except Exception as e:  # never lose the headline line over a secondary leg
+                out["other_configs"]["concurrent_callers"] = {"error": str(e)[:300]}
             # the distance kernel on its own (ExpandBeam::expand_beam batched): 20 000 queries x 256
             # random row ids -> n_evals x 512 B of gathers; kernel time by HIP events (clock 1)
             gq, gl = 20000, 256
@@ -498,9 +597,11 @@ def main():
                                                      "bytes = HBM + 256 MiB Infinity Cache hits")
         except (OSError, KeyError, ValueError):
             pass
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, prov, base_h, start, queries.cpu().numpy(), chosen, W, k,
-                                                evaluate.last_ids)
+        if oix_head is not None:  # rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(args, oix_head, qh_all, chosen, W, k, evaluate.last_ids)
+            if not args.no_extras:
+                out["other_configs"].update(cpu_small_regimes(oix_head, qh_all, chosen, W, k))
+            del oix_head
         # the same kernel on a working set far beyond the 256 MiB Infinity Cache (the honest HBM fraction)
         if args.large != "none" and not args.no_extras and world == 1:
             del base, queries, gt
@@ -519,6 +620,34 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def callers_variant(prov, qh, L, k, same_as_oracle):
+    """N host threads x single-query calls on the shared index (diskann-benchmark-core/src/search/api.rs:409-425): through
+    the launch path (every call its own kernel launch, calls of different threads side by side on the context pool) and
+    through the resident server (dann_search_submit / dann_search_wait; depth = tickets outstanding per thread, 1 =
+    strictly synchronous calls).  Native threads (dann_debug_concurrent_callers); latency = submit -> result in the
+    caller's buffer, host clock."""
+    res = {}
+    for threads in (1, 16):
+        nq = 1500 * threads
+        prov.concurrent_callers(qh[:128 * threads], L, k, threads=threads, mode=0)
+        ids, d, lat, secs = prov.concurrent_callers(qh[:nq], L, k, threads=threads, mode=0)
+        res[f"launch_path_{threads}_threads"] = {"qps": nq / secs, "queries": nq, **pct(lat),
+                                                "ids_identical_to_oracle": same_as_oracle(ids, d, L, nq)}
+    prov.server_start(L, k, workers=1024, ring=8192)
+    try:
+        for threads, depth in ((1, 1), (16, 1), (16, 64)):
+            nq = min(qh.shape[0], 2000 if depth == 1 and threads == 1 else 20000 if depth == 1 else 100000)
+            prov.concurrent_callers(qh[:2048], L, k, threads=threads, mode=1, depth=depth)
+            ids, d, lat, secs = prov.concurrent_callers(qh[:nq], L, k, threads=threads, mode=1, depth=depth)
+            res[f"server_{threads}_threads_depth_{depth}"] = {"qps": nq / secs, "queries": nq, "workers": 1024, **pct(lat),
+                                                             "ids_identical_to_oracle": same_as_oracle(ids, d, L, nq)}
+        sub, rel = prov.server_stats()
+        res["server_tickets"], res["server_relaunches"] = sub, rel
+    finally:
+        prov.server_stop()
+    return res
 
 
 def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, Lf32, full_prov):
@@ -889,28 +1018,34 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
             "qps": args.nq / (ms / nl * 1e-3)}
 
 
-def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
-    """The CPU restatement of the reference path (oracle, AVX2 kernels) on the same graph
-    bytes, same queries, all host cores, static block partition of the queries
-    (diskann-benchmark-core/src/search/api.rs:399-436)."""
-    import oracle
-    adj = prov.download_graph()
-    oix = oracle.Index(oracle.F32, oracle.L2, args.dim, args.n, args.max_degree, start)
-    oix.rows[:args.n, :] = base_h.view(np.uint8).reshape(args.n, -1)
-    oix.adj[:] = adj
-    # host cores this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes expose 256
-    # logical CPUs but cap the container at 16 CPUs' worth of time; more threads than that only measure a burst)
+def host_cores():
+    """host cores this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs but cap the container at 16 CPUs' worth of time; more threads than that only measure a burst)"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota_note = ""
+    note = ""
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             lim = max(1, int(np.ceil(int(q) / int(per))))
             if lim < cores:
                 cores = lim
-                quota_note = f" (cgroup cpu.max {q}/{per})"
+                note = f" (cgroup cpu.max {q}/{per})"
     except (OSError, ValueError):
         pass
+    return cores, note
+
+
+def pct(lat_us):
+    lat_us = np.asarray(lat_us, dtype=np.float64)
+    return {"mean_us": float(lat_us.mean()), "p50_us": float(np.percentile(lat_us, 50)),
+            "p90_us": float(np.percentile(lat_us, 90)), "p99_us": float(np.percentile(lat_us, 99))}
+
+
+def cpu_baseline(args, oix, queries_h, L, W, k, gpu_ids):
+    """The CPU restatement of the reference path (oracle, AVX2 kernels) on the same graph
+    bytes, same queries, all host cores, static block partition of the queries
+    (diskann-benchmark-core/src/search/api.rs:399-436)."""
+    cores, quota_note = host_cores()
     nqc = min(args.cpu_queries, queries_h.shape[0])
     qs = queries_h[:nqc]
     oix.search_batch(qs[:256], L, W, k, threads=cores, fast=True)  # warm
@@ -931,6 +1066,24 @@ def cpu_baseline(args, prov, base_h, start, queries_h, L, W, k, gpu_ids):
                   f"{quota_note}",
         "ids_identical_to_gpu": same,
     }
+
+
+def cpu_small_regimes(oix, queries_h, L, W, k):
+    """The CPU path beside BASELINE configs 2 and 3: one thread, one query at a time at L = 64 (per-query latency as the
+    reference reports it: mean / p90 / p99, search/graph/knn.rs:300-330), and 1024 queries over all host cores."""
+    cores, quota_note = host_cores()
+    n1 = min(2000, queries_h.shape[0])
+    oix.search_batch(queries_h[:64], 64, 1, k, threads=1, fast=True)
+    _, _, _, _, ns = oix.search_batch(queries_h[:n1], 64, 1, k, threads=1, fast=True, timing=True)
+    single = {"threads": 1, "queries": n1, **pct(ns.astype(np.float64) / 1e3)}
+    best = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        oix.search_batch(queries_h[:1024], L, W, k, threads=cores, fast=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"cpu_single_query_L64": single,
+            "cpu_1024_queries_at_L": {"qps": 1024 / best, "threads": cores, "note": f"best of 5{quota_note}"}}
 
 
 if __name__ == "__main__":

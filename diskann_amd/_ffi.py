@@ -47,6 +47,14 @@ class Rng(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("uniform_index", RNG_INDEX_FN), ("uniform_f64", RNG_F64_FN)]
 
 
+COMM_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    """dann_comm_ops: a caller-supplied all-gather over device buffers (tests: gloo through host memory)."""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather", COMM_ALL_GATHER_FN)]
+
+
 class ServerConfig(C.Structure):
     """dann_server_config: the resident search server (dann_server_start)."""
     _fields_ = [("l_value", C.c_uint32), ("k", C.c_uint32), ("workers", C.c_uint32), ("ring", C.c_uint32),
@@ -133,6 +141,24 @@ SYMBOLS = {
     "dann_kernel_time_reset": (_i32, [_vp]),
     "dann_set_visited_bits": (_i32, [_vp, _u32]),
     "dann_set_max_concurrency": (_i32, [_vp, _u32]),
+    "dann_comm_create_callbacks": (_i32, [_vp, _P(_vp)]),
+    "dann_comm_rccl_unique_id": (_i32, [_vp]),
+    "dann_comm_create_rccl": (_i32, [_vp, _u32, _u32, _i32, _P(_vp)]),
+    "dann_comm_create_local": (_i32, [_vp, _u32, _vp]),
+    "dann_comm_destroy": (_i32, [_vp]),
+    "dann_comm_rank": (_i32, [_vp]),
+    "dann_comm_world": (_i32, [_vp]),
+    "dann_comm_all_gather_device": (_i32, [_vp, _i32, _vp, _vp, _u64]),
+    "dann_build_sharded": (_i32, [_vp, _vp, _P(BuildConfig), _u32, _u32, _f32, _u32, _vp]),
+    "dann_search_sharded": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "dann_memcpy_device": (_i32, [_i32, _vp, _vp, _u64, _i32]),
+    "dann_multi_create": (_i32, [_P(Config), _vp, _u64, _vp, _u32, _P(_vp)]),
+    "dann_multi_destroy": (_i32, [_vp]),
+    "dann_multi_size": (_i32, [_vp]),
+    "dann_multi_replica": (_vp, [_vp, _u32]),
+    "dann_multi_set_elements": (_i32, [_vp, _u32, _u32, _vp, _u64]),
+    "dann_multi_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32, _vp]),
+    "dann_multi_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "dann_server_start": (_i32, [_vp, _vp]),
     "dann_server_stop": (_i32, [_vp]),
     "dann_search_submit": (_i32, [_vp, _vp, _P(_u64)]),

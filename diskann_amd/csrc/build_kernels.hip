@@ -1822,6 +1822,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                             uint32_t n, const uint32_t* d_pending, uint32_t rank = 0, uint32_t world = 1,
                             uint32_t* d_rows_out = nullptr, uint32_t rows_cap = 0, uint32_t* count_out = nullptr) {
     if (count_out) *count_out = 0;
+    s.bootstrap_too_big = false;
     const IndexView ix = idx->view();
     PruneCfg pc = to_prune_cfg(cfg);
     pc.counters = s.counters.as<unsigned long long>();
@@ -2019,6 +2020,14 @@ static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg
 }  // namespace dann
 
 using namespace dann;
+
+namespace dann {
+// the last commit on this handle stopped because its batch needs a bootstrap larger than one prune pool (nothing was
+// written to the graph): the callers that own a batch schedule (dann_build, dann_build_sharded) halve the batch
+bool build_bootstrap_too_big(dann_index* idx) {
+    return idx->build_scratch && static_cast<BuildScratch*>(idx->build_scratch)->bootstrap_too_big;
+}
+}  // namespace dann
 
 static BuildScratch& scratch_of(dann_index* idx) {
     if (!idx->build_scratch) {

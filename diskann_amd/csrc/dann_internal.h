@@ -152,6 +152,7 @@ struct SearchArgs {
     uint32_t grid = 0;               // 0: one wave per query; else `grid` persistent waves share the nq queries through
     uint32_t* work_next = nullptr;   //    this counter (zeroed before the launch): dann_set_max_concurrency
     ServerView srv;                  // srv.ring != 0: the launch is the persistent server (grid = workers + 1 waves)
+    uint32_t team = 0;               // 1: several wavefronts per query (latency regime; plain fixed-length searches only)
 };
 
 // Everything one in-flight search call needs besides the (read-only) index: its own stream and events, the retry

@@ -183,11 +183,94 @@ __device__ __forceinline__ float f32_load(const float* p) {
 //                 same launch: single query L = 64 235 -> 217 us, 1024 concurrent queries +8 %.
 //   kModeGeneral  any beam width, inline tags, any degree; no filter
 //   kModeFiltered the filtered searches (inline / multihop / AdaptiveL); generic-length instantiations only
+constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (SearchLds beam[1])
+// one wave's share of a team gather: candidate c = c0 + wave * GROUPS + g of every block of TEAM * GROUPS candidates,
+// one row per lane group and block (the single-wave form keeps kGatherRows rows per group in flight instead)
+template <int DT, int OP, bool NORM, int DIM, int TEAM>
+__device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t wave, uint32_t nc, const uint32_t* cand_id,
+                                                  float* cand_d, const F4 (&xq)[(DIM > 0 && !Scheme<DT, OP, false>::kInt) ? DIM / (4 * Scheme<DT, OP, false>::G) : 1],
+                                                  const uint4& xqi, int xx_pre, const uint8_t* qs, const SqParams& sqp, int g,
+                                                  int v) {
+    using S = Scheme<DT, OP, false>;
+    constexpr int G = S::G, GROUPS = kWave / G;
+    using RT = typename RowType<DT>::type;
+    for (uint32_t c0 = 0; c0 < nc; c0 += TEAM * GROUPS) {
+        const uint32_t c = c0 + wave * GROUPS + (uint32_t)g;
+        const bool act1 = c < nc;
+        const uint32_t id = act1 ? cand_id[c] : 0u;
+        if constexpr (!S::kInt) {
+            const RT* rows[1] = {reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride)};
+            const bool act[1] = {act1};
+            float out[1];
+            group_distance_pre<S::NACC, OP, DIM, 1>(xq, rows, act, v, out);
+            if (act1 && v == 0) cand_d[c] = post_op<OP, NORM>(out[0]);
+        } else {
+            const uint8_t* rows[1] = {ix.rows + (uint64_t)id * ix.row_stride};
+            float out[1];
+            group_distance_int_pre<OP, DT == DT_I8, 1>(xqi, xx_pre, rows, v, out);
+            if (act1 && v == 0) cand_d[c] = finish_distance<DT, OP, NORM>(out[0], qs, rows[0], ix.dim, sqp);
+        }
+    }
+}
+
+// waves 1 .. TEAM-1 of a team: wait for wave 0's candidates, evaluate their share, repeat until released
+template <int DT, int OP, bool NORM, int QS, int DIM, int TEAM>
+__device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) {
+    using S = Scheme<DT, OP, false>;
+    constexpr int G = S::G;
+    constexpr bool kInt = S::kInt;
+    const IndexView& ix = a.ix;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t qbytes = kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u;
+    const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, QS * kWave, qbytes);
+    const uint8_t* qs = smem + L.q_off;
+    const uint32_t* cand_id = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off);
+    float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
+    const uint32_t* beam = reinterpret_cast<const uint32_t*>(smem + L.beam_off);
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    __syncthreads();  // the query is staged
+    const int g = lane / G, v = lane % G;
+    constexpr int NTQ = (!kInt) ? DIM / (4 * G) : 1;
+    F4 xq[NTQ];
+    uint4 xqi = {0u, 0u, 0u, 0u};
+    int xx_pre = 0;
+    if constexpr (!kInt) {
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) xq[t] = load4(reinterpret_cast<const float*>(qs) + t * 4 * G + 4 * v);
+    } else {
+        xqi = *reinterpret_cast<const uint4*>(qs + 16 * v);
+        xx_pre = group_norm_int_pre<DT == DT_I8>(xqi);
+    }
+    for (;;) {
+        __syncthreads();  // candidates ready (or release)
+        const uint32_t nc = beam[1];
+        if (nc == kTeamExit) break;
+        team_gather_share<DT, OP, NORM, DIM, TEAM>(ix, wave, nc, cand_id, cand_d, xq, xqi, xx_pre, qs, sqp, g, v);
+        __syncthreads();  // distances ready
+    }
+}
+
 enum : int { kModePlain = 0, kModeGeneral = 1, kModeFiltered = 2 };
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE>
+// TEAM > 1 (latency regime: fewer queries than the chip has wave slots): a workgroup of TEAM wavefronts serves one
+// query.  Wave 0 runs the search exactly as the single-wave form does (queue, visited filter, merge); the other waves
+// only take a share of every gather -- the rows of a hop are split TEAM ways, so a lane issues a quarter of the
+// requests and FMAs, and the 512-byte rows of a 32-neighbour hop are in flight from four SIMDs at once.  Two workgroup
+// barriers per gather (candidates ready / distances ready); every other synchronisation of wave 0 stays wave-local.
+// Distances come from the same lane groups and the same arithmetic: results are identical by construction.
+__device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int TEAM = 1>
 __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint32_t slot, uint8_t* smem) {
     constexpr bool FILT = MODE == kModeFiltered;
     constexpr bool PLAIN = MODE == kModePlain;
+    static_assert(TEAM == 1 || (PLAIN && DIM > 0), "teams serve the plain fixed-length searches");
+    // synchronisation of this wave with itself (LDS written by some lanes, read by others): the workgroup barrier of a
+    // one-wave workgroup, a counter drain when helper waves share the workgroup
+    auto WS = [&]() {
+        if constexpr (TEAM > 1) team_wave_sync();
+        else __syncthreads();
+    };
     using S = Scheme<DT, OP, false>;
     constexpr int G = (DIM > 0) ? S::G : S::GS;  // fixed-length path: narrow groups, query slice in registers
     constexpr int GROUPS = kWave / G;
@@ -251,7 +334,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
         for (uint32_t i = lane * 4u; i < ht_size; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
     }
-    __syncthreads();
+    __syncthreads();  // (TEAM: all waves -- the helpers read the staged query after it)
 
     const int g = lane / G, v = lane % G;
     // query slice of this lane in registers for the fixed-length float path
@@ -324,6 +407,16 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
     const uint32_t tag_off = PLAIN ? 0u : ix.tag_off;
     auto gather = [&](uint32_t nc) -> uint32_t {
+        if constexpr (TEAM > 1) {
+            // candidates ready -> every wave evaluates its share (wave 0: rows [c0, c0 + GROUPS) of every block of
+            // TEAM * GROUPS) -> distances ready
+            if (lane == 0) beam[1] = nc;
+            __syncthreads();
+            team_gather_share<DT, OP, NORM, DIM, TEAM>(ix, 0u, nc, cand_id, cand_d, xq, xqi, xx_pre,
+                                                       reinterpret_cast<const uint8_t*>(qs), sqp, g, v);
+            __syncthreads();
+            return nc;
+        } else
         if constexpr (DIM > 0 && !kInt) {
             constexpr int U = kGatherRows;
             for (uint32_t c0 = 0; c0 < nc; c0 += GROUPS * U) {
@@ -435,21 +528,21 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if (!tag_off) return nc;
         // drop the unreadable slots, emission order kept (forward compaction: writes never pass the reads)
         uint32_t w = 0;
-        __syncthreads();
+        WS();
         for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
             const uint32_t c = c0 + lane;
             const uint32_t id = c < nc ? cand_id[c] : kEmpty;
             const float d = c < nc ? cand_d[c] : 0.0f;
             const bool ok = id != kEmpty;
             const uint64_t m = ballot64(ok);
-            __syncthreads();
+            WS();
             if (ok) {
                 const uint32_t r = w + mbcnt(m);
                 cand_id[r] = id;
                 cand_d[r] = d;
             }
             w += (uint32_t)__popcll(m);
-            __syncthreads();
+            WS();
         }
         return w;
     };
@@ -518,12 +611,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         } else {
         if (nv != n) {  // compact the survivors, emission order preserved
             const uint32_t cj = mbcnt(km);
-            __syncthreads();
+            WS();
             if (nvalid) {
                 cand_d[m0 + cj] = nd;
                 cand_id[m0 + cj] = nid;
             }
-            __syncthreads();
+            WS();
             has = lane < nv;
             nd = has ? cand_d[m0 + lane] : 0.0f;
             nid = has ? cand_id[m0 + lane] : kEmpty;
@@ -535,7 +628,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             before += ((dj < nd) | ((dj == nd) & (jj > lane))) ? 1u : 0u;
         }
         if (has) snew[before] = nd;
-        __syncthreads();
+        WS();
         // old elements: shift = #{new <= d_e}  (upper bound in snew[0..nv))
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
@@ -570,7 +663,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if (has && pos_new < qcap) stage[pos_new] = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
         const uint32_t total = size + nv;
         size = total < qcap ? total : qcap;
-        __syncthreads();
+        WS();
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             const uint32_t p = (uint32_t)(s * kWave) + lane;
@@ -657,12 +750,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             ht_visit(ht, ht_mod, ix.capacity + i, true);
         }
         ht_count = ns;
-        __syncthreads();
+        WS();
         // start points are created FROZEN (store.rs:766-772) and the host refuses to unpublish them; should one be
         // unreadable all the same, the search fails as the reference's does
         const uint32_t nsk = gather(ns);
         if (nsk != ns) status = (uint32_t)(-DANN_EINVAL);  // "could not retrieve start point" (provider.rs:408-431)
-        __syncthreads();
+        WS();
         // the filtered searches do not count the start points as comparisons (inline_filter_search.rs:186-197)
         cmps = fmode ? 0u : nsk;
         if (fmode == DANN_FILTER_INLINE) append_matched(nsk);
@@ -741,13 +834,13 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         }
         if (nb == 0 || status) break;
         hops += nb;
-        if (W > 1) __syncthreads();
+        if (W > 1) WS();
         PH_T(ph1);
         PH_ADD(0, ph0, ph1);
 
         const uint32_t nc_seen = expand(nb, false, W == 1);
         if (status) break;
-        __syncthreads();
+        WS();
         PH_T(ph2);
         PH_ADD(1, ph1, ph2);
         // speculative adjacency prefetch: while the candidate rows are in flight, fetch the
@@ -788,7 +881,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                     : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4));
             }
         }
-        __syncthreads();
+        WS();
         PH_T(ph3);
         PH_ADD(2, ph2, ph3);
         cmps += nc;
@@ -810,19 +903,19 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             }
             const uint32_t nrej = (uint32_t)__popcll(rm);
             const uint32_t nsel = nrej < R / 2 ? nrej : R / 2;
-            __syncthreads();
+            WS();
             if (acc) {  // accepted one-hop neighbours, emission order kept
                 const uint32_t r = mbcnt(am);
                 cand_id[r] = cid;
                 cand_d[r] = cd;
             }
-            __syncthreads();
+            WS();
             if (na) merge(0, na);
-            __syncthreads();
+            WS();
             if (rej && rank < nsel) cand_id[rank] = cid;
-            __syncthreads();
+            WS();
             const uint32_t sel = lane < nsel ? cand_id[lane] : kEmpty;
-            __syncthreads();
+            WS();
             const uint32_t gsz = (cmax / R) < (uint32_t)kMaxBeam ? (cmax / R) : (uint32_t)kMaxBeam;
             for (uint32_t b0 = 0; b0 < nsel && !status; b0 += gsz) {
                 const uint32_t gb = nsel - b0 < gsz ? nsel - b0 : gsz;
@@ -830,16 +923,16 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                     const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)sel, (int)(b0 + t));
                     if (lane == 0) beam[t] = node;
                 }
-                __syncthreads();
+                WS();
                 const uint32_t nc2_seen = expand(gb, true);
                 if (status) break;
-                __syncthreads();
+                WS();
                 const uint32_t nc2 = gather(nc2_seen);
-                __syncthreads();
+                WS();
                 cmps += nc2;
                 for (uint32_t m0 = 0; m0 < nc2; m0 += kWave)
                     merge(m0, (nc2 - m0) < (uint32_t)kWave ? (nc2 - m0) : (uint32_t)kWave);
-                __syncthreads();
+                WS();
             }
             if (status) break;
             hops += nsel;
@@ -961,10 +1054,10 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if (!status && nf >= a.range_thresh && nw < a.range_max) {
             range_second = 1;
             // visited := ids of in_range; range_frontier := in_range (:190-199)
-            __syncthreads();
+            WS();
             for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
             if (spill) spill_wipe(spill, spill_size, lane);
-            __syncthreads();
+            WS();
             lds_open = true;
             ht_count = 0;
             spill_count = 0;
@@ -976,7 +1069,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 else if (i < nf) ht_visit(ht, ht_mod, u32_load(m_ids + i), true);
                 ht_count += cnt;
             }
-            __syncthreads();
+            WS();
             const float nav = a.radius * a.range_slack;
             uint32_t front = 0;
             // filtered_range_search_internal (:263-330): cmps and hops keep accumulating
@@ -985,12 +1078,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < nb) beam[lane] = u32_load(m_ids + front + lane);
                 front += nb;
-                __syncthreads();
+                WS();
                 const uint32_t nc_seen = expand(nb);
                 if (status) break;
-                __syncthreads();
+                WS();
                 const uint32_t nc = gather(nc_seen);
-                __syncthreads();
+                WS();
                 cmps += nc;
                 hops += nb;
                 for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
@@ -1072,10 +1165,10 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if (!status && nr >= a.range_thresh && nr < a.range_max) {
             range_second = 1;
             // visited := ids of in_range only (range_search.rs:297-301)
-            __syncthreads();
+            WS();
             for (uint32_t i = lane; i < ht_size; i += kWave) ht[i] = kEmpty;
             if (spill) spill_wipe(spill, spill_size, lane);
-            __syncthreads();
+            WS();
             lds_open = true;
             ht_count = 0;
             spill_count = 0;
@@ -1087,7 +1180,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 else if (i < nr) ht_visit(ht, ht_mod, rids[i], true);
                 ht_count += cnt;
             }
-            __syncthreads();
+            WS();
             const float rlimit = a.radius * a.range_slack;
             uint32_t front = 0;
             while (!status && front < nr && nr < a.range_max) {
@@ -1096,12 +1189,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 __threadfence_block();  // rids[] written and re-read by this wave only
                 if (lane < nb) beam[lane] = rids[front + lane];
                 front += nb;
-                __syncthreads();
+                WS();
                 const uint32_t nc_seen = expand(nb);
                 if (status) break;
-                __syncthreads();
+                WS();
                 const uint32_t nc = gather(nc_seen);
-                __syncthreads();
+                WS();
                 hops += nb;
                 // append survivors in emission order while the list has room
                 for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
@@ -1158,10 +1251,14 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     if (lane == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&a.phase_cycles[i], ph_acc[i]);
 #endif
+    if constexpr (TEAM > 1) {  // no gather follows: release the helper waves (they leave the barrier count)
+        if (lane == 0) beam[1] = kTeamExit;
+        __syncthreads();
+    }
     if (spill) {  // hand the spill table back clean
-        __syncthreads();
+        WS();
         spill_wipe(spill, spill_size, lane);
-        __syncthreads();
+        WS();
         if (lane == 0) atomicExch(a.spill_next + 16 + (uint32_t)((spill - a.spill) >> a.spill_bits), 0u);
     }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----
@@ -1296,10 +1393,17 @@ __device__ void server_dispatch(const ServerView& sv) {
 // serve the submission ring of dann_server_start until told to stop.  Results do not depend on it.  Separate
 // instantiations (plain mode only): the loop around the body costs the one-wave-per-query launch 3-5 % when it is
 // compiled into the same kernel.
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP>
-__global__ __launch_bounds__(kWave) void beam_search_kernel(SearchArgs a) {
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP, int TEAM = 1>
+__global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if constexpr (LOOP == 0) {
+    if constexpr (TEAM > 1) {
+        static_assert(LOOP == 0, "teams serve one-shot launches");
+        if (threadIdx.x >= (uint32_t)kWave) {
+            team_helper<DT, OP, NORM, QS, DIM, TEAM>(a, smem);
+            return;
+        }
+        beam_search_one<DT, OP, NORM, QS, DIM, MODE, TEAM>(a, blockIdx.x, smem);
+    } else if constexpr (LOOP == 0) {
         beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, blockIdx.x, smem);
     } else if constexpr (LOOP == 1) {
         uint32_t slot = blockIdx.x;
@@ -1388,9 +1492,15 @@ inline bool plain_mode(const SearchArgs& a) {
            a.ix.nstart <= (uint32_t)kWave;
 }
 
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0>
+constexpr int kTeam = 4;  // wavefronts per query in the latency regime (SearchArgs::team)
+
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0, int TEAM = 1>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
-    if constexpr (MODE == kModePlain && LOOP == 0) {
+    if constexpr (MODE == kModePlain && LOOP == 0 && TEAM == 1 && DIM > 0 && QS <= 4 && DT != DT_PQ) {
+        if (a.team && !a.srv.ring && !a.grid && !regs_out)
+            return launch_one<DT, OP, NORM, QS, DIM, MODE, 0, kTeam>(a, lds, stream, regs_out);
+    }
+    if constexpr (MODE == kModePlain && LOOP == 0 && TEAM == 1) {
         if (a.srv.ring && !regs_out) {
             if constexpr (QS <= 4) return launch_one<DT, OP, NORM, QS, DIM, MODE, 2>(a, lds, stream, regs_out);
             set_error("the search server supports L + start points <= 256");
@@ -1398,7 +1508,7 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
         }
         if (a.grid && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, 1>(a, lds, stream, regs_out);
     }
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, LOOP>;
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, LOOP, TEAM>;
     if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
         hipFuncAttributes attr;
         hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));
@@ -1418,7 +1528,7 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
         }
     }
     const uint32_t grid = LOOP == 2 ? a.srv.workers + 1u : LOOP == 1 ? a.grid : a.nq;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * TEAM), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
     return DANN_OK;

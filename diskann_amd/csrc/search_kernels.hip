@@ -238,6 +238,17 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     }
     // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
     if (inflight <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
+    // ... and with at most one query per SIMD the other wave slots are idle: a team of wavefronts per query (the rows of
+    // a hop split four ways).  Knn searches only (the launch falls back to one wave per query where no team
+    // instantiation exists).  DANN_TUNE_OFF bit 4 / DANN_TEAM_MAX_QUERIES: development switches.
+    {
+        static const uint32_t team_max = [] {
+            const char* e = getenv("DANN_TEAM_MAX_QUERIES");
+            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
+        }();
+        const uint32_t limit = std::min<uint32_t>(team_max, 4u * idx->num_cus);
+        a.team = (inflight <= limit && !a.grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && !tune_env(4)) ? 1u : 0u;
+    }
     return DANN_OK;
 }
 

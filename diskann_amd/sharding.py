@@ -1,5 +1,9 @@
 """Query-stream sharding across the GPUs of one node (replicated index, no data-path collective).
 
+The multi-GPU build and search live behind the C ABI (csrc/sharded.hip: dann_comm_*, dann_build_sharded,
+dann_search_sharded, dann_multi_*); this module binds them (`Comm`, `MultiProvider`, `build_sharded`) and keeps the
+pure-Python statement of the exchange protocol that the CPU tests drive over gloo with a host-memory provider.
+
 `partition` is the reference's task partition (diskann/src/utils/async_tools.rs:289-365,
 used by diskann-benchmark-core/src/search/api.rs:410 to split the query set over tasks):
 ranges are contiguous, disjoint, cover 0..nitems, and differ in length by at most one.
@@ -69,8 +73,170 @@ def batch_schedule(first, n, growth, max_batch):
         done += b
 
 
+class Comm:
+    """dann_comm: the collective the sharded build / search run on.
+
+    Comm.local(devices)      one process, one host thread per device (in-process all-gather: hipMemcpyPeer)
+    Comm.from_torch(group)   one process per GPU under torch.distributed: "nccl" -> an RCCL communicator created by the
+                             library (the unique id travels through torch.distributed, the collectives are ncclAllGather
+                             calls issued from C++ on device buffers); "gloo" -> a callback communicator whose all-gather
+                             goes through host memory (CPU collective; tests with several ranks on one device)"""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep  # callback objects must outlive the communicator
+
+    @staticmethod
+    def local(devices):
+        import ctypes as C
+        from . import _ffi
+        devs = (C.c_int32 * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        _ffi.check(_ffi.lib().dann_comm_create_local(devs, len(devices), out), "dann_comm_create_local")
+        return [Comm(C.c_void_p(h)) for h in out]
+
+    @staticmethod
+    def from_torch(group=None, device=-1):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _ffi
+        lib = _ffi.lib()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        h = C.c_void_p()
+        if dist.get_backend(group) == "nccl":
+            uid = (C.c_char * 128)()
+            if rank == 0:
+                _ffi.check(lib.dann_comm_rccl_unique_id(uid), "dann_comm_rccl_unique_id")
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(torch.device("cuda", torch.cuda.current_device()))
+            dist.broadcast(t, 0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+            _ffi.check(lib.dann_comm_create_rccl(uid, rank, world, device, C.byref(h)), "dann_comm_create_rccl")
+            return Comm(h)
+
+        def all_gather(_ctx, d_send, d_recv, nbytes, _stream):  # device -> host -> gloo -> device
+            try:
+                send = np.empty(nbytes, np.uint8)
+                _ffi.check(lib.dann_memcpy_device(device, send.ctypes.data, d_send, nbytes, 1), "dann_memcpy_device")
+                recv = torch.empty(world * nbytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(recv, torch.from_numpy(send), group=group)
+                r = recv.numpy()
+                _ffi.check(lib.dann_memcpy_device(device, d_recv, r.ctypes.data, world * nbytes, 0), "dann_memcpy_device")
+                return 0
+            except Exception:  # noqa: BLE001 -- nothing may unwind into C
+                return -5
+        cb = _ffi.COMM_ALL_GATHER_FN(all_gather)
+        ops = _ffi.CommOps(None, rank, world, cb)
+        _ffi.check(lib.dann_comm_create_callbacks(C.byref(ops), C.byref(h)), "dann_comm_create_callbacks")
+        return Comm(h, keep=(cb, ops))
+
+    def close(self):
+        if self._h:
+            from . import _ffi
+            _ffi.lib().dann_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def build_sharded_native(provider, cfg, first, n, growth, max_batch, comm, stats=None):
+    """dann_build_sharded: the whole batch loop, both all-gathers and the owner-partitioned commit in C++ (device
+    buffers end to end).  Collective over `comm`; returns the number of batches."""
+    import ctypes as C
+    from . import _ffi
+    st = (C.c_uint64 * 4)()
+    nb = _ffi.check(_ffi.lib().dann_build_sharded(provider._h, comm._h, C.byref(cfg), first, n, growth, max_batch, st),
+                    "dann_build_sharded")
+    if stats is not None:
+        stats["rounds"] = stats.get("rounds", 0) + st[0]
+        stats["bytes_gathered"] = stats.get("bytes_gathered", 0) + st[1]
+        stats["rows_rewritten"] = stats.get("rows_rewritten", 0) + st[2]
+        stats["bytes_gathered_rows"] = stats.get("bytes_gathered_rows", 0) + st[3]
+    return nb
+
+
+def search_sharded_native(provider, comm, queries, l_value, beam_width, k):
+    """dann_search_sharded: every rank passes the same query block and receives every result."""
+    from . import _ffi
+    q = np.ascontiguousarray(queries, dtype=provider.query_dtype).reshape(-1, provider.query_elems)
+    ids = np.empty((q.shape[0], k), np.uint32)
+    dists = np.empty((q.shape[0], k), np.float32)
+    _ffi.check(_ffi.lib().dann_search_sharded(provider._h, comm._h, q.ctypes.data, q.shape[0], l_value, beam_width, k,
+                                              ids.ctypes.data, dists.ctypes.data), "dann_search_sharded")
+    return ids, dists
+
+
+class MultiProvider:
+    """dann_multi: one process driving several devices -- one replica per entry of `devices` (an ordinal may repeat)."""
+
+    def __init__(self, dtype, metric, dim, capacity, max_degree, start_points, devices):
+        import ctypes as C
+        from . import _ffi
+        from .provider import NP_DTYPE
+        self.dtype, self.dim = dtype, int(dim)
+        sp = np.ascontiguousarray(start_points, dtype=NP_DTYPE[dtype]).reshape(-1, self.dim)
+        cfg = _ffi.Config(dtype, metric, self.dim, int(capacity), int(max_degree), sp.shape[0], 0, -1, 0.0, 0.0, 0, 0)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().dann_multi_create(C.byref(cfg), sp.ctypes.data, sp.nbytes, devs, len(devices), C.byref(h)),
+                   "dann_multi_create")
+        self._h, self.ndev, self.max_degree, self.capacity, self.nstart = h, len(devices), int(max_degree), int(capacity), sp.shape[0]
+        self._np = NP_DTYPE[dtype]
+
+    def set_elements(self, first_slot, rows):
+        from . import _ffi
+        r = np.ascontiguousarray(rows, dtype=self._np).reshape(-1, self.dim)
+        _ffi.check(_ffi.lib().dann_multi_set_elements(self._h, first_slot, r.shape[0], r.ctypes.data, r.nbytes),
+                   "dann_multi_set_elements")
+
+    def build(self, cfg, first, n, growth=0.02, max_batch=16384):
+        import ctypes as C
+        from . import _ffi
+        st = (C.c_uint64 * 4)()
+        nb = _ffi.check(_ffi.lib().dann_multi_build(self._h, C.byref(cfg), first, n, growth, max_batch, st), "dann_multi_build")
+        return nb, {"rounds": st[0], "bytes_gathered": st[1], "rows_rewritten": st[2], "bytes_gathered_rows": st[3]}
+
+    def search(self, params, queries, k=10):
+        from . import _ffi
+        from .provider import STATS_DTYPE
+        q = np.ascontiguousarray(queries, dtype=self._np).reshape(-1, self.dim)
+        ids = np.empty((q.shape[0], k), np.uint32)
+        dists = np.empty((q.shape[0], k), np.float32)
+        stats = np.zeros(q.shape[0], STATS_DTYPE)
+        _ffi.check(_ffi.lib().dann_multi_search_batch(self._h, q.ctypes.data, q.shape[0], params.l_value, params.beam_width, k,
+                                                      ids.ctypes.data, dists.ctypes.data, stats.ctypes.data),
+                   "dann_multi_search_batch")
+        return ids, dists, stats
+
+    def download_graph(self, replica):
+        import ctypes as C
+        from . import _ffi
+        lib = _ffi.lib()
+        h = lib.dann_multi_replica(self._h, replica)
+        rows = self.capacity + self.nstart
+        adj = np.empty((rows, self.max_degree + 1), np.uint32)
+        _ffi.check(lib.dann_download_graph(C.c_void_p(h), adj.ctypes.data, rows), "dann_download_graph")
+        return adj
+
+    def close(self):
+        if self._h:
+            from . import _ffi
+            _ffi.lib().dann_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0, world=1, group=None, stats=None,
-                  owner_prunes=True):
+                  owner_prunes=True, comm=None):
     """Multi-GPU index build over identical replicas (one `provider` per rank, rows already stored).
 
     Every batch is one multi_insert (diskann/src/graph/index.rs:815-1030): each rank generates the
@@ -89,6 +255,18 @@ def build_sharded(provider, cfg, first, n, growth=0.02, max_batch=16384, rank=0,
     import torch
 
     from ._ffi import DannError, EUNSUPPORTED
+    # the HIP provider: the loop below exists in C++ behind the C ABI (dann_build_sharded) -- collectives on device
+    # buffers issued by the library.  The Python statement of the protocol stays for the host-memory stand-in of the
+    # CPU tests and for the un-partitioned commit (owner_prunes=False).
+    if getattr(provider, "_h", None) is not None and provider.device >= 0 and owner_prunes and (comm is not None or world > 1):
+        own = comm is None
+        if own:
+            comm = Comm.from_torch(group, provider.device)
+        try:
+            return build_sharded_native(provider, cfg, first, n, growth, max_batch, comm, stats)
+        finally:
+            if own:
+                comm.close()
     # (a provider on device -1 is a host-memory stand-in: the CPU tests drive this exchange protocol over gloo)
     dev = torch.device("cuda", provider.device) if provider.device >= 0 else torch.device("cpu")
 

@@ -422,7 +422,7 @@ int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, u
                               float* out_gram, float* out_nrm);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
-#define DANN_ABI_VERSION 2
+#define DANN_ABI_VERSION 3
 int32_t dann_abi_version(void);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
@@ -443,6 +443,62 @@ int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
  * of its batch.  Applies to the plain searches (beam width 1, no filter, no inline tags, degree <= 64: Knn, Range,
  * the insert search); the other modes keep one wavefront per query.  Never affects results. */
 int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight);
+
+/* ---- multi-GPU (replicated index per device).  Search shards with no data-path collective; the build splits every
+ * multi_insert batch at its only exchange point (diskann/src/graph/index.rs:815-1030, :911-1024): candidates per rank,
+ * all-gather of the pending adjacency rows, the same graph update on every replica with the prunes of overflowing
+ * back-edge targets done by their owner (id % world) and a second all-gather of the rewritten rows.  The collectives
+ * are issued by the library on device buffers: RCCL (ncclAllGather over xGMI, librccl bound at run time), an in-process
+ * form for one process driving several devices, or the caller's own callback. ---- */
+typedef struct dann_comm dann_comm;
+typedef struct { char internal[128]; } dann_rccl_unique_id; /* == ncclUniqueId */
+typedef struct {
+    void* ctx;
+    uint32_t rank, world;
+    /* all-gather `bytes` bytes per rank, device buffers (d_recv holds world * bytes), enqueued on `hip_stream` (a
+     * hipStream_t) or complete on return; 0 = ok */
+    int32_t (*all_gather)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes, void* hip_stream);
+} dann_comm_ops;
+int32_t dann_comm_create_callbacks(const dann_comm_ops* ops, dann_comm** out);
+/* one process per GPU: rank 0 draws the id, the host distributes it (MPI / torch.distributed / a socket), every rank
+ * creates its communicator on its device (-1 = current).  DANN_EUNSUPPORTED when librccl cannot be loaded. */
+int32_t dann_comm_rccl_unique_id(dann_rccl_unique_id* out);
+int32_t dann_comm_create_rccl(const dann_rccl_unique_id* id, uint32_t rank, uint32_t world, int32_t device, dann_comm** out);
+/* one process, `world` devices (ranks = host threads): out receives `world` communicators */
+int32_t dann_comm_create_local(const int32_t* devices, uint32_t world, dann_comm** out);
+int32_t dann_comm_destroy(dann_comm* comm);
+int32_t dann_comm_rank(const dann_comm* comm);
+int32_t dann_comm_world(const dann_comm* comm);
+/* the communicator's all-gather on caller buffers (device pointers on `device`); the build's primitive, exported for
+ * pre-flight checks of a deployment */
+int32_t dann_comm_all_gather_device(dann_comm* comm, int32_t device, const void* d_send, void* d_recv, uint64_t bytes);
+/* dann_build over `world` identical replicas (rows already stored on every rank): same batch schedule, same graph on
+ * every replica as a single-GPU dann_build.  Collective: every rank calls it with the same arguments.  Returns the
+ * number of batches; stats (optional, 4 entries): exchange rounds, bytes of pending rows gathered, rows rewritten by
+ * their owners, bytes of rewritten rows gathered. */
+int32_t dann_build_sharded(dann_index* idx, dann_comm* comm, const dann_build_config* cfg, uint32_t first, uint32_t n,
+                           float growth, uint32_t max_batch, uint64_t* stats);
+/* every rank holds the same nq queries (host) and receives all nq results: rank r searches partition r of the block
+ * (diskann/src/utils/async_tools.rs:289-365), the k results per query are all-gathered.  Collective. */
+int32_t dann_search_sharded(dann_index* idx, dann_comm* comm, const void* queries, uint32_t nq, uint32_t l_value,
+                            uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists);
+/* plain copies for hosts without HIP bindings (kind 0 host->device, 1 device->host, 2 device->device; synchronous) */
+int32_t dann_memcpy_device(int32_t device, void* dst, const void* src, uint64_t bytes, int32_t kind);
+
+/* one process driving several devices ("device mask"): one replica per entry of `devices` (an ordinal may repeat).
+ * set_elements replicates the rows, build runs dann_build_sharded on one host thread per replica over the in-process
+ * communicator, search_batch partitions the query block over the replicas (host buffers; out_stats optional). */
+typedef struct dann_multi dann_multi;
+int32_t dann_multi_create(const dann_config* cfg, const void* start_rows, uint64_t start_len, const int32_t* devices,
+                          uint32_t ndev, dann_multi** out);
+int32_t dann_multi_destroy(dann_multi* m);
+int32_t dann_multi_size(const dann_multi* m);
+dann_index* dann_multi_replica(dann_multi* m, uint32_t i);
+int32_t dann_multi_set_elements(dann_multi* m, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len);
+int32_t dann_multi_build(dann_multi* m, const dann_build_config* cfg, uint32_t first, uint32_t n, float growth,
+                         uint32_t max_batch, uint64_t* stats);
+int32_t dann_multi_search_batch(dann_multi* m, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
+                                uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats);
 
 /* ---- search server: the reference's serving model -- N workers calling DiskANNIndex::search on one shared index,
  * one query per call (diskann-benchmark-core/src/search/api.rs:399-436, tokio.rs:10-14) -- without a kernel launch

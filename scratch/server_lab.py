@@ -38,7 +38,7 @@ for threads in (1, 16):
     nq = 2000 * threads
     p.concurrent_callers(qh[:256], L, k, threads=threads, mode=0)
     ids, d, lat, secs = p.concurrent_callers(qh[:nq], L, k, threads=threads, mode=0)
-    out[f"launch_path_{threads}_threads"] = {"qps": nq / secs, "identical": bool(np.array_equal(ids, ref_ids[:nq])), **pct(lat)}
+    out[f"launch_path_{threads}_threads"] = {"qps": nq / secs, "identical": bool(np.array_equal(ids[:20000], ref_ids[:nq])), **pct(lat)}
     print(json.dumps({f"launch_path_{threads}_threads": out[f"launch_path_{threads}_threads"]}), flush=True)
 for workers in (1024, 2048):
     p.server_start(L, k, workers=workers, ring=8192)

@@ -157,3 +157,86 @@ def test_config5_layout_f16_replica_with_f32_owner_rerank(tmp_path):
            "127.0.0.1", "--master-port", "29543", str(script), ROOT]
     r = _run(cmd, env)
     assert r.stdout.count("ok") == 2
+
+
+def _oracle_build(dtype, metric, data, start, Rp, maxdeg, lb, growth, max_batch):
+    import numpy as np
+    import oracle
+    from diskann_amd.sharding import batch_schedule
+    n, dim = data.shape
+    o = oracle.Index(dtype, metric, dim, n, maxdeg, start)
+    o.set_rows(0, data)
+    ocfg = oracle.build_config(Rp, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    nb = 0
+    for s0, b in batch_schedule(0, n, growth, max_batch):
+        o.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
+        nb += 1
+    return o, nb
+
+
+def test_one_process_several_replicas_through_the_c_abi():
+    """dann_multi (one process driving several devices; here two replicas on device 0): dann_multi_build runs
+    dann_build_sharded on one host thread per replica over the in-process communicator -- every replica's graph equals
+    the oracle's multi_insert -- and dann_multi_search_batch partitions the query block over the replicas."""
+    import numpy as np
+    import oracle
+    import diskann_amd as da
+    from helpers import bits, rand_vectors
+    rng = np.random.default_rng(99)
+    n, dim, Rp, maxdeg, lb = 3000, 32, 10, 12, 32
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    growth, max_batch = 0.1, 400
+    o, nb_o = _oracle_build(oracle.F32, oracle.L2, data, start, Rp, maxdeg, lb, growth, max_batch)
+    for ndev in (2, 3):
+        m = da.MultiProvider(da.F32, da.L2, dim, n, maxdeg, start, [0] * ndev)
+        m.set_elements(0, data)
+        nb, st = m.build(da.build_config(Rp, maxdeg, lb, intra_batch_candidates=da.IBC_NONE), 0, n, growth, max_batch)
+        assert nb == nb_o
+        assert st["rounds"] == nb and st["bytes_gathered"] > 0 and st["rows_rewritten"] > 0
+        for r in range(ndev):
+            assert np.array_equal(m.download_graph(r), o.adj), (ndev, r)
+        q = rand_vectors(rng, oracle.F32, 301, dim)
+        ids, d, stats = m.search(da.Knn(40, 1), q, 10)
+        oi, od, _, ost = o.search_batch(q, 40, 1, 10)
+        assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od)) and np.array_equal(stats["cmps"], ost[:, 0])
+        m.close()
+
+
+def test_rccl_communicator_preflight_on_one_gpu():
+    """RCCL itself (librccl bound at run time): unique id, a world-1 communicator on device 0, ncclAllGather of a device
+    buffer, and dann_build_sharded over it == dann_build.  What one GPU allows of the path the 8-GPU run takes."""
+    import ctypes as C
+    import numpy as np
+    import oracle
+    import diskann_amd as da
+    from diskann_amd import _ffi
+    from diskann_amd.sharding import Comm, build_sharded_native
+    from helpers import rand_vectors
+    lib = _ffi.lib()
+    uid = (C.c_char * 128)()
+    _ffi.check(lib.dann_comm_rccl_unique_id(uid), "dann_comm_rccl_unique_id")
+    h = C.c_void_p()
+    _ffi.check(lib.dann_comm_create_rccl(uid, 0, 1, 0, C.byref(h)), "dann_comm_create_rccl")
+    comm = Comm(h)
+    assert lib.dann_comm_world(h) == 1 and lib.dann_comm_rank(h) == 0
+    import torch
+    src = torch.arange(1000, dtype=torch.int32, device="cuda:0")
+    dst = torch.zeros(1000, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    _ffi.check(lib.dann_comm_all_gather_device(h, 0, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 4000),
+               "dann_comm_all_gather_device")
+    assert torch.equal(src, dst)
+    rng = np.random.default_rng(8)
+    n, dim, Rp, maxdeg, lb = 2000, 24, 8, 10, 24
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    cfg = da.build_config(Rp, maxdeg, lb, intra_batch_candidates=da.IBC_NONE)
+    a = da.Provider(da.F32, da.L2, dim, n, maxdeg, start)
+    a.set_elements(0, data)
+    nb = build_sharded_native(a, cfg, 0, n, 0.1, 256, comm)
+    b = da.Provider(da.F32, da.L2, dim, n, maxdeg, start)
+    b.set_elements(0, data)
+    assert b.build(cfg, 0, n, 0.1, 256) == nb
+    assert np.array_equal(a.download_graph(), b.download_graph())
+    comm.close()
