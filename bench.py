@@ -84,6 +84,11 @@ def parse():
     ap.add_argument("--sq8-stride", type=int, default=256,
                     help="row stride of the SQ-8 store: 256 keeps the 128 code bytes of a row in one 128-byte line (the "
                          "L2 kernel never reads the compensation); 0 = payload rounded to 16 B (144: rows straddle lines)")
+    ap.add_argument("--build-spec", default="10000000:768:64:56:128:f32",
+                    help="--only build768: 'n:dim:R:pruned:l_build:f32|f16' -- the index-build workload at the size one "
+                         "MI355X holds (config 5's row shape): data generated on the device chunk by chunk, built by "
+                         "dann_build, recall on a 1 000-query exact (f64) ground truth, a 256-query replay through the CPU "
+                         "oracle on the bytes the searches touch")
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
     ap.add_argument("--query-sets", type=int, default=4,
                     help="distinct query sets of --nq queries each; timed step i searches set i %% query_sets")
@@ -167,6 +172,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.only == "build768":
+        print(json.dumps(_strict({"build_large": build_large_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
+        return
     if args.only in ("gather", "sq8", "u8"):
         print(json.dumps(_strict({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
@@ -616,10 +624,30 @@ def main():
                 except Exception as e:
                     out[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
+        if isinstance(out.get("roofline_large"), dict) and "frac" in out["roofline_large"]:
+            # the HBM-side fraction of the same kernel: the 6.4 GB index, 25 x the Infinity Cache
+            out["roofline"]["hbm_side_frac"] = out["roofline_large"]["frac"]
+            out["roofline"]["hbm_side_workload"] = out["roofline_large"]["workload"]
         print(json.dumps(_strict(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def oracle_sample(prov, odt, metric, dim, n, R, start_rows, stored_rows_h, queries_h, L, W, k, nsample=256, **okw):
+    """`nsample` queries of a leg through the CPU oracle on the same row bytes and the same graph"""
+    import oracle
+    import diskann_amd as da
+    oix = oracle.Index(odt, metric, dim, n, R, start_rows, **okw)
+    oix.rows[:n, :oix.row_bytes] = stored_rows_h.view(np.uint8).reshape(n, -1)[:, :oix.row_bytes]
+    oix.adj[:] = prov.download_graph()
+    qh = queries_h[:nsample]
+    gi, gd, gst = prov.search(da.Knn(L, W), qh, k)
+    oi, od, oc, ost = oix.search_batch(qh, L, W, k, threads=min(16, os.cpu_count() or 1), fast=True)
+    return {"queries": int(qh.shape[0]), "ids_identical_to_gpu": bool(np.array_equal(gi, oi)),
+            "distances_cmps_hops_identical": bool(np.array_equal(gd.view(np.uint32), od.view(np.uint32)) and
+                                                  np.array_equal(gst["cmps"], ost[:, 0]) and
+                                                  np.array_equal(gst["hops"], ost[:, 1]))}
 
 
 def callers_variant(prov, qh, L, k, same_as_oracle):
@@ -713,6 +741,13 @@ def sq8_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoi
     dt = (time.perf_counter() - t0) / 10
     alg = (int(st[:, 0].sum()) * (args.dim + 4) + int(st[:, 1].sum()) * (args.max_degree + 1) * 4
            + args.nq * chosen * args.dim * 4)
+    import oracle
+    try:
+        res["oracle_sample"] = oracle_sample(prov, oracle.SQ8, oracle.L2, args.dim, args.n, args.max_degree,
+                                             codes[medoid:medoid + 1], codes, qcodes, chosen, W, k, sq_scale=scale,
+                                             sq_shift_norm_sq=snorm)
+    except Exception as e:  # noqa: BLE001
+        res["oracle_sample"] = {"error": str(e)[:200]}
     res["with_rerank"] = {"L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4), "qps": args.nq / dt,
                           "mean_cmps": float(st[:, 0].mean()), "ms_per_100k_queries": dt * 1e3 * 1e5 / args.nq,
                           "algorithmic_bytes_per_query": alg / args.nq}
@@ -771,7 +806,13 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     alg = (int(st[:, 0].sum()) * nch + int(st[:, 1].sum()) * (args.max_degree + 1) * 4 + args.nq * chosen * dim * 4)
-    return {"chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
+    import oracle
+    try:
+        osample = oracle_sample(prov, oracle.PQ, oracle.L2, dim, args.n, args.max_degree, codes_h[medoid:medoid + 1], codes_h,
+                                queries.cpu().numpy(), chosen, W, k, pq_pivots=pivots_h, pq_offsets=bounds)
+    except Exception as e:  # noqa: BLE001
+        osample = {"error": str(e)[:200]}
+    return {"oracle_sample": osample, "chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
             "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()),
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
             "train_seconds_kmeanspp_plus_10_lloyds_131072_rows": round(t_train, 3),
@@ -941,6 +982,170 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     return res
 
 
+class _DevView:
+    """a device buffer of the library as a torch tensor (zero copy): __cuda_array_interface__ over the raw address"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), True), "version": 2}
+
+
+def build_large_variant(args, torch, da, lib, _ffi, dev, local):
+    """BASELINE config 5's per-GPU shape on ONE MI355X: n x dim rows generated on the device (the benchmark mixture at the
+    headline's per-blob density), Vamana build by dann_build (insert searches + RobustPrune on the matrix cores), search
+    evaluation against an exact ground truth, and a replay of a query sample through the CPU oracle."""
+    import oracle
+    f = args.build_spec.split(":")
+    n, dim, R, pruned, lb = (int(x) for x in f[:5])
+    f16 = len(f) > 5 and f[5] == "f16"
+    esz, tname, dt, odt = (2, "f16", da.F16, oracle.F16) if f16 else (4, "f32", da.F32, oracle.F32)
+    nblobs = max(256, n // 3906)
+    chunk = 1 << 20
+    k, nq, ngt = 10, min(args.nq, 20000), 1000
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(0xD15CA11)
+    centers = torch.rand((nblobs, dim), generator=g0, device=dev, dtype=torch.float32)
+    basis = torch.randn((16, dim), generator=g0, device=dev, dtype=torch.float32) / 4.0
+
+    def draw(m, gen):
+        lab = torch.randint(0, nblobs, (m,), generator=gen, device=dev)
+        z = torch.randn((m, 16), generator=gen, device=dev, dtype=torch.float32)
+        noise = torch.randn((m, dim), generator=gen, device=dev, dtype=torch.float32)
+        return centers[lab] + 0.25 * (z @ basis) + 0.02 * noise
+
+    def chunks():  # deterministic: chunk c depends on its own seed only, so every pass sees the same rows
+        for c, s0 in enumerate(range(0, n, chunk)):
+            g = torch.Generator(device=dev)
+            g.manual_seed(0xC0FFEE00 + c)
+            yield s0, draw(min(chunk, n - s0), g)
+    t0 = time.time()
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(0xD15CA12)
+    queries = draw(nq, gq)
+    # pass 1: f64 mean; pass 2: medoid (diskann-utils/src/sampling/medoid.rs:15-48)
+    acc = torch.zeros(dim, dtype=torch.float64, device=dev)
+    for s0, b in chunks():
+        acc += b.double().sum(0)
+    mean = (acc / n).float()
+    best = (float("inf"), -1, None)
+    for s0, b in chunks():
+        d = ((b - mean[None, :]) ** 2).sum(1)
+        i = int(torch.argmin(d).item())
+        if float(d[i]) < best[0]:
+            best = (float(d[i]), s0 + i, b[i:i + 1].clone())
+    medoid = best[1]
+    start = (best[2].half() if f16 else best[2]).cpu().numpy()
+    prov = da.Provider(dt, da.L2, dim, n, R, start, device=local)
+    # pass 3: rows into the index (device to device) + the exact ground truth of the first `ngt` queries in the same pass
+    qd = queries[:ngt].double()
+    best_d = torch.full((ngt, k), float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.zeros((ngt, k), dtype=torch.int64, device=dev)
+    for s0, b in chunks():
+        rows = b.half().contiguous() if f16 else b.contiguous()
+        torch.cuda.synchronize()
+        prov.set_elements_device(s0, rows.data_ptr(), rows.shape[0])
+        bn = (b * b).sum(1)
+        d = bn[None, :] - 2.0 * (queries[:ngt] @ b.T)
+        cand = torch.topk(d, 4 * k, dim=1, largest=False).indices
+        del d
+        diff = b[cand].double() - qd[:, None, :]
+        dd = (diff * diff).sum(-1)
+        alld = torch.cat([best_d, dd], 1)
+        alli = torch.cat([best_i, cand + s0], 1)
+        o = torch.argsort(alld, dim=1)[:, :k]
+        best_d, best_i = torch.gather(alld, 1, o), torch.gather(alli, 1, o)
+        del rows, b
+    gt = best_i.cpu().numpy()
+    torch.cuda.empty_cache()
+    t_data = time.time() - t0
+    log(f"[build768] {n}x{dim} {tname}: data + upload + ground truth {t_data:.1f}s, medoid {medoid}")
+    # ---- the build ---------------------------------------------------------------------------------------------------
+    cfg = da.build_config(pruned, R, lb, intra_batch_candidates=da.IBC_NONE)
+    max_batch = 16384
+    t1 = time.time()
+    nb = prov.build(cfg, 0, n, args.growth, max_batch)
+    torch.cuda.synchronize()
+    t_build = time.time() - t1
+    c = [int(x) for x in prov.build_counters()]
+    row_b, adj_b = dim * esz, (R + 1) * 4
+    log(f"[build768] build {t_build:.1f}s ({n / t_build:,.0f} pts/s), {nb} batches")
+    res = {
+        "workload": f"dann_build of a {n}x{dim} {tname} index (Vamana R={R}, pruned {pruned}, l_build={lb}, alpha 1.2, growth "
+                    f"{args.growth}, max_batch {max_batch}) on one GPU: {n * row_b / 1e9:.1f} GB rows + {(n + 1) * adj_b / 1e9:.1f} GB "
+                    f"adjacency resident in HBM; data: the benchmark mixture, {nblobs} blobs, generated on the device",
+        "build_seconds": t_build, "points_per_second": n / t_build, "batches": nb, "data_seconds": t_data,
+        "insert_search": {"cmps": c[2], "hops": c[3], "algorithmic_bytes": c[2] * row_b + c[3] * adj_b},
+        "prune": {"row_kernel_pair_distances": c[4], "list_distances": c[5], "gram_rows": c[6], "gram_entries": c[7],
+                  "mfma_flop": 2 * c[7] * dim, "pairs_asked_by_gram_sweeps": c[8], "of_those_exact_rechecks": c[9],
+                  "backedge_prunes_mfma": c[0], "backedge_prunes_too_long_for_gram": c[1],
+                  "mfma_share_of_all_prune_pair_distances": (c[8] - c[9]) / max(1, c[8] - c[9] + c[4])},
+    }
+    # ---- search evaluation ---------------------------------------------------------------------------------------------
+    qs = queries.half().contiguous() if f16 else queries
+    sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]
+    L, rec, st, run, hist = _sweep(torch, lib, _ffi, prov, qs, nq, k, 1, gt, ngt, sweep, args.target_recall)
+    reached = L is not None
+    L = L or sweep[-1]
+    run(L)
+    prov.kernel_time_reset()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(5):
+        run(L)
+    torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t2) / 5
+    ms, nl = prov.kernel_time(0)
+    alg = int(st[:, 0].sum()) * row_b + int(st[:, 1].sum()) * adj_b
+    res["search"] = {"recall_at_10": round(rec, 4), "recall_target_reached": reached, "recall_by_L": hist,
+                     "ground_truth": f"exact (shortlist of 40 per 2^20-row chunk re-ranked in f64), first {ngt} queries",
+                     "L": L, "queries_per_launch": nq, "qps": nq / dt_s, "mean_cmps": float(st[:, 0].mean()),
+                     "mean_hops": float(st[:, 1].mean()), "avg_kernel_ms": ms / max(nl, 1),
+                     "algorithmic_GBps": alg / (ms / max(nl, 1) * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": alg / (ms / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # ---- parity at this scale: a query sample replayed through the CPU oracle on the bytes the searches touch.
+    # The GPU's VisitedSearchRecord names every node a search expanded; those nodes' adjacency rows name every row it
+    # compared.  The oracle runs the reference algorithm on exactly that sub-graph (ids renumbered, adjacency of
+    # non-expanded nodes empty): if it returns the GPU's ids, distances, cmps and hops it never left the sub-graph,
+    # i.e. its run equals a run on the whole index.
+    ms_n = 256
+    qh = qs[:ms_n].cpu().numpy()
+    gi, gd, gst = prov.search(da.Knn(L, 1), qh, k)
+    rid, _, rn, _ = prov.search_record_queries(qh, L)
+    p_rows, p_adj = prov.device_pointers()
+    adj_t = torch.as_tensor(_DevView(p_adj, (n + 1, R + 1), "<i4"), device=dev)
+    stride_e = prov.row_stride // esz
+    rows_t = torch.as_tensor(_DevView(p_rows, (n + 1, stride_e), "<f2" if f16 else "<f4"), device=dev)
+    expanded = np.unique(np.concatenate([rid[i, :rn[i]] for i in range(ms_n)] + [np.array([n], np.uint32)]))
+    ex_t = torch.as_tensor(expanded.astype(np.int64), device=dev)
+    ex_adj = adj_t[ex_t].cpu().numpy().view(np.uint32)                       # [len, ids...] of every expanded node
+    lens = np.minimum(ex_adj[:, 0], R)
+    nbrs = np.unique(np.concatenate([ex_adj[i, 1:1 + lens[i]] for i in range(len(expanded))]))
+    touched = np.unique(np.concatenate([expanded, nbrs]))                    # sorted global ids; the start point n is last
+    assert touched[-1] == n
+    remap = {int(g): i for i, g in enumerate(touched[:-1])}
+    m = len(touched) - 1
+    sub_rows = rows_t[torch.as_tensor(touched.astype(np.int64), device=dev)][:, :dim].contiguous().cpu().numpy()
+    oix = oracle.Index(odt, oracle.L2, dim, m, R, sub_rows[-1:])
+    oix.set_rows(0, sub_rows[:-1])
+    remap[n] = m  # the start point keeps the last slot
+    lut = np.full(n + 1, 0xFFFFFFFF, np.uint32)
+    lut[touched[:-1]] = np.arange(m, dtype=np.uint32)
+    lut[n] = m
+    for i, gnode in enumerate(expanded):
+        row = ex_adj[i, 1:1 + lens[i]]
+        oix.adj[int(lut[gnode]), 0] = lens[i]
+        oix.adj[int(lut[gnode]), 1:1 + lens[i]] = lut[row]
+    oi, od, oc, ost = oix.search_batch(qh, L, 1, k, threads=min(16, os.cpu_count() or 1), fast=True)
+    back = np.concatenate([touched[:-1], np.array([n, 0xFFFFFFFF], np.uint32)]).astype(np.uint32)
+    oi_g = np.where(oi == 0xFFFFFFFF, 0xFFFFFFFF, back[np.minimum(oi, m + 1)])
+    res["oracle_replay"] = {"queries": ms_n, "rows_touched": int(m), "nodes_expanded": int(len(expanded)),
+                            "ids_identical_to_gpu": bool(np.array_equal(gi, oi_g)),
+                            "distances_cmps_hops_identical": bool(
+                                np.array_equal(gd.view(np.uint32), od.view(np.uint32)) and
+                                np.array_equal(gst["cmps"], ost[:, 0]) and np.array_equal(gst["hops"], ost[:, 1]))}
+    prov.close()
+    return res
+
+
 def only_variant(args, torch, da, lib, _ffi, dev, local):
     """One secondary workload per process (so that a rocprofv3 pass sees only its kernel at full weight)."""
     k, W = 10, args.beam_width
@@ -1011,7 +1216,15 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
     # recall of the quantised search alone against the exact f32 ground truth (no rerank), for orientation
     gt = ground_truth(torch, base, queries[:10000], k)
     rec = recall_at_k(d_ids[:10000].cpu().numpy().view(np.uint32), gt, k)
-    return {"kernel": "beam_search_kernel", "rows": args.only, "row_bytes": row_bytes, "L": L, "nq": args.nq,
+    import oracle
+    okw = dict(sq_scale=scale, sq_shift_norm_sq=snorm) if args.only == "sq8" else {}
+    try:
+        osample = oracle_sample(prov, oracle.SQ8 if args.only == "sq8" else oracle.U8, oracle.L2, args.dim, args.n,
+                                args.max_degree, rows[medoid:medoid + 1], rows, qrows, L, W, k, **okw)
+    except Exception as e:  # noqa: BLE001
+        osample = {"error": str(e)[:200]}
+    return {"oracle_sample": osample,
+            "kernel": "beam_search_kernel", "rows": args.only, "row_bytes": row_bytes, "L": L, "nq": args.nq,
             "recall_at_10_vs_exact_f32_no_rerank": round(rec, 4), "mean_cmps": float(st[:, 0].mean()),
             "mean_hops": float(st[:, 1].mean()), "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": ms / nl,
             "achieved_GBps": alg / (ms / nl * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms / nl * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -79,6 +79,9 @@ SYMBOLS = {
     "dann_set_element": (_i32, [_vp, _u32, _vp, _u64]),
     "dann_set_elements": (_i32, [_vp, _u32, _u32, _vp, _u64]),
     "dann_get_element": (_i32, [_vp, _u32, _vp, _u64]),
+    "dann_set_elements_device": (_i32, [_vp, _u32, _u32, _vp, _u64]),
+    "dann_index_device_pointers": (_i32, [_vp, _P(_vp), _P(_vp)]),
+    "dann_search_record_queries": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),
     "dann_upload_store": (_i32, [_vp, _vp, _u64, _u32]),
     "dann_set_tags": (_i32, [_vp, _u32, _u32, _vp]),
     "dann_get_tags": (_i32, [_vp, _u32, _u32, _vp]),

@@ -372,6 +372,37 @@ int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, cons
     return DANN_OK;
 } DANN_CATCH_ALL
 
+int32_t dann_set_elements_device(dann_index* idx, uint32_t first_slot, uint32_t n, const void* d_rows, uint64_t src_stride) try {
+    CHECK_IDX(idx);
+    if (n == 0) return DANN_OK;
+    if (!d_rows) return DANN_EINVAL;
+    if (src_stride < idx->layer_bytes) {
+        set_error("source stride %llu is shorter than the layer's %u bytes", (unsigned long long)src_stride, idx->layer_bytes);
+        return DANN_ELENGTH;
+    }
+    if ((uint64_t)first_slot + n > idx->cfg.capacity) {
+        set_error("slot range [%u, %llu) exceeds capacity %u", first_slot, (unsigned long long)first_slot + n,
+                  idx->cfg.capacity);
+        return DANN_EBOUNDS;
+    }
+    DANN_HIP(hipMemcpy2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride, idx->cfg.row_stride, d_rows, src_stride,
+                              idx->layer_bytes, n, hipMemcpyDeviceToDevice, idx->main.stream));
+    if (idx->cfg.inline_tags) {  // Slot::publish (store.rs:776-782)
+        DANN_HIP(hipMemset2DAsync(idx->d_rows + (size_t)first_slot * idx->cfg.row_stride + idx->layer_bytes,
+                                  idx->cfg.row_stride, 254, 1, n, idx->main.stream));
+        std::fill(idx->h_tags.begin() + first_slot, idx->h_tags.begin() + first_slot + n, (uint8_t)254);
+    }
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_index_device_pointers(const dann_index* idx, const void** d_rows, const uint32_t** d_adjacency) try {
+    if (!idx) return DANN_EINVAL;
+    if (d_rows) *d_rows = idx->d_rows;
+    if (d_adjacency) *d_adjacency = idx->d_adj;
+    return DANN_OK;
+} DANN_CATCH_ALL
+
 int32_t dann_set_tags(dann_index* idx, uint32_t first_slot, uint32_t n, const uint8_t* tags) try {
     CHECK_IDX(idx);
     if (n == 0) return DANN_OK;
@@ -1352,6 +1383,38 @@ int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_
     int32_t rc = search_device(idx, idx->main, nullptr, bsl.as<uint32_t>(), nq, l_value, 1, 0, nullptr, nullptr,
                                bs.as<dann_search_stats>(), bri.as<uint32_t>(), brd.as<float>(), rec_stride,
                                brn.as<uint32_t>());
+    if (rc != DANN_OK) return rc;
+    std::vector<dann_search_stats> stats(nq);
+    DANN_HIP(hipMemcpyAsync(rec_ids, bri.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(rec_dists, brd.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(rec_n, brn.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
+                            idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
+    if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
+    for (uint32_t i = 0; i < nq; ++i)
+        if (stats[i].status) {
+            set_error("query %u: visited table or record buffer exhausted", i);
+            return DANN_EOVERFLOW;
+        }
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_search_record_queries(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t* rec_ids,
+                                   float* rec_dists, uint32_t rec_stride, uint32_t* rec_n, dann_search_stats* out_stats) try {
+    CHECK_IDX(idx);
+    if (nq == 0) return DANN_OK;
+    if (!queries || !rec_ids || !rec_dists || !rec_n || rec_stride == 0) return DANN_EINVAL;
+    const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
+    DevBuf bq, bri, brd, brn, bs;
+    DANN_HIP(bq.alloc((size_t)nq * qb + 16));
+    DANN_HIP(bri.alloc((size_t)nq * rec_stride * 4));
+    DANN_HIP(brd.alloc((size_t)nq * rec_stride * 4));
+    DANN_HIP(brn.alloc((size_t)nq * 4));
+    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->main.stream));
+    int32_t rc = search_device(idx, idx->main, bq.p, nullptr, nq, l_value, 1, 0, nullptr, nullptr, bs.as<dann_search_stats>(),
+                               bri.as<uint32_t>(), brd.as<float>(), rec_stride, brn.as<uint32_t>());
     if (rc != DANN_OK) return rc;
     std::vector<dann_search_stats> stats(nq);
     DANN_HIP(hipMemcpyAsync(rec_ids, bri.p, (size_t)nq * rec_stride * 4, hipMemcpyDeviceToHost, idx->main.stream));

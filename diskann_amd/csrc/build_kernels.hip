@@ -616,6 +616,7 @@ struct GramCtx {
     float escale;        // 1.0; tests widen the error interval (DANN_GRAM_ESCALE) to drive every decision through the exact path
     float c1, c2;        // error interval E = c1 (|x|^2 + |y|^2) + c2 |d'| of this Gram's arithmetic
     bool count_rows;     // add this list to the Gram row / flop counters (the tiles kernel counts its own)
+    bool prefetch;       // g lives in global memory: touch the next candidates' rows ahead of their look-ups
 };
 
 // All 4 waves of the workgroup: G[i][j] = <row ids[i], row ids[j]> for i < nrows, j < ncols (ncols <= nrows; the square
@@ -864,9 +865,25 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
         }
         return b;
     };
+    // Gram in global memory (three-kernel pool prune): every look-up of a candidate's row is a dependent round trip to
+    // L2 / the Infinity Cache / HBM, and the sweep is a chain of them.  The rows of the next two candidates are touched
+    // (one dword per 128-byte line of the row's <= 96 columns) while the current one is examined: pure prefetch into a
+    // register nothing ever reads, never waited for (the loop's own loads drain the in-order queue behind it).
+    uint32_t gpf = 0;
+    auto touch_row = [&](uint32_t r) {
+        if (!gc.prefetch || r >= gc.nrows) return;
+        uint32_t col = lane < 3u ? lane * 32u : 0u;  // unconditional, clamped: no exec-mask block around the request
+        col = col < gc.ncols ? col : 0u;
+        const float* pr = gc.g + (size_t)r * gc.ld + col;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(gpf) : "v"(pr));
+    };
     if (N > 0) {
         while (found < degree) {
+            touch_row(0);
+            touch_row(1);
             for (uint32_t i = 0; i < N && found < degree; ++i) {
+                asm volatile("" ::"v"(gpf));
+                touch_row(i + 2);
                 const float o = occ[i];
                 uint32_t l = last[i];
                 if (o == kMax) continue;                      // selected or excluded
@@ -906,6 +923,10 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
             const float next = cur_alpha * inc;
             cur_alpha = next < alpha ? next : alpha;
         }
+    }
+    if (gc.prefetch) {  // no prefetch load may still be in flight when its landing register is released
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(gpf));
     }
     wave_sync();
     uint32_t nout = found;
@@ -1025,7 +1046,7 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
     if (mode == 1) {
         const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
         sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, src, N, smem, L, false, arow,
-                                             GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale, kGramC1, ga.c2, true});
+                                             GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale, kGramC1, ga.c2, true, false});
     } else {
         prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
     }
@@ -1361,7 +1382,7 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, a.locs[item], N, smem, L, a.force_saturate != 0,
                                          a.out + (uint64_t)wi * a.out_stride,
                                          GramCtx{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
-                                                 nr, nc, true, sa.escale, sa.c1, sa.c2, false});
+                                                 nr, nc, true, sa.escale, sa.c1, sa.c2, false, true});
 }
 
 __global__ __launch_bounds__(256) void gram_debug_kernel(IndexView ix, uint32_t cnt, float* out) {

@@ -426,6 +426,30 @@ class Provider:
     def set_visited_bits(self, bits):
         check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")
 
+    def set_elements_device(self, first_slot, device_ptr, n, src_stride=0):
+        """n rows from device memory on the index's device (device to device; src_stride 0 = packed rows)"""
+        check(_ffi.lib().dann_set_elements_device(self._h, int(first_slot), int(n), C.c_void_p(int(device_ptr)),
+                                                  int(src_stride) or self.layer_bytes), "dann_set_elements_device")
+
+    def device_pointers(self):
+        """(rows, adjacency) device addresses of the index's buffers (zero-copy interop; read-only)"""
+        r, a = C.c_void_p(), C.c_void_p()
+        check(_ffi.lib().dann_index_device_pointers(self._h, C.byref(r), C.byref(a)), "dann_index_device_pointers")
+        return r.value, a.value
+
+    def search_record_queries(self, queries, l_value, rec_stride=None):
+        """VisitedSearchRecord of a Knn search (beam 1) per external query: (ids[nq, stride], dists, n[nq], stats)"""
+        q = np.ascontiguousarray(queries, dtype=self.query_dtype).reshape(-1, self.query_elems)
+        nq = q.shape[0]
+        stride = int(rec_stride or 4 * (l_value + self.num_start_points) + 64)
+        rid = np.empty((nq, stride), np.uint32)
+        rd = np.empty((nq, stride), np.float32)
+        rn = np.zeros(nq, np.uint32)
+        stats = np.zeros(nq, STATS_DTYPE)
+        check(_ffi.lib().dann_search_record_queries(self._h, _p(q), nq, int(l_value), _p(rid), _p(rd), stride, _p(rn),
+                                                    _p(stats)), "dann_search_record_queries")
+        return rid, rd, rn, stats
+
     def set_max_concurrency(self, n):
         """Queries in flight per search call (0 = all): n persistent wavefronts share the call's queries."""
         check(_ffi.lib().dann_set_max_concurrency(self._h, n), "dann_set_max_concurrency")

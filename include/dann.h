@@ -141,6 +141,13 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out);
 int32_t dann_set_element(dann_index* idx, uint32_t slot, const void* bytes, uint64_t len);
 int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len);
 int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint64_t len);
+/* the same from DEVICE memory on the index's device: n rows, `src_stride` bytes apart (>= layer bytes), copied device to
+ * device -- a data set that is produced or already resident on the GPU never crosses PCIe */
+int32_t dann_set_elements_device(dann_index* idx, uint32_t first_slot, uint32_t n, const void* d_rows, uint64_t src_stride);
+/* read-only views of the index's device buffers for zero-copy interop (rows: (capacity + start points) x row_stride bytes;
+ * adjacency: the Neighbors layout, (capacity + start points) x (max_degree + 1) u32).  Valid until the index is
+ * destroyed; contents change under mutations. */
+int32_t dann_index_device_pointers(const dann_index* idx, const void** d_rows, const uint32_t** d_adjacency);
 /* upload a whole diskann-inmem Store buffer verbatim (rows at `stride`; with dann_config::inline_tags the tag
  * byte after each payload is uploaded too and decides readability, otherwise tag bytes are ignored) */
 int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows);
@@ -267,6 +274,11 @@ int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_
 int32_t dann_search_record_batch(dann_index* idx, const uint32_t* slots, uint32_t nq, uint32_t l_value,
                                  uint32_t* rec_ids, float* rec_dists, uint32_t rec_stride, uint32_t* rec_n,
                                  dann_search_stats* out_stats);
+
+/* the same for external queries (host pointer, layer bytes each): the VisitedSearchRecord of an ordinary Knn search
+ * with beam width 1 -- every node the search expanded, in expansion order.  Diagnostics / replay checks. */
+int32_t dann_search_record_queries(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t* rec_ids,
+                                   float* rec_dists, uint32_t rec_stride, uint32_t* rec_n, dann_search_stats* out_stats);
 
 /* ---- build ------------------------------------------------------------------------ */
 /* occlude_list / robust_prune over caller pools (index.rs:2565-2650, prune.rs:106-259):
