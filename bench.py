@@ -986,7 +986,7 @@ class _DevView:
     """a device buffer of the library as a torch tensor (zero copy): __cuda_array_interface__ over the raw address"""
 
     def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 def build_large_variant(args, torch, da, lib, _ffi, dev, local):

@@ -574,32 +574,29 @@ __global__ __launch_bounds__(kWave) void backedge_kernel(BackArgs a) {
 
 
 // ======================================================================================================
-// MFMA path (f32 rows): pair similarities of one candidate list as a Gram matrix on the matrix cores.
+// MFMA path (f32 / f16 rows): pair similarities of one candidate list as a Gram matrix on the matrix cores.
 //
 // prune::robust_prune asks for d(c_i, c_j) between a candidate and the candidates already selected
-// (prune.rs:196-232, `compute_distance`).  For a back-edge prune nearly every candidate ends up selected, so
-// nearly all pairs of the list are asked for; instead of evaluating them one dependent row pair at a time,
-// the whole list's Gram matrix G = C C^T is computed with v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, restarted
-// every 32 elements and summed in f64) and kept in LDS.  From G the sweep derives an *approximation* of every
-// pair distance together with a rigorous bound of its deviation from the reference's own f32 value:
+// (prune.rs:196-232, `compute_distance`) -- for a back-edge prune nearly every pair of the list, for the pool prune of
+// an inserted point ~2 200 pairs among the first ~140 sorted candidates.  Instead of evaluating them one dependent row
+// pair at a time, the lower triangle of the list's Gram matrix G = C C^T is computed with v_mfma_f32_32x32x2_f32
+// (gram_tiles_kernel) and the sweep derives from it an *approximation* of every pair distance together with a rigorous
+// bound of its deviation from the reference's own f32 value:
 //     L2:  d' = |x|^2 + |y|^2 - 2<x,y>,   IP: d' = -<x,y>,   CosineNormalized: d' = 1 - <x,y>
-//     |d' - d_ref| <= E = kGramC1 * (|x|^2 + |y|^2) + kGramC2 * |d'|
-// (32-term f32 chains: gamma_32 = 1.9e-6 per unit of sum|x_e y_e| <= (|x|^2+|y|^2)/2; f64 block sum; one f32
-// rounding of G; three f32 operations for d'; the reference's own chains of dim/32 terms + tree: < 2e-6 * d.)
+//     |d' - d_ref| <= E = c1 * (|x|^2 + |y|^2) + c2 * |d'|
 // Every decision of the sweep is a comparison of d_ref with a threshold; where the interval [d' - E, d' + E]
 // does not decide it, the pair is re-evaluated with the bit-exact row kernel.  The adjacency lists are therefore
 // identical to the lazy path's (and the oracle's) by construction; tests/test_gpu_build.py checks it.
 // ======================================================================================================
-// Two Gram arithmetics exist, each with its own C1 (relative to |x|^2 + |y|^2):
-//   blocked (backedge_gram_kernel, gram_mfma_f32): chains of 32 terms summed in f64 -> 3 gamma_32 = 6e-6;
-//   chained (gram_tiles_kernel): one f32 FMA chain over the whole row, K = dim rounded up to 32 terms:
+// The Gram arithmetic (gram_tiles_kernel): one f32 FMA chain over the whole row per entry, K = dim rounded up to 32 terms:
 //       |G_ij - <x,y>| <= gamma_K sum|x_e y_e| <= K u (|x|^2 + |y|^2) / 2, u = 2^-24;  d' = (|x|^2 + |y|^2) - 2 G_ij
-//       with the norms accumulated in f64 -> (K + 4) u (|x|^2 + |y|^2) covers G, the norms' rounding and the two f32
-//       operations on terms of that size (5 % slack on top).
-// C2 (relative to |d'|) covers the final subtraction and the reference's own f32 rounding, which grows with the row
+//       with the norms accumulated in f64 -> c1 = (K + 4) u (+ 5 % slack) covers G, the norms' rounding and the two f32
+//       operations on terms of that size.
+// c2 (relative to |d'|) covers the final subtraction and the reference's own f32 rounding, which grows with the row
 // length: its L2 / IP kernels run dim / (8 NACC) terms per chain plus the combine and sum_tree adds and round x - y
 // before squaring -> (dim / 8 + 16) u bounds every row type and strategy (never below the 3e-6 of the 128-d analysis).
-constexpr float kGramC1 = 6.0e-6f, kGramC2 = 3.0e-6f;
+// tests/test_gram_interval.py evaluates both sides on the CPU (pairs built to cancel) and checks the bound.
+constexpr float kGramC2 = 3.0e-6f;
 constexpr float kUnitRoundoff = 5.9604645e-8f;  // 2^-24
 inline float gram_c2_for_dim(uint32_t dim) {
     const float c = ((float)(dim / 8u) + 16.0f) * kUnitRoundoff;
@@ -618,117 +615,6 @@ struct GramCtx {
     bool count_rows;     // add this list to the Gram row / flop counters (the tiles kernel counts its own)
     bool prefetch;       // g lives in global memory: touch the next candidates' rows ahead of their look-ups
 };
-
-// All 4 waves of the workgroup: G[i][j] = <row ids[i], row ids[j]> for i < nrows, j < ncols (ncols <= nrows; the square
-// part uses the symmetry), and nrm[i] = |row ids[i]|^2.  K-slabs of 32 elements go through LDS (row stride 33 floats:
-// conflict-free operand reads); the next slab's global loads are issued before the current slab's MFMAs.
-constexpr int kGramMaxTiles = 3;   // 32x32 tiles per wave: 10 symmetric tiles of a 128 x 128 block over 4 waves
-constexpr int kGramMaxPasses = 4;  // 32-row fill passes: nrows <= 128
-__device__ void gram_mfma_f32(const IndexView& ix, const uint32_t* ids, uint32_t nrows, uint32_t ncols, float* g, uint32_t ld,
-                              float* nrm, float* slab) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t TR = (nrows + 31u) >> 5, TC = (ncols + 31u) >> 5;
-    f32x16 acc[kGramMaxTiles];
-    double tot[kGramMaxTiles][16];
-    uint32_t trb[kGramMaxTiles], tcb[kGramMaxTiles];
-    int nt = 0;
-    {
-        uint32_t m = 0;
-        for (uint32_t rb = 0; rb < TR; ++rb)
-            for (uint32_t cb = 0; cb <= rb && cb < TC; ++cb, ++m)
-                if ((m & 3u) == wave && nt < kGramMaxTiles) {
-                    trb[nt] = rb;
-                    tcb[nt] = cb;
-                    ++nt;
-                }
-    }
-#pragma unroll
-    for (int t = 0; t < kGramMaxTiles; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tot[t][r] = 0.0;
-    const uint32_t dim = ix.dim;
-    const uint32_t lr = tid >> 3, c4 = (tid & 7u) << 2;  // slab fill: 8 threads x 16 bytes per row, 32 rows per pass
-    const float* rowp[kGramMaxPasses];
-    double nsq[kGramMaxPasses];
-#pragma unroll
-    for (int pass = 0; pass < kGramMaxPasses; ++pass) {
-        const uint32_t r = ((uint32_t)pass << 5) + lr;
-        rowp[pass] = (pass < (int)TR && r < nrows && ids[r] < ix.nslots)
-                         ? reinterpret_cast<const float*>(ix.rows + (uint64_t)ids[r] * ix.row_stride)
-                         : nullptr;  // rows of ids the sweep excludes anyway read as zero
-        nsq[pass] = 0.0;
-    }
-    float4 nxt[kGramMaxPasses];
-    auto fetch = [&](uint32_t k0) {
-#pragma unroll
-        for (int pass = 0; pass < kGramMaxPasses; ++pass) {
-            float4 q = {0.f, 0.f, 0.f, 0.f};
-            const uint32_t k = k0 + c4;
-            if (rowp[pass] && k < dim) {
-                if (k + 3u < dim) {
-                    q = *reinterpret_cast<const float4*>(rowp[pass] + k);
-                } else {
-                    q.x = rowp[pass][k];
-                    if (k + 1u < dim) q.y = rowp[pass][k + 1u];
-                    if (k + 2u < dim) q.z = rowp[pass][k + 2u];
-                }
-            }
-            nxt[pass] = q;
-        }
-    };
-    fetch(0);
-    for (uint32_t k0 = 0; k0 < dim; k0 += 32u) {
-#pragma unroll
-        for (int pass = 0; pass < kGramMaxPasses; ++pass) {
-            if (pass < (int)TR) {
-                const float4 q = nxt[pass];
-                float* dst = slab + (((uint32_t)pass << 5) + lr) * 33u + c4;
-                dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
-                nsq[pass] += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
-            }
-        }
-        __syncthreads();
-        if (k0 + 32u < dim) fetch(k0 + 32u);  // in flight while the matrix cores work on this slab
-#pragma unroll
-        for (int t = 0; t < kGramMaxTiles; ++t) {
-            if (t < nt) {
-                const float* pa = slab + ((trb[t] << 5) + (lane & 31u)) * 33u + (lane >> 5);
-                const float* pb = slab + ((tcb[t] << 5) + (lane & 31u)) * 33u + (lane >> 5);
-                f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) c = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk], pb[2 * kk], c, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[t][r] += (double)c[r];
-                acc[t] = c;
-            }
-        }
-        __syncthreads();
-    }
-    (void)acc;
-#pragma unroll
-    for (int t = 0; t < kGramMaxTiles; ++t) {
-        if (t < nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t i = (trb[t] << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                const uint32_t j = (tcb[t] << 5) + (lane & 31u);
-                const float v = (float)tot[t][r];
-                g[i * ld + j] = v;             // i < 32 * TR, j < 32 * TC: inside the LDS block
-                if (trb[t] < TC) g[j * ld + i] = v;
-            }
-        }
-    }
-    // squared norms: the 8 threads of a row hold f64 partial sums (error far below the Gram's bound)
-#pragma unroll
-    for (int pass = 0; pass < kGramMaxPasses; ++pass) {
-        double v = nsq[pass];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        const uint32_t r = ((uint32_t)pass << 5) + lr;
-        if (pass < (int)TR && (tid & 7u) == 0 && r < nrows) nrm[r] = (float)v;
-    }
-}
 
 // prune_sorted_pool with the pair distances taken from the Gram matrix (exact re-check where the error interval
 // does not decide).  Single wave (lanes 0..63 of the workgroup); the other waves have exited.
@@ -958,107 +844,212 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     }
 }
 
-// back-edges, one 4-wave workgroup per distinct target: list build (wave 0) -> Gram on the matrix cores (4 waves)
-// -> sort + sweep (wave 0).  Lists longer than `pg` rows take the lazy path inside the same kernel.
-struct BackGramArgs {
-    BackArgs b;
-    uint32_t pg;       // Gram rows available in LDS (multiple of 32, <= 128)
-    float escale;      // error-interval scale (1.0)
-    float c2;          // gram_c2_for_dim(dim)
-    uint32_t* stats;   // optional: [0] MFMA prunes [1] lazy prunes (list too long)
-};
-
-template <int OP, bool NORM>
-__global__ __launch_bounds__(256) void backedge_gram_kernel(BackGramArgs ga) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int DT = DT_F32;
-    const BackArgs& a = ga.b;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t seg = a.work ? a.work[blockIdx.x] : blockIdx.x;
-    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
-    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
-    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
-    const uint32_t gld = ga.pg + 1u;
-    float* gram = reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u));
-    float* slab = gram + ga.pg * gld;
-    float* gnrm = slab + ga.pg * 33u;
-    uint32_t* shared = reinterpret_cast<uint32_t*>(gnrm + ga.pg);  // [0] mode, [1] list length
-    const uint32_t start = a.seg_start[seg];
-    const uint32_t src = (uint32_t)(a.keys[start] >> 32);
-    uint32_t* arow = a.ix.adj + (uint64_t)src * a.ix.adj_stride;
-    if (wave == 0) {  // ---- list = adj(src) ++ unique new sources (as backedge_kernel; one wave, in-order LDS)
-        uint32_t mode = 0;  // 0 nothing left to do, 1 MFMA prune, 2 lazy prune
-        uint32_t len = arow[0];
-        len = len < a.ix.max_degree ? len : a.ix.max_degree;
-        for (uint32_t i = lane; i < len; i += kWave) pid[i] = arow[1 + i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t cnt = len;
-        bool overflow = false;
-        const uint32_t end = start + a.seg_len[start];
-        for (uint32_t k0 = start; k0 < end; k0 += kWave) {
-            const uint32_t k = k0 + lane;
-            const bool mine = k < end;
-            const uint32_t id = mine ? (uint32_t)a.keys[k] : kEmpty;
-            bool take = mine;
-            if (mine)
-                for (uint32_t e = 0; e < len; ++e) take &= (pid[e] != id);
-            const uint64_t tm = ballot64(take);
-            const uint32_t ntake = (uint32_t)__popcll(tm);
-            if (cnt + ntake > a.pcap) {
-                overflow = true;
-                break;
+// The same sweep for lists whose Gram lives in global memory, eight candidates at a time.  In the form above every
+// candidate costs a chain of dependent round trips (its queue state from LDS, then one Gram row from L2 / HBM, then the
+// decision, then the state back to LDS): ~4 000 cycles each, 2.3 ms per pool prune of ~350 candidate visits.  Here a
+// 64-candidate window of the sweep state is read once, the raw Gram rows of the next eight candidates that need a visit
+// are requested together (two coalesced requests each: columns [0, 64) and [64, 128)), and the eight visits then run from
+// registers: lane c stands for the c-th selected entry and picks G(i, sel_c) out of the row with one cross-lane read, so
+// entries selected a moment ago need no new request.  The decisions, their order and the exact re-checks are those of
+// sweep_sorted_pool_gram (same classes, same first-exceed rule); requires pruned_degree <= 64 (one lane per selected
+// entry), a Gram indexed by sorted position and at most 128 Gram columns.
+template <int DT, int OP, bool NORM>
+__device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t N,
+                                   uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out, const GramCtx gc) {
+    constexpr int B = 8;
+    using S = Scheme<DT, OP, true>;
+    constexpr int G = S::G;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
+    const float* sd = reinterpret_cast<const float*>(smem + L.sd_off);
+    float* occ = reinterpret_cast<float*>(smem + L.occ_off);
+    uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
+    float* nrml = reinterpret_cast<float*>(smem + L.keys_off);  // the sort keys are dead: the norms of the Gram rows
+    for (uint32_t i = lane; i < gc.nrows; i += kWave) nrml[i] = gc.nrm[i];
+    wave_sync();
+    const uint32_t degree = cfg.pruned_degree;
+    const bool occluding = (ix.metric == M_IP);
+    const float alpha = cfg.alpha;
+    const float inc = alpha < 1.2f ? alpha : 1.2f;
+    const float kMax = 3.402823466e+38f;
+    float cur_alpha = 1.0f;
+    uint32_t found = 0, nexact = 0, nasked = 0;
+    uint32_t my_sel = kEmpty;  // lane c < found: sorted position of the c-th selected entry
+    float my_njj = 0.0f;       // its squared norm
+    const int v = lane % G;
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    const uint32_t col_lo = lane < gc.ncols ? lane : 0u, col_hi = lane + 64u < gc.ncols ? lane + 64u : 0u;
+    while (N > 0 && found < degree) {
+        uint32_t i0 = 0;
+        while (i0 < N && found < degree) {
+            // ---- a window of 64 candidates: who needs a visit in this pass
+            const uint32_t wi = i0 + lane;
+            float wocc = kMax;
+            uint32_t wlast = 0, wsid = kEmpty;
+            if (wi < N) {
+                wocc = occ[wi];
+                wlast = last[wi];
+                wsid = sid[wi];
             }
-            if (take) pid[cnt + mbcnt(tm)] = id;
-            cnt += ntake;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t added = cnt - len;
-        if (overflow) {
-            if (lane == 0) *a.err = 1;
-        } else if (added != 0) {
-            if (cnt <= a.cfg.max_degree) {
-                const uint32_t slack = a.ix.max_degree - len;
-                const uint32_t take = added < slack ? added : slack;
-                for (uint32_t i = lane; i < take; i += kWave) arow[1 + len + i] = pid[len + i];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    arow[0] = len + take;
-                    if (a.counters) atomicAdd(&a.counters[0], 1u);
+            const bool need = wi < N && wocc != kMax && !(occluding && wocc > cur_alpha);
+            uint64_t nm = ballot64(need);
+            if (!nm) {
+                i0 += kWave;
+                continue;
+            }
+            uint32_t idx[B];
+            uint32_t nb = 0;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                if (nm) {
+                    idx[j] = i0 + (uint32_t)__builtin_ctzll(nm);
+                    nm &= nm - 1;
+                    nb = (uint32_t)j + 1u;
+                } else {
+                    idx[j] = idx[j > 0 ? j - 1 : 0];
                 }
-            } else {
-                mode = cnt <= ga.pg ? 1u : 2u;
             }
+            // ---- their Gram rows, all requests up front (clamped, unconditional)
+            float rlo[B], rhi[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const uint32_t r = idx[j] < gc.nrows ? idx[j] : 0u;
+                const float* row = gc.g + (size_t)r * gc.ld;
+                rlo[j] = row[col_lo];
+                rhi[j] = row[col_hi];
+            }
+            // ---- the visits, in order
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                if ((uint32_t)j >= nb || found >= degree) break;
+                const uint32_t i = idx[j];
+                const int wl = (int)(i - i0);
+                uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)wlast, wl);
+                const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)wsid, wl);
+                if (idi == location || idi >= ix.nslots) {  // excluded / not retrievable
+                    if (lane == 0) occ[i] = kMax;
+                    continue;
+                }
+                const bool irow = i < gc.nrows;
+                const float gii = irow ? nrml[i] : 0.0f;
+                const float di = sd[i];
+                const float thr = cur_alpha * di;  // occluding rule: d_jk < alpha * d_ik (config/mod.rs:98)
+                const uint8_t* xi = ix.rows + (uint64_t)idi * ix.row_stride;
+                // G(i, sel_c): one cross-lane read out of the raw row (every lane takes part: the source lanes must be live)
+                const uint32_t srcl = my_sel & 63u;
+                const float glo = __shfl(rlo[j], (int)srcl), ghi = __shfl(rhi[j], (int)srcl);
+                const bool have = lane < found && my_sel < i;  // the lazy scan skips selected entries that sort after i
+                int cls = 0;  // 0: certainly not, 1: certainly exceeds, 2: the error interval does not decide / not covered
+                if (have) {
+                    cls = 2;
+                    if (irow && my_sel < gc.ncols) {
+                        const float gij = (my_sel & 64u) ? ghi : glo;
+                        const float nsum = gii + my_njj;
+                        float dp;
+                        if (OP == OP_L2) dp = nsum - 2.0f * gij;
+                        else dp = NORM ? 1.0f - gij : -gij;
+                        const float e = gc.escale * (gc.c1 * nsum + gc.c2 * __builtin_fabsf(dp));
+                        const float lo = dp - e, hi = dp + e;
+                        if (occluding) {
+                            if (hi < thr) cls = 1;
+                            else if (lo >= thr) cls = 0;
+                        } else if (lo > 0.0f && di >= 0.0f) {
+                            const float rmin = di / hi, rmax = di / lo;
+                            if (rmin > cur_alpha * 1.000001f) cls = 1;
+                            else if (rmax < cur_alpha * 0.999999f) cls = 0;
+                        }
+                    }
+                }
+                const uint64_t valid = ballot64(have), m1 = ballot64(cls == 1), m2 = ballot64(cls == 2);
+                // first selected entry in sel[a..b) that makes update_occlude exceed the current alpha, or b
+                auto first_exceed = [&](uint32_t a, uint32_t b) -> uint32_t {
+                    const uint64_t below_b = b >= 64u ? ~0ull : ((1ull << b) - 1ull);
+                    const uint64_t range = below_b & ~((1ull << a) - 1ull);
+                    uint64_t tu = (m1 | m2) & range;
+                    while (tu) {
+                        const int f = __builtin_ctzll(tu);
+                        const uint64_t upto = f >= 63 ? ~0ull : ((2ull << f) - 1ull);
+                        if ((m1 >> f) & 1ull) {
+                            nasked += (uint32_t)__popcll(valid & range & upto);
+                            return (uint32_t)f;
+                        }
+                        ++nexact;  // bit-exact pair distance (every lane group evaluates the same pair)
+                        const uint32_t rpf = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, f);
+                        const uint8_t* y = ix.rows + (uint64_t)sid[rpf] * ix.row_stride;
+                        const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(xi, y, (int)ix.dim, v), xi, y,
+                                                                      ix.dim, sqp);
+                        const float dg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 0));
+                        if (update_occlude<OP>(di, dg, 0.0f, cur_alpha, occluding) > cur_alpha) {
+                            nasked += (uint32_t)__popcll(valid & range & upto);
+                            return (uint32_t)f;
+                        }
+                        tu &= tu - 1;
+                    }
+                    nasked += (uint32_t)__popcll(valid & range);
+                    return b;
+                };
+                // TriangleInequality kind: the stored maximum ratio is only ever compared with the current alpha; it is
+                // re-derived from the entries already examined (sel[0..l))
+                if (!occluding && l != 0 && first_exceed(0, l) != l) continue;
+                bool rejected = false;
+                if (l != found) {
+                    const uint32_t at = first_exceed(l, found);
+                    if (at != found) {
+                        l = at + 1;
+                        rejected = true;
+                    } else {
+                        l = found;
+                    }
+                }
+                if (lane == 0) {
+                    last[i] = (uint16_t)l;
+                    if (rejected) {
+                        if (occluding) occ[i] = cur_alpha + 0.01f;
+                    } else {
+                        occ[i] = kMax;
+                        sel[found] = i;
+                    }
+                }
+                if (!rejected) {
+                    if (lane == found) {
+                        my_sel = i;
+                        my_njj = gii;
+                    }
+                    ++found;
+                }
+            }
+            wave_sync();  // lane 0's state updates before the next window is read
+            i0 = idx[nb - 1u] + 1u;
         }
-        if (lane == 0) {
-            shared[0] = mode;
-            shared[1] = cnt;
+        if (cur_alpha == alpha) break;
+        const float next = cur_alpha * inc;
+        cur_alpha = next < alpha ? next : alpha;
+    }
+    wave_sync();
+    uint32_t nout = found;
+    if (force_saturate || (cfg.saturate_after_prune && alpha > 1.0f)) {
+        for (uint32_t i = 0; i < N && nout < degree; ++i) {
+            const uint32_t id = sid[i];
+            if (id == location) continue;
+            bool dup = false;
+            for (uint32_t n = lane; n < nout; n += kWave) dup |= (sid[sel[n]] == id);
+            if (ballot64(dup)) continue;
+            if (lane == 0) sel[nout] = i;
+            ++nout;
+            wave_sync();
         }
     }
-    __syncthreads();
-    const uint32_t mode = shared[0], cnt = shared[1];
-    if (mode == 0) return;
-    if (mode == 1) gram_mfma_f32(a.ix, pid, cnt, cnt, gram, gld, gnrm, slab);
-    __syncthreads();
-    if (wave != 0) return;  // ended waves leave the barrier count: wave 0 goes on alone
-    fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
-    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
-    __syncthreads();
-    if (mode == 1) {
-        const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
-        sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, src, N, smem, L, false, arow,
-                                             GramCtx{gram, gnrm, gld, cnt, cnt, false, ga.escale, kGramC1, ga.c2, true, false});
-    } else {
-        prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
-    }
+    wave_sync();
+    for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
     if (lane == 0) {
-        if (a.counters) atomicAdd(&a.counters[1], 1u);
-        if (ga.stats) atomicAdd(&ga.stats[mode - 1u], 1u);
+        out[0] = nout;
+        if (cfg.counters) {
+            atomicAdd(&cfg.counters[0], (unsigned long long)nexact);
+            atomicAdd(&cfg.counters[4], (unsigned long long)nasked);
+            atomicAdd(&cfg.counters[5], (unsigned long long)nexact);
+        }
     }
-}
-
-inline size_t backedge_gram_lds(uint32_t pcap, uint32_t degree, uint32_t pg) {
-    const size_t base = (pool_lds_layout(pcap, degree).total + 15u) & ~(size_t)15u;
-    return base + (size_t)pg * (pg + 1u) * 4u + (size_t)pg * 33u * 4u + (size_t)pg * 4u + 16u;
 }
 
 // ======================================================================================================
@@ -1352,6 +1343,12 @@ struct SweepArgs {
     const float* nrm;
     uint32_t ng, mg;
     float escale, c1, c2;
+    // back-edge prunes (add_edge_and_prune): the location of item i is out_loc[i] and the result goes straight into its
+    // adjacency row (nobody else reads that row during the back-edge phase); null = pool prune (p.locs, p.out)
+    const uint32_t* out_loc = nullptr;
+    uint32_t* prunes = nullptr;      // [0] += 1 per pruned list (BackArgs::counters + 1)
+    uint32_t* mfma_prunes = nullptr; // optional statistic
+    uint32_t one_by_one = 0;         // development switch (DANN_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
 };
 
 template <int DT, int OP, bool NORM>
@@ -1360,8 +1357,8 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     const PoolArgs& a = sa.p;
     const uint32_t lane = threadIdx.x, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
     const uint32_t N = sa.sn[wi];
-    if (N == 0) {  // overflow (reported by pool_sort_kernel) or an empty pool
-        if (lane == 0) a.out[(uint64_t)wi * a.out_stride] = 0;
+    if (N == 0) {  // pool prune: overflow (reported by pool_sort_kernel) or an empty pool; back-edges: nothing to prune
+        if (lane == 0 && !sa.out_loc) a.out[(uint64_t)wi * a.out_stride] = 0;
         return;
     }
     const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
@@ -1379,46 +1376,97 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     }
     wave_sync();
     const uint32_t nr = N < sa.ng ? N : sa.ng, nc = N < sa.mg ? N : sa.mg;
-    sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, a.locs[item], N, smem, L, a.force_saturate != 0,
-                                         a.out + (uint64_t)wi * a.out_stride,
-                                         GramCtx{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
-                                                 nr, nc, true, sa.escale, sa.c1, sa.c2, false, true});
+    const uint32_t location = sa.out_loc ? sa.out_loc[wi] : a.locs[item];
+    uint32_t* out = sa.out_loc ? a.ix.adj + (uint64_t)location * a.ix.adj_stride : a.out + (uint64_t)wi * a.out_stride;
+    const GramCtx gc{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
+                     nr, nc, true, sa.escale, sa.c1, sa.c2, false, true};
+    if (a.cfg.pruned_degree <= (uint32_t)kWave && sa.mg <= 128u && !sa.one_by_one)
+        sweep_gram_batched<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc);
+    else
+        sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc);
+    if (lane == 0 && sa.out_loc) {
+        if (sa.prunes) atomicAdd(sa.prunes, 1u);
+        if (sa.mfma_prunes) atomicAdd(sa.mfma_prunes, 1u);
+    }
 }
 
-__global__ __launch_bounds__(256) void gram_debug_kernel(IndexView ix, uint32_t cnt, float* out) {
+// back-edges on the matrix cores, first of three kernels (the other two are gram_tiles_kernel and pool_sweep_kernel):
+// one wave per target of the short worklist builds the list adj(target) ++ unique new sources exactly as
+// backedge_kernel does, appends when it still fits, and otherwise evaluates d(target, c) for the list, sorts it
+// (SortedNeighbors::new) and leaves the sorted (id, distance) list in global memory for the Gram and the sweep.
+struct BackListArgs {
+    BackArgs b;
+    uint32_t* sid;   // n x pcap
+    float* sd;
+    uint32_t* sn;    // n: sorted list length, 0 = nothing to prune for this item
+    uint32_t* loc;   // n: the target
+};
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void backedge_list_kernel(BackListArgs la) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t pg = (cnt + 31u) & ~31u, ld = pg + 1u;
-    uint32_t* pid = reinterpret_cast<uint32_t*>(smem);
-    float* gram = reinterpret_cast<float*>(smem + pg * 4u);
-    float* slab = gram + pg * ld;
-    float* gnrm = slab + pg * 33u;
-    for (uint32_t i = threadIdx.x; i < pg; i += blockDim.x) pid[i] = i;
-    __syncthreads();
-    gram_mfma_f32(ix, pid, cnt, cnt, gram, ld, gnrm, slab);
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < cnt * cnt; t += blockDim.x) out[t] = gram[(t / cnt) * ld + (t % cnt)];
-}
-
-int32_t launch_backedge_gram(const IndexView& ix, const BackGramArgs& ga, size_t lds, hipStream_t stream) {
-    int op;
-    bool norm;
-    if (!resolve_metric(ix.dtype, ix.metric, &op, &norm) || ix.dtype != DT_F32 || op == OP_COS) return DANN_EUNSUPPORTED;
-    auto run = [&](auto kern) -> int32_t {
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-            raised = true;
+    const BackArgs& a = la.b;
+    const uint32_t lane = threadIdx.x, wi = blockIdx.x, seg = a.work ? a.work[wi] : wi;
+    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    uint32_t* pid = reinterpret_cast<uint32_t*>(smem + L.pid_off);
+    float* pd = reinterpret_cast<float*>(smem + L.pd_off);
+    const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
+    const float* sd = reinterpret_cast<const float*>(smem + L.sd_off);
+    const uint32_t start = a.seg_start[seg];
+    const uint32_t src = (uint32_t)(a.keys[start] >> 32);
+    uint32_t* arow = a.ix.adj + (uint64_t)src * a.ix.adj_stride;
+    if (lane == 0) {
+        la.sn[wi] = 0;
+        la.loc[wi] = src;
+    }
+    uint32_t len = arow[0];
+    len = len < a.ix.max_degree ? len : a.ix.max_degree;
+    for (uint32_t i = lane; i < len; i += kWave) pid[i] = arow[1 + i];
+    wave_sync();
+    // extend_from_slice(sorted sources): unique append
+    uint32_t cnt = len;
+    const uint32_t end = start + a.seg_len[start];
+    for (uint32_t k0 = start; k0 < end; k0 += kWave) {
+        const uint32_t k = k0 + lane;
+        const bool mine = k < end;
+        const uint32_t id = mine ? (uint32_t)a.keys[k] : kEmpty;
+        bool take = mine;
+        if (mine)
+            for (uint32_t e = 0; e < len; ++e) take &= (pid[e] != id);
+        const uint64_t tm = ballot64(take);
+        const uint32_t ntake = (uint32_t)__popcll(tm);
+        if (cnt + ntake > a.pcap) {
+            if (lane == 0) *a.err = 1;
+            return;
         }
-        hipLaunchKernelGGL(kern, dim3(ga.b.nseg), dim3(256), lds, stream, ga);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "backedge_gram_kernel launch");
-        return DANN_OK;
-    };
-    if (op == OP_L2) return run(backedge_gram_kernel<OP_L2, false>);
-    if (norm) return run(backedge_gram_kernel<OP_IP, true>);
-    return run(backedge_gram_kernel<OP_IP, false>);
+        if (take) pid[cnt + mbcnt(tm)] = id;
+        cnt += ntake;
+    }
+    wave_sync();
+    const uint32_t added = cnt - len;
+    if (added == 0) return;
+    if (cnt <= a.cfg.max_degree) {  // append_vector with the provider-capacity clamp (provider.rs:795-822)
+        const uint32_t slack = a.ix.max_degree - len;
+        const uint32_t take = added < slack ? added : slack;
+        for (uint32_t i = lane; i < take; i += kWave) arow[1 + len + i] = pid[len + i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            arow[0] = len + take;
+            if (a.counters) atomicAdd(&a.counters[0], 1u);
+        }
+        return;
+    }
+    fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
+    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
+    wave_sync();
+    const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
+    uint32_t* gs = la.sid + (uint64_t)wi * a.pcap;
+    float* gd = la.sd + (uint64_t)wi * a.pcap;
+    for (uint32_t i = lane; i < N; i += kWave) {
+        gs[i] = sid[i];
+        gd[i] = sd[i];
+    }
+    if (lane == 0) la.sn[wi] = N;
 }
 
 // ---- small utility kernels -------------------------------------------------------------------
@@ -1537,6 +1585,7 @@ int32_t dispatch_float(const IndexView& ix, const Args& a, uint32_t grid, size_t
 }
 DANN_LAUNCHER(SortLauncher, pool_sort_kernel, SortArgs)
 DANN_LAUNCHER(SweepLauncher, pool_sweep_kernel, SweepArgs)
+DANN_LAUNCHER(BackListLauncher, backedge_list_kernel, BackListArgs)
 
 int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) {
     const size_t lds = (size_t)a.ng * 33u * 4u;
@@ -1552,6 +1601,11 @@ uint32_t next_pow2(uint32_t x) {
     uint32_t p = 64;
     while (p < x) p <<= 1;
     return p;
+}
+
+uint32_t sweep_one_by_one() {
+    const char* e = getenv("DANN_SWEEP_ONE_BY_ONE");
+    return e && atoi(e) != 0 ? 1u : 0u;
 }
 
 // development switch: DANN_POOL_GRAM=0 keeps the row kernel for the pool prune of large rows (A/B runs)
@@ -1628,7 +1682,7 @@ struct BuildScratch {
     DevBuf counters;  // 8 x u64, see PruneCfg::counters (accumulate until dann_build_counters_reset)
     size_t sort_tmp_bytes = 0;
     // MFMA pool prune: sorted pools, Gram blocks and norms of one batch slice (grow-only)
-    DevBuf g_sid, g_sd, g_sn, g_gram, g_nrm;
+    DevBuf g_sid, g_sd, g_sn, g_loc, g_gram, g_nrm;
     size_t g_sorted_elems = 0, g_items = 0, g_gram_elems = 0, g_nrm_elems = 0;
 };
 
@@ -1663,6 +1717,34 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
     s.batch_cap = cap;
     s.rec_stride = rec_stride;
     s.degree = degree;
+    return DANN_OK;
+}
+
+// grow-only buffers of the MFMA prunes: sorted lists, Gram blocks and norms of `items` lists
+int32_t ensure_gram_scratch(BuildScratch& s, size_t items, uint32_t pcap, uint32_t ng, uint32_t mg) {
+    const size_t sorted_elems = items * pcap, gram_elems = items * ng * mg, nrm_elems = items * ng;
+    if (s.g_sorted_elems < sorted_elems) {
+        s.g_sorted_elems = 0;
+        DANN_HIP(s.g_sid.alloc(sorted_elems * 4));
+        DANN_HIP(s.g_sd.alloc(sorted_elems * 4));
+        s.g_sorted_elems = sorted_elems;
+    }
+    if (s.g_items < items) {
+        s.g_items = 0;
+        DANN_HIP(s.g_sn.alloc(items * 4));
+        DANN_HIP(s.g_loc.alloc(items * 4));
+        s.g_items = items;
+    }
+    if (s.g_gram_elems < gram_elems) {
+        s.g_gram_elems = 0;
+        DANN_HIP(s.g_gram.alloc(gram_elems * 4));
+        s.g_gram_elems = gram_elems;
+    }
+    if (s.g_nrm_elems < nrm_elems) {
+        s.g_nrm_elems = 0;
+        DANN_HIP(s.g_nrm.alloc(nrm_elems * 4));
+        s.g_nrm_elems = nrm_elems;
+    }
     return DANN_OK;
 }
 
@@ -1753,28 +1835,8 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         uint32_t mg = ce ? (uint32_t)atoi(ce) : 96u;
         mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
         const uint32_t ng = std::max<uint32_t>(mg, std::min<uint32_t>(32u * kTileRowBlocks, (h_recmax + nex + 31u) & ~31u));
-        const size_t sorted_elems = (size_t)m * pa.pcap, gram_elems = (size_t)m * ng * mg, nrm_elems = (size_t)m * ng;
-        if (s.g_sorted_elems < sorted_elems) {
-            s.g_sorted_elems = 0;
-            DANN_HIP(s.g_sid.alloc(sorted_elems * 4));
-            DANN_HIP(s.g_sd.alloc(sorted_elems * 4));
-            s.g_sorted_elems = sorted_elems;
-        }
-        if (s.g_items < m) {
-            s.g_items = 0;
-            DANN_HIP(s.g_sn.alloc((size_t)m * 4));
-            s.g_items = m;
-        }
-        if (s.g_gram_elems < gram_elems) {
-            s.g_gram_elems = 0;
-            DANN_HIP(s.g_gram.alloc(gram_elems * 4));
-            s.g_gram_elems = gram_elems;
-        }
-        if (s.g_nrm_elems < nrm_elems) {
-            s.g_nrm_elems = 0;
-            DANN_HIP(s.g_nrm.alloc(nrm_elems * 4));
-            s.g_nrm_elems = nrm_elems;
-        }
+        rc = ensure_gram_scratch(s, m, pa.pcap, ng, mg);
+        if (rc != DANN_OK) return rc;
         SortArgs so;
         so.p = pa;
         so.sid = s.g_sid.as<uint32_t>();
@@ -1807,6 +1869,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.escale = es ? (float)atof(es) : 1.0f;
         sw.c1 = gram_c1_chained(ix.dim);
         sw.c2 = gram_c2_for_dim(ix.dim);
+        sw.one_by_one = sweep_one_by_one();
         rc = dispatch_float<SweepLauncher>(ix, sw, m, lds, st);
         if (rc != DANN_OK) return rc;
         pool_gram = true;
@@ -1930,7 +1993,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         //     is sized by the longest of them -- one hub no longer sets the occupancy of the whole batch.
         // default policy: rows of 1 KiB and more (where it is measured to win: 1 M x 768 build 3.50 -> 3.24 s) take the
         // MFMA path unless DANN_BUILD_ROW_KERNEL_ONLY is set; DANN_BUILD_MFMA_BACKEDGE forces it for any row size
-        const bool want_gram = ix.dtype == DT_F32 && ix.metric != M_COSINE &&
+        const bool want_gram = (ix.dtype == DT_F32 || ix.dtype == DT_F16) && ix.metric != M_COSINE &&
                                ((idx->build_flags & DANN_BUILD_MFMA_BACKEDGE) ||
                                 (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u));
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
@@ -1975,15 +2038,54 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
             bs.nseg = h_counts[0];
             bs.pcap = short_pcap;
             bool gram = false;
-            if (want_gram && pg > ix.max_degree && backedge_gram_lds(bs.pcap, pc.pruned_degree, pg) <= 160u * 1024u) {
-                BackGramArgs ga;
-                ga.b = bs;
-                ga.pg = pg;
-                ga.stats = meta + 8;
+            if (want_gram && pg > ix.max_degree) {
+                // three kernels: list + d(target, c) + sort; Gram tiles of the sorted list on the matrix cores; sweep
+                const uint32_t nshort = h_counts[0], mg = std::min<uint32_t>(pg, 32u * kTileColBlocks);
+                rc = ensure_gram_scratch(s, nshort, bs.pcap, pg, mg);
+                if (rc != DANN_OK) return rc;
+                const size_t lds_pool = pool_lds_layout(bs.pcap, pc.pruned_degree).total;
+                BackListArgs la;
+                la.b = bs;
+                la.sid = s.g_sid.as<uint32_t>();
+                la.sd = s.g_sd.as<float>();
+                la.sn = s.g_sn.as<uint32_t>();
+                la.loc = s.g_loc.as<uint32_t>();
+                rc = dispatch_float<BackListLauncher>(ix, la, nshort, lds_pool, st);
+                if (rc != DANN_OK) return rc;
+                TileArgs ta;
+                ta.ix = ix;
+                ta.sid = la.sid;
+                ta.sn = la.sn;
+                ta.pcap = bs.pcap;
+                ta.ng = pg;
+                ta.mg = mg;
+                ta.gram = s.g_gram.as<float>();
+                ta.nrm = s.g_nrm.as<float>();
+                ta.counters = pc.counters;
+                rc = launch_gram_tiles(ta, nshort, st);
+                if (rc != DANN_OK) return rc;
+                SweepArgs sw;
+                sw.p = PoolArgs{};
+                sw.p.ix = ix;
+                sw.p.cfg = pc;
+                sw.p.pcap = bs.pcap;
+                sw.p.force_saturate = 0;
+                sw.sid = la.sid;
+                sw.sd = la.sd;
+                sw.sn = la.sn;
+                sw.gram = ta.gram;
+                sw.nrm = ta.nrm;
+                sw.ng = pg;
+                sw.mg = mg;
                 const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
-                ga.escale = es ? (float)atof(es) : 1.0f;
-                ga.c2 = gram_c2_for_dim(ix.dim);
-                rc = launch_backedge_gram(ix, ga, backedge_gram_lds(bs.pcap, pc.pruned_degree, pg), st);
+                sw.escale = es ? (float)atof(es) : 1.0f;
+                sw.c1 = gram_c1_chained(ix.dim);
+                sw.c2 = gram_c2_for_dim(ix.dim);
+                sw.one_by_one = sweep_one_by_one();
+                sw.out_loc = la.loc;
+                sw.prunes = meta + 5;       // BackArgs::counters[1]
+                sw.mfma_prunes = meta + 8;
+                rc = dispatch_float<SweepLauncher>(ix, sw, nshort, lds_pool, st);
                 if (rc != DANN_OK) return rc;
                 gram = true;
             }
@@ -2155,31 +2257,6 @@ int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows,
     hipLaunchKernelGGL(apply_rows_kernel, dim3(count), dim3(kWave), 0, idx->main.stream, idx->view(), d_rows, count);
     DANN_HIP(hipGetLastError());
     DANN_HIP(hipStreamSynchronize(idx->main.stream));
-    return DANN_OK;
-} DANN_CATCH_ALL
-
-int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t dim, float* out) try {
-    if (!rows || !out || n == 0 || n > 128 || dim == 0) return DANN_EINVAL;
-    DeviceGuard guard(device < 0 ? 0 : device);
-    const size_t stride = ((size_t)dim * 4 + 15) & ~(size_t)15;
-    DevBuf dr, dout;
-    DANN_HIP(dr.alloc(stride * n + 256));
-    DANN_HIP(dout.alloc((size_t)n * n * 4));
-    DANN_HIP(hipMemset(dr.p, 0, stride * n + 256));
-    DANN_HIP(hipMemcpy2D(dr.p, stride, rows, (size_t)dim * 4, (size_t)dim * 4, n, hipMemcpyHostToDevice));
-    IndexView ix{};
-    ix.rows = dr.as<uint8_t>();
-    ix.row_stride = stride;
-    ix.dim = dim;
-    ix.dtype = DT_F32;
-    ix.nslots = n;
-    const uint32_t pg = (n + 31u) & ~31u;
-    const size_t lds = (size_t)pg * 4 + (size_t)pg * (pg + 1) * 4 + (size_t)pg * 33 * 4 + (size_t)pg * 4;
-    if (lds > 64 * 1024) DANN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_debug_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(gram_debug_kernel, dim3(1), dim3(256), lds, 0, ix, n, dout.as<float>());
-    DANN_HIP(hipGetLastError());
-    DANN_HIP(hipMemcpy(out, dout.p, (size_t)n * n * 4, hipMemcpyDeviceToHost));
     return DANN_OK;
 } DANN_CATCH_ALL
 

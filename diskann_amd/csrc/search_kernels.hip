@@ -238,6 +238,10 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     }
     // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
     if (inflight <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
+    {   // development switch DANN_TUNE_ON bit 1: the row prefetch in the throughput regime too (A/B on large indexes)
+        const char* e = getenv("DANN_TUNE_ON");
+        if (e && (strtoul(e, nullptr, 0) & 1u)) a.tune |= kTuneRowPrefetch;
+    }
     // ... and with at most one query per SIMD the other wave slots are idle: a team of wavefronts per query (the rows of
     // a hop split four ways).  Knn searches only (the launch falls back to one wave per query where no team
     // instantiation exists).  DANN_TUNE_OFF bit 4 / DANN_TEAM_MAX_QUERIES: development switches.

@@ -401,18 +401,17 @@ int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t d
  * flight per lane), averaged over `reps` launches -- the achievable line to hold next to the 8 TB/s peak */
 int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps);
 
-/* build-path options (never change the resulting graph): DANN_BUILD_MFMA_BACKEDGE evaluates the pair similarities
- * of every back-edge prune (add_edge_and_prune -> robust_prune_list, diskann/src/graph/index.rs:2264-2341,
- * graph/internal/prune.rs:196-232) as one Gram matrix per candidate list on the matrix cores
- * (v_mfma_f32_32x32x2_f32), with a bit-exact re-evaluation of every comparison the rounding-error interval of the
- * Gram value does not decide.  f32 rows, L2 / inner product / cosine-normalized; other configurations ignore it. */
-enum { DANN_BUILD_MFMA_BACKEDGE = 1,
-       /* the same for the pool prune of every inserted point (robust_prune_with, index.rs:2476-2532), f32 and f16 rows:
-        * three kernels -- sort, Gram tiles of the first <= 256 sorted candidates against the first 96 on the matrix
-        * cores (lower triangle only), sweep; pairs outside that block use the row kernel */
+/* build-path options (never change the resulting graph).  The matrix-core path evaluates the pair similarities a
+ * RobustPrune asks for (prune.rs:196-232) as the lower triangle of one Gram matrix per candidate list
+ * (v_mfma_f32_32x32x2_f32; three kernels: list / sort, Gram tiles, sweep), with a bit-exact re-evaluation of every
+ * comparison the rounding-error interval of the Gram value does not decide.  f32 and f16 rows, L2 / inner product /
+ * cosine-normalized; other configurations ignore the flags.  Default: rows of 1 KiB and more use it. */
+enum { /* back-edge prunes (add_edge_and_prune -> robust_prune_list, diskann/src/graph/index.rs:2264-2341) of any row size */
+       DANN_BUILD_MFMA_BACKEDGE = 1,
+       /* the pool prune of every inserted point (robust_prune_with, index.rs:2476-2532) of any row size: Gram of the
+        * first <= 256 sorted candidates against the first 96; pairs outside that block use the row kernel */
        DANN_BUILD_MFMA_POOL = 2,
-       /* never use the matrix-core paths (by default float rows of 1 KiB and more use them: back-edge prunes of f32
-        * rows, pool prunes of f32 and f16 rows) */
+       /* never use the matrix-core path */
        DANN_BUILD_ROW_KERNEL_ONLY = 4 };
 int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
 /* work counters of the build path since index creation (the algorithmic-bytes model of profiles/): out[0] back-edge
@@ -423,11 +422,7 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
  * an exact re-evaluation by the row kernel (the rest were answered from a Gram).  n <= 10 entries are written. */
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
-/* diagnostic: the Gram matrix of n <= 128 f32 rows exactly as the MFMA back-edge path computes it (f32 FMA chains of
- * 32 terms in k order on v_mfma_f32_32x32x2_f32, block results summed in f64, one rounding to f32) */
-int32_t dann_debug_gram(int32_t device, const float* rows, uint32_t n, uint32_t dim, float* out);
-
-/* diagnostic: the Gram block of the three-kernel MFMA pool prune (gram_tiles_kernel) for n <= 256 rows of dtype
+/* diagnostic: the Gram block of the MFMA prunes (gram_tiles_kernel) for n <= 256 rows of dtype
  * DANN_F32 / DANN_F16: out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain
  * over k = 0 .. dim-1 of row_i[k] * row_j[k] (f16 rows widened exactly); out_nrm[i] = |row_i|^2 accumulated in f64 */
 int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,

@@ -113,8 +113,6 @@ def lib():
     L.orc_range_search.argtypes = [P(OrcIndex), vp, u32, u32, f32, i32, f32, f32, f32, u64, vp, vp, u64, vp]
     L.orc_expand_beam.restype = i32
     L.orc_expand_beam.argtypes = [P(OrcIndex), vp, vp, u32, vp, vp]
-    L.orc_gram_blocked.restype = None
-    L.orc_gram_blocked.argtypes = [vp, u32, u32, vp]
     L.orc_gram_chain.restype = None
     L.orc_gram_chain.argtypes = [vp, u32, u32, vp]
     L.orc_prune_pool.restype = i32
@@ -400,14 +398,6 @@ def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_si
     return OrcBuildConfig(pruned_degree, max_degree, l_build, alpha, max_occlusion_size,
                           pruned_degree if max_backedges is None else max_backedges,
                           intra_batch_candidates, int(saturate_after_prune))
-
-
-def gram_blocked(rows):
-    """checker of dann_debug_gram: blocked f32 fmaf chains (32 terms), f64 block sum, one rounding"""
-    r = np.ascontiguousarray(rows, dtype=np.float32)
-    out = np.empty((r.shape[0], r.shape[0]), np.float32)
-    lib().orc_gram_blocked(_p(r), r.shape[0], r.shape[1], _p(out))
-    return out
 
 
 def gram_chain(rows):

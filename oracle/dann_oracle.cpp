@@ -1438,23 +1438,6 @@ int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* 
     return (int32_t)m;
 }
 
-/* Checker for the MFMA Gram of the GPU build path (no reference counterpart: the reference evaluates pair
- * distances one at a time): out[i][j] = sum over 32-element blocks of an f32 fmaf chain in k order (what
- * v_mfma_f32_32x32x2_f32 computes), block results added in f64, one rounding to f32. */
-void orc_gram_blocked(const float* rows, uint32_t n, uint32_t dim, float* out) {
-    for (uint32_t i = 0; i < n; ++i)
-        for (uint32_t j = 0; j < n; ++j) {
-            double tot = 0.0;
-            for (uint32_t k0 = 0; k0 < dim; k0 += 32) {
-                float acc = 0.0f;
-                for (uint32_t k = k0; k < std::min(dim, k0 + 32); ++k)
-                    acc = std::fmaf(rows[(size_t)i * dim + k], rows[(size_t)j * dim + k], acc);
-                tot += (double)acc;
-            }
-            out[(size_t)i * n + j] = (float)tot;
-        }
-}
-
 /* checker for gram_tiles_kernel (dann_debug_gram_tiles): one f32 fmaf chain over k = 0 .. dim-1 per entry (what
  * v_mfma_f32_32x32x2_f32 computes when its accumulator runs through the whole row; zero padding adds nothing) */
 void orc_gram_chain(const float* rows, uint32_t n, uint32_t dim, float* out) {

@@ -154,9 +154,7 @@ void orc_paged_end(orc_paged* s);
 int32_t orc_expand_beam(const orc_index* ix, const void* query, const uint32_t* ids, uint32_t n,
                         uint32_t* out_ids, float* out_dists);
 
-/* checker for the GPU build path's MFMA Gram (dann_debug_gram): blocked f32 fmaf chains, f64 block sum */
-void orc_gram_blocked(const float* rows, uint32_t n, uint32_t dim, float* out);
-/* checker for the three-kernel MFMA pool prune's Gram (dann_debug_gram_tiles): one f32 fmaf chain per entry */
+/* checker for the GPU build path's MFMA Gram (dann_debug_gram_tiles): one f32 fmaf chain per entry */
 void orc_gram_chain(const float* rows, uint32_t n, uint32_t dim, float* out);
 
 /* ---- build ----------------------------------------------------------- */

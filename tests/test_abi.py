@@ -74,3 +74,15 @@ def test_c_caller_end_to_end(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "recall@10" in r.stdout
+
+
+def test_rust_declarations_cover_the_header():
+    """bindings/rust/dann_sys.rs (generated from the header by gen_dann_sys.py) declares every export, with the header's
+    const-ness (an out-parameter is never `*const`)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "dann.h")).read()
+    declared = set(re.findall(r"\b(dann_[a-z0-9_]+)\s*\(", hdr))
+    rs = open(os.path.join(root, "bindings", "rust", "dann_sys.rs")).read()
+    in_rs = set(re.findall(r"pub fn (dann_[a-z0-9_]+)\(", rs))
+    assert declared == in_rs, declared ^ in_rs
+    assert "dann_index_get_config(idx: *const DannIndex, out: *mut DannConfig)" in rs

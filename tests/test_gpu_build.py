@@ -253,24 +253,7 @@ def test_build_splits_batches_that_need_an_oversized_bootstrap():
         p2.insert_batch(cfg, np.arange(8000, dtype=np.uint32))
 
 
-# ---- MFMA path of the back-edge prune (BUILD_MFMA_BACKEDGE) ---------------------------------------------------------
-def test_mfma_gram_equals_blocked_fmaf_chains():
-    """v_mfma_f32_32x32x2_f32 is a k-ordered f32 FMA chain (MI355X guide): the Gram of the build path (chains restarted
-    every 32 elements, block results summed in f64, one rounding) is bit-identical to the CPU restatement of exactly
-    that arithmetic -- for sizes that exercise partial tiles, the zero-padded K tail and all four waves."""
-    import ctypes as C
-    rng = np.random.default_rng(5)
-    lib = da._ffi.lib()
-    for n, dim in ((1, 8), (7, 33), (32, 128), (33, 100), (70, 768), (96, 96), (128, 260)):
-        rows = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 30.0, (n, 1))).astype(np.float32)
-        got = np.empty((n, n), np.float32)
-        da._ffi.check(lib.dann_debug_gram(-1, rows.ctypes.data_as(C.c_void_p), n, dim, got.ctypes.data_as(C.c_void_p)),
-                      "dann_debug_gram")
-        want = oracle.gram_blocked(rows)
-        assert np.array_equal(bits(got), bits(want)), (n, dim)
-        assert np.array_equal(got, got.T)
-
-
+# ---- MFMA path of the prunes (BUILD_MFMA_BACKEDGE / BUILD_MFMA_POOL; default for rows of 1 KiB and more) ------------------
 @pytest.mark.parametrize("metric,dim,R,maxdeg", [
     (oracle.L2, 128, 24, 32),                  # pg = 64
     (oracle.L2, 100, 56, 64),                  # K tail (100 = 3 x 32 + 4), pg = 96
@@ -278,8 +261,9 @@ def test_mfma_gram_equals_blocked_fmaf_chains():
     (oracle.COSINE_NORMALIZED, 64, 20, 24),    # 1 - <x, y> on unit vectors
 ])
 def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeypatch):
-    """dann_build with the MFMA back-edge path == the oracle's multi_insert, adjacency byte for byte (tie-free data);
-    the same again with the error interval widened 10^6 x, which drives every comparison through the exact re-check."""
+    """dann_build with the MFMA back-edge and pool prunes == the oracle's multi_insert, adjacency byte for byte (tie-free
+    data); the same again with the error interval widened 10^6 x, which drives every comparison through the exact
+    re-check."""
     from diskann_amd.sharding import batch_schedule
     rng = np.random.default_rng(1000 + dim)
     n, lb = 6000, 48
