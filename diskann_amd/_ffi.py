@@ -122,7 +122,7 @@ SYMBOLS = {
     "dann_build": (_i32, [_vp, _P(BuildConfig), _u32, _u32, _f32, _u32]),
     "dann_set_build_options": (_i32, [_vp, _u32]),
     "dann_build_counters": (_i32, [_vp, _vp, _u32]),
-    "dann_debug_gram_tiles": (_i32, [_i32, _i32, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
+    "dann_debug_gram_tiles": (_i32, [_i32, _i32, _vp, _u32, _u32, _u32, _vp, _vp]),
     "dann_save_graph": (_i32, [_vp, C.c_char_p]),
     "dann_load_graph": (_i32, [_vp, C.c_char_p, _P(_u32), _P(_u64), _P(_u64)]),
     "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),

@@ -603,9 +603,6 @@ inline float gram_c2_for_dim(uint32_t dim) {
     return c > kGramC2 ? c : kGramC2;
 }
 inline float gram_c1_chained(uint32_t dim) { return 1.05f * ((float)((dim + 31u) & ~31u) + 4.0f) * kUnitRoundoff; }
-// centred Gram (L2): the rows are fl(x - p); each component carries a relative error u, which moves a distance by at
-// most 4 u (|x - p|^2 + |y - p|^2)
-inline float gram_c1_centred(uint32_t dim) { return 1.05f * ((float)((dim + 31u) & ~31u) + 8.0f) * kUnitRoundoff; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GramCtx {
@@ -1158,12 +1155,6 @@ struct TileArgs {
     float* gram;          // n x ng x mg, entry (p, q) valid for q < p (and on the diagonal blocks)
     float* nrm;           // n x ng
     unsigned long long* counters;  // PruneCfg::counters: [2] += rows, [3] += tiles * 1024 (x dim x 2 = MFMA flop)
-    // L2 only: the Gram is taken of the rows MINUS the row of center[item] (the prune's location).  Squared distances
-    // do not change under a translation, but the error of a Gram-derived distance is proportional to |x|^2 + |y|^2: with
-    // the candidates' common neighbour as origin that is the scale of the distances themselves (~d(p, c)) instead of
-    // the data's distance from the coordinate origin -- on the benchmark mixture 200 x smaller, and with it the share of
-    // comparisons the interval cannot decide (1.9 % -> < 0.1 %; each of those costs a row-kernel evaluation).
-    const uint32_t* center = nullptr;
 };
 
 constexpr int kTileRowBlocks = 8;  // ng <= 256: wave w of the 8-wave workgroup owns row block w
@@ -1258,9 +1249,6 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
         nsq[p] = 0.0;
     }
     float4 nxt[kTilePasses];
-    const bool centered = a.center != nullptr;
-    const uint8_t* cenp = a.ix.rows + (uint64_t)(centered ? a.center[item] : 0u) * a.ix.row_stride + (size_t)c4 * sizeof(RT);
-    float4 cnx = {0.f, 0.f, 0.f, 0.f};  // this thread's four elements of the centre row, next slab
     const uint32_t dim_full = dim & ~31u;  // slabs below this are complete: one 4-element request per thread and row
     // tiles of this wave: row block `wave`, column blocks 0 .. min(wave, TC - 1)
     const uint32_t nt = wave < TR ? ((wave < TC ? wave : TC - 1u) + 1u) : 0u;
@@ -1279,7 +1267,6 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
             const uint32_t r = ((uint32_t)p << 6) + lr;
             if (r < fill_rows) {
                 float4 q = nxt[p];
-                if (centered) q = float4{q.x - cnx.x, q.y - cnx.y, q.z - cnx.z, q.w - cnx.w};  // one IEEE subtraction each
                 if (!rowok[p]) q = float4{0.f, 0.f, 0.f, 0.f};
                 float* dst = slab + r * 33u + c4;
                 dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
@@ -1298,14 +1285,12 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
         // s_waitcnt.  The last iteration re-requests its own slab instead of branching around the prefetch.
 #pragma unroll
         for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p]);
-        cnx = tile_load4<RT>(cenp);
         for (uint32_t k0 = 0; k0 < dim_full; k0 += 32u) {
             write_slab();
             __syncthreads();
             const uint32_t kn = k0 + 32u < dim_full ? k0 + 32u : k0;
 #pragma unroll
             for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p] + (size_t)kn * sizeof(RT));
-            cnx = tile_load4<RT>(cenp + (size_t)kn * sizeof(RT));
             mfma_slab();
             __syncthreads();
         }
@@ -1313,7 +1298,6 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
     if (dim_full < dim) {  // the last, partial slab (dim % 32 != 0): element-wise requests, once per item
 #pragma unroll
         for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_fetch4<RT>(rowp[p] - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
-        cnx = tile_fetch4<RT>(cenp - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
         write_slab();
         __syncthreads();
         mfma_slab();
@@ -1619,12 +1603,6 @@ uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-// development switch: DANN_GRAM_CENTRE=0 keeps the Gram of the raw rows for L2 (A/B runs)
-bool gram_centring() {
-    const char* e = getenv("DANN_GRAM_CENTRE");
-    return !e || atoi(e) != 0;
-}
-
 uint32_t sweep_one_by_one() {
     const char* e = getenv("DANN_SWEEP_ONE_BY_ONE");
     return e && atoi(e) != 0 ? 1u : 0u;
@@ -1876,8 +1854,6 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         ta.gram = s.g_gram.as<float>();
         ta.nrm = s.g_nrm.as<float>();
         ta.counters = pc.counters;
-        const bool centred = ix.metric == M_L2 && gram_centring();
-        ta.center = centred ? d_slots + lo : nullptr;  // the location of work item i is locs[pos0 + i]
         rc = launch_gram_tiles(ta, m, st);
         if (rc != DANN_OK) return rc;
         SweepArgs sw;
@@ -1891,7 +1867,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.mg = mg;
         const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
         sw.escale = es ? (float)atof(es) : 1.0f;
-        sw.c1 = centred ? gram_c1_centred(ix.dim) : gram_c1_chained(ix.dim);
+        sw.c1 = gram_c1_chained(ix.dim);
         sw.c2 = gram_c2_for_dim(ix.dim);
         sw.one_by_one = sweep_one_by_one();
         rc = dispatch_float<SweepLauncher>(ix, sw, m, lds, st);
@@ -2086,8 +2062,6 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 ta.gram = s.g_gram.as<float>();
                 ta.nrm = s.g_nrm.as<float>();
                 ta.counters = pc.counters;
-                const bool centred = ix.metric == M_L2 && gram_centring();
-                ta.center = centred ? la.loc : nullptr;
                 rc = launch_gram_tiles(ta, nshort, st);
                 if (rc != DANN_OK) return rc;
                 SweepArgs sw;
@@ -2105,7 +2079,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.mg = mg;
                 const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
                 sw.escale = es ? (float)atof(es) : 1.0f;
-                sw.c1 = centred ? gram_c1_centred(ix.dim) : gram_c1_chained(ix.dim);
+                sw.c1 = gram_c1_chained(ix.dim);
                 sw.c2 = gram_c2_for_dim(ix.dim);
                 sw.one_by_one = sweep_one_by_one();
                 sw.out_loc = la.loc;
@@ -2287,16 +2261,15 @@ int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows,
 } DANN_CATCH_ALL
 
 int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
-                              int32_t center_row, float* out_gram, float* out_nrm) try {
-    if (!rows || !out_gram || !out_nrm || n == 0 || n > 32u * kTileRowBlocks || dim == 0 || (dtype != DT_F32 && dtype != DT_F16) ||
-        center_row >= (int32_t)n)
+                              float* out_gram, float* out_nrm) try {
+    if (!rows || !out_gram || !out_nrm || n == 0 || n > 32u * kTileRowBlocks || dim == 0 || (dtype != DT_F32 && dtype != DT_F16))
         return DANN_EINVAL;
     mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
     DeviceGuard guard(device < 0 ? 0 : device);
     const size_t esz = dtype == DT_F32 ? 4 : 2;
     const size_t stride = ((size_t)dim * esz + 15) & ~(size_t)15;
     const uint32_t ng = (n + 31u) & ~31u;
-    DevBuf dr, dids, dsn, dg, dn, dcen;
+    DevBuf dr, dids, dsn, dg, dn;
     DANN_HIP(dr.alloc(stride * n + 256));
     DANN_HIP(dids.alloc((size_t)ng * 4));
     DANN_HIP(dsn.alloc(4));
@@ -2324,12 +2297,6 @@ int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, u
     ta.gram = dg.as<float>();
     ta.nrm = dn.as<float>();
     ta.counters = nullptr;
-    if (center_row >= 0) {
-        const uint32_t c = (uint32_t)center_row;
-        DANN_HIP(dcen.alloc(4));
-        DANN_HIP(hipMemcpy(dcen.p, &c, 4, hipMemcpyHostToDevice));
-        ta.center = dcen.as<uint32_t>();
-    }
     int32_t rc = launch_gram_tiles(ta, 1, 0);
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipDeviceSynchronize());

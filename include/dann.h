@@ -422,12 +422,11 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
  * an exact re-evaluation by the row kernel (the rest were answered from a Gram).  n <= 10 entries are written. */
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
-/* diagnostic: the Gram block of the MFMA prunes (gram_tiles_kernel) for n <= 256 rows of dtype DANN_F32 / DANN_F16:
- * out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain over k = 0 .. dim-1
- * of y_i[k] * y_j[k] with y = the row (f16 rows widened exactly), or, with center_row >= 0, y = fl32(row - rows[center_row])
- * (how the L2 prunes centre a list at its location); out_nrm[i] = |y_i|^2 accumulated in f64 */
+/* diagnostic: the Gram block of the MFMA prunes (gram_tiles_kernel) for n <= 256 rows of dtype
+ * DANN_F32 / DANN_F16: out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain
+ * over k = 0 .. dim-1 of row_i[k] * row_j[k] (f16 rows widened exactly); out_nrm[i] = |row_i|^2 accumulated in f64 */
 int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
-                              int32_t center_row, float* out_gram, float* out_nrm);
+                              float* out_gram, float* out_nrm);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
 #define DANN_ABI_VERSION 3

@@ -337,21 +337,18 @@ def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
     for n, dim, mg in ((1, 8, 32), (7, 33, 32), (33, 100, 64), (70, 768, 96), (96, 96, 96), (130, 260, 96), (200, 128, 96),
                        (256, 64, 96), (160, 1536, 96)):
         rows = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 8.0, (n, 1))).astype(npdt)
-        for center in (-1, n // 2):  # the raw rows (IP / cosine-normalized), and centred at one of them (the L2 prunes)
-            got = np.empty((n, mg), np.float32)
-            nrm = np.empty(n, np.float32)
-            da._ffi.check(lib.dann_debug_gram_tiles(-1, dtype, rows.ctypes.data_as(C.c_void_p), n, dim, mg, center,
-                                                    got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
-                          "dann_debug_gram_tiles")
-            wide = rows.astype(np.float32)
-            if center >= 0:
-                wide = wide - wide[center][None, :]  # one IEEE f32 subtraction per component, as the slab fill does
-            want = oracle.gram_chain(wide)
-            for i in range(n):
-                m = min(i + 1, mg)  # columns j <= i inside the block
-                assert np.array_equal(bits(got[i, :m]), bits(want[i, :m])), (n, dim, i, center)
-            exact = (wide.astype(np.float64) ** 2).sum(1)
-            assert np.all(np.abs(nrm.astype(np.float64) - exact) <= np.spacing(exact.astype(np.float32)).astype(np.float64)), (n, dim)
+        got = np.empty((n, mg), np.float32)
+        nrm = np.empty(n, np.float32)
+        da._ffi.check(lib.dann_debug_gram_tiles(-1, dtype, rows.ctypes.data_as(C.c_void_p), n, dim, mg,
+                                                got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
+                      "dann_debug_gram_tiles")
+        wide = rows.astype(np.float32)
+        want = oracle.gram_chain(wide)
+        for i in range(n):
+            m = min(i + 1, mg)  # columns j <= i inside the block
+            assert np.array_equal(bits(got[i, :m]), bits(want[i, :m])), (n, dim, i)
+        exact = (wide.astype(np.float64) ** 2).sum(1)
+        assert np.all(np.abs(nrm.astype(np.float64) - exact) <= np.spacing(exact.astype(np.float32)).astype(np.float64)), (n, dim)
 
 
 @pytest.mark.parametrize("dtype,metric,dim", [(oracle.F16, oracle.L2, 96), (oracle.F16, oracle.INNER_PRODUCT, 100),
