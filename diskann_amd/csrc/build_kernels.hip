@@ -466,11 +466,16 @@ __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
     const uint32_t end = start + a.seg_len[start];
     const bool owned = a.world <= 1u || src % a.world == a.rank;
     if (end - start > (uint32_t)kWave) {
-        // a hub hit by many back-edges: no serial scan here, the long-list kernel de-duplicates 64 sources at a time
-        // (len + #sources bounds its list; it also handles the case that everything still fits)
+        // a hub hit by many back-edges: no serial scan here, the prune kernels de-duplicate 64 sources at a time
+        // (len + #sources bounds the list; they also handle the case that everything still fits)
         if (lane == 0 && owned) {
-            a.work_long[atomicAdd(&a.counts[1], 1u)] = seg;
-            atomicMax(&a.counts[2], len + (end - start));
+            const uint32_t bound = len + (end - start);
+            if (bound <= a.short_cap) {
+                a.work_short[atomicAdd(&a.counts[0], 1u)] = seg;
+            } else {
+                a.work_long[atomicAdd(&a.counts[1], 1u)] = seg;
+                atomicMax(&a.counts[2], bound);
+            }
         }
         return;
     }
@@ -853,13 +858,17 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
 // entries selected a moment ago need no new request.  The decisions, their order and the exact re-checks are those of
 // sweep_sorted_pool_gram (same classes, same first-exceed rule); requires pruned_degree <= 64 (one lane per selected
 // entry), a Gram indexed by sorted position and at most 128 Gram columns.
+constexpr uint32_t kSweepRowsLds = 8u * 128u * 4u + 64u;  // LDS behind the pool layout: the raw Gram rows of one block of visits
+
 template <int DT, int OP, bool NORM>
 __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t N,
-                                   uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out, const GramCtx gc) {
+                                   uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out, const GramCtx gc,
+                                   float* rowsl) {
     constexpr int B = 8;
     using S = Scheme<DT, OP, true>;
-    constexpr int G = S::G;
+    constexpr int G = S::G, GROUPS = kWave / G;
     const uint32_t lane = threadIdx.x & 63u;
+    const int g = (int)(lane / G);
     const uint32_t* sid = reinterpret_cast<const uint32_t*>(smem + L.sid_off);
     const float* sd = reinterpret_cast<const float*>(smem + L.sd_off);
     float* occ = reinterpret_cast<float*>(smem + L.occ_off);
@@ -910,20 +919,32 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
                     idx[j] = idx[j > 0 ? j - 1 : 0];
                 }
             }
-            // ---- their Gram rows, all requests up front (clamped, unconditional)
-            float rlo[B], rhi[B];
+            // ---- their Gram rows, all requests up front (clamped, unconditional), parked in LDS: the visits below
+            //      then run as an ordinary loop (one copy of the code) and pick G(i, sel_c) with one LDS read
+            {
+                float rlo[B], rhi[B];
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                const uint32_t r = idx[j] < gc.nrows ? idx[j] : 0u;
-                const float* row = gc.g + (size_t)r * gc.ld;
-                rlo[j] = row[col_lo];
-                rhi[j] = row[col_hi];
+                for (int j = 0; j < B; ++j) {
+                    const uint32_t r = idx[j] < gc.nrows ? idx[j] : 0u;
+                    const float* row = gc.g + (size_t)r * gc.ld;
+                    rlo[j] = row[col_lo];
+                    rhi[j] = row[col_hi];
+                }
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    rowsl[j * 128 + (int)lane] = rlo[j];
+                    rowsl[j * 128 + 64 + (int)lane] = rhi[j];
+                }
             }
-            // ---- the visits, in order
+            uint32_t* idxl = reinterpret_cast<uint32_t*>(rowsl + B * 128);  // the block's candidate indices
+            if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                if ((uint32_t)j >= nb || found >= degree) break;
-                const uint32_t i = idx[j];
+                for (int j = 0; j < B; ++j) idxl[j] = idx[j];
+            }
+            wave_sync();
+            // ---- the visits, in order
+            for (uint32_t j = 0; j < nb && found < degree; ++j) {
+                const uint32_t i = idxl[j];
                 const int wl = (int)(i - i0);
                 uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)wlast, wl);
                 const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)wsid, wl);
@@ -936,15 +957,14 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
                 const float di = sd[i];
                 const float thr = cur_alpha * di;  // occluding rule: d_jk < alpha * d_ik (config/mod.rs:98)
                 const uint8_t* xi = ix.rows + (uint64_t)idi * ix.row_stride;
-                // G(i, sel_c): one cross-lane read out of the raw row (every lane takes part: the source lanes must be live)
-                const uint32_t srcl = my_sel & 63u;
-                const float glo = __shfl(rlo[j], (int)srcl), ghi = __shfl(rhi[j], (int)srcl);
+                // G(i, sel_c) out of the parked row
+                const float gsel = rowsl[j * 128u + (my_sel & 127u)];
                 const bool have = lane < found && my_sel < i;  // the lazy scan skips selected entries that sort after i
                 int cls = 0;  // 0: certainly not, 1: certainly exceeds, 2: the error interval does not decide / not covered
                 if (have) {
                     cls = 2;
                     if (irow && my_sel < gc.ncols) {
-                        const float gij = (my_sel & 64u) ? ghi : glo;
+                        const float gij = gsel;
                         const float nsum = gii + my_njj;
                         float dp;
                         if (OP == OP_L2) dp = nsum - 2.0f * gij;
@@ -974,17 +994,49 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
                             nasked += (uint32_t)__popcll(valid & range & upto);
                             return (uint32_t)f;
                         }
-                        ++nexact;  // bit-exact pair distance (every lane group evaluates the same pair)
-                        const uint32_t rpf = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, f);
-                        const uint8_t* y = ix.rows + (uint64_t)sid[rpf] * ix.row_stride;
+                        // bit-exact pair distances, one lane group per pair: the undecided / uncovered entries that
+                        // follow in scan order (up to the next certain one) are evaluated together -- the pairs a Gram
+                        // block does not cover come in runs (the selected entries beyond its last column), and one
+                        // evaluation costs a dependent fetch of two rows whether one group works or all of them.
+                        // Consumed in scan order; the lazy scan stops at the first that exceeds (the rest is discarded).
+                        int fs[GROUPS];
+                        int ne = 0;
+                        {
+                            uint64_t t2 = tu;
+#pragma unroll
+                            for (int q = 0; q < GROUPS; ++q) {
+                                fs[q] = 0;
+                                if (t2 && ne == q) {
+                                    const int f2 = __builtin_ctzll(t2);
+                                    if (!((m1 >> f2) & 1ull)) {
+                                        fs[q] = f2;
+                                        ne = q + 1;
+                                        t2 &= t2 - 1;
+                                    }
+                                }
+                            }
+                        }
+                        uint32_t my_rp = 0;
+#pragma unroll
+                        for (int q = 0; q < GROUPS; ++q) {
+                            const uint32_t rq = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, fs[q]);
+                            if (g == q) my_rp = rq;
+                        }
+                        const bool evalme = g < ne;
+                        const uint8_t* y = ix.rows + (uint64_t)(evalme ? sid[my_rp] : idi) * ix.row_stride;
                         const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(xi, y, (int)ix.dim, v), xi, y,
                                                                       ix.dim, sqp);
-                        const float dg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 0));
-                        if (update_occlude<OP>(di, dg, 0.0f, cur_alpha, occluding) > cur_alpha) {
-                            nasked += (uint32_t)__popcll(valid & range & upto);
-                            return (uint32_t)f;
+                        nexact += (uint32_t)ne;
+                        for (int q = 0; q < ne; ++q) {
+                            const float dg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), q * G));
+                            const int fq = fs[q];
+                            if (update_occlude<OP>(di, dg, 0.0f, cur_alpha, occluding) > cur_alpha) {
+                                const uint64_t uq = fq >= 63 ? ~0ull : ((2ull << fq) - 1ull);
+                                nasked += (uint32_t)__popcll(valid & range & uq);
+                                return (uint32_t)fq;
+                            }
+                            tu &= ~(1ull << fq);
                         }
-                        tu &= tu - 1;
                     }
                     nasked += (uint32_t)__popcll(valid & range);
                     return b;
@@ -1020,7 +1072,7 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
                 }
             }
             wave_sync();  // lane 0's state updates before the next window is read
-            i0 = idx[nb - 1u] + 1u;
+            i0 = idxl[nb - 1u] + 1u;
         }
         if (cur_alpha == alpha) break;
         const float next = cur_alpha * inc;
@@ -1381,7 +1433,8 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     const GramCtx gc{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
                      nr, nc, true, sa.escale, sa.c1, sa.c2, false, true};
     if (a.cfg.pruned_degree <= (uint32_t)kWave && sa.mg <= 128u && !sa.one_by_one)
-        sweep_gram_batched<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc);
+        sweep_gram_batched<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc,
+                                         reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u)));
     else
         sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc);
     if (lane == 0 && sa.out_loc) {
@@ -1870,7 +1923,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.c1 = gram_c1_chained(ix.dim);
         sw.c2 = gram_c2_for_dim(ix.dim);
         sw.one_by_one = sweep_one_by_one();
-        rc = dispatch_float<SweepLauncher>(ix, sw, m, lds, st);
+        rc = dispatch_float<SweepLauncher>(ix, sw, m, ((lds + 15u) & ~(size_t)15u) + kSweepRowsLds, st);
         if (rc != DANN_OK) return rc;
         pool_gram = true;
     }
@@ -1996,7 +2049,14 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         const bool want_gram = (ix.dtype == DT_F32 || ix.dtype == DT_F16) && ix.metric != M_COSINE &&
                                ((idx->build_flags & DANN_BUILD_MFMA_BACKEDGE) ||
                                 (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u));
+        // Gram rows per list: the tiles kernel covers up to 256; lists beyond (hubs hit by hundreds of back-edges in one
+        // batch) stay on the row kernel.  DANN_BACKEDGE_GRAM_ROWS: development switch (the round-2 policy was degree + 8).
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
+        if (want_gram) {
+            pg = 32u * kTileRowBlocks;
+            if (const char* e = getenv("DANN_BACKEDGE_GRAM_ROWS")) pg = std::min<uint32_t>(pg, ((uint32_t)atoi(e) + 31u) & ~31u);
+            pg = std::max<uint32_t>(pg, 32u);
+        }
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
         // small rows without the MFMA path: the single-kernel form (list build + prune per target, pool sized by the
@@ -2085,7 +2145,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.out_loc = la.loc;
                 sw.prunes = meta + 5;       // BackArgs::counters[1]
                 sw.mfma_prunes = meta + 8;
-                rc = dispatch_float<SweepLauncher>(ix, sw, nshort, lds_pool, st);
+                rc = dispatch_float<SweepLauncher>(ix, sw, nshort, ((lds_pool + 15u) & ~(size_t)15u) + kSweepRowsLds, st);
                 if (rc != DANN_OK) return rc;
                 gram = true;
             }
