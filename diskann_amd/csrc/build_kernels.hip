@@ -2049,13 +2049,14 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         const bool want_gram = (ix.dtype == DT_F32 || ix.dtype == DT_F16) && ix.metric != M_COSINE &&
                                ((idx->build_flags & DANN_BUILD_MFMA_BACKEDGE) ||
                                 (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u));
-        // Gram rows per list: the tiles kernel covers up to 256; lists beyond (hubs hit by hundreds of back-edges in one
-        // batch) stay on the row kernel.  DANN_BACKEDGE_GRAM_ROWS: development switch (the round-2 policy was degree + 8).
+        // Gram rows per list: degree + 8 rounded up (96 at R = 64) covers the lists of a steady-state batch; the tiles kernel
+        // could take up to 256, but sizing every list's LDS pool and Gram stride for the rare hub costs more than the hubs
+        // save (1 M x 768: 3.18 s at 256 against 2.81 s; DANN_BACKEDGE_GRAM_ROWS raises it for experiments).  Longer
+        // lists stay on the row kernel.
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
         if (want_gram) {
-            pg = 32u * kTileRowBlocks;
-            if (const char* e = getenv("DANN_BACKEDGE_GRAM_ROWS")) pg = std::min<uint32_t>(pg, ((uint32_t)atoi(e) + 31u) & ~31u);
-            pg = std::max<uint32_t>(pg, 32u);
+            if (const char* e = getenv("DANN_BACKEDGE_GRAM_ROWS"))
+                pg = std::min<uint32_t>(32u * kTileRowBlocks, std::max<uint32_t>(pg, ((uint32_t)atoi(e) + 31u) & ~31u));
         }
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
