@@ -351,7 +351,8 @@ int32_t dann_pq_lloyds(int32_t device, const float* data, uint64_t n, uint32_t d
  * diskann-quantization/src/random.rs:33-44), so that the GPU consumes exactly the reference's stream:
  *   uniform_index(ctx, chunk, n)   == Uniform::new(0, n).unwrap().sample(rng_chunk)              (plusplus.rs:417)
  *   uniform_f64(ctx, chunk, high)  == Uniform::<f64>::new(0.0, high).unwrap().sample(rng_chunk)  (plusplus.rs:440-444)
- * Called from the calling thread only, chunk by chunk, in the reference's order within a chunk. */
+ * Called from the calling thread only.  Draws of different chunks are interleaved (centre by centre across the
+ * chunks); within one chunk they come in the reference's order -- which is all a per-chunk generator can observe. */
 typedef struct {
     void* ctx;
     uint64_t (*uniform_index)(void* ctx, uint32_t chunk, uint64_t n);
