@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DANN_LIB_PATH") or os.path.join(_HERE, "libdann_hip.s
 
 F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
-OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED, EINTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
 BUILD_MFMA_BACKEDGE, BUILD_MFMA_POOL, BUILD_ROW_KERNEL_ONLY = 1, 2, 4
 

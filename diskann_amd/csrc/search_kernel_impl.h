@@ -21,7 +21,9 @@ constexpr int kGatherRows = 4;
 #endif
 constexpr int kWideRows = DANN_WIDE_ROWS;  // rows per lane group and trip in the wide (f16) gather
 constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
+constexpr uint32_t kSeqInsert = 8;  // survivors inserted one by one, the queue never leaving its registers
 constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
+constexpr uint32_t kTuneNoSpeculation = 2u;  // teams: no speculative expansion of the predicted next node
 constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
 
 // optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
@@ -33,8 +35,9 @@ constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (disk
 #define PH_ADD(idx, t0, t1)
 #endif  // rows in flight per lane group in the fixed-length gather
 
+constexpr uint32_t kAdjLandBytes = 256u;
 struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, stage_off, snew_off, beam_off, q_off, total;
+    uint32_t ht_off, cand_id_off, cand_d_off, cand2_id_off, cand2_d_off, adj_off, stage_off, snew_off, beam_off, q_off, total;
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -50,7 +53,7 @@ __host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
 // query bytes) -- compile-time constants in the plain fixed-length instantiations, where the region pointers cost no
 // SGPRs and the LDS instructions carry immediate offsets.
 __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
-                                                       uint32_t qbytes) {
+                                                       uint32_t qbytes, bool team = false) {
     SearchLds l;
     uint32_t off = 0;
     l.q_off = off;
@@ -59,6 +62,16 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     off += round16(cmax * 4u);
     l.cand_d_off = off;
     off += round16(cmax * 4u);
+    // teams: a second candidate buffer -- wave 0 fills it with the next hop's candidates while the helper waves still
+    // evaluate the current hop's (the speculative expansion of the predicted next node, §3.5 of DESIGN.md)
+    l.cand2_id_off = off;
+    if (team) off += round16(cmax * 4u);
+    l.cand2_d_off = off;
+    if (team) off += round16(cmax * 4u);
+    // teams: two landing buffers of 64 dwords for adjacency rows requested ahead of their use (length + at most 63
+    // neighbours each; the loads write LDS directly, see adj_fetch_lds)
+    l.adj_off = off;
+    if (team) off += 2u * kAdjLandBytes;
     l.stage_off = off;  // the queue image, (id, distance bits) pairs: every merge scatters the register-resident queue
     off += round16(qcap * 8u);  // here and reloads it (one 8-byte LDS access per entry).  One buffer is enough: nothing
                                 // is read from it between the first scatter write and the reload (ranks come from
@@ -108,6 +121,26 @@ __device__ __forceinline__ bool ht_insert_open(uint32_t* ht, uint32_t mod, uint3
             pending = old != kEmpty && old != id;
         }
     }
+    return isnew;
+}
+// the same, also reporting the slot the id went into (for a rollback of speculative inserts: the slot is set back to
+// kEmpty, which restores the table exactly -- an insert only ever fills an empty slot)
+__device__ __forceinline__ bool ht_insert_open_slot(uint32_t* ht, uint32_t mod, uint32_t id, bool active, uint32_t* slot) {
+    uint32_t h = __umulhi(id * 2654435761u, mod);
+    uint32_t old = active ? atomicCAS(&ht[h], kEmpty, id) : id;
+    bool isnew = active && old == kEmpty;
+    bool pending = active && old != kEmpty && old != id;
+    if (ballot64(pending)) {
+        const uint32_t step = 1u + __umulhi(id * 2246822519u + 0x9E3779B9u, mod - 1u);
+        while (pending) {
+            h += step;
+            h = h >= mod ? h - mod : h;
+            old = atomicCAS(&ht[h], kEmpty, id);
+            isnew = old == kEmpty;
+            pending = old != kEmpty && old != id;
+        }
+    }
+    *slot = h;
     return isnew;
 }
 // Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
@@ -183,32 +216,61 @@ __device__ __forceinline__ float f32_load(const float* p) {
 //                 same launch: single query L = 64 235 -> 217 us, 1024 concurrent queries +8 %.
 //   kModeGeneral  any beam width, inline tags, any degree; no filter
 //   kModeFiltered the filtered searches (inline / multihop / AdaptiveL); generic-length instantiations only
+// minimum of a non-NaN value over the wave: DPP row shifts inside the rows of 16, then the two row broadcasts
+// (lane 63 ends up with the minimum of all lanes)
+__device__ __forceinline__ float wave_min_f32(float v) {
+    constexpr int kInf = 0x7F800000;
+#define DANN_MIN_STEP(CTRL, ROWMASK)                                                                                  \
+    {                                                                                                                  \
+        const float t = __builtin_bit_cast(                                                                            \
+            float, __builtin_amdgcn_update_dpp(kInf, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));          \
+        v = t < v ? t : v;                                                                                             \
+    }
+    DANN_MIN_STEP(0x111, 0xf)  // row_shr:1
+    DANN_MIN_STEP(0x112, 0xf)  // row_shr:2
+    DANN_MIN_STEP(0x114, 0xf)  // row_shr:4
+    DANN_MIN_STEP(0x118, 0xf)  // row_shr:8   -> lane 15 of every row: the row's minimum
+    DANN_MIN_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    DANN_MIN_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef DANN_MIN_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (SearchLds beam[1])
-// one wave's share of a team gather: candidate c = c0 + wave * GROUPS + g of every block of TEAM * GROUPS candidates,
-// one row per lane group and block (the single-wave form keeps kGatherRows rows per group in flight instead)
-template <int DT, int OP, bool NORM, int DIM, int TEAM>
-__device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t wave, uint32_t nc, const uint32_t* cand_id,
+// one helper wave's share of a team gather: the NW helper waves split every block of NW * GROUPS * 2 candidates, two
+// rows per lane group in flight (wave 0 does not gather: it expands the predicted next node meanwhile)
+template <int DT, int OP, bool NORM, int DIM, int NW>
+__device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t wi, uint32_t nc, const uint32_t* cand_id,
                                                   float* cand_d, const F4 (&xq)[(DIM > 0 && !Scheme<DT, OP, false>::kInt) ? DIM / (4 * Scheme<DT, OP, false>::G) : 1],
                                                   const uint4& xqi, int xx_pre, const uint8_t* qs, const SqParams& sqp, int g,
                                                   int v) {
     using S = Scheme<DT, OP, false>;
-    constexpr int G = S::G, GROUPS = kWave / G;
+    constexpr int G = S::G, GROUPS = kWave / G, U = 2;
     using RT = typename RowType<DT>::type;
-    for (uint32_t c0 = 0; c0 < nc; c0 += TEAM * GROUPS) {
-        const uint32_t c = c0 + wave * GROUPS + (uint32_t)g;
-        const bool act1 = c < nc;
-        const uint32_t id = act1 ? cand_id[c] : 0u;
+    for (uint32_t c0 = 0; c0 < nc; c0 += NW * GROUPS * U) {
+        uint32_t c[U];
+        bool act[U];
+        const uint8_t* rowb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c[u] = c0 + ((uint32_t)u * NW + wi) * GROUPS + (uint32_t)g;
+            act[u] = c[u] < nc;
+            const uint32_t id = act[u] ? cand_id[c[u]] : 0u;
+            rowb[u] = ix.rows + (uint64_t)id * ix.row_stride;
+        }
+        float out[U];
         if constexpr (!S::kInt) {
-            const RT* rows[1] = {reinterpret_cast<const RT*>(ix.rows + (uint64_t)id * ix.row_stride)};
-            const bool act[1] = {act1};
-            float out[1];
-            group_distance_pre<S::NACC, OP, DIM, 1>(xq, rows, act, v, out);
-            if (act1 && v == 0) cand_d[c] = post_op<OP, NORM>(out[0]);
+            const RT* rows[U] = {reinterpret_cast<const RT*>(rowb[0]), reinterpret_cast<const RT*>(rowb[1])};
+            group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, out);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (act[u] && v == 0) cand_d[c[u]] = post_op<OP, NORM>(out[u]);
         } else {
-            const uint8_t* rows[1] = {ix.rows + (uint64_t)id * ix.row_stride};
-            float out[1];
-            group_distance_int_pre<OP, DT == DT_I8, 1>(xqi, xx_pre, rows, v, out);
-            if (act1 && v == 0) cand_d[c] = finish_distance<DT, OP, NORM>(out[0], qs, rows[0], ix.dim, sqp);
+            const uint8_t* rows[U] = {rowb[0], rowb[1]};
+            group_distance_int_pre<OP, DT == DT_I8, U>(xqi, xx_pre, rows, v, out);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (act[u] && v == 0) cand_d[c[u]] = finish_distance<DT, OP, NORM>(out[u], qs, rows[u], ix.dim, sqp);
         }
     }
 }
@@ -223,10 +285,12 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qbytes = kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u;
-    const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, QS * kWave, qbytes);
+    const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, QS * kWave, qbytes, true);
     const uint8_t* qs = smem + L.q_off;
-    const uint32_t* cand_id = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off);
-    float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
+    // the two candidate buffers sit one fixed stride apart; addressing them as base + buffer * stride (never through a
+    // table of pointers) keeps every access an LDS instruction -- a selected pointer decays to a flat address, whose
+    // loads also wait for the global-memory counter
+    const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
     const uint32_t* beam = reinterpret_cast<const uint32_t*>(smem + L.beam_off);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     __syncthreads();  // the query is staged
@@ -244,9 +308,12 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     }
     for (;;) {
         __syncthreads();  // candidates ready (or release)
-        const uint32_t nc = beam[1];
-        if (nc == kTeamExit) break;
-        team_gather_share<DT, OP, NORM, DIM, TEAM>(ix, wave, nc, cand_id, cand_d, xq, xqi, xx_pre, qs, sqp, g, v);
+        const uint32_t word = beam[1];
+        if (word == kTeamExit) break;
+        const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
+        team_gather_share<DT, OP, NORM, DIM, TEAM - 1>(
+            ix, wave - 1u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
+            reinterpret_cast<float*>(smem + L.cand_d_off + buf * cstride), xq, xqi, xx_pre, qs, sqp, g, v);
         __syncthreads();  // distances ready
     }
 }
@@ -292,11 +359,17 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t qbytes = DIM > 0 ? (kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u)
                                     : query_lds_bytes(ix);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
-    const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes);
+    const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes, TEAM > 1);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
     float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
+    // teams: the two candidate buffers and which one the current hop uses (wave 0 swaps after a successful speculation)
+    // (base + buffer * stride, never a table of pointers: see team_helper)
+    const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
+    uint32_t cur = 0;
+    uint32_t spec_node = kEmpty, spec_nc = 0, spec_new = 0, spec_slot = 0;
+    bool spec_isnew = false;
     uint2* stage = reinterpret_cast<uint2*>(smem + L.stage_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     float* snew = reinterpret_cast<float*>(smem + L.snew_off);
@@ -363,7 +436,40 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         qd[s] = 0.0f;
     }
     uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
-    uint32_t pf_node = kEmpty, pf_len = 0, pf_val = kEmpty, node0 = kEmpty;
+    // adjacency rows requested ahead of their use: the node, its row's first dwords per lane (lane 0: the length) and
+    // neighbour `lane`.  pf_*: the best unexpanded queue entry; nb_*: (teams) a new candidate that overtook it.  The
+    // length stays in a vector register until it is needed -- a scalar copy would wait for the load on the spot -- and
+    // the two requests never share a variable, so no register copy (and its wait) appears where their paths join.
+    uint32_t pf_node = kEmpty, pf_lenv = 0, pf_val = kEmpty, node0 = kEmpty;
+    uint32_t nb_node = kEmpty;
+    auto adj_fetch = [&](uint32_t node, uint32_t& lenv, uint32_t& val) {
+        const uint32_t* prow = ix.adj + (uint64_t)node * ix.adj_stride;
+        lenv = prow[lane <= R ? lane : R];  // (max_degree >= 1; the same cache lines as the neighbours)
+        val = prow[1u + (lane < R ? lane : R - 1u)];
+    };
+    auto adj_len = [&](uint32_t lenv) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)lenv, 0); };
+    // teams: the same requests, but the row lands in LDS (buffer 0: pf_node's, buffer 1: nb_node's) through
+    // global_load_lds_dword: lane l's dword goes to M0 + 4 l.  No register is written, so the compiler has nothing to
+    // copy or to wait for while the load is in flight -- wave 0 merges in the meantime -- and the consumer waits
+    // explicitly (adj_landed).  One instruction covers the length and max_degree <= 63 neighbours (teams require it).
+    auto adj_fetch_lds = [&](uint32_t node, uint32_t which) {
+        const uint32_t* p = ix.adj + (uint64_t)node * ix.adj_stride + (lane <= R ? lane : R);
+        const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(
+            __attribute__((address_space(3))) uint8_t*)(smem + L.adj_off + which * kAdjLandBytes));
+        uint32_t m0_saved;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "global_load_lds_dword %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0_saved)
+            : "v"(p), "s"(lds)
+            : "memory");
+    };
+    auto adj_landed = [&](uint32_t which) -> const uint32_t* {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return reinterpret_cast<const uint32_t*>(smem + L.adj_off + which * kAdjLandBytes);
+    };
     uint32_t pf_dummy = 0;  // landing register of the row-prefetch loads (latency mode)
     bool lds_open = true;
 #ifdef DANN_PHASE_CYCLES
@@ -401,20 +507,90 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         return added;
     };
 
+    // row prefetch of the latency regime: one dword per 128-byte line of row `id`, all landing in one scratch register
+    // nothing ever reads (see the beam loop)
+    auto touch_row = [&](uint32_t id, bool on) {
+        if (on) {
+            const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
+            const uint32_t last = ix.layer_bytes - 4u;
+            const uint8_t* p1 = prow + (128u < last ? 128u : last);
+            const uint8_t* p2 = prow + (256u < last ? 256u : last);
+            const uint8_t* p3 = prow + (384u < last ? 384u : last);
+            const uint8_t* p4 = prow + last;
+            asm volatile(
+                "global_load_dword %0, %1, off\n\t"
+                "global_load_dword %0, %2, off\n\t"
+                "global_load_dword %0, %3, off\n\t"
+                "global_load_dword %0, %4, off\n\t"
+                "global_load_dword %0, %5, off"
+                : "+v"(pf_dummy)  // read-write: the register stays reserved around the whole loop, so a load that
+                                  // lands late never finds it holding something else
+                : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4));
+        }
+    };
+    bool spec_touched = false;
+
     // distance of every candidate in cand_id[0..nc) -> cand_d.  Stores with inline tags (ix.tag_off, store.rs:133-158):
     // the tag byte of each row is requested together with the row (no extra round trip), an unreadable slot
     // (tag < PUBLISHED) is marked kEmpty and compacted away afterwards -- expand_beam_inner skips it after the
     // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
     const uint32_t tag_off = PLAIN ? 0u : ix.tag_off;
+    // teams: wave 0 hands cand_id[0..nc) of the current buffer to the helper waves ("candidates ready")
+    auto team_start = [&](uint32_t nc) {
+        if (lane == 0) beam[1] = nc | (cur << 16);
+        __syncthreads();
+    };
+    // teams: while the helper waves evaluate the current hop's candidates, wave 0 runs the visited filter of the node
+    // the next hop will most likely expand (pf_node: the best unexpanded queue entry, its adjacency row requested just
+    // before) into the other candidate buffer.  If that node is indeed expanded next, the hop starts with its
+    // candidates in place; if not, the inserts are taken back (every insert filled an empty slot: setting those slots
+    // to kEmpty again restores the table exactly) and the hop expands normally.  The visited *set* a search ends with
+    // does not depend on the order of inserts.
+    auto speculate = [&]() {
+        spec_node = kEmpty;
+        spec_touched = false;
+        if (pf_node != kEmpty && lds_open && !(a.tune & kTuneNoSpeculation)) {
+            const uint32_t* row = adj_landed(0);
+            const uint32_t plen = row[0];
+            const uint32_t len = plen < R ? plen : R;
+            pf_val = row[1u + (lane < R ? lane : R - 1u)];  // (kept for the row prefetch below)
+            pf_lenv = plen;
+            if (ht_count + len <= ht_mod - (ht_mod >> 2)) {  // (expand() would not have to freeze the table)
+                const uint32_t id = lane < len ? pf_val : kEmpty;
+                const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &spec_slot);
+                const bool keep = isnew && id < ix.nslots;
+                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                if (keep) reinterpret_cast<uint32_t*>(smem + L.cand_id_off + (cur ^ 1u) * cstride)[mbcnt(km)] = id;
+                spec_node = pf_node;
+                spec_nc = (uint32_t)__popcll(km);
+                spec_new = (uint32_t)__popcll(nm);
+                spec_isnew = isnew;
+                // latency regime: request the rows of exactly these candidates now, a whole gather ahead of the
+                // hop that evaluates them
+                if ((a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u) {
+                    touch_row(id, keep);
+                    spec_touched = true;
+                }
+            }
+        }
+    };
+    auto spec_rollback = [&]() {
+        if (spec_isnew) ht[spec_slot] = kEmpty;
+        spec_node = kEmpty;
+        WS();
+    };
+    auto spec_commit = [&]() -> uint32_t {  // the speculated node is the one expanded: its candidates are in the other buffer
+        cur ^= 1u;
+        cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + cur * cstride);
+        cand_d = reinterpret_cast<float*>(smem + L.cand_d_off + cur * cstride);
+        ht_count += spec_new;
+        spec_node = kEmpty;
+        return spec_nc;
+    };
     auto gather = [&](uint32_t nc) -> uint32_t {
         if constexpr (TEAM > 1) {
-            // candidates ready -> every wave evaluates its share (wave 0: rows [c0, c0 + GROUPS) of every block of
-            // TEAM * GROUPS) -> distances ready
-            if (lane == 0) beam[1] = nc;
-            __syncthreads();
-            team_gather_share<DT, OP, NORM, DIM, TEAM>(ix, 0u, nc, cand_id, cand_d, xq, xqi, xx_pre,
-                                                       reinterpret_cast<const uint8_t*>(qs), sqp, g, v);
-            __syncthreads();
+            team_start(nc);
+            __syncthreads();  // "distances ready"
             return nc;
         } else
         if constexpr (DIM > 0 && !kInt) {
@@ -553,12 +729,21 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // than its last element can be dropped up front (queue.rs:142-146), (2) a surviving
     // candidate j lands at  #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)},
     // (3) an old element e moves up by #{surviving j: d_j <= d_e}.
-    auto merge = [&](uint32_t m0, uint32_t n) {
-        bool has = lane < n;
-        float nd = has ? cand_d[m0 + lane] : 0.0f;
-        uint32_t nid = has ? cand_id[m0 + lane] : kEmpty;
+    // (the candidates in registers: lane j holds candidate j of n; cbi / cbd: n words each of LDS the slow path may use
+    // to compact the survivors -- the candidates' own buffer)
+    // distance of queue entry p (wave-uniform), from the registers
+    auto queue_dist = [&](uint32_t p) -> float {
+        float r = 0.0f;
+#pragma unroll
+        for (int s = 0; s < QS; ++s)
+            if ((p >> 6) == (uint32_t)s)
+                r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), (int)(p & 63u)));
+        return r;
+    };
+    bool stage_stale = false;  // the LDS image of the queue is behind the registers (only the slow path reads it)
+    auto merge_regs = [&](bool has, float nd, uint32_t nid, const uint32_t n, uint32_t* cbi, float* cbd) {
         bool nvalid = has && !(nd != nd);  // NaN distances are ignored (queue.rs:131-134)
-        if (size == qcap && qcap > 0) nvalid = nvalid && !(stage_dist(size - 1) < nd);
+        if (size == qcap && qcap > 0) nvalid = nvalid && !(queue_dist(size - 1) < nd);
         const uint64_t km = ballot64(nvalid);
         const uint32_t nv = (uint32_t)__popcll(km);
 #ifdef DANN_PHASE_CYCLES
@@ -568,6 +753,44 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
 #endif
         if (nv == 0) return;
         PH_T(phm0);
+        if (QS <= 4 && nv <= kSeqInsert) {
+            // a few survivors (the steady state of a full queue): the sequential inserts themselves, in emission order,
+            // on the register-resident queue.  The lower bound is a ballot count; "move the tail up by one" is a DPP
+            // wave shift per slot, lane 63 of one slot carried into lane 0 of the next.  No LDS, no cross-lane
+            // round trip.  (Entries at or beyond `size` hold don't-care values, as everywhere.)
+            for (uint64_t mm = km; mm; mm &= mm - 1) {
+                const int j = __builtin_ctzll(mm);
+                const int dj_bits = __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), j);
+                const float dj = __builtin_bit_cast(float, dj_bits);
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nid, j);
+                uint32_t pos = 0;
+#pragma unroll
+                for (int s = 0; s < QS; ++s)
+                    pos += (uint32_t)__popcll(ballot64(((uint32_t)(s * kWave) + lane < size) && qd[s] < dj));
+                if (pos >= qcap) continue;  // behind a full queue's last entry (it was equal to it when tested, not any more)
+#pragma unroll
+                for (int s = QS - 1; s >= 0; --s) {
+                    const uint32_t p = (uint32_t)(s * kWave) + lane;
+                    // lane l <- lane l - 1; lane 0 <- lane 63 of the slot below (the `old` operand of the DPP move)
+                    const int cd = s > 0 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s > 0 ? s - 1 : 0]), 63) : 0;
+                    const int ci = s > 0 ? __builtin_amdgcn_readlane((int)qid[s > 0 ? s - 1 : 0], 63) : 0;
+                    const int sd = __builtin_amdgcn_update_dpp(cd, __builtin_bit_cast(int, qd[s]), 0x138, 0xf, 0xf, false);
+                    const int si = __builtin_amdgcn_update_dpp(ci, (int)qid[s], 0x138, 0xf, 0xf, false);
+                    if (p > pos) {
+                        qd[s] = __builtin_bit_cast(float, sd);
+                        qid[s] = (uint32_t)si;
+                    } else if (p == pos) {
+                        qd[s] = dj;
+                        qid[s] = idj;
+                    }
+                }
+                size = size < qcap ? size + 1u : qcap;
+            }
+            stage_stale = true;
+            PH_T(phm1s);
+            PH_ADD(11, phm0, phm1s);
+            return;
+        }
         uint32_t shift[QS];
         uint32_t pos_new = 0;
         if (QS <= 4 && nv <= kRegMerge) {
@@ -609,17 +832,25 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             __builtin_amdgcn_wave_barrier();  // one wave: LDS accesses retire in program order
             pos_new = nvalid ? slot[before] : 0u;
         } else {
+        if (stage_stale) {  // the lower-bound search below reads the queue's LDS image
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t p = (uint32_t)(s * kWave) + lane;
+                if (p < size) stage[p] = make_uint2(qid[s], __builtin_bit_cast(uint32_t, qd[s]));
+            }
+            WS();
+        }
         if (nv != n) {  // compact the survivors, emission order preserved
             const uint32_t cj = mbcnt(km);
             WS();
             if (nvalid) {
-                cand_d[m0 + cj] = nd;
-                cand_id[m0 + cj] = nid;
+                cbd[cj] = nd;
+                cbi[cj] = nid;
             }
             WS();
             has = lane < nv;
-            nd = has ? cand_d[m0 + lane] : 0.0f;
-            nid = has ? cand_id[m0 + lane] : kEmpty;
+            nd = has ? cbd[lane] : 0.0f;
+            nid = has ? cbi[lane] : kEmpty;
         }
         // rank among the survivors
         uint32_t before = 0;
@@ -663,6 +894,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if (has && pos_new < qcap) stage[pos_new] = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
         const uint32_t total = size + nv;
         size = total < qcap ? total : qcap;
+        stage_stale = false;
         WS();
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
@@ -673,6 +905,10 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 qd[s] = __builtin_bit_cast(float, e.y);
             }
         }
+    };
+    auto merge = [&](uint32_t m0, uint32_t n) {
+        const bool has = lane < n;
+        merge_regs(has, has ? cand_d[m0 + lane] : 0.0f, has ? cand_id[m0 + lane] : kEmpty, n, cand_id + m0, cand_d + m0);
     };
 
     // expand `nb` nodes of beam[]: adjacency rows in pop order, ids in stored order, visited filter
@@ -685,10 +921,15 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const uint32_t node = node_in_reg ? node0 : beam[b];  // the main loop's single pop stays in a register
             const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
             const bool hit = (node == pf_node);
+            const bool hit2 = TEAM > 1 && !hit && (node == nb_node);
 #ifdef DANN_PHASE_CYCLES
             ph_acc[hit ? 5 : 6] += 1;
 #endif
-            uint32_t len = hit ? pf_len : arow[0];
+            const uint32_t* landed = nullptr;
+            if constexpr (TEAM > 1) {
+                if (hit || hit2) landed = adj_landed(hit ? 0u : 1u);
+            }
+            uint32_t len = TEAM > 1 ? ((hit || hit2) ? landed[0] : arow[0]) : (hit ? adj_len(pf_lenv) : arow[0]);
             len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
             if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
                 // freeze the LDS table, claim a spill table (kept once claimed)
@@ -721,7 +962,9 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
                 const uint32_t j = j0 + lane;
                 const bool inb = j < len;
-                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
+                uint32_t id;
+                if constexpr (TEAM > 1) id = !inb ? kEmpty : (hit || hit2) ? landed[1 + j] : arow[1 + j];
+                else id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
                 const bool act = inb && id != kEmpty && (!accept_only || fmatch(id));
                 if (lds_open) {
@@ -764,44 +1007,185 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
 
     uint32_t* const rec_i = a.rec_ids ? a.rec_ids + (uint64_t)qi * a.rec_stride : nullptr;  // wave-uniform
     float* const rec_d = a.rec_ids ? a.rec_dists + (uint64_t)qi * a.rec_stride : nullptr;
+    // W == 1 pop (queue.rs:297-313), one scan: the first unexpanded entry is popped (node0: kept in a register, no LDS
+    // round trip); the second one (pf_next, distance pf_next_d) is the node the next hop will expand unless a new
+    // candidate gets in front of it, the third one (pf_next2) the node after that
+    auto pop_one = [&](uint32_t& pf_next, float& pf_next_d, uint32_t& pf_next2, float& pf_next2_d) -> uint32_t {
+        uint32_t got = 0;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            if (got >= 3u) continue;
+            const bool cand = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
+            uint64_t m = ballot64(cand);
+            if (got == 0u && m) {
+                const int l = __builtin_ctzll(m);
+                const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l);
+                if ((int)lane == l) qid[s] |= kVisitedBit;
+                node0 = id;
+                if (rec_i) {  // VisitedSearchRecord::record (search/record.rs:86-93)
+                    if (nrec < a.rec_stride) {
+                        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l));
+                        if (lane == 0) {
+                            rec_i[nrec] = id;
+                            rec_d[nrec] = d;
+                        }
+                    } else {
+                        status = (uint32_t)(-DANN_EOVERFLOW);
+                    }
+                    ++nrec;
+                }
+                got = 1;
+                m &= m - 1;
+            }
+            if (got == 1u && m) {
+                const int l2 = __builtin_ctzll(m);
+                pf_next = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l2);
+                pf_next_d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l2));
+                got = 2;
+                m &= m - 1;
+            }
+            if (got == 2u && m) {
+                const int l3 = __builtin_ctzll(m);
+                pf_next2 = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l3);
+                pf_next2_d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l3));
+                got = 3;
+            }
+        }
+        return got ? 1u : 0u;
+    };
+    // ---- beam loop, a team of wavefronts -------------------------------------------------------------------------
+    // The hop's dependent chain is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  With
+    // helper waves evaluating the rows, wave 0 takes the merge, the visited filter and the adjacency row off that chain:
+    //  * while the helpers evaluate hop h, wave 0 filters the neighbours of pf_next (the best unexpanded entry left in
+    //    the queue) into the other candidate buffer (speculate());
+    //  * when hop h's distances are ready, comparisons against pf_next and pf_next2 decide, *before* the merge, which
+    //    node hop h + 1 expands and which node will be the best unexpanded entry after that: hop h + 1 expands pf_next
+    //    unless a new candidate is at most as far (lower-bound insert, queue.rs:150-170: it goes in front; of equal new
+    //    candidates the one inserted last goes first).  If it is pf_next, the helpers start on its candidates at once;
+    //    if it is a new candidate, its adjacency row is requested at once.  The adjacency row of the predicted
+    //    runner-up is requested too, and only then does the merge of hop h run -- beside the helpers' gather and the
+    //    adjacency loads.
+    // The queue, the visited set and the order of expansions are exactly those of the one-wave loop: the early decisions
+    // only predict what the pop after the merge returns (an early start that the pop contradicts is an internal error;
+    // a runner-up the pop contradicts just costs the next hop its speculation).
+    if constexpr (TEAM > 1) {
+        // argmin over the lanes of `on` by (distance ascending, lane descending); `on` must not be empty
+        auto best_lane = [&](bool on, float d) -> int {
+            const float m = wave_min_f32(on ? d : __builtin_inff());
+            return 63 - __builtin_clzll(ballot64(on && d == m));
+        };
+        uint32_t nc_cur = 0, early_node = kEmpty;
+        uint32_t pf_next = kEmpty, pf_next2 = kEmpty;
+        float pf_next_d = 0.0f, pf_next2_d = 0.0f;
+        bool started = false;  // the helpers already evaluate the candidates of the node the next pop returns
+        bool running = false;  // the helpers evaluate a hop (between "candidates ready" and "distances ready")
+        if (pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d) && !status) {
+            hops += 1;
+            nc_cur = expand(1, false, true);
+            if (!status) {
+                team_start(nc_cur);
+                running = true;
+                pf_node = pf_next;
+                if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
+            }
+        }
+        while (running) {
+            PH_T(ph2);
+            speculate();
+            if ((a.tune & kTuneRowPrefetch) && pf_node != kEmpty && ix.layer_bytes <= 512u && !spec_touched) {
+                const uint32_t* row = adj_landed(0);
+                const uint32_t plen = row[0];
+                const uint32_t v = row[1u + (lane < R ? lane : R - 1u)];
+                touch_row(v, lane < (plen < R ? plen : R) && v < ix.nslots);
+            }
+            PH_T(pg2);
+            PH_ADD(13, ph2, pg2);
+            __syncthreads();  // "distances ready"
+            running = false;
+            PH_T(ph3);
+            PH_ADD(14, pg2, ph3);
+            PH_ADD(2, ph2, ph3);
+            const uint32_t nc = nc_cur;
+            cmps += nc;
+            const bool has = lane < nc;
+            const float nd = has ? cand_d[lane] : 0.0f;
+            const uint32_t nid = has ? cand_id[lane] : kEmpty;
+            uint32_t* const cbi = cand_id;  // (this hop's buffer: the helpers move on to the other one)
+            float* const cbd = cand_d;
+            started = false;
+            uint32_t pred = kEmpty;  // the predicted best unexpanded entry after the next pop
+            bool keep_pf = false;    // pf_* already hold (or were asked for) the row the next steps need
+            if (pf_next != kEmpty) {
+                const bool ahead = has && nd <= pf_next_d;  // (a NaN distance never enters the queue)
+                if (ballot64(ahead) == 0) {
+                    if (spec_node == pf_next) {  // hop h + 1 expands pf_next, and its candidates are ready
+                        nc_cur = spec_commit();
+                        team_start(nc_cur);
+                        started = running = true;
+                        early_node = pf_next;
+                        if (pf_next2 != kEmpty) {
+                            const bool ahead2 = has && nd <= pf_next2_d;
+                            pred = ballot64(ahead2) ? (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd))
+                                                    : pf_next2;
+                        }
+                    } else {
+                        keep_pf = pf_node == pf_next;  // no speculation ran: the next expansion reads pf_* itself
+                    }
+                } else {
+                    // hop h + 1 expands the closest new candidate
+                    if (spec_node != kEmpty) spec_rollback();
+                    const int bj = best_lane(ahead, nd);
+                    nb_node = (uint32_t)__builtin_amdgcn_readlane((int)nid, bj);
+                    adj_fetch_lds(nb_node, 1);
+                    const bool rest = ahead && (int)lane != bj;
+                    if (ballot64(rest)) pred = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(rest, nd));
+                    else keep_pf = pf_node == pf_next;  // pf_next stays the runner-up, its row is here already
+                }
+            } else if (spec_node != kEmpty) {
+                spec_rollback();  // (cannot happen: nothing is speculated without a pf_next)
+            }
+            if (pred != kEmpty) {
+                pf_node = pred;
+                adj_fetch_lds(pred, 0);
+            } else if (!keep_pf) {
+                pf_node = kEmpty;
+            }
+            merge_regs(has, nd, nid, nc, cbi, cbd);
+            PH_T(ph4);
+            PH_ADD(3, ph3, ph4);
+            pf_next = pf_next2 = kEmpty;
+            const uint32_t nb = pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d);
+            if (nb == 0 || status) break;
+            hops += 1;
+            PH_T(ph5);
+            PH_ADD(0, ph4, ph5);
+            if (started) {
+                if (node0 != early_node) status = (uint32_t)(-DANN_EINTERNAL);
+            } else {
+                nc_cur = expand(1, false, true);  // (adjacency row: pf_* or nb_* if the node is theirs)
+                if (status) break;
+                team_start(nc_cur);
+                running = true;
+            }
+            nb_node = kEmpty;
+            if (pf_node != pf_next) pf_node = kEmpty;  // the runner-up is another node: no speculation this hop
+            PH_T(ph6);
+            PH_ADD(1, ph5, ph6);
+            PH_ADD(4, ph2, ph6);
+        }
+        if (running) __syncthreads();  // (the helpers are on their way to "distances ready")
+    } else
     // ---- beam loop ----------------------------------------------------------------------
     for (;;) {
         PH_T(ph0);
         // pop up to W closest unexpanded entries (queue.rs:297-313)
         uint32_t nb = 0;
         uint32_t pf_next = kEmpty;  // W == 1: the best entry still unexpanded after this pop (the prefetch target)
+        float pf_next_d = 0.0f;
         if (W == 1) {
-            // one scan: the first unexpanded entry is popped (kept in a register, no LDS round trip), the second one
-            // is the node the next hop will expand unless a new candidate beats it
-            bool found = false;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                if (pf_next != kEmpty) continue;
-                const bool cand = ((uint32_t)(s * kWave) + lane < size) && !(qid[s] & kVisitedBit);
-                uint64_t m = ballot64(cand);
-                if (!found && m) {
-                    const int l = __builtin_ctzll(m);
-                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], l);
-                    if ((int)lane == l) qid[s] |= kVisitedBit;
-                    node0 = id;
-                    if (rec_i) {  // VisitedSearchRecord::record (search/record.rs:86-93)
-                        if (nrec < a.rec_stride) {
-                            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s]), l));
-                            if (lane == 0) {
-                                rec_i[nrec] = id;
-                                rec_d[nrec] = d;
-                            }
-                        } else {
-                            status = (uint32_t)(-DANN_EOVERFLOW);
-                        }
-                        ++nrec;
-                    }
-                    nb = 1;
-                    found = true;
-                    m &= m - 1;
-                }
-                if (found && m) pf_next = (uint32_t)__builtin_amdgcn_readlane((int)qid[s], __builtin_ctzll(m));
-            }
+            uint32_t pf_next2 = kEmpty;
+            float pf_next2_d = 0.0f;
+            nb = pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d);
         } else
         for (uint32_t w = 0; w < W; ++w) {
             bool found = false;
@@ -849,11 +1233,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         pf_node = kEmpty;
         if (PLAIN || (W == 1 && R <= (uint32_t)kWave)) {
             pf_node = pf_next;
-            if (pf_node != kEmpty) {
-                const uint32_t* prow = ix.adj + (uint64_t)pf_node * ix.adj_stride;
-                pf_len = prow[0];
-                pf_val = lane < R ? prow[1 + lane] : kEmpty;
-            }
+            if (pf_node != kEmpty) adj_fetch(pf_node, pf_lenv, pf_val);
         }
         const uint32_t nc = gather(nc_seen);
         // latency mode (few queries in flight, bandwidth to spare): touch the rows of the predicted next node's
@@ -863,23 +1243,8 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         // that hop's gather has drained the in-order load queue; the loop exit drains it explicitly).
         asm volatile("" ::"v"(pf_dummy));
         if ((a.tune & kTuneRowPrefetch) && pf_node != kEmpty && ix.layer_bytes <= 512u) {
-            const uint32_t plen = pf_len < R ? pf_len : R;
-            if (lane < plen && pf_val < ix.nslots) {
-                const uint8_t* prow = ix.rows + (uint64_t)pf_val * ix.row_stride;
-                const uint32_t last = ix.layer_bytes - 4u;
-                const uint8_t* p1 = prow + (128u < last ? 128u : last);
-                const uint8_t* p2 = prow + (256u < last ? 256u : last);
-                const uint8_t* p3 = prow + (384u < last ? 384u : last);
-                const uint8_t* p4 = prow + last;
-                asm volatile(
-                    "global_load_dword %0, %1, off\n\t"
-                    "global_load_dword %0, %2, off\n\t"
-                    "global_load_dword %0, %3, off\n\t"
-                    "global_load_dword %0, %4, off\n\t"
-                    "global_load_dword %0, %5, off"
-                    : "=&v"(pf_dummy)
-                    : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4));
-            }
+            const uint32_t plen = adj_len(pf_lenv);
+            touch_row(pf_val, lane < (plen < R ? plen : R) && pf_val < ix.nslots);
         }
         WS();
         PH_T(ph3);

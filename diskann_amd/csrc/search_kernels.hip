@@ -51,7 +51,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 
 size_t search_lds_bytes(const SearchArgs& a) {
     const uint32_t qcap = std::max(a.l_value + a.ix.nstart, a.qcap_max);
-    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix)).total;
+    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix), a.team != 0).total;
 }
 
 // ---- sizing of the LDS visited table ---------------------------------------------------------
@@ -192,6 +192,20 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     a.spill_bits = ctx.spill_bits;
     a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
     DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
+    // latency regime with at most one query per SIMD: a team of wavefronts per query (the rows of a hop split over the
+    // helper waves, wave 0 expands the predicted next node meanwhile).  Knn searches only (the launch falls back to one
+    // wave per query where no team instantiation exists).  Decided before the table is sized: teams carry a second
+    // candidate buffer.  DANN_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_TEAM_MAX_QUERIES: development switches.
+    {
+        static const uint32_t team_max = [] {
+            const char* e = getenv("DANN_TEAM_MAX_QUERIES");
+            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
+        }();
+        const uint32_t limit = std::min<uint32_t>(team_max, 4u * idx->num_cus);
+        a.team = (inflight <= limit && !a.grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && plain_mode(a) &&
+                  a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !tune_env(4)) ? 1u : 0u;
+        if (tune_env(8)) a.tune |= kTuneNoSpeculation;
+    }
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = calib_key(a);
     // calibration state of this (L, beam, mode) -- shared by concurrent callers: read and written under stat_mu
@@ -242,17 +256,6 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         const char* e = getenv("DANN_TUNE_ON");
         if (e && (strtoul(e, nullptr, 0) & 1u)) a.tune |= kTuneRowPrefetch;
     }
-    // ... and with at most one query per SIMD the other wave slots are idle: a team of wavefronts per query (the rows of
-    // a hop split four ways).  Knn searches only (the launch falls back to one wave per query where no team
-    // instantiation exists).  DANN_TUNE_OFF bit 4 / DANN_TEAM_MAX_QUERIES: development switches.
-    {
-        static const uint32_t team_max = [] {
-            const char* e = getenv("DANN_TEAM_MAX_QUERIES");
-            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
-        }();
-        const uint32_t limit = std::min<uint32_t>(team_max, 4u * idx->num_cus);
-        a.team = (inflight <= limit && !a.grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && !tune_env(4)) ? 1u : 0u;
-    }
     return DANN_OK;
 }
 
@@ -295,6 +298,7 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     const uint64_t key = calib_key(a);
     if (int32_t prc = prepare_launch(idx, ctx, a, inflight)) return prc;
     cap_grid(a);  // (the counter lives behind the spill pool prepare_launch has just attached)
+    if (a.grid) a.team = 0;  // persistent waves over a block: one wave per query
     volatile uint32_t* hflag = ctx.h_flag;
     *hflag = 0;
     a.fail_flag = ctx.h_flag;

@@ -68,7 +68,8 @@ enum {
     DANN_EHIP = -5,      /* a HIP runtime call failed; see dann_last_error()          */
     DANN_ENOMEM = -6,
     DANN_EOVERFLOW = -7, /* per-query scratch (visited table / record) exhausted      */
-    DANN_EUNSUPPORTED = -8
+    DANN_EUNSUPPORTED = -8,
+    DANN_EINTERNAL = -9  /* a consistency check inside a kernel failed (a bug, never an input)  */
 } /* dann_status */;
 
 typedef struct dann_index dann_index; /* == diskann_inmem::Provider<Full<T>, _> + DiskANNIndex */

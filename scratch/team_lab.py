@@ -47,7 +47,7 @@ def timed(nq, L, reps):
 
 
 out = {}
-for label, env in (("team", None), ("one_wave", "4"), ("team", None), ("one_wave", "4")):
+for label, env in (("team_spec", None), ("team_nospec", "8"), ("one_wave", "4"), ("team_spec", None), ("team_nospec", "8"), ("one_wave", "4")):
     if env is None:
         os.environ.pop("DANN_TUNE_OFF", None)
     else:

@@ -265,23 +265,28 @@ def test_spill_tables_recycled_under_load():
 def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric, monkeypatch):
     """Latency regime: launches with few queries give every query a team of wavefronts (the rows of a hop split four
     ways, everything else on wave 0).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query
-    launch's (DANN_TUNE_OFF bit 4 switches the teams off), with several start points and for every queue size the
-    team instantiations cover (L + start points <= 256) and beyond."""
+    launch's (DANN_TUNE_OFF bit 4 switches the teams off, bit 8 the speculative expansion of the predicted next node by
+    wave 0 -- visited-table inserts that are rolled back when the prediction fails), with several start points and for
+    every queue size the team instantiations cover (L + start points <= 256) and beyond; a small explicit visited table
+    makes searches freeze the LDS table and spill, where speculation must stand back."""
     rng = np.random.default_rng(777)
     n, dim, R, nstart = 6000, 128, 32, 3
     data = rand_vectors(rng, dtype, n, dim)
     adj = random_graph(rng, n, R, nstart=nstart)
     oix, gix = make_pair(dtype, metric, data, adj, data[:nstart], R)
-    for nq in (1, 7, 64):
+    for nq, vbits in ((1, 0), (7, 0), (64, 0), (33, 8)):
+        gix.set_visited_bits(vbits)   # 8: a 256-entry table -- freezes within a few hops
         queries = rand_vectors(rng, dtype, nq, dim)
         for L, k in ((1, 1), (10, 10), (26, 10), (64, 10), (125, 20), (253, 50), (300, 10)):
             oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
             monkeypatch.delenv("DANN_TUNE_OFF", raising=False)
-            gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)
+            gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)        # teams + speculative expansion of the predicted node
+            monkeypatch.setenv("DANN_TUNE_OFF", "8")
+            ni, nd, nst = gix.search(da.Knn(L, 1), queries, k)        # teams, no speculation
             monkeypatch.setenv("DANN_TUNE_OFF", "4")
-            si, sd, sst = gix.search(da.Knn(L, 1), queries, k)
+            si, sd, sst = gix.search(da.Knn(L, 1), queries, k)        # one wave per query
             monkeypatch.delenv("DANN_TUNE_OFF", raising=False)
-            for ids, d, st in ((gi, gd, gst), (si, sd, sst)):
+            for ids, d, st in ((gi, gd, gst), (ni, nd, nst), (si, sd, sst)):
                 assert np.array_equal(oi, ids), (nq, L)
                 assert np.array_equal(bits(od), bits(d)), (nq, L)
                 assert np.array_equal(ost[:, 0], st["cmps"]) and np.array_equal(ost[:, 1], st["hops"]), (nq, L)
