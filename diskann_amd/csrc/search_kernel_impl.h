@@ -21,7 +21,7 @@ constexpr int kGatherRows = 4;
 #endif
 constexpr int kWideRows = DANN_WIDE_ROWS;  // rows per lane group and trip in the wide (f16) gather
 constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
-constexpr uint32_t kSeqInsert = 8;  // survivors inserted one by one, the queue never leaving its registers
+constexpr uint32_t kSeqInsert = 2;  // survivors inserted one by one, the queue never leaving its registers
 constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
 constexpr uint32_t kTuneNoSpeculation = 2u;  // teams: no speculative expansion of the predicted next node
 constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
@@ -37,7 +37,7 @@ constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (disk
 
 constexpr uint32_t kAdjLandBytes = 256u;
 struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, cand2_id_off, cand2_d_off, adj_off, stage_off, snew_off, beam_off, q_off, total;
+    uint32_t ht_off, cand_id_off, cand_d_off, cand2_id_off, cand2_d_off, adj_off, slots_off, mscr_off, stage_off, snew_off, beam_off, q_off, total;
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -72,6 +72,12 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     // neighbours each; the loads write LDS directly, see adj_fetch_lds)
     l.adj_off = off;
     if (team) off += 2u * kAdjLandBytes;
+    // teams: the table slots of the visited wave's speculative inserts (wave 0 takes them back through these), and 64
+    // (id, distance) words of scratch for wave 0's merge (the candidate buffer it merges from is already being refilled)
+    l.slots_off = off;
+    if (team) off += 256u;
+    l.mscr_off = off;
+    if (team) off += 512u;
     l.stage_off = off;  // the queue image, (id, distance bits) pairs: every merge scatters the register-resident queue
     off += round16(qcap * 8u);  // here and reloads it (one 8-byte LDS access per entry).  One buffer is enough: nothing
                                 // is read from it between the first scatter write and the reload (ranks come from
@@ -237,6 +243,17 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 }
 
 constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (SearchLds beam[1])
+// the team's mailbox (SearchLds beam[], plain searches use none of it otherwise)
+enum : int {
+    kTwGather = 1,    // wave 0 -> gather waves: candidate count | buffer << 16, or kTeamExit
+    kTwSpecNode = 2,  // wave 0 -> visited wave: node whose neighbours to filter speculatively (kEmpty: none)
+    kTwHtCount = 3,   //   ids in the visited table
+    kTwSpecBuf = 4,   //   candidate buffer the survivors go to
+    kTwSpecRan = 5,   // visited wave -> wave 0: 1 if the filter ran
+    kTwSpecNc = 6,    //   candidates kept
+    kTwSpecNew = 7,   //   ids inserted
+};
+constexpr uint32_t kAdjPending = 0xFFFFFFFEu;  // "not landed yet" (never an id: ids stay below 2^31; never a length)
 // one helper wave's share of a team gather: the NW helper waves split every block of NW * GROUPS * 2 candidates, two
 // rows per lane group in flight (wave 0 does not gather: it expands the predicted next node meanwhile)
 template <int DT, int OP, bool NORM, int DIM, int NW>
@@ -306,13 +323,94 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
         xqi = *reinterpret_cast<const uint4*>(qs + 16 * v);
         xx_pre = group_norm_int_pre<DT == DT_I8>(xqi);
     }
+    if (wave == 1u) {
+        // ---- the visited wave: between "candidates ready" and "distances ready" it runs the visited filter of the node
+        // wave 0 names (the predicted next expansion) into the spare candidate buffer.  Wave 0 requested that node's
+        // adjacency row into landing buffer 0 (kAdjPending in every dword first); the row's arrival is seen by polling.
+        uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
+        uint32_t* const mail = reinterpret_cast<uint32_t*>(smem + L.beam_off);
+        const uint32_t* const landing = reinterpret_cast<const uint32_t*>(smem + L.adj_off);
+        uint32_t* const slots = reinterpret_cast<uint32_t*>(smem + L.slots_off);
+        const uint32_t ht_mod = a.ht_prime, R = ix.max_degree;
+        const bool touch = (a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u;
+        uint32_t pf_dummy = 0;
+        for (;;) {
+            __syncthreads();  // candidates ready (or release)
+            if (mail[kTwGather] == kTeamExit) break;
+            const uint32_t node = mail[kTwSpecNode];
+            uint32_t ran = 0, kept = 0, fresh = 0;
+            if (node != kEmpty) {
+                // wait for the row: first the length, then every neighbour slot below it
+                uint32_t len = kAdjPending, val = kAdjPending, spins = 0;
+                for (;;) {
+                    len = landing[0];
+                    val = landing[1u + (lane < R ? lane : R - 1u)];
+                    const uint32_t n = len == kAdjPending ? 0u : (len < R ? len : R);
+                    if (len != kAdjPending && ballot64(lane < n && val == kAdjPending) == 0) break;
+                    if (++spins > (1u << 16)) {  // (never observed; a speculation skipped costs nothing but time)
+                        len = kAdjPending;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (len != kAdjPending) {
+                    len = len < R ? len : R;
+                    if (mail[kTwHtCount] + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not freeze the table)
+                        const uint32_t id = lane < len ? val : kEmpty;
+                        uint32_t slot = 0;
+                        const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
+                        const bool keep = isnew && id < ix.nslots;
+                        const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                        uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + mail[kTwSpecBuf] * cstride);
+                        if (keep) out[mbcnt(km)] = id;
+                        slots[lane] = isnew ? slot : kEmpty;
+                        ran = 1;
+                        kept = (uint32_t)__popcll(km);
+                        fresh = (uint32_t)__popcll(nm);
+                        // latency regime: request the rows of exactly these candidates now, a whole gather ahead of
+                        // the hop that evaluates them (one dword per 128-byte line; nothing ever reads pf_dummy)
+                        if (touch && keep) {
+                            const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
+                            const uint32_t last = ix.layer_bytes - 4u;
+                            const uint8_t* p1 = prow + (128u < last ? 128u : last);
+                            const uint8_t* p2 = prow + (256u < last ? 256u : last);
+                            const uint8_t* p3 = prow + (384u < last ? 384u : last);
+                            const uint8_t* p4 = prow + last;
+                            // ... and its adjacency row, should the candidate be expanded straight away
+                            const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
+                            const uint32_t* a1 = a0 + R;
+                            asm volatile(
+                                "global_load_dword %0, %1, off\n\t"
+                                "global_load_dword %0, %2, off\n\t"
+                                "global_load_dword %0, %3, off\n\t"
+                                "global_load_dword %0, %4, off\n\t"
+                                "global_load_dword %0, %5, off\n\t"
+                                "global_load_dword %0, %6, off\n\t"
+                                "global_load_dword %0, %7, off"
+                                : "+v"(pf_dummy)
+                                : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+                mail[kTwSpecRan] = ran;
+                mail[kTwSpecNc] = kept;
+                mail[kTwSpecNew] = fresh;
+            }
+            __syncthreads();  // distances ready
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(pf_dummy));
+        return;
+    }
     for (;;) {
         __syncthreads();  // candidates ready (or release)
-        const uint32_t word = beam[1];
+        const uint32_t word = beam[kTwGather];
         if (word == kTeamExit) break;
         const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
-        team_gather_share<DT, OP, NORM, DIM, TEAM - 1>(
-            ix, wave - 1u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
+        team_gather_share<DT, OP, NORM, DIM, TEAM - 2>(
+            ix, wave - 2u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
             reinterpret_cast<float*>(smem + L.cand_d_off + buf * cstride), xq, xqi, xx_pre, qs, sqp, g, v);
         __syncthreads();  // distances ready
     }
@@ -368,8 +466,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // (base + buffer * stride, never a table of pointers: see team_helper)
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
     uint32_t cur = 0;
-    uint32_t spec_node = kEmpty, spec_nc = 0, spec_new = 0, spec_slot = 0;
-    bool spec_isnew = false;
+    uint32_t spec_node = kEmpty, spec_nc = 0, spec_new = 0;
     uint2* stage = reinterpret_cast<uint2*>(smem + L.stage_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     float* snew = reinterpret_cast<float*>(smem + L.snew_off);
@@ -456,8 +553,11 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         const uint32_t* p = ix.adj + (uint64_t)node * ix.adj_stride + (lane <= R ? lane : R);
         const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(
             __attribute__((address_space(3))) uint8_t*)(smem + L.adj_off + which * kAdjLandBytes));
+        // (buffer 0 is also read by the visited wave, which has no counter to wait on: it polls for the row)
+        if (which == 0u) reinterpret_cast<uint32_t*>(smem + L.adj_off)[lane] = kAdjPending;
         uint32_t m0_saved;
         asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
             "global_load_lds_dword %1, off\n\t"
@@ -528,54 +628,41 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4));
         }
     };
-    bool spec_touched = false;
 
     // distance of every candidate in cand_id[0..nc) -> cand_d.  Stores with inline tags (ix.tag_off, store.rs:133-158):
     // the tag byte of each row is requested together with the row (no extra round trip), an unreadable slot
     // (tag < PUBLISHED) is marked kEmpty and compacted away afterwards -- expand_beam_inner skips it after the
     // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
     const uint32_t tag_off = PLAIN ? 0u : ix.tag_off;
-    // teams: wave 0 hands cand_id[0..nc) of the current buffer to the helper waves ("candidates ready")
+    // teams: wave 0 hands cand_id[0..nc) of the current buffer to the gather waves ("candidates ready") and names the
+    // node whose neighbours the visited wave filters meanwhile: pf_node, the predicted next expansion, whose adjacency
+    // row wave 0 has requested into landing buffer 0.  If that node is indeed expanded next, the hop starts with its
+    // candidates in place (spec_commit); if not, the inserts are taken back (every insert filled an empty slot: setting
+    // those slots to kEmpty again restores the table exactly) and the hop expands normally.  The visited *set* a search
+    // ends with does not depend on the order of inserts.
+    uint32_t spec_sent = kEmpty;
     auto team_start = [&](uint32_t nc) {
-        if (lane == 0) beam[1] = nc | (cur << 16);
+        spec_sent = (pf_node != kEmpty && lds_open && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
+        if (lane == 0) {
+            beam[kTwGather] = nc | (cur << 16);
+            beam[kTwSpecNode] = spec_sent;
+            beam[kTwHtCount] = ht_count;
+            beam[kTwSpecBuf] = cur ^ 1u;
+        }
         __syncthreads();
     };
-    // teams: while the helper waves evaluate the current hop's candidates, wave 0 runs the visited filter of the node
-    // the next hop will most likely expand (pf_node: the best unexpanded queue entry, its adjacency row requested just
-    // before) into the other candidate buffer.  If that node is indeed expanded next, the hop starts with its
-    // candidates in place; if not, the inserts are taken back (every insert filled an empty slot: setting those slots
-    // to kEmpty again restores the table exactly) and the hop expands normally.  The visited *set* a search ends with
-    // does not depend on the order of inserts.
-    auto speculate = [&]() {
+    // after "distances ready": what the visited wave did
+    auto spec_collect = [&]() {
         spec_node = kEmpty;
-        spec_touched = false;
-        if (pf_node != kEmpty && lds_open && !(a.tune & kTuneNoSpeculation)) {
-            const uint32_t* row = adj_landed(0);
-            const uint32_t plen = row[0];
-            const uint32_t len = plen < R ? plen : R;
-            pf_val = row[1u + (lane < R ? lane : R - 1u)];  // (kept for the row prefetch below)
-            pf_lenv = plen;
-            if (ht_count + len <= ht_mod - (ht_mod >> 2)) {  // (expand() would not have to freeze the table)
-                const uint32_t id = lane < len ? pf_val : kEmpty;
-                const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &spec_slot);
-                const bool keep = isnew && id < ix.nslots;
-                const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                if (keep) reinterpret_cast<uint32_t*>(smem + L.cand_id_off + (cur ^ 1u) * cstride)[mbcnt(km)] = id;
-                spec_node = pf_node;
-                spec_nc = (uint32_t)__popcll(km);
-                spec_new = (uint32_t)__popcll(nm);
-                spec_isnew = isnew;
-                // latency regime: request the rows of exactly these candidates now, a whole gather ahead of the
-                // hop that evaluates them
-                if ((a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u) {
-                    touch_row(id, keep);
-                    spec_touched = true;
-                }
-            }
+        if (spec_sent != kEmpty && beam[kTwSpecRan]) {
+            spec_node = spec_sent;
+            spec_nc = beam[kTwSpecNc];
+            spec_new = beam[kTwSpecNew];
         }
     };
     auto spec_rollback = [&]() {
-        if (spec_isnew) ht[spec_slot] = kEmpty;
+        const uint32_t slot = reinterpret_cast<const uint32_t*>(smem + L.slots_off)[lane];
+        if (slot != kEmpty) ht[slot] = kEmpty;
         spec_node = kEmpty;
         WS();
     };
@@ -591,6 +678,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         if constexpr (TEAM > 1) {
             team_start(nc);
             __syncthreads();  // "distances ready"
+            spec_collect();
             return nc;
         } else
         if constexpr (DIM > 0 && !kInt) {
@@ -770,6 +858,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 if (pos >= qcap) continue;  // behind a full queue's last entry (it was equal to it when tested, not any more)
 #pragma unroll
                 for (int s = QS - 1; s >= 0; --s) {
+                    if (pos >= (uint32_t)((s + 1) * kWave) || size < (uint32_t)(s * kWave)) continue;  // slot untouched
                     const uint32_t p = (uint32_t)(s * kWave) + lane;
                     // lane l <- lane l - 1; lane 0 <- lane 63 of the slot below (the `old` operand of the DPP move)
                     const int cd = s > 0 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[s > 0 ? s - 1 : 0]), 63) : 0;
@@ -794,15 +883,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         uint32_t shift[QS];
         uint32_t pos_new = 0;
         if (QS <= 4 && nv <= kRegMerge) {
-            // few survivors (the steady state once the queue is full; queues beyond 256 entries always take the
-            // LDS path below, whose cost does not grow with the number of register slots).  One pass over them gives every survivor its
-            // rank among the survivors (`before`) and every queue entry e the number of survivors that go in front
-            // of it (shift_e = #{j: d_j <= d_e}) -- VALU only, no cross-lane reduction.  The queue is sorted, so
-            // shift is non-decreasing along it, and the survivor of rank r lands right after the last entry with
-            // shift <= r:  slot(r) = r + #{e: shift_e <= r}  (== r + #{e: d_e < d_j}, the lower bound of (3)).
-            // Entry p therefore owns the ranks [shift_{p-1}, shift_p) and writes their slots r + p; ranks past the
-            // last entry default to r + size.
-            uint32_t before = 0;
+            // few survivors (queues beyond 256 entries always take the LDS path below, whose cost does not grow with
+            // the number of register slots).  One pass over them gives every survivor its rank among the survivors
+            // (`before`) and its lower bound in the queue (a ballot count per slot, wave-uniform, kept in the
+            // survivor's own lane), and every queue entry e the number of survivors that go in front of it
+            // (shift_e = #{j: d_j <= d_e}).  No LDS before the scatter.
+            uint32_t before = 0, lbound = 0;
 #pragma unroll
             for (int s = 0; s < QS; ++s) shift[s] = 0;
             for (uint64_t mm = km; mm; mm &= mm - 1) {
@@ -810,27 +896,16 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), j));
                 before += (dj < nd) ? 1u : 0u;
                 before += ((dj == nd) & ((uint32_t)j > lane)) ? 1u : 0u;
+                uint32_t lb = 0;
 #pragma unroll
-                for (int s = 0; s < QS; ++s) shift[s] += (dj <= qd[s]) ? 1u : 0u;  // entries >= size: never scattered
-            }
-            uint32_t* slot = reinterpret_cast<uint32_t*>(snew);
-            if (lane < nv) slot[lane] = lane + size;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const uint32_t p = (uint32_t)(s * kWave) + lane;
-                uint32_t prev = __shfl_up(shift[s], 1);  // shift of entry p - 1
-                if (s == 0) {
-                    prev = lane == 0 ? 0u : prev;
-                } else {
-                    const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)shift[s > 0 ? s - 1 : 0], kWave - 1);
-                    prev = lane == 0 ? carry : prev;
+                for (int s = 0; s < QS; ++s) {
+                    shift[s] += (dj <= qd[s]) ? 1u : 0u;  // entries >= size: never scattered
+                    lb += (uint32_t)__popcll(ballot64(((uint32_t)(s * kWave) + lane < size) && qd[s] < dj));
                 }
-                if (p < size)
-                    for (uint32_t r = prev; r < shift[s]; ++r) slot[r] = r + p;
+                lbound = (int)lane == j ? lb : lbound;
             }
             has = nvalid;
-            __builtin_amdgcn_wave_barrier();  // one wave: LDS accesses retire in program order
-            pos_new = nvalid ? slot[before] : 0u;
+            pos_new = lbound + before;
         } else {
         if (stage_stale) {  // the lower-bound search below reads the queue's LDS image
 #pragma unroll
@@ -923,7 +998,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const bool hit = (node == pf_node);
             const bool hit2 = TEAM > 1 && !hit && (node == nb_node);
 #ifdef DANN_PHASE_CYCLES
-            ph_acc[hit ? 5 : 6] += 1;
+            if constexpr (TEAM == 1) ph_acc[hit ? 5 : 6] += 1;
 #endif
             const uint32_t* landed = nullptr;
             if constexpr (TEAM > 1) {
@@ -975,6 +1050,18 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const bool keep = isnew && id < ix.nslots;
                 const uint64_t nm = ballot64(isnew), km = ballot64(keep);
                 if (keep) cand_id[nc + mbcnt(km)] = id;
+                if constexpr (TEAM > 1) {
+                    // latency regime: should one of these be expanded straight away, its adjacency row is in L2 by then
+                    if ((a.tune & kTuneRowPrefetch) && keep) {
+                        const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
+                        const uint32_t* a1 = a0 + R;
+                        asm volatile(
+                            "global_load_dword %0, %1, off\n\t"
+                            "global_load_dword %0, %2, off"
+                            : "+v"(pf_dummy)
+                            : "v"(a0), "v"(a1));
+                    }
+                }
                 nc += (uint32_t)__popcll(km);
                 if (lds_open) ht_count += (uint32_t)__popcll(nm);
                 else spill_count += (uint32_t)__popcll(nm);
@@ -1054,10 +1141,11 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         return got ? 1u : 0u;
     };
     // ---- beam loop, a team of wavefronts -------------------------------------------------------------------------
-    // The hop's dependent chain is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  With
-    // helper waves evaluating the rows, wave 0 takes the merge, the visited filter and the adjacency row off that chain:
-    //  * while the helpers evaluate hop h, wave 0 filters the neighbours of pf_next (the best unexpanded entry left in
-    //    the queue) into the other candidate buffer (speculate());
+    // The hop's dependent chain is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  A team
+    // has three roles -- wave 0 owns the queue, wave 1 the speculative visited filter, the other waves evaluate rows --
+    // and takes the merge, the visited filter and the adjacency row off that chain:
+    //  * while the gather waves evaluate hop h, the visited wave filters the neighbours of the predicted next expansion
+    //    (pf_node) into the other candidate buffer (team_helper);
     //  * when hop h's distances are ready, comparisons against pf_next and pf_next2 decide, *before* the merge, which
     //    node hop h + 1 expands and which node will be the best unexpanded entry after that: hop h + 1 expands pf_next
     //    unless a new candidate is at most as far (lower-bound insert, queue.rs:150-170: it goes in front; of equal new
@@ -1083,25 +1171,18 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             hops += 1;
             nc_cur = expand(1, false, true);
             if (!status) {
-                team_start(nc_cur);
-                running = true;
                 pf_node = pf_next;
                 if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
+                team_start(nc_cur);
+                running = true;
             }
         }
         while (running) {
             PH_T(ph2);
-            speculate();
-            if ((a.tune & kTuneRowPrefetch) && pf_node != kEmpty && ix.layer_bytes <= 512u && !spec_touched) {
-                const uint32_t* row = adj_landed(0);
-                const uint32_t plen = row[0];
-                const uint32_t v = row[1u + (lane < R ? lane : R - 1u)];
-                touch_row(v, lane < (plen < R ? plen : R) && v < ix.nslots);
-            }
             PH_T(pg2);
-            PH_ADD(13, ph2, pg2);
             __syncthreads();  // "distances ready"
             running = false;
+            spec_collect();
             PH_T(ph3);
             PH_ADD(14, pg2, ph3);
             PH_ADD(2, ph2, ph3);
@@ -1110,8 +1191,8 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const bool has = lane < nc;
             const float nd = has ? cand_d[lane] : 0.0f;
             const uint32_t nid = has ? cand_id[lane] : kEmpty;
-            uint32_t* const cbi = cand_id;  // (this hop's buffer: the helpers move on to the other one)
-            float* const cbd = cand_d;
+            uint32_t* const cbi = reinterpret_cast<uint32_t*>(smem + L.mscr_off);  // (this hop's buffer is refilled
+            float* const cbd = reinterpret_cast<float*>(smem + L.mscr_off + 256u);    //  by the visited wave meanwhile)
             started = false;
             uint32_t pred = kEmpty;  // the predicted best unexpanded entry after the next pop
             bool keep_pf = false;    // pf_* already hold (or were asked for) the row the next steps need
@@ -1120,26 +1201,46 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 if (ballot64(ahead) == 0) {
                     if (spec_node == pf_next) {  // hop h + 1 expands pf_next, and its candidates are ready
                         nc_cur = spec_commit();
-                        team_start(nc_cur);
-                        started = running = true;
                         early_node = pf_next;
+                        // the runner-up after that pop, named to the visited wave with this very start
                         if (pf_next2 != kEmpty) {
                             const bool ahead2 = has && nd <= pf_next2_d;
                             pred = ballot64(ahead2) ? (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd))
                                                     : pf_next2;
                         }
+                        pf_node = pred;
+                        if (pred != kEmpty) adj_fetch_lds(pred, 0);
+                        team_start(nc_cur);
+                        started = running = true;
+                        pred = kEmpty;
+                        keep_pf = true;
                     } else {
-                        keep_pf = pf_node == pf_next;  // no speculation ran: the next expansion reads pf_* itself
+                        if (spec_node != kEmpty) spec_rollback();  // (a runner-up the pop contradicted)
+                        keep_pf = pf_node == pf_next;  // the next expansion reads the landed row itself
                     }
                 } else {
-                    // hop h + 1 expands the closest new candidate
+                    // hop h + 1 expands the closest new candidate: its adjacency row is requested (the visited wave
+                    // touched it when the candidate was found, so it comes from L2), the runner-up is worked out while
+                    // it travels, and the expansion runs before the merge -- which then has the gather beside it
                     if (spec_node != kEmpty) spec_rollback();
                     const int bj = best_lane(ahead, nd);
                     nb_node = (uint32_t)__builtin_amdgcn_readlane((int)nid, bj);
                     adj_fetch_lds(nb_node, 1);
                     const bool rest = ahead && (int)lane != bj;
-                    if (ballot64(rest)) pred = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(rest, nd));
-                    else keep_pf = pf_node == pf_next;  // pf_next stays the runner-up, its row is here already
+                    uint32_t runner = pf_next;  // pf_next stays the runner-up unless a second new candidate is ahead too
+                    if (ballot64(rest)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(rest, nd));
+                    keep_pf = true;
+                    node0 = nb_node;
+                    nc_cur = expand(1, false, true);
+                    if (status) break;
+                    nb_node = kEmpty;
+                    early_node = node0;
+                    if (pf_node != runner) {  // (pf_next's row is here already unless the last pop contradicted it)
+                        pf_node = runner;
+                        adj_fetch_lds(pf_node, 0);
+                    }
+                    team_start(nc_cur);
+                    started = running = true;
                 }
             } else if (spec_node != kEmpty) {
                 spec_rollback();  // (cannot happen: nothing is speculated without a pf_next)
@@ -1150,8 +1251,14 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             } else if (!keep_pf) {
                 pf_node = kEmpty;
             }
+            PH_T(phq);
+#ifdef DANN_PHASE_CYCLES
+            ph_acc[started && early_node == pf_next ? 12 : 13] += phq - ph3;
+            ph_acc[started && early_node == pf_next ? 5 : 6] += 1;
+#endif
             merge_regs(has, nd, nid, nc, cbi, cbd);
             PH_T(ph4);
+            PH_ADD(15, phq, ph4);
             PH_ADD(3, ph3, ph4);
             pf_next = pf_next2 = kEmpty;
             const uint32_t nb = pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d);
@@ -1161,14 +1268,18 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             PH_ADD(0, ph4, ph5);
             if (started) {
                 if (node0 != early_node) status = (uint32_t)(-DANN_EINTERNAL);
+                // (a runner-up the pop contradicts: the visited wave's work on it is taken back after this hop)
             } else {
-                nc_cur = expand(1, false, true);  // (adjacency row: pf_* or nb_* if the node is theirs)
+                nc_cur = expand(1, false, true);  // (adjacency row: a landing buffer if the node is pf_node / nb_node)
                 if (status) break;
+                if (pf_node != pf_next) {  // the runner-up is another node than predicted (or none was): ask now
+                    pf_node = pf_next;
+                    if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
+                }
                 team_start(nc_cur);
                 running = true;
             }
             nb_node = kEmpty;
-            if (pf_node != pf_next) pf_node = kEmpty;  // the runner-up is another node: no speculation this hop
             PH_T(ph6);
             PH_ADD(1, ph5, ph6);
             PH_ADD(4, ph2, ph6);
