@@ -37,7 +37,7 @@ constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (disk
 
 constexpr uint32_t kAdjLandBytes = 256u;
 struct SearchLds {
-    uint32_t ht_off, cand_id_off, cand_d_off, cand2_id_off, cand2_d_off, adj_off, slots_off, mscr_off, stage_off, snew_off, beam_off, q_off, total;
+    uint32_t ht_off, cand_id_off, cand_d_off, cand2_id_off, cand2_d_off, adj_off, slots_off, mscr_off, mail_off, stage_off, snew_off, beam_off, q_off, total;
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -62,8 +62,8 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     off += round16(cmax * 4u);
     l.cand_d_off = off;
     off += round16(cmax * 4u);
-    // teams: a second candidate buffer -- wave 0 fills it with the next hop's candidates while the helper waves still
-    // evaluate the current hop's (the speculative expansion of the predicted next node, §3.5 of DESIGN.md)
+    // teams: a second candidate buffer -- the visited wave fills it with the next hop's candidates while the gather wave
+    // still evaluates the current hop's (the speculative expansion of the predicted next node, §3.5 of DESIGN.md)
     l.cand2_id_off = off;
     if (team) off += round16(cmax * 4u);
     l.cand2_d_off = off;
@@ -78,6 +78,8 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     if (team) off += 256u;
     l.mscr_off = off;
     if (team) off += 512u;
+    l.mail_off = off;  // teams: the mailbox the four waves of a team talk through (64 words, see kMb*)
+    if (team) off += 256u;
     l.stage_off = off;  // the queue image, (id, distance bits) pairs: every merge scatters the register-resident queue
     off += round16(qcap * 8u);  // here and reloads it (one 8-byte LDS access per entry).  One buffer is enough: nothing
                                 // is read from it between the first scatter write and the reload (ranks come from
@@ -242,27 +244,63 @@ __device__ __forceinline__ float wave_min_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (SearchLds beam[1])
-// the team's mailbox (SearchLds beam[], plain searches use none of it otherwise)
+constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (kMbGo)
+// the team's mailbox (SearchLds mail_off, 64 words).  Hops are numbered from 0 (the start points); pops from 1 (pop n
+// returns the node hop n expands).  Words that one wave rewrites while another may still read the previous value are
+// double-buffered by the parity of the hop / pop they belong to.
 enum : int {
-    kTwGather = 1,    // wave 0 -> gather waves: candidate count | buffer << 16, or kTeamExit
-    kTwSpecNode = 2,  // wave 0 -> visited wave: node whose neighbours to filter speculatively (kEmpty: none)
-    kTwHtCount = 3,   //   ids in the visited table
-    kTwSpecBuf = 4,   //   candidate buffer the survivors go to
-    kTwSpecRan = 5,   // visited wave -> wave 0: 1 if the filter ran
-    kTwSpecNc = 6,    //   candidates kept
-    kTwSpecNew = 7,   //   ids inserted
+    kMbGo = 0,        // control (hop 0: queue) wave -> gather & visited waves: (hop + 1) | candidates << 20 | buffer << 27
+                      // of the hop to work on, or kTeamExit
+    kMbVReply = 1,    // visited wave -> control wave: ran | kept << 8 | inserted << 16
+    kMbLoaded = 2,    // queue wave -> control wave: hop + 1 of the last hop whose distances it holds in registers
+    kMbDStatus = 3,   // control wave -> queue wave, at the end: its status ...
+    kMbDCmps = 4,     //   ... and the candidates it had evaluated
+    kMbHtCount0 = 5,  // queue wave -> control wave: ids in the visited table after the start points
+    kMbHop = 8,       // + 8 * (hop & 1):  +0 candidates | buffer << 16   +1 node for the visited wave (kEmpty: none)
+                      //                   +2 ids in the visited table    +3 buffer for the visited wave's candidates
+    kMbPop = 24,      // + 8 * (pop & 1):  +0 pop number (written last)  +1 found  +2 node  +3 best unexpanded entry left
+                      //                   +4 its distance  +5 the one after it  +6 its distance
 };
+__device__ __forceinline__ uint32_t mb_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// publishes what this wave wrote to LDS before: one wave's LDS instructions execute in issue order, so all it takes is
+// that the compiler keeps them in program order (a release fence would also drain the global-memory counter, and the
+// prefetch loads in flight with it)
+__device__ __forceinline__ void mb_store(uint32_t* p, uint32_t v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// wait until *p != seen (another wave of the team writes it); returns the new value
+// (a wait that outlasts about a second is a protocol bug: abort the dispatch rather than hang the device)
+__device__ __forceinline__ uint32_t mb_wait_change(const uint32_t* p, uint32_t seen) {
+    uint32_t v, spins = 0;
+    while ((v = mb_load(p)) == seen) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) __builtin_trap();
+    }
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void mb_wait_at_least(const uint32_t* p, uint32_t want) {
+    uint32_t spins = 0;
+    while (mb_load(p) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) __builtin_trap();
+    }
+    asm volatile("" ::: "memory");
+}
 constexpr uint32_t kAdjPending = 0xFFFFFFFEu;  // "not landed yet" (never an id: ids stay below 2^31; never a length)
-// one helper wave's share of a team gather: the NW helper waves split every block of NW * GROUPS * 2 candidates, two
-// rows per lane group in flight (wave 0 does not gather: it expands the predicted next node meanwhile)
-template <int DT, int OP, bool NORM, int DIM, int NW>
+// a gather wave's share of a team gather: NW gather waves split every block of NW * GROUPS * U candidates, U rows per
+// lane group in flight (a team has one gather wave, U = 4: the whole 32-neighbour hop in one pass)
+template <int DT, int OP, bool NORM, int DIM, int NW, int U>
 __device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t wi, uint32_t nc, const uint32_t* cand_id,
                                                   float* cand_d, const F4 (&xq)[(DIM > 0 && !Scheme<DT, OP, false>::kInt) ? DIM / (4 * Scheme<DT, OP, false>::G) : 1],
                                                   const uint4& xqi, int xx_pre, const uint8_t* qs, const SqParams& sqp, int g,
                                                   int v) {
     using S = Scheme<DT, OP, false>;
-    constexpr int G = S::G, GROUPS = kWave / G, U = 2;
+    constexpr int G = S::G, GROUPS = kWave / G;
     using RT = typename RowType<DT>::type;
     for (uint32_t c0 = 0; c0 < nc; c0 += NW * GROUPS * U) {
         uint32_t c[U];
@@ -277,13 +315,17 @@ __device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t 
         }
         float out[U];
         if constexpr (!S::kInt) {
-            const RT* rows[U] = {reinterpret_cast<const RT*>(rowb[0]), reinterpret_cast<const RT*>(rowb[1])};
+            const RT* rows[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rows[u] = reinterpret_cast<const RT*>(rowb[u]);
             group_distance_pre<S::NACC, OP, DIM, U>(xq, rows, act, v, out);
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (act[u] && v == 0) cand_d[c[u]] = post_op<OP, NORM>(out[u]);
         } else {
-            const uint8_t* rows[U] = {rowb[0], rowb[1]};
+            const uint8_t* rows[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rows[u] = rowb[u];
             group_distance_int_pre<OP, DT == DT_I8, U>(xqi, xx_pre, rows, v, out);
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -292,9 +334,385 @@ __device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t 
     }
 }
 
-// waves 1 .. TEAM-1 of a team: wait for wave 0's candidates, evaluate their share, repeat until released
+// synchronisation of one wave with itself (LDS written by some lanes, read by others) where other waves share the
+// workgroup: a counter drain instead of the workgroup barrier
+__device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---- a team of four wavefronts per query (latency regime) -----------------------------------------------------------
+// The dependent chain of a hop is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  A team
+// gives every link its own wave and overlaps them:
+//   wave 0, queue:    merge of hop h's distances, pop, publication of (node, best and second-best unexpanded entry left)
+//                     -- the code of the one-wave search (beam_search_one), it also stages the query and writes results;
+//   wave 1, control:  when hop h's distances are ready, decides *before the merge* which node hop h + 1 expands (the best
+//                     unexpanded entry unless a new candidate is at most as far: lower-bound insert, queue.rs:150-170)
+//                     and which node will be best after that; expands where no speculation covers it; starts the hop;
+//   wave 2, visited:  while hop h + 1's rows are evaluated, runs the visited filter of the predicted hop h + 2 node into
+//                     the spare candidate buffer (taken back by the control wave if the prediction fails);
+//   wave 3, gather:   evaluates the candidate rows.
+// One workgroup barrier per hop ("distances ready"); everything else goes through the LDS mailbox (kMb*).  The queue, the
+// visited set and the order of expansions are exactly those of the one-wave search: the early decisions only predict
+// what the pop after the merge returns, and the control wave checks every one of them against the queue wave's
+// publication (a mismatch is DANN_EINTERNAL).  The visited table never spills here: a query that would need it reports
+// DANN_EOVERFLOW and the host re-runs it with one wave.
+template <int DT, int OP, bool NORM, int QS, int DIM>
+__device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* smem, const SearchLds& L, const uint32_t lane) {
+    const IndexView& ix = a.ix;
+    uint32_t* const mail = reinterpret_cast<uint32_t*>(smem + L.mail_off);
+    uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
+    const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
+    const uint32_t ht_mod = a.ht_prime, R = ix.max_degree;
+    const uint32_t ht_limit = ht_mod - (ht_mod >> 2);
+    const bool latency = (a.tune & kTuneRowPrefetch) != 0;
+    uint32_t pf_dummy = 0;  // landing register of prefetch loads nothing reads
+    auto buf_ids = [&](uint32_t b) { return reinterpret_cast<uint32_t*>(smem + L.cand_id_off + b * cstride); };
+    auto buf_d = [&](uint32_t b) { return reinterpret_cast<const float*>(smem + L.cand_d_off + b * cstride); };
+    // an adjacency row requested ahead of its use lands in LDS (buffer 0: the node named to the visited wave, buffer 1:
+    // a new candidate this wave expands itself) through global_load_lds_dword: lane l's dword goes to M0 + 4 l.  No
+    // register is written, so nothing waits for the load before its consumer does (adj_landed here, polling in the
+    // visited wave -- hence kAdjPending in buffer 0 first).  One instruction covers the length and max_degree <= 63
+    // neighbours (teams require it).
+    auto adj_fetch_lds = [&](uint32_t node, uint32_t which) {
+        const uint32_t* p = ix.adj + (uint64_t)node * ix.adj_stride + (lane <= R ? lane : R);
+        const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(
+            __attribute__((address_space(3))) uint8_t*)(smem + L.adj_off + which * kAdjLandBytes));
+        // (an earlier request into the same buffer must have landed: its tail would overwrite the marks)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (which == 0u) reinterpret_cast<uint32_t*>(smem + L.adj_off)[lane] = kAdjPending;
+        uint32_t m0_saved;
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "global_load_lds_dword %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0_saved)
+            : "v"(p), "s"(lds)
+            : "memory");
+    };
+    auto adj_landed = [&](uint32_t which) -> const uint32_t* {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return reinterpret_cast<const uint32_t*>(smem + L.adj_off + which * kAdjLandBytes);
+    };
+    // argmin over the lanes of `on` by (distance ascending, lane descending); `on` must not be empty
+    auto best_lane = [&](bool on, float d) -> int {
+        const float m = wave_min_f32(on ? d : __builtin_inff());
+        return 63 - __builtin_clzll(ballot64(on && d == m));
+    };
+
+    uint32_t hop = 0;                // the hop in flight / last finished
+    uint32_t cur = 0, nc_cur = 0;    // its candidate buffer and count
+    uint32_t ht_count = 0, status = 0, cmps = 0;
+    uint32_t pf_node = kEmpty;       // node whose adjacency row is in (or on its way to) landing buffer 0
+    uint32_t spec_sent = kEmpty, spec_node = kEmpty, spec_nc = 0, spec_new = 0;
+    uint32_t early_node = kEmpty;    // the node the hop in flight expands (the queue wave's pop must agree)
+
+    // start hop `hop + 1` on `nc` candidates in buffer `buf`; the visited wave works on pf_node meanwhile
+#ifdef DANN_PHASE_CYCLES
+    unsigned long long ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    uint32_t loaded_seen = 0;  // the last value of kMbLoaded this wave has read
+    auto team_start = [&](uint32_t nc, uint32_t buf) {
+        PH_T(pts0);
+        ++hop;
+        // the visited wave refills the previous hop's buffer: the queue wave must hold those distances in registers
+        if (loaded_seen < hop) mb_wait_at_least(mail + kMbLoaded, hop);
+        spec_sent = (pf_node != kEmpty && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
+        if (lane == 0) {
+            uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
+            *reinterpret_cast<uint4*>(w) = make_uint4(nc | (buf << 16), spec_sent, ht_count, buf ^ 1u);
+            mb_store(mail + kMbGo, ((hop + 1u) & 0xFFFFFu) | (nc << 20) | (buf << 27));
+        }
+        cur = buf;
+        nc_cur = nc;
+        PH_T(pts1);
+        PH_ADD(2, pts0, pts1);
+    };
+    auto spec_rollback = [&]() {
+        const uint32_t slot = reinterpret_cast<const uint32_t*>(smem + L.slots_off)[lane];
+        if (slot != kEmpty) ht[slot] = kEmpty;
+        spec_node = kEmpty;
+        team_wave_sync();
+    };
+    // neighbours of `node` through the visited filter into buffer `buf` (provider.rs:448-454); the row comes from landing
+    // buffer `landed` (0 / 1) or, landed < 0, straight from memory
+    uint32_t touch_id = kEmpty;  // (per lane) a candidate the last expansion found
+    auto expand = [&](uint32_t node, int landed, uint32_t buf) -> uint32_t {
+        uint32_t len, id;
+        const uint32_t col = lane < R ? lane : R - 1u;
+        if (landed >= 0) {
+            const uint32_t* row = adj_landed((uint32_t)landed);
+            len = row[0];
+            id = row[1u + col];
+        } else {
+            const uint32_t* row = ix.adj + (uint64_t)node * ix.adj_stride;
+            len = row[0];
+            id = row[1u + col];
+        }
+        len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
+        if (ht_count + len > ht_limit) {
+            status = (uint32_t)(-DANN_EOVERFLOW);
+            return 0;
+        }
+        id = lane < len ? id : kEmpty;
+        const bool isnew = ht_insert_open(ht, ht_mod, id, id != kEmpty);
+        const bool keep = isnew && id < ix.nslots;
+        const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+        if (keep) buf_ids(buf)[mbcnt(km)] = id;
+        touch_id = keep ? id : kEmpty;
+        ht_count += (uint32_t)__popcll(nm);
+        return (uint32_t)__popcll(km);
+    };
+    // latency regime: should one of the candidates an expansion has just found be expanded straight away, its adjacency
+    // row is in L2 by then.  (Issued after the runner-up's row request, which waits for the loads before it.)
+    auto touch_found = [&]() {
+        if (latency && touch_id != kEmpty) {
+            const uint32_t* a0 = ix.adj + (uint64_t)touch_id * ix.adj_stride;
+            const uint32_t* a1 = a0 + R;
+            asm volatile(
+                "global_load_dword %0, %1, off\n\t"
+                "global_load_dword %0, %2, off"
+                : "+v"(pf_dummy)
+                : "v"(a0), "v"(a1));
+        }
+        touch_id = kEmpty;
+    };
+    struct Pub {
+        uint32_t found, node, pf_next, pf_next2;
+        float pf_next_d, pf_next2_d;
+    };
+    auto read_pub = [&](uint32_t n) -> Pub {  // publication of pop n (waits for it)
+        const uint32_t* w = mail + kMbPop + 8u * (n & 1u);
+        mb_wait_at_least(w, n);
+        const uint4 lo = *reinterpret_cast<const uint4*>(w), hi = *reinterpret_cast<const uint4*>(w + 4);
+        Pub r;
+        r.found = lo.y;
+        r.node = lo.z;
+        r.pf_next = lo.w;
+        r.pf_next_d = __builtin_bit_cast(float, hi.x);
+        r.pf_next2 = hi.y;
+        r.pf_next2_d = __builtin_bit_cast(float, hi.z);
+        return r;
+    };
+
+    __syncthreads();  // the query is staged, the table wiped, the mailbox cleared (queue wave)
+    __syncthreads();  // hop 0 (the start points): distances ready -- the queue wave merges them and pops the first node
+    for (;;) {
+        bool started = false;
+        bool overtaken = false;
+        PH_T(pd0);
+        if (hop > 0) {
+            // ---- hop `hop`'s distances are ready
+            // (everything this decision reads was written before the barrier: one batch of LDS loads, one wait)
+            const uint32_t* wp = mail + kMbPop + 8u * (hop & 1u);
+            const uint4 plo = *reinterpret_cast<const uint4*>(wp), phi = *reinterpret_cast<const uint4*>(wp + 4);
+            const uint32_t r = mail[kMbVReply];
+            loaded_seen = mail[kMbLoaded];
+            const bool has = lane < nc_cur;
+            const float nd = has ? buf_d(cur)[lane] : 0.0f;
+            const uint32_t nid = has ? buf_ids(cur)[lane] : kEmpty;
+            Pub pub;
+            pub.found = plo.y;
+            pub.node = plo.z;
+            pub.pf_next = plo.w;
+            pub.pf_next_d = __builtin_bit_cast(float, phi.x);
+            pub.pf_next2 = phi.y;
+            pub.pf_next2_d = __builtin_bit_cast(float, phi.z);
+            spec_node = kEmpty;
+            if (spec_sent != kEmpty && (r & 1u)) {
+                spec_node = spec_sent;
+                spec_nc = (r >> 8) & 0xFFu;
+                spec_new = (r >> 16) & 0xFFu;
+            }
+            if (plo.x != hop || !pub.found || pub.node != early_node) status = (uint32_t)(-DANN_EINTERNAL);
+            if (status) break;
+            cmps += nc_cur;
+            const uint32_t pf_next = pub.pf_next, pf_next2 = pub.pf_next2;
+#ifdef DANN_PHASE_CYCLES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PH_T(pdl);
+            ph_acc[1] += pdl - pd0;
+#endif
+            if (pf_next != kEmpty) {
+                const bool ahead = has && nd <= pub.pf_next_d;  // (a NaN distance never enters the queue)
+                uint32_t next, runner, nc;
+                if (ballot64(ahead) == 0) {
+                    // the next hop expands pf_next; the runner-up after that pop: pf_next2 unless a new candidate is
+                    // at most as far
+                    next = pf_next;
+                    runner = pf_next2;
+                    if (pf_next2 != kEmpty) {
+                        const bool ahead2 = has && nd <= pub.pf_next2_d;
+                        if (ballot64(ahead2)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd));
+                    }
+                    if (spec_node == pf_next) {  // ... and the visited wave has its candidates ready
+                        ht_count += spec_new;
+                        nc = spec_nc;
+                        spec_node = kEmpty;
+                    } else {
+                        overtaken = true;  // (statistics: not the short path)
+                        if (spec_node != kEmpty) spec_rollback();  // (a runner-up the pop contradicted)
+                        nc = expand(next, pf_node == next ? 0 : -1, cur ^ 1u);
+                        if (status) break;
+                    }
+                } else {
+                    // the next hop expands the closest new candidate (of equal ones the one inserted last): its
+                    // adjacency row was touched when the candidate was found and comes from L2; the runner-up is
+                    // worked out while it travels
+                    overtaken = true;
+                    if (spec_node != kEmpty) spec_rollback();
+                    const int bj = best_lane(ahead, nd);
+                    next = (uint32_t)__builtin_amdgcn_readlane((int)nid, bj);
+                    adj_fetch_lds(next, 1);
+                    const bool rest = ahead && (int)lane != bj;
+                    runner = pf_next;  // stays the runner-up unless a second new candidate is ahead of it too
+                    if (ballot64(rest)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(rest, nd));
+                    nc = expand(next, 1, cur ^ 1u);
+                    if (status) break;
+                }
+                early_node = next;
+                if (pf_node != runner) {  // (else its row is in landing buffer 0 already)
+                    pf_node = runner;
+                    if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
+                }
+                touch_found();
+                team_start(nc, cur ^ 1u);
+                started = true;
+            }
+        }
+        if (!started) {
+            // no unexpanded entry is known to be left (or this is the first hop): the queue wave's merge and pop decide
+            if (spec_node != kEmpty) spec_rollback();
+            const Pub pub = read_pub(hop + 1u);
+            if (hop == 0) ht_count = mb_load(mail + kMbHtCount0);
+            if (!pub.found) break;  // the search is over
+            const uint32_t nc = expand(pub.node, pf_node == pub.node ? 0 : -1, cur ^ 1u);
+            if (status) break;
+            early_node = pub.node;
+            if (pf_node != pub.pf_next) {
+                pf_node = pub.pf_next;
+                if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
+            }
+            touch_found();
+            team_start(nc, cur ^ 1u);
+#ifdef DANN_PHASE_CYCLES
+            overtaken = true;
+            ph_acc[7] += 1;
+#endif
+        }
+        PH_T(pd1);
+#ifdef DANN_PHASE_CYCLES
+        ph_acc[overtaken ? 13 : 12] += pd1 - pd0;
+        ph_acc[overtaken ? 6 : 5] += 1;
+#endif
+        __syncthreads();  // "distances ready" of the hop just started
+        PH_T(pd2);
+        PH_ADD(15, pd1, pd2);
+    }
+#ifdef DANN_PHASE_CYCLES
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i)
+            if (ph_acc[i]) atomicAdd(&a.phase_cycles[i], ph_acc[i]);
+#endif
+    if (lane == 0) {
+        mail[kMbDStatus] = status;
+        mail[kMbDCmps] = cmps;
+        mb_store(mail + kMbGo, kTeamExit);
+    }
+    __syncthreads();  // the release: every wave of the team meets here once more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pf_dummy));
+}
+
+// the visited wave
+__device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* smem, const SearchLds& L, const uint32_t lane) {
+    const IndexView& ix = a.ix;
+    uint32_t* const mail = reinterpret_cast<uint32_t*>(smem + L.mail_off);
+    uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
+    const uint32_t* const landing = reinterpret_cast<const uint32_t*>(smem + L.adj_off);
+    uint32_t* const slots = reinterpret_cast<uint32_t*>(smem + L.slots_off);
+    const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
+    const uint32_t ht_mod = a.ht_prime, R = ix.max_degree;
+    const bool touch = (a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u;
+    uint32_t pf_dummy = 0;
+    __syncthreads();  // the query is staged, the table wiped, the mailbox cleared
+    uint32_t seen = 0;
+    for (uint32_t hop = 0;; ++hop) {
+        seen = mb_wait_change(mail + kMbGo, seen);
+        if (seen == kTeamExit) break;
+        const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
+        const uint32_t node = w[1];
+        uint32_t ran = 0, kept = 0, fresh = 0;
+        if (node != kEmpty) {
+            // the control wave asked for the node's adjacency row (kAdjPending in every dword first): wait for the
+            // length, then for every neighbour slot below it
+            // (all 64 dwords of the request, also those beyond the length: a part still in flight would land on top
+            // of the *next* request's kAdjPending marks and pass for its data)
+            uint32_t len = kAdjPending, val = kAdjPending, spins = 0;
+            for (;;) {
+                const uint32_t mine = mb_load(landing + lane);
+                if (ballot64(mine == kAdjPending) == 0) {
+                    len = mb_load(landing);
+                    val = mb_load(landing + 1u + (lane < R ? lane : R - 1u));
+                    break;
+                }
+                if (++spins > (1u << 16)) {  // (never observed; a speculation skipped costs nothing but time)
+                    len = kAdjPending;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (len != kAdjPending) {
+                len = len < R ? len : R;
+                if (w[2] + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not overflow the table)
+                    const uint32_t id = lane < len ? val : kEmpty;
+                    uint32_t slot = 0;
+                    const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
+                    const bool keep = isnew && id < ix.nslots;
+                    const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                    uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + w[3] * cstride);
+                    if (keep) out[mbcnt(km)] = id;
+                    slots[lane] = isnew ? slot : kEmpty;
+                    ran = 1;
+                    kept = (uint32_t)__popcll(km);
+                    fresh = (uint32_t)__popcll(nm);
+                    // latency regime: request the rows of exactly these candidates now, a whole gather ahead of the hop
+                    // that evaluates them (one dword per 128-byte line; nothing ever reads pf_dummy), and their
+                    // adjacency rows, should a candidate be expanded straight away
+                    if (touch && keep) {
+                        const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
+                        const uint32_t last = ix.layer_bytes - 4u;
+                        const uint8_t* p1 = prow + (128u < last ? 128u : last);
+                        const uint8_t* p2 = prow + (256u < last ? 256u : last);
+                        const uint8_t* p3 = prow + (384u < last ? 384u : last);
+                        const uint8_t* p4 = prow + last;
+                        const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
+                        const uint32_t* a1 = a0 + R;
+                        asm volatile(
+                            "global_load_dword %0, %1, off\n\t"
+                            "global_load_dword %0, %2, off\n\t"
+                            "global_load_dword %0, %3, off\n\t"
+                            "global_load_dword %0, %4, off\n\t"
+                            "global_load_dword %0, %5, off\n\t"
+                            "global_load_dword %0, %6, off\n\t"
+                            "global_load_dword %0, %7, off"
+                            : "+v"(pf_dummy)
+                            : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
+                    }
+                }
+            }
+        }
+        if (lane == 0) mail[kMbVReply] = ran | (kept << 8) | (fresh << 16);
+        __syncthreads();  // distances ready
+    }
+    __syncthreads();  // the release
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pf_dummy));
+}
+
+// waves 1 .. 3 of a team
 template <int DT, int OP, bool NORM, int QS, int DIM, int TEAM>
 __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) {
+    static_assert(TEAM == 4, "a team is four wavefronts: queue, control, visited, gather");
     using S = Scheme<DT, OP, false>;
     constexpr int G = S::G;
     constexpr bool kInt = S::kInt;
@@ -303,12 +721,21 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qbytes = kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u;
     const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, QS * kWave, qbytes, true);
+    if (wave == 1u) {
+        team_control_wave<DT, OP, NORM, QS, DIM>(a, smem, L, lane);
+        return;
+    }
+    if (wave == 2u) {
+        team_visited_wave(a, smem, L, lane);
+        return;
+    }
+    // ---- the gather wave: four rows per lane group in flight, as the one-wave search
     const uint8_t* qs = smem + L.q_off;
     // the two candidate buffers sit one fixed stride apart; addressing them as base + buffer * stride (never through a
     // table of pointers) keeps every access an LDS instruction -- a selected pointer decays to a flat address, whose
     // loads also wait for the global-memory counter
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
-    const uint32_t* beam = reinterpret_cast<const uint32_t*>(smem + L.beam_off);
+    const uint32_t* mail = reinterpret_cast<const uint32_t*>(smem + L.mail_off);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     __syncthreads();  // the query is staged
     const int g = lane / G, v = lane % G;
@@ -323,108 +750,21 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
         xqi = *reinterpret_cast<const uint4*>(qs + 16 * v);
         xx_pre = group_norm_int_pre<DT == DT_I8>(xqi);
     }
-    if (wave == 1u) {
-        // ---- the visited wave: between "candidates ready" and "distances ready" it runs the visited filter of the node
-        // wave 0 names (the predicted next expansion) into the spare candidate buffer.  Wave 0 requested that node's
-        // adjacency row into landing buffer 0 (kAdjPending in every dword first); the row's arrival is seen by polling.
-        uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
-        uint32_t* const mail = reinterpret_cast<uint32_t*>(smem + L.beam_off);
-        const uint32_t* const landing = reinterpret_cast<const uint32_t*>(smem + L.adj_off);
-        uint32_t* const slots = reinterpret_cast<uint32_t*>(smem + L.slots_off);
-        const uint32_t ht_mod = a.ht_prime, R = ix.max_degree;
-        const bool touch = (a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u;
-        uint32_t pf_dummy = 0;
-        for (;;) {
-            __syncthreads();  // candidates ready (or release)
-            if (mail[kTwGather] == kTeamExit) break;
-            const uint32_t node = mail[kTwSpecNode];
-            uint32_t ran = 0, kept = 0, fresh = 0;
-            if (node != kEmpty) {
-                // wait for the row: first the length, then every neighbour slot below it
-                uint32_t len = kAdjPending, val = kAdjPending, spins = 0;
-                for (;;) {
-                    len = landing[0];
-                    val = landing[1u + (lane < R ? lane : R - 1u)];
-                    const uint32_t n = len == kAdjPending ? 0u : (len < R ? len : R);
-                    if (len != kAdjPending && ballot64(lane < n && val == kAdjPending) == 0) break;
-                    if (++spins > (1u << 16)) {  // (never observed; a speculation skipped costs nothing but time)
-                        len = kAdjPending;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (len != kAdjPending) {
-                    len = len < R ? len : R;
-                    if (mail[kTwHtCount] + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not freeze the table)
-                        const uint32_t id = lane < len ? val : kEmpty;
-                        uint32_t slot = 0;
-                        const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
-                        const bool keep = isnew && id < ix.nslots;
-                        const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                        uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + mail[kTwSpecBuf] * cstride);
-                        if (keep) out[mbcnt(km)] = id;
-                        slots[lane] = isnew ? slot : kEmpty;
-                        ran = 1;
-                        kept = (uint32_t)__popcll(km);
-                        fresh = (uint32_t)__popcll(nm);
-                        // latency regime: request the rows of exactly these candidates now, a whole gather ahead of
-                        // the hop that evaluates them (one dword per 128-byte line; nothing ever reads pf_dummy)
-                        if (touch && keep) {
-                            const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
-                            const uint32_t last = ix.layer_bytes - 4u;
-                            const uint8_t* p1 = prow + (128u < last ? 128u : last);
-                            const uint8_t* p2 = prow + (256u < last ? 256u : last);
-                            const uint8_t* p3 = prow + (384u < last ? 384u : last);
-                            const uint8_t* p4 = prow + last;
-                            // ... and its adjacency row, should the candidate be expanded straight away
-                            const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
-                            const uint32_t* a1 = a0 + R;
-                            asm volatile(
-                                "global_load_dword %0, %1, off\n\t"
-                                "global_load_dword %0, %2, off\n\t"
-                                "global_load_dword %0, %3, off\n\t"
-                                "global_load_dword %0, %4, off\n\t"
-                                "global_load_dword %0, %5, off\n\t"
-                                "global_load_dword %0, %6, off\n\t"
-                                "global_load_dword %0, %7, off"
-                                : "+v"(pf_dummy)
-                                : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
-                        }
-                    }
-                }
-            }
-            if (lane == 0) {
-                mail[kTwSpecRan] = ran;
-                mail[kTwSpecNc] = kept;
-                mail[kTwSpecNew] = fresh;
-            }
-            __syncthreads();  // distances ready
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" ::"v"(pf_dummy));
-        return;
-    }
+    uint32_t seen = 0;
     for (;;) {
-        __syncthreads();  // candidates ready (or release)
-        const uint32_t word = beam[kTwGather];
-        if (word == kTeamExit) break;
-        const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
-        team_gather_share<DT, OP, NORM, DIM, TEAM - 2>(
-            ix, wave - 2u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
+        seen = mb_wait_change(mail + kMbGo, seen);
+        if (seen == kTeamExit) break;
+        const uint32_t nc = (seen >> 20) & 0x7Fu, buf = (seen >> 27) & 1u;
+        team_gather_share<DT, OP, NORM, DIM, 1, 4>(
+            ix, 0u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
             reinterpret_cast<float*>(smem + L.cand_d_off + buf * cstride), xq, xqi, xx_pre, qs, sqp, g, v);
         __syncthreads();  // distances ready
     }
+    __syncthreads();  // the release
 }
 
 enum : int { kModePlain = 0, kModeGeneral = 1, kModeFiltered = 2 };
-// TEAM > 1 (latency regime: fewer queries than the chip has wave slots): a workgroup of TEAM wavefronts serves one
-// query.  Wave 0 runs the search exactly as the single-wave form does (queue, visited filter, merge); the other waves
-// only take a share of every gather -- the rows of a hop are split TEAM ways, so a lane issues a quarter of the
-// requests and FMAs, and the 512-byte rows of a 32-neighbour hop are in flight from four SIMDs at once.  Two workgroup
-// barriers per gather (candidates ready / distances ready); every other synchronisation of wave 0 stays wave-local.
-// Distances come from the same lane groups and the same arithmetic: results are identical by construction.
-__device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
+// TEAM > 1: this is the queue wave of a team (see team_control_wave)
 template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int TEAM = 1>
 __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint32_t slot, uint8_t* smem) {
     constexpr bool FILT = MODE == kModeFiltered;
@@ -462,16 +802,15 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
     float* cand_d = reinterpret_cast<float*>(smem + L.cand_d_off);
-    // teams: the two candidate buffers and which one the current hop uses (wave 0 swaps after a successful speculation)
-    // (base + buffer * stride, never a table of pointers: see team_helper)
+    // teams: the two candidate buffers (base + buffer * stride, never a table of pointers: see team_helper)
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
-    uint32_t cur = 0;
-    uint32_t spec_node = kEmpty, spec_nc = 0, spec_new = 0;
     uint2* stage = reinterpret_cast<uint2*>(smem + L.stage_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     float* snew = reinterpret_cast<float*>(smem + L.snew_off);
     constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
     uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
+    uint32_t* mail = reinterpret_cast<uint32_t*>(smem + L.mail_off);  // (teams)
+    if constexpr (TEAM > 1) mail[lane] = 0u;
 
     // ---- stage the query (f16 query widened to f32 once: layers/full.rs:421-423) -------
     {
@@ -533,43 +872,16 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         qd[s] = 0.0f;
     }
     uint32_t size = 0, cmps = 0, hops = 0, ht_count = 0, status = 0, nrec = 0;
-    // adjacency rows requested ahead of their use: the node, its row's first dwords per lane (lane 0: the length) and
-    // neighbour `lane`.  pf_*: the best unexpanded queue entry; nb_*: (teams) a new candidate that overtook it.  The
-    // length stays in a vector register until it is needed -- a scalar copy would wait for the load on the spot -- and
-    // the two requests never share a variable, so no register copy (and its wait) appears where their paths join.
+    // the adjacency row requested ahead of its use: the node (the best unexpanded queue entry), its row's first dwords
+    // per lane (lane 0: the length) and neighbour `lane`.  The length stays in a vector register until it is needed -- a
+    // scalar copy would wait for the load on the spot.
     uint32_t pf_node = kEmpty, pf_lenv = 0, pf_val = kEmpty, node0 = kEmpty;
-    uint32_t nb_node = kEmpty;
     auto adj_fetch = [&](uint32_t node, uint32_t& lenv, uint32_t& val) {
         const uint32_t* prow = ix.adj + (uint64_t)node * ix.adj_stride;
         lenv = prow[lane <= R ? lane : R];  // (max_degree >= 1; the same cache lines as the neighbours)
         val = prow[1u + (lane < R ? lane : R - 1u)];
     };
     auto adj_len = [&](uint32_t lenv) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)lenv, 0); };
-    // teams: the same requests, but the row lands in LDS (buffer 0: pf_node's, buffer 1: nb_node's) through
-    // global_load_lds_dword: lane l's dword goes to M0 + 4 l.  No register is written, so the compiler has nothing to
-    // copy or to wait for while the load is in flight -- wave 0 merges in the meantime -- and the consumer waits
-    // explicitly (adj_landed).  One instruction covers the length and max_degree <= 63 neighbours (teams require it).
-    auto adj_fetch_lds = [&](uint32_t node, uint32_t which) {
-        const uint32_t* p = ix.adj + (uint64_t)node * ix.adj_stride + (lane <= R ? lane : R);
-        const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(
-            __attribute__((address_space(3))) uint8_t*)(smem + L.adj_off + which * kAdjLandBytes));
-        // (buffer 0 is also read by the visited wave, which has no counter to wait on: it polls for the row)
-        if (which == 0u) reinterpret_cast<uint32_t*>(smem + L.adj_off)[lane] = kAdjPending;
-        uint32_t m0_saved;
-        asm volatile(
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "global_load_lds_dword %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(m0_saved)
-            : "v"(p), "s"(lds)
-            : "memory");
-    };
-    auto adj_landed = [&](uint32_t which) -> const uint32_t* {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return reinterpret_cast<const uint32_t*>(smem + L.adj_off + which * kAdjLandBytes);
-    };
     uint32_t pf_dummy = 0;  // landing register of the row-prefetch loads (latency mode)
     bool lds_open = true;
 #ifdef DANN_PHASE_CYCLES
@@ -634,51 +946,15 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // (tag < PUBLISHED) is marked kEmpty and compacted away afterwards -- expand_beam_inner skips it after the
     // visited insert and does not count it (provider.rs:448-473, 681-686).  Returns the number of candidates kept.
     const uint32_t tag_off = PLAIN ? 0u : ix.tag_off;
-    // teams: wave 0 hands cand_id[0..nc) of the current buffer to the gather waves ("candidates ready") and names the
-    // node whose neighbours the visited wave filters meanwhile: pf_node, the predicted next expansion, whose adjacency
-    // row wave 0 has requested into landing buffer 0.  If that node is indeed expanded next, the hop starts with its
-    // candidates in place (spec_commit); if not, the inserts are taken back (every insert filled an empty slot: setting
-    // those slots to kEmpty again restores the table exactly) and the hop expands normally.  The visited *set* a search
-    // ends with does not depend on the order of inserts.
-    uint32_t spec_sent = kEmpty;
-    auto team_start = [&](uint32_t nc) {
-        spec_sent = (pf_node != kEmpty && lds_open && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
-        if (lane == 0) {
-            beam[kTwGather] = nc | (cur << 16);
-            beam[kTwSpecNode] = spec_sent;
-            beam[kTwHtCount] = ht_count;
-            beam[kTwSpecBuf] = cur ^ 1u;
-        }
-        __syncthreads();
-    };
-    // after "distances ready": what the visited wave did
-    auto spec_collect = [&]() {
-        spec_node = kEmpty;
-        if (spec_sent != kEmpty && beam[kTwSpecRan]) {
-            spec_node = spec_sent;
-            spec_nc = beam[kTwSpecNc];
-            spec_new = beam[kTwSpecNew];
-        }
-    };
-    auto spec_rollback = [&]() {
-        const uint32_t slot = reinterpret_cast<const uint32_t*>(smem + L.slots_off)[lane];
-        if (slot != kEmpty) ht[slot] = kEmpty;
-        spec_node = kEmpty;
-        WS();
-    };
-    auto spec_commit = [&]() -> uint32_t {  // the speculated node is the one expanded: its candidates are in the other buffer
-        cur ^= 1u;
-        cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + cur * cstride);
-        cand_d = reinterpret_cast<float*>(smem + L.cand_d_off + cur * cstride);
-        ht_count += spec_new;
-        spec_node = kEmpty;
-        return spec_nc;
-    };
     auto gather = [&](uint32_t nc) -> uint32_t {
         if constexpr (TEAM > 1) {
-            team_start(nc);
+            // (only the start points come this way: hop 0 of the team, started by this wave; cand_id is buffer 0)
+            if (lane == 0) {
+                mail[kMbHop + 0] = nc;
+                mail[kMbHop + 1] = kEmpty;
+                mb_store(mail + kMbGo, 1u | (nc << 20));
+            }
             __syncthreads();  // "distances ready"
-            spec_collect();
             return nc;
         } else
         if constexpr (DIM > 0 && !kInt) {
@@ -996,15 +1272,10 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const uint32_t node = node_in_reg ? node0 : beam[b];  // the main loop's single pop stays in a register
             const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
             const bool hit = (node == pf_node);
-            const bool hit2 = TEAM > 1 && !hit && (node == nb_node);
 #ifdef DANN_PHASE_CYCLES
-            if constexpr (TEAM == 1) ph_acc[hit ? 5 : 6] += 1;
+            ph_acc[hit ? 5 : 6] += 1;
 #endif
-            const uint32_t* landed = nullptr;
-            if constexpr (TEAM > 1) {
-                if (hit || hit2) landed = adj_landed(hit ? 0u : 1u);
-            }
-            uint32_t len = TEAM > 1 ? ((hit || hit2) ? landed[0] : arow[0]) : (hit ? adj_len(pf_lenv) : arow[0]);
+            uint32_t len = hit ? adj_len(pf_lenv) : arow[0];
             len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
             if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
                 // freeze the LDS table, claim a spill table (kept once claimed)
@@ -1037,9 +1308,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             for (uint32_t j0 = 0; j0 < len; j0 += kWave) {
                 const uint32_t j = j0 + lane;
                 const bool inb = j < len;
-                uint32_t id;
-                if constexpr (TEAM > 1) id = !inb ? kEmpty : (hit || hit2) ? landed[1 + j] : arow[1 + j];
-                else id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
+                const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
                 const bool act = inb && id != kEmpty && (!accept_only || fmatch(id));
                 if (lds_open) {
@@ -1050,18 +1319,6 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const bool keep = isnew && id < ix.nslots;
                 const uint64_t nm = ballot64(isnew), km = ballot64(keep);
                 if (keep) cand_id[nc + mbcnt(km)] = id;
-                if constexpr (TEAM > 1) {
-                    // latency regime: should one of these be expanded straight away, its adjacency row is in L2 by then
-                    if ((a.tune & kTuneRowPrefetch) && keep) {
-                        const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
-                        const uint32_t* a1 = a0 + R;
-                        asm volatile(
-                            "global_load_dword %0, %1, off\n\t"
-                            "global_load_dword %0, %2, off"
-                            : "+v"(pf_dummy)
-                            : "v"(a0), "v"(a1));
-                    }
-                }
                 nc += (uint32_t)__popcll(km);
                 if (lds_open) ht_count += (uint32_t)__popcll(nm);
                 else spill_count += (uint32_t)__popcll(nm);
@@ -1140,151 +1397,48 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         }
         return got ? 1u : 0u;
     };
-    // ---- beam loop, a team of wavefronts -------------------------------------------------------------------------
-    // The hop's dependent chain is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  A team
-    // has three roles -- wave 0 owns the queue, wave 1 the speculative visited filter, the other waves evaluate rows --
-    // and takes the merge, the visited filter and the adjacency row off that chain:
-    //  * while the gather waves evaluate hop h, the visited wave filters the neighbours of the predicted next expansion
-    //    (pf_node) into the other candidate buffer (team_helper);
-    //  * when hop h's distances are ready, comparisons against pf_next and pf_next2 decide, *before* the merge, which
-    //    node hop h + 1 expands and which node will be the best unexpanded entry after that: hop h + 1 expands pf_next
-    //    unless a new candidate is at most as far (lower-bound insert, queue.rs:150-170: it goes in front; of equal new
-    //    candidates the one inserted last goes first).  If it is pf_next, the helpers start on its candidates at once;
-    //    if it is a new candidate, its adjacency row is requested at once.  The adjacency row of the predicted
-    //    runner-up is requested too, and only then does the merge of hop h run -- beside the helpers' gather and the
-    //    adjacency loads.
-    // The queue, the visited set and the order of expansions are exactly those of the one-wave loop: the early decisions
-    // only predict what the pop after the merge returns (an early start that the pop contradicts is an internal error;
-    // a runner-up the pop contradicts just costs the next hop its speculation).
+    // ---- beam loop of a team's queue wave (see team_control_wave): pop, publish, wait for the hop's distances, merge -----
     if constexpr (TEAM > 1) {
-        // argmin over the lanes of `on` by (distance ascending, lane descending); `on` must not be empty
-        auto best_lane = [&](bool on, float d) -> int {
-            const float m = wave_min_f32(on ? d : __builtin_inff());
-            return 63 - __builtin_clzll(ballot64(on && d == m));
-        };
-        uint32_t nc_cur = 0, early_node = kEmpty;
-        uint32_t pf_next = kEmpty, pf_next2 = kEmpty;
-        float pf_next_d = 0.0f, pf_next2_d = 0.0f;
-        bool started = false;  // the helpers already evaluate the candidates of the node the next pop returns
-        bool running = false;  // the helpers evaluate a hop (between "candidates ready" and "distances ready")
-        if (pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d) && !status) {
-            hops += 1;
-            nc_cur = expand(1, false, true);
-            if (!status) {
-                pf_node = pf_next;
-                if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
-                team_start(nc_cur);
-                running = true;
-            }
-        }
-        while (running) {
-            PH_T(ph2);
-            PH_T(pg2);
-            __syncthreads();  // "distances ready"
-            running = false;
-            spec_collect();
-            PH_T(ph3);
-            PH_ADD(14, pg2, ph3);
-            PH_ADD(2, ph2, ph3);
-            const uint32_t nc = nc_cur;
-            cmps += nc;
-            const bool has = lane < nc;
-            const float nd = has ? cand_d[lane] : 0.0f;
-            const uint32_t nid = has ? cand_id[lane] : kEmpty;
-            uint32_t* const cbi = reinterpret_cast<uint32_t*>(smem + L.mscr_off);  // (this hop's buffer is refilled
-            float* const cbd = reinterpret_cast<float*>(smem + L.mscr_off + 256u);    //  by the visited wave meanwhile)
-            started = false;
-            uint32_t pred = kEmpty;  // the predicted best unexpanded entry after the next pop
-            bool keep_pf = false;    // pf_* already hold (or were asked for) the row the next steps need
-            if (pf_next != kEmpty) {
-                const bool ahead = has && nd <= pf_next_d;  // (a NaN distance never enters the queue)
-                if (ballot64(ahead) == 0) {
-                    if (spec_node == pf_next) {  // hop h + 1 expands pf_next, and its candidates are ready
-                        nc_cur = spec_commit();
-                        early_node = pf_next;
-                        // the runner-up after that pop, named to the visited wave with this very start
-                        if (pf_next2 != kEmpty) {
-                            const bool ahead2 = has && nd <= pf_next2_d;
-                            pred = ballot64(ahead2) ? (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd))
-                                                    : pf_next2;
-                        }
-                        pf_node = pred;
-                        if (pred != kEmpty) adj_fetch_lds(pred, 0);
-                        team_start(nc_cur);
-                        started = running = true;
-                        pred = kEmpty;
-                        keep_pf = true;
-                    } else {
-                        if (spec_node != kEmpty) spec_rollback();  // (a runner-up the pop contradicted)
-                        keep_pf = pf_node == pf_next;  // the next expansion reads the landed row itself
-                    }
-                } else {
-                    // hop h + 1 expands the closest new candidate: its adjacency row is requested (the visited wave
-                    // touched it when the candidate was found, so it comes from L2), the runner-up is worked out while
-                    // it travels, and the expansion runs before the merge -- which then has the gather beside it
-                    if (spec_node != kEmpty) spec_rollback();
-                    const int bj = best_lane(ahead, nd);
-                    nb_node = (uint32_t)__builtin_amdgcn_readlane((int)nid, bj);
-                    adj_fetch_lds(nb_node, 1);
-                    const bool rest = ahead && (int)lane != bj;
-                    uint32_t runner = pf_next;  // pf_next stays the runner-up unless a second new candidate is ahead too
-                    if (ballot64(rest)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(rest, nd));
-                    keep_pf = true;
-                    node0 = nb_node;
-                    nc_cur = expand(1, false, true);
-                    if (status) break;
-                    nb_node = kEmpty;
-                    early_node = node0;
-                    if (pf_node != runner) {  // (pf_next's row is here already unless the last pop contradicted it)
-                        pf_node = runner;
-                        adj_fetch_lds(pf_node, 0);
-                    }
-                    team_start(nc_cur);
-                    started = running = true;
-                }
-            } else if (spec_node != kEmpty) {
-                spec_rollback();  // (cannot happen: nothing is speculated without a pf_next)
-            }
-            if (pred != kEmpty) {
-                pf_node = pred;
-                adj_fetch_lds(pred, 0);
-            } else if (!keep_pf) {
-                pf_node = kEmpty;
-            }
-            PH_T(phq);
-#ifdef DANN_PHASE_CYCLES
-            ph_acc[started && early_node == pf_next ? 12 : 13] += phq - ph3;
-            ph_acc[started && early_node == pf_next ? 5 : 6] += 1;
-#endif
-            merge_regs(has, nd, nid, nc, cbi, cbd);
-            PH_T(ph4);
-            PH_ADD(15, phq, ph4);
-            PH_ADD(3, ph3, ph4);
-            pf_next = pf_next2 = kEmpty;
+        mb_store(mail + kMbHtCount0, ht_count);
+        if (lane == 0) mail[kMbLoaded] = 1u;  // (the start points' distances went into the queue above)
+        for (uint32_t npop = 1;; ++npop) {
+            PH_T(ph0);
+            uint32_t pf_next = kEmpty, pf_next2 = kEmpty;
+            float pf_next_d = 0.0f, pf_next2_d = 0.0f;
             const uint32_t nb = pop_one(pf_next, pf_next_d, pf_next2, pf_next2_d);
-            if (nb == 0 || status) break;
-            hops += 1;
-            PH_T(ph5);
-            PH_ADD(0, ph4, ph5);
-            if (started) {
-                if (node0 != early_node) status = (uint32_t)(-DANN_EINTERNAL);
-                // (a runner-up the pop contradicts: the visited wave's work on it is taken back after this hop)
-            } else {
-                nc_cur = expand(1, false, true);  // (adjacency row: a landing buffer if the node is pf_node / nb_node)
-                if (status) break;
-                if (pf_node != pf_next) {  // the runner-up is another node than predicted (or none was): ask now
-                    pf_node = pf_next;
-                    if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
-                }
-                team_start(nc_cur);
-                running = true;
+            hops += nb;
+            if (lane == 0) {
+                uint32_t* w = mail + kMbPop + 8u * (npop & 1u);
+                w[1] = nb;
+                w[2] = node0;
+                w[3] = pf_next;
+                w[4] = __builtin_bit_cast(uint32_t, pf_next_d);
+                w[5] = pf_next2;
+                w[6] = __builtin_bit_cast(uint32_t, pf_next2_d);
+                mb_store(w, npop);
             }
-            nb_node = kEmpty;
-            PH_T(ph6);
-            PH_ADD(1, ph5, ph6);
-            PH_ADD(4, ph2, ph6);
+            PH_T(ph1);
+            PH_ADD(0, ph0, ph1);
+            __syncthreads();  // "distances ready" of hop npop -- or the release
+            PH_T(ph2);
+            PH_ADD(14, ph1, ph2);
+            if (mb_load(mail + kMbGo) == kTeamExit) break;
+            const uint32_t word = mail[kMbHop + 8u * (npop & 1u)];
+            const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
+            const bool has = lane < nc;
+            const float nd = has ? reinterpret_cast<const float*>(smem + L.cand_d_off + buf * cstride)[lane] : 0.0f;
+            const uint32_t nid = has ? reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride)[lane] : kEmpty;
+            WS();
+            if (lane == 0) mb_store(mail + kMbLoaded, npop + 1u);  // the buffer may be refilled now
+            merge_regs(has, nd, nid, nc, reinterpret_cast<uint32_t*>(smem + L.mscr_off),
+                       reinterpret_cast<float*>(smem + L.mscr_off + 256u));
+            PH_T(ph4);
+            PH_ADD(3, ph2, ph4);
+            PH_ADD(4, ph0, ph4);
         }
-        if (running) __syncthreads();  // (the helpers are on their way to "distances ready")
+        const uint32_t dstatus = mail[kMbDStatus];
+        if (!status) status = dstatus;
+        cmps += mail[kMbDCmps];
     } else
     // ---- beam loop ----------------------------------------------------------------------
     for (;;) {
@@ -1727,10 +1881,6 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     if (lane == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&a.phase_cycles[i], ph_acc[i]);
 #endif
-    if constexpr (TEAM > 1) {  // no gather follows: release the helper waves (they leave the barrier count)
-        if (lane == 0) beam[1] = kTeamExit;
-        __syncthreads();
-    }
     if (spill) {  // hand the spill table back clean
         WS();
         spill_wipe(spill, spill_size, lane);

@@ -192,10 +192,10 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     a.spill_bits = ctx.spill_bits;
     a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
     DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
-    // latency regime with at most one query per SIMD: a team of wavefronts per query (the rows of a hop split over the
-    // helper waves, wave 0 expands the predicted next node meanwhile).  Knn searches only (the launch falls back to one
-    // wave per query where no team instantiation exists).  Decided before the table is sized: teams carry a second
-    // candidate buffer.  DANN_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_TEAM_MAX_QUERIES: development switches.
+    // latency regime with at most one query per SIMD: a team of four wavefronts per query -- queue, control, visited
+    // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches only (the launch falls back to one wave
+    // per query where no team instantiation exists).  Decided before the table is sized: teams carry more LDS.
+    // DANN_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_TEAM_MAX_QUERIES: development switches.
     {
         static const uint32_t team_max = [] {
             const char* e = getenv("DANN_TEAM_MAX_QUERIES");
@@ -367,8 +367,12 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
         DANN_HIP(hipMemcpyAsync(&h, count, 4, hipMemcpyDeviceToHost, st));
         DANN_HIP(hipStreamSynchronize(st));
         if (h == 0) return DANN_OK;
-        if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status
-        a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
+        if (a.team) {
+            a.team = 0;  // a team never spills its visited table: the same table, one wave per query (which does)
+        } else {
+            if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status
+            a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
+        }
         a.qmap = qmap = lists[round & 1];
         a.nq = n = h;
         cap_grid(a);

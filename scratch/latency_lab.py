@@ -73,9 +73,9 @@ def timed(nq, L, reps):
         line += (f"\n      hops/q {hops / reps / nq:.1f} cmps/q {cmps / reps / nq:.0f} | cycles/hop: pop {v[0]:.0f} expand {v[1]:.0f} "
                  f"(visited loop {v[7]:.0f}) gather {v[2]:.0f} merge {v[3]:.0f} (ranks {v[11]:.0f}) total {v[4]:.0f} | "
                  f"pf hit {buf[5] / max(buf[5] + buf[6], 1):.2f} | survivors/merge {buf[8] / max(buf[10], 1):.1f} "
-                 f"slow merges {buf[9] / max(buf[10], 1):.3f} | team: decision when pf_next wins {buf[12] / max(buf[5], 1):.0f} "
-                 f"(x{buf[5] / max(buf[5] + buf[6], 1):.2f}) when a new candidate wins {buf[13] / max(buf[6], 1):.0f} merge proper {v[15]:.0f} "
-                 f"wait barrier B {v[14]:.0f}")
+                 f"slow merges {buf[9] / max(buf[10], 1):.3f} | team: control wave's decision with the visited wave's candidates {buf[12] / max(buf[5], 1):.0f} "
+                 f"(x{buf[5] / max(buf[5] + buf[6], 1):.2f}) otherwise {buf[13] / max(buf[6], 1):.0f} (waited for the pop x{buf[7] / max(buf[5] + buf[6], 1):.2f}) "
+                 f"its loads {v[1]:.0f} start {v[2]:.0f} barrier wait {v[15]:.0f} | queue wave's barrier wait {v[14]:.0f}")
     print(line, flush=True)
 
 

@@ -263,12 +263,13 @@ def test_spill_tables_recycled_under_load():
 @pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.F16, oracle.L2), (oracle.U8, oracle.L2),
                                           (oracle.I8, oracle.INNER_PRODUCT), (oracle.U8, oracle.COSINE)])
 def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric, monkeypatch):
-    """Latency regime: launches with few queries give every query a team of wavefronts (the rows of a hop split four
-    ways, everything else on wave 0).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query
-    launch's (DANN_TUNE_OFF bit 4 switches the teams off, bit 8 the speculative expansion of the predicted next node by
-    wave 0 -- visited-table inserts that are rolled back when the prediction fails), with several start points and for
-    every queue size the team instantiations cover (L + start points <= 256) and beyond; a small explicit visited table
-    makes searches freeze the LDS table and spill, where speculation must stand back."""
+    """Latency regime: launches with few queries give every query a team of four wavefronts (queue / control / visited
+    filter / row gather, talking through an LDS mailbox; the control wave decides the next expansion before the merge,
+    the visited wave filters the predicted one after that speculatively -- inserts that are taken back when the prediction
+    fails).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query launch's (DANN_TUNE_OFF bit 4
+    switches the teams off, bit 8 the speculation), with several start points and for every queue size the team
+    instantiations cover (L + start points <= 256) and beyond; a small explicit visited table makes a team give the query
+    back (a team never spills) and the host re-run it with one wave."""
     rng = np.random.default_rng(777)
     n, dim, R, nstart = 6000, 128, 32, 3
     data = rand_vectors(rng, dtype, n, dim)
@@ -291,3 +292,23 @@ def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric, mon
                 assert np.array_equal(bits(od), bits(d)), (nq, L)
                 assert np.array_equal(ost[:, 0], st["cmps"]) and np.array_equal(ost[:, 1], st["hops"]), (nq, L)
                 assert np.array_equal(oc, st["written"])
+
+
+def test_team_single_queries_at_tiny_queues_follow_the_oracle():
+    """Hundreds of one-query launches at queue sizes where almost every hop takes another path through the control wave
+    (no unexpanded entry left, a new candidate overtaking, a contradicted runner-up): the waves of a team only meet at one
+    barrier per hop, everything else is mailbox traffic -- a lost ordering shows up here as a different number of
+    comparisons long before it changes a result."""
+    rng = np.random.default_rng(4242)
+    n, dim, R, nstart = 6000, 128, 32, 3
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R, nstart=nstart)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:nstart], R)
+    queries = rand_vectors(rng, oracle.F32, 150, dim)
+    for L, k in ((1, 1), (2, 1), (5, 3), (40, 10)):
+        oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
+        for q in range(len(queries)):
+            gi, gd, st = gix.search(da.Knn(L, 1), queries[q:q + 1], k)
+            assert st["status"][0] == 0
+            assert np.array_equal(gi[0], oi[q]) and np.array_equal(bits(gd[0]), bits(od[q])), (L, q)
+            assert st["cmps"][0] == ost[q, 0] and st["hops"][0] == ost[q, 1], (L, q, st["cmps"][0], ost[q, 0])
