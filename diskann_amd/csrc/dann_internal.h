@@ -78,13 +78,18 @@ struct IndexView {
 // number; wave 0 of the kernel (the dispatcher) polls the publication words over PCIe, 64 at a time, and advances
 // `avail` in device memory; the worker waves draw tickets from `head`, wait for avail > ticket, stage the query into
 // device memory, run the ordinary beam search and write the result plus a completion word back to the host ring.
+// lap tag of a submission-ring entry: never 0 (the ring starts zeroed), consecutive laps differ
+__host__ __device__ inline uint32_t server_lap_tag(unsigned long long ticket, uint32_t ring_shift) {
+    return (uint32_t)((ticket >> ring_shift) % 4095ull) + 1u;
+}
 struct ServerView {
     const uint8_t* h_queries = nullptr;  // host ring: ring x qstride bytes
-    const uint32_t* h_pub = nullptr;     // host: ring publication words ((ticket / ring) + 1 once slot is filled)
+    const uint32_t* h_pub = nullptr;     // host: submission ring, entry of ticket t at t % ring: lap tag << 20 | result slot
+    uint32_t* h_ack = nullptr;           // host: lap tag of the last entry a worker has taken from each ring position
     uint32_t* h_res_ids = nullptr;       // host: ring x k
     float* h_res_d = nullptr;            // host: ring x k
     dann_search_stats* h_res_stats = nullptr;  // host: ring
-    uint32_t* h_done = nullptr;          // host: ring completion words ((ticket / ring) + 1 once the result is written)
+    uint32_t* h_done = nullptr;          // host: per result slot, low 32 bits of (ticket + 1) once the result is written
     uint32_t* h_ctl = nullptr;           // host: [0] stop request (host -> GPU), [1] the dispatcher has decided to exit
     unsigned long long* d_head = nullptr;   // device: next ticket a worker draws
     unsigned long long* d_avail = nullptr;  // device: tickets below this are published

@@ -256,6 +256,7 @@ enum : int {
     kMbDStatus = 3,   // control wave -> queue wave, at the end: its status ...
     kMbDCmps = 4,     //   ... and the candidates it had evaluated
     kMbHtCount0 = 5,  // queue wave -> control wave: ids in the visited table after the start points
+    kMbSpecSeq = 6,   // control (hop 0: queue) wave -> visited wave: hop + 1 of the hop whose kMbHop words are complete
     kMbHop = 8,       // + 8 * (hop & 1):  +0 candidates | buffer << 16   +1 node for the visited wave (kEmpty: none)
                       //                   +2 ids in the visited table    +3 buffer for the visited wave's candidates
     kMbPop = 24,      // + 8 * (pop & 1):  +0 pop number (written last)  +1 found  +2 node  +3 best unexpanded entry left
@@ -411,19 +412,24 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     unsigned long long ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     uint32_t loaded_seen = 0;  // the last value of kMbLoaded this wave has read
-    auto team_start = [&](uint32_t nc, uint32_t buf) {
-        PH_T(pts0);
+    // start hop `hop + 1` on `nc` candidates in buffer `buf`: the gather wave first (team_go) -- the hop's critical
+    // path --, then the visited wave with the node to work on meanwhile, pf_node (team_spec)
+    auto team_go = [&](uint32_t nc, uint32_t buf) {
         ++hop;
+        if (lane == 0) mb_store(mail + kMbGo, ((hop + 1u) & 0xFFFFFu) | (nc << 20) | (buf << 27));
+        cur = buf;
+        nc_cur = nc;
+    };
+    auto team_spec = [&]() {
+        PH_T(pts0);
         // the visited wave refills the previous hop's buffer: the queue wave must hold those distances in registers
         if (loaded_seen < hop) mb_wait_at_least(mail + kMbLoaded, hop);
         spec_sent = (pf_node != kEmpty && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
         if (lane == 0) {
             uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
-            *reinterpret_cast<uint4*>(w) = make_uint4(nc | (buf << 16), spec_sent, ht_count, buf ^ 1u);
-            mb_store(mail + kMbGo, ((hop + 1u) & 0xFFFFFu) | (nc << 20) | (buf << 27));
+            *reinterpret_cast<uint4*>(w) = make_uint4(nc_cur | (cur << 16), spec_sent, ht_count, cur ^ 1u);
+            mb_store(mail + kMbSpecSeq, hop + 1u);
         }
-        cur = buf;
-        nc_cur = nc;
         PH_T(pts1);
         PH_ADD(2, pts0, pts1);
     };
@@ -539,20 +545,22 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                     // the next hop expands pf_next; the runner-up after that pop: pf_next2 unless a new candidate is
                     // at most as far
                     next = pf_next;
-                    runner = pf_next2;
-                    if (pf_next2 != kEmpty) {
-                        const bool ahead2 = has && nd <= pub.pf_next2_d;
-                        if (ballot64(ahead2)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd));
-                    }
-                    if (spec_node == pf_next) {  // ... and the visited wave has its candidates ready
+                    if (spec_node == pf_next) {  // ... and the visited wave has its candidates ready: go
                         ht_count += spec_new;
                         nc = spec_nc;
                         spec_node = kEmpty;
+                        team_go(nc, cur ^ 1u);
+                        started = true;
                     } else {
                         overtaken = true;  // (statistics: not the short path)
                         if (spec_node != kEmpty) spec_rollback();  // (a runner-up the pop contradicted)
                         nc = expand(next, pf_node == next ? 0 : -1, cur ^ 1u);
                         if (status) break;
+                    }
+                    runner = pf_next2;
+                    if (pf_next2 != kEmpty) {
+                        const bool ahead2 = has && nd <= pub.pf_next2_d;
+                        if (ballot64(ahead2)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, best_lane(ahead2, nd));
                     }
                 } else {
                     // the next hop expands the closest new candidate (of equal ones the one inserted last): its
@@ -575,7 +583,8 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                     if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
                 }
                 touch_found();
-                team_start(nc, cur ^ 1u);
+                if (!started) team_go(nc, cur ^ 1u);
+                team_spec();
                 started = true;
             }
         }
@@ -593,7 +602,8 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                 if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
             }
             touch_found();
-            team_start(nc, cur ^ 1u);
+            team_go(nc, cur ^ 1u);
+            team_spec();
 #ifdef DANN_PHASE_CYCLES
             overtaken = true;
             ph_acc[7] += 1;
@@ -639,6 +649,7 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
     for (uint32_t hop = 0;; ++hop) {
         seen = mb_wait_change(mail + kMbGo, seen);
         if (seen == kTeamExit) break;
+        mb_wait_at_least(mail + kMbSpecSeq, hop + 1u);  // (the gather wave is started first)
         const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
         const uint32_t node = w[1];
         uint32_t ran = 0, kept = 0, fresh = 0;
@@ -952,6 +963,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             if (lane == 0) {
                 mail[kMbHop + 0] = nc;
                 mail[kMbHop + 1] = kEmpty;
+                mail[kMbSpecSeq] = 1u;
                 mb_store(mail + kMbGo, 1u | (nc << 20));
             }
             __syncthreads();  // "distances ready"
@@ -1973,6 +1985,7 @@ __device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) {
 __device__ __forceinline__ void sys_store_u32(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
 // wave 0: turns the host's publication words into the device-side `avail` counter; leaves on a stop request or
 // after idle_timeout_us without a new submission
 __device__ void server_dispatch(const ServerView& sv) {
@@ -1986,8 +1999,8 @@ __device__ void server_dispatch(const ServerView& sv) {
     const uint32_t max_idle_iters = sv.idle_timeout_us * 4u + 1024u;
     for (;;) {
         const unsigned long long t = avail + lane;
-        const uint32_t expect = (uint32_t)(t >> sv.ring_shift) + 1u;
-        const bool ready = sys_load_u32(sv.h_pub + (uint32_t)(t & (sv.ring - 1u))) == expect;
+        const uint32_t expect = server_lap_tag(t, sv.ring_shift);
+        const bool ready = (sys_load_u32(sv.h_pub + (uint32_t)(t & (sv.ring - 1u))) >> 20) == expect;
         const uint64_t m = ballot64(ready);
         const uint32_t n = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);  // published tickets form a prefix
         if (n) {
@@ -2073,7 +2086,16 @@ __global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a)
                 for (uint32_t b = 0; b < naps; ++b) __builtin_amdgcn_s_sleep(32);
             }
             if (leave) break;
-            const uint32_t slot = (uint32_t)(t & (sv.ring - 1u));
+            // the ring entry names the result slot (slots are handed out by the host independently of ticket order, so
+            // that a caller who collects its tickets late, or out of order, holds up nobody's submission); taking the
+            // entry is acknowledged at once -- the position is free for the next lap long before the search ends
+            const uint32_t pos = (uint32_t)(t & (sv.ring - 1u));
+            uint32_t entry = 0;
+            if (lane == 0) {
+                entry = sys_load_u32(sv.h_pub + pos);
+                sys_store_u32(sv.h_ack + pos, entry >> 20);  // (the stored value depends on the load: it cannot pass it)
+            }
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry) & 0xFFFFFu;
             // ---- stage the query: host ring -> this worker's device buffer (system-scope 16-byte loads)
             {
                 const uint8_t* src = sv.h_queries + (size_t)slot * sv.qstride;
@@ -2105,7 +2127,7 @@ __global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the result words before the completion word
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) sys_store_u32(sv.h_done + slot, (uint32_t)(t >> sv.ring_shift) + 1u);
+                if (lane == 0) sys_store_u32(sv.h_done + slot, (uint32_t)t + 1u);
             }
             __syncthreads();  // the next query reuses this wave's LDS
         }

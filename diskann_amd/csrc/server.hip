@@ -9,13 +9,19 @@
 // Nothing on this path takes the index's exclusive lock or calls into the HIP runtime.
 //
 //   host                                       device (one launch, grid = workers + 1 wavefronts)
-//   ticket = next++                            wave 0 (dispatcher): polls pub[] over PCIe, 64 slots per poll,
-//   wait until slot (ticket % ring) is free                         advances `avail` in device memory
-//   ring.query[slot] = query                   worker: ticket' = head++; waits for avail > ticket'
-//   pub[slot] = lap + 1        ------------>            stages ring.query[slot] into device memory, runs the search
-//   ...                                                  result -> ring.result[slot]; done[slot] = lap + 1
-//   spin on done[slot] == lap + 1  <--------
-//   copy result out; slot free for ticket + ring
+//   slot = a free result slot                  wave 0 (dispatcher): polls the submission ring over PCIe, 64 entries
+//   ring.query[slot] = query                                        per poll, advances `avail` in device memory
+//   seq = next++                               worker: seq' = head++; waits for avail > seq'
+//   wait until ring[seq % ring] was taken               takes ring[seq' % ring] (-> slot), acknowledges it,
+//   ring[seq % ring] = lap tag | slot  ------>          stages ring.query[slot] into device memory, runs the search
+//   ...                                                  result -> ring.result[slot]; done[slot] = seq' + 1
+//   spin on done[slot] == seq + 1  <--------
+//   copy result out; slot back to the free list
+//
+// Result slots and ring positions are separate on purpose: a ring position is free again as soon as a worker has taken
+// its entry, whatever its caller does with the ticket -- a caller that collects tickets late or out of order (or is
+// descheduled with tickets outstanding) cannot stall other callers' submissions.  Only running out of result slots
+// (`ring` tickets submitted and not waited for) makes dann_search_submit wait.
 //
 // The kernel leaves when the host asks (dann_server_stop) or after idle_timeout_us without a submission, so that a
 // device-wide synchronisation elsewhere in the process never waits on an idle server; the next submission (or a waiter
@@ -45,8 +51,27 @@ struct dann_server {
     uint32_t* d_out_ids = nullptr;
     float* d_out_d = nullptr;
     dann_search_stats* d_stats = nullptr;
-    std::atomic<uint64_t> next{0};            // next ticket
-    std::atomic<uint64_t>* slot_free = nullptr;  // per slot: the ticket that may use it next
+    std::atomic<uint64_t> next{0};            // next sequence number (position in the submission ring)
+    std::atomic<uint64_t>* slot_owner = nullptr;  // per result slot: the ticket outstanding on it + 1, 0 = free
+    std::atomic<uint64_t> free_head{0};       // free result slots, a Treiber stack: slot + 1 (0: empty) | ABA tag << 32
+    uint32_t* free_next = nullptr;            //   next slot + 1 of each free slot
+    uint32_t take_slot() {                    // kEmpty32 if none is free right now
+        uint64_t h = free_head.load(std::memory_order_acquire);
+        for (;;) {
+            const uint32_t top = (uint32_t)h;
+            if (!top) return 0xFFFFFFFFu;
+            const uint64_t nh = (((h >> 32) + 1) << 32) | free_next[top - 1];
+            if (free_head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return top - 1;
+        }
+    }
+    void give_slot(uint32_t slot) {
+        uint64_t h = free_head.load(std::memory_order_acquire);
+        for (;;) {
+            free_next[slot] = (uint32_t)h;
+            const uint64_t nh = (((h >> 32) + 1) << 32) | (slot + 1u);
+            if (free_head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return;
+        }
+    }
     std::mutex launch_mu;
     bool launched = false;
     std::atomic<uint64_t> relaunches{0};
@@ -168,7 +193,8 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
         s->ctx.destroy();
         if (s->h_block) (void)hipHostFree(s->h_block);
         if (s->d_block) (void)hipFree(s->d_block);
-        delete[] s->slot_free;
+        delete[] s->slot_owner;
+        delete[] s->free_next;
         delete s;
         return rc;
     };
@@ -179,7 +205,8 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     // host ring
     const size_t o_q = 0, o_pub = o_q + (size_t)ring * qbytes, o_ids = o_pub + (size_t)ring * 4,
                  o_d = o_ids + (size_t)ring * k * 4, o_st = o_d + (size_t)ring * k * 4,
-                 o_done = o_st + (size_t)ring * sizeof(dann_search_stats), o_ctl = o_done + (size_t)ring * 4;
+                 o_done = o_st + (size_t)ring * sizeof(dann_search_stats), o_ack = o_done + (size_t)ring * 4,
+                 o_ctl = o_ack + (size_t)ring * 4;
     s->h_bytes = o_ctl + 64;
     hipError_t e = hipHostMalloc((void**)&s->h_block, s->h_bytes, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) return fail(hip_fail(e, "hipHostMalloc(server ring)"));
@@ -202,6 +229,7 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     sv.h_res_d = reinterpret_cast<float*>(dev_view + o_d);
     sv.h_res_stats = reinterpret_cast<dann_search_stats*>(dev_view + o_st);
     sv.h_done = reinterpret_cast<uint32_t*>(dev_view + o_done);
+    sv.h_ack = reinterpret_cast<uint32_t*>(dev_view + o_ack);
     sv.h_ctl = reinterpret_cast<uint32_t*>(dev_view + o_ctl);
     sv.d_head = reinterpret_cast<unsigned long long*>(db);
     sv.d_avail = reinterpret_cast<unsigned long long*>(db + 8);
@@ -219,9 +247,14 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     s->d_out_ids = reinterpret_cast<uint32_t*>(db + d_ids);
     s->d_out_d = reinterpret_cast<float*>(db + d_d);
     s->d_stats = reinterpret_cast<dann_search_stats*>(db + d_st);
-    s->slot_free = new (std::nothrow) std::atomic<uint64_t>[ring];
-    if (!s->slot_free) return fail(DANN_ENOMEM);
-    for (uint32_t i = 0; i < ring; ++i) s->slot_free[i].store(i, std::memory_order_relaxed);
+    s->slot_owner = new (std::nothrow) std::atomic<uint64_t>[ring];
+    s->free_next = new (std::nothrow) uint32_t[ring];
+    if (!s->slot_owner || !s->free_next) return fail(DANN_ENOMEM);
+    for (uint32_t i = 0; i < ring; ++i) {
+        s->slot_owner[i].store(0, std::memory_order_relaxed);
+        s->free_next[i] = i + 1 < ring ? i + 2 : 0;  // slot 0 on top
+    }
+    s->free_head.store(1, std::memory_order_release);
     s->hv = sv;
     s->hv.h_queries = s->h_block + o_q;
     s->hv.h_pub = reinterpret_cast<const uint32_t*>(s->h_block + o_pub);
@@ -229,6 +262,7 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     s->hv.h_res_d = reinterpret_cast<float*>(s->h_block + o_d);
     s->hv.h_res_stats = reinterpret_cast<dann_search_stats*>(s->h_block + o_st);
     s->hv.h_done = reinterpret_cast<uint32_t*>(s->h_block + o_done);
+    s->hv.h_ack = reinterpret_cast<uint32_t*>(s->h_block + o_ack);
     s->hv.h_ctl = reinterpret_cast<uint32_t*>(s->h_block + o_ctl);
     idx->server = s;
     // the first launch happens under the index's exclusive lock (no search is running)
@@ -260,7 +294,8 @@ int32_t dann_server_stop(dann_index* idx) try {
     s->ctx.destroy();
     if (s->h_block) (void)hipHostFree(s->h_block);
     if (s->d_block) (void)hipFree(s->d_block);
-    delete[] s->slot_free;
+    delete[] s->slot_owner;
+    delete[] s->free_next;
     delete s;
     return DANN_OK;
 } DANN_CATCH_ALL
@@ -273,24 +308,44 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
         return DANN_EINVAL;
     }
     const ServerView& sv = s->hv;
-    const uint64_t t = s->next.fetch_add(1, std::memory_order_relaxed);
-    const uint32_t slot = (uint32_t)(t & (sv.ring - 1u));
     std::chrono::steady_clock::time_point began{};
-    // the slot's previous occupant (ticket t - ring) must have been collected by its waiter
-    for (uint64_t spins = 0; s->slot_free[slot].load(std::memory_order_acquire) != t; ++spins) {
+    // a result slot: only `ring` tickets submitted and not yet waited for make this wait
+    uint32_t slot;
+    for (uint64_t spins = 0; (slot = s->take_slot()) == 0xFFFFFFFFu; ++spins) {
         if (spins < 64) {
             cpu_relax();
         } else {
             std::this_thread::yield();
             if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
-                set_error("dann_search_submit: ring slot %u was not released within %u s (every ticket must be waited for)",
-                          slot, kWaitLimitSeconds);
+                set_error("dann_search_submit: no result slot was released within %u s (%u tickets outstanding: every ticket "
+                          "must be waited for)", kWaitLimitSeconds, sv.ring);
                 return DANN_EOVERFLOW;
             }
         }
     }
     memcpy(const_cast<uint8_t*>(sv.h_queries) + (size_t)slot * sv.qstride, query, sv.qbytes);
-    __atomic_store_n(host_u32(sv.h_pub) + slot, (uint32_t)(t >> sv.ring_shift) + 1u, __ATOMIC_RELEASE);
+    const uint64_t seq = s->next.fetch_add(1, std::memory_order_relaxed);
+    const uint64_t t = (seq << 20) | slot;
+    s->slot_owner[slot].store(t + 1, std::memory_order_release);
+    // the ring position: free once a worker has taken the previous lap's entry -- which depends on nothing but the
+    // workers getting through older tickets (a relaunch included: this thread may be the one that has to do it)
+    const uint32_t pos = (uint32_t)(seq & (sv.ring - 1u));
+    const uint32_t prev_tag = (seq >> sv.ring_shift) ? server_lap_tag(seq - sv.ring, sv.ring_shift) : 0u;
+    began = {};
+    for (uint64_t spins = 0; __atomic_load_n(sv.h_ack + pos, __ATOMIC_ACQUIRE) != prev_tag; ++spins) {
+        if (spins < 64) {
+            cpu_relax();
+        } else {
+            if ((spins & 63u) == 0)
+                if (int32_t rc = relaunch_if_exited(idx, s)) return rc;
+            std::this_thread::yield();
+            if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
+                set_error("dann_search_submit: ring position %u was not taken by a worker within %u s", pos, kWaitLimitSeconds);
+                return DANN_EHIP;
+            }
+        }
+    }
+    __atomic_store_n(host_u32(sv.h_pub) + pos, (server_lap_tag(seq, sv.ring_shift) << 20) | slot, __ATOMIC_RELEASE);
     *ticket = t;
     return relaunch_if_exited(idx, s);
 } DANN_CATCH_ALL
@@ -298,8 +353,9 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
 int32_t dann_search_poll(dann_index* idx, uint64_t ticket) try {
     if (!idx || !idx->server) return DANN_EINVAL;
     const ServerView& sv = idx->server->hv;
-    const uint32_t slot = (uint32_t)(ticket & (sv.ring - 1u));
-    return __atomic_load_n(sv.h_done + slot, __ATOMIC_ACQUIRE) == (uint32_t)(ticket >> sv.ring_shift) + 1u ? 1 : 0;
+    const uint32_t slot = (uint32_t)(ticket & 0xFFFFFu);
+    if (slot >= sv.ring) return DANN_EINVAL;
+    return __atomic_load_n(sv.h_done + slot, __ATOMIC_ACQUIRE) == (uint32_t)(ticket >> 20) + 1u ? 1 : 0;
 } DANN_CATCH_ALL
 
 int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
@@ -310,9 +366,9 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
         return DANN_EINVAL;
     }
     const ServerView& sv = s->hv;
-    const uint32_t slot = (uint32_t)(ticket & (sv.ring - 1u));
-    const uint32_t expect = (uint32_t)(ticket >> sv.ring_shift) + 1u;
-    if (s->slot_free[slot].load(std::memory_order_acquire) != ticket) {
+    const uint32_t slot = (uint32_t)(ticket & 0xFFFFFu);
+    const uint32_t expect = (uint32_t)(ticket >> 20) + 1u;
+    if (slot >= sv.ring || s->slot_owner[slot].load(std::memory_order_acquire) != ticket + 1) {
         set_error("dann_search_wait: ticket %llu is not outstanding (already waited for, or never submitted)",
                   (unsigned long long)ticket);
         return DANN_EINVAL;
@@ -337,7 +393,8 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
     dann_search_stats st = sv.h_res_stats[slot];
     std::vector<uint8_t> q;
     if (st.status) q.assign(sv.h_queries + (size_t)slot * sv.qstride, sv.h_queries + (size_t)slot * sv.qstride + sv.qbytes);
-    s->slot_free[slot].store(ticket + sv.ring, std::memory_order_release);
+    s->slot_owner[slot].store(0, std::memory_order_release);
+    s->give_slot(slot);
     if (st.status) {
         // the resident waves carry a fixed LDS visited table: the rare query that outgrows it (and the spill pool) is
         // re-run through the launch path, which retries with larger tables

@@ -515,7 +515,8 @@ int32_t dann_multi_search_batch(dann_multi* m, const void* queries, uint32_t nq,
  * l_value, k results); dann_search_submit copies one query (host pointer, layer bytes) into a ring in host-mapped
  * memory and returns a ticket; dann_search_wait blocks until that query's result has arrived and copies it out
  * (ids are slot ids, unwritten entries 0xFFFFFFFF / +inf, as dann_search_batch).  Every ticket must be waited for
- * exactly once; a slot of the ring is reused `ring` tickets later, so at most `ring` tickets can be outstanding.
+ * exactly once, in any order and by any thread; at most `ring` tickets can be outstanding (a further submit waits for a
+ * dann_search_wait to return a result slot; collecting tickets late never holds up another caller's submission).
  * Submit / wait / poll may be called from any number of threads concurrently and take no lock on the index; results are
  * identical to dann_search_batch.  Mutations of the index (set / insert / build) must not run while tickets are
  * outstanding.  The resident kernel leaves after idle_timeout_us without a submission (default 100 ms) and is
