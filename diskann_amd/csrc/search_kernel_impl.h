@@ -262,7 +262,13 @@ enum : int {
     kMbPop = 24,      // + 8 * (pop & 1):  +0 pop number (written last)  +1 found  +2 node  +3 best unexpanded entry left
                       //                   +4 its distance  +5 the one after it  +6 its distance
 };
+// (every mailbox word is the same for all lanes of the reader: handing it over as a scalar keeps the branches on it
+// scalar branches instead of nests of exec-masked regions)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t mb_load(const uint32_t* p) {
+    return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ uint32_t lds_poll_lane(const uint32_t* p) {  // (a per-lane address)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // publishes what this wave wrote to LDS before: one wave's LDS instructions execute in issue order, so all it takes is
@@ -447,11 +453,11 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
         const uint32_t col = lane < R ? lane : R - 1u;
         if (landed >= 0) {
             const uint32_t* row = adj_landed((uint32_t)landed);
-            len = row[0];
+            len = uni(row[0]);
             id = row[1u + col];
         } else {
             const uint32_t* row = ix.adj + (uint64_t)node * ix.adj_stride;
-            len = row[0];
+            len = uni(row[0]);
             id = row[1u + col];
         }
         len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
@@ -491,12 +497,12 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
         mb_wait_at_least(w, n);
         const uint4 lo = *reinterpret_cast<const uint4*>(w), hi = *reinterpret_cast<const uint4*>(w + 4);
         Pub r;
-        r.found = lo.y;
-        r.node = lo.z;
-        r.pf_next = lo.w;
-        r.pf_next_d = __builtin_bit_cast(float, hi.x);
-        r.pf_next2 = hi.y;
-        r.pf_next2_d = __builtin_bit_cast(float, hi.z);
+        r.found = uni(lo.y);
+        r.node = uni(lo.z);
+        r.pf_next = uni(lo.w);
+        r.pf_next_d = __builtin_bit_cast(float, uni(hi.x));
+        r.pf_next2 = uni(hi.y);
+        r.pf_next2_d = __builtin_bit_cast(float, uni(hi.z));
         return r;
     };
 
@@ -511,25 +517,27 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
             // (everything this decision reads was written before the barrier: one batch of LDS loads, one wait)
             const uint32_t* wp = mail + kMbPop + 8u * (hop & 1u);
             const uint4 plo = *reinterpret_cast<const uint4*>(wp), phi = *reinterpret_cast<const uint4*>(wp + 4);
-            const uint32_t r = mail[kMbVReply];
+            const uint32_t r_v = mail[kMbVReply];
             loaded_seen = mail[kMbLoaded];
             const bool has = lane < nc_cur;
             const float nd = has ? buf_d(cur)[lane] : 0.0f;
             const uint32_t nid = has ? buf_ids(cur)[lane] : kEmpty;
             Pub pub;
-            pub.found = plo.y;
-            pub.node = plo.z;
-            pub.pf_next = plo.w;
-            pub.pf_next_d = __builtin_bit_cast(float, phi.x);
-            pub.pf_next2 = phi.y;
-            pub.pf_next2_d = __builtin_bit_cast(float, phi.z);
+            pub.found = uni(plo.y);
+            pub.node = uni(plo.z);
+            pub.pf_next = uni(plo.w);
+            pub.pf_next_d = __builtin_bit_cast(float, uni(phi.x));
+            pub.pf_next2 = uni(phi.y);
+            pub.pf_next2_d = __builtin_bit_cast(float, uni(phi.z));
+            loaded_seen = uni(loaded_seen);
+            const uint32_t r = uni(r_v);
             spec_node = kEmpty;
             if (spec_sent != kEmpty && (r & 1u)) {
                 spec_node = spec_sent;
                 spec_nc = (r >> 8) & 0xFFu;
                 spec_new = (r >> 16) & 0xFFu;
             }
-            if (plo.x != hop || !pub.found || pub.node != early_node) status = (uint32_t)(-DANN_EINTERNAL);
+            if (uni(plo.x) != hop || !pub.found || pub.node != early_node) status = (uint32_t)(-DANN_EINTERNAL);
             if (status) break;
             cmps += nc_cur;
             const uint32_t pf_next = pub.pf_next, pf_next2 = pub.pf_next2;
@@ -651,7 +659,7 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
         if (seen == kTeamExit) break;
         mb_wait_at_least(mail + kMbSpecSeq, hop + 1u);  // (the gather wave is started first)
         const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
-        const uint32_t node = w[1];
+        const uint32_t node = uni(w[1]), table_ids = uni(w[2]), out_buf = uni(w[3]);
         uint32_t ran = 0, kept = 0, fresh = 0;
         if (node != kEmpty) {
             // the control wave asked for the node's adjacency row (kAdjPending in every dword first): wait for the
@@ -660,10 +668,10 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
             // of the *next* request's kAdjPending marks and pass for its data)
             uint32_t len = kAdjPending, val = kAdjPending, spins = 0;
             for (;;) {
-                const uint32_t mine = mb_load(landing + lane);
+                const uint32_t mine = lds_poll_lane(landing + lane);
                 if (ballot64(mine == kAdjPending) == 0) {
                     len = mb_load(landing);
-                    val = mb_load(landing + 1u + (lane < R ? lane : R - 1u));
+                    val = lds_poll_lane(landing + 1u + (lane < R ? lane : R - 1u));
                     break;
                 }
                 if (++spins > (1u << 16)) {  // (never observed; a speculation skipped costs nothing but time)
@@ -674,13 +682,13 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
             }
             if (len != kAdjPending) {
                 len = len < R ? len : R;
-                if (w[2] + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not overflow the table)
+                if (table_ids + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not overflow the table)
                     const uint32_t id = lane < len ? val : kEmpty;
                     uint32_t slot = 0;
                     const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
                     const bool keep = isnew && id < ix.nslots;
                     const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                    uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + w[3] * cstride);
+                    uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + out_buf * cstride);
                     if (keep) out[mbcnt(km)] = id;
                     slots[lane] = isnew ? slot : kEmpty;
                     ran = 1;
@@ -1435,7 +1443,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             PH_T(ph2);
             PH_ADD(14, ph1, ph2);
             if (mb_load(mail + kMbGo) == kTeamExit) break;
-            const uint32_t word = mail[kMbHop + 8u * (npop & 1u)];
+            const uint32_t word = uni(mail[kMbHop + 8u * (npop & 1u)]);
             const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
             const bool has = lane < nc;
             const float nd = has ? reinterpret_cast<const float*>(smem + L.cand_d_off + buf * cstride)[lane] : 0.0f;
