@@ -250,8 +250,11 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             return DANN_EINVAL;
         }
     }
-    // latency mode: at most ~2 waves per SIMD are resident and the launch is bound by per-hop latency, not bandwidth
-    if (inflight <= 8u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
+    // latency mode: the launch is bound by per-hop latency, not bandwidth -- rows (and, in teams, adjacency rows) of the
+    // predicted next hop are requested a hop ahead.  Measured on 1 M x 128 f32, L = 26 (scratch/prefetch_ab.py, kernel
+    // time with / without): 64 queries 131 / 144 us, 256: 146 / 161, 512: 164 / 175, 1024: 200 / 189, 2048: 304 / 246 --
+    // from about three queries per CU on, the requests of mispredicted hops cost more than the early ones gain.
+    if (inflight <= 3u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
     {   // development switch DANN_TUNE_ON bit 1: the row prefetch in the throughput regime too (A/B on large indexes)
         const char* e = getenv("DANN_TUNE_ON");
         if (e && (strtoul(e, nullptr, 0) & 1u)) a.tune |= kTuneRowPrefetch;

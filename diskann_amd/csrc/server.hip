@@ -32,6 +32,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -51,25 +52,43 @@ struct dann_server {
     uint32_t* d_out_ids = nullptr;
     float* d_out_d = nullptr;
     dann_search_stats* d_stats = nullptr;
-    std::atomic<uint64_t> next{0};            // next sequence number (position in the submission ring)
+    alignas(64) std::atomic<uint64_t> next{0};  // next sequence number (position in the submission ring); own cache line
     std::atomic<uint64_t>* slot_owner = nullptr;  // per result slot: the ticket outstanding on it + 1, 0 = free
-    std::atomic<uint64_t> free_head{0};       // free result slots, a Treiber stack: slot + 1 (0: empty) | ABA tag << 32
+    // free result slots: kFreeStacks independent Treiber stacks (slot + 1 on top, 0: empty | ABA tag << 32), each head on
+    // its own cache line.  A caller thread pops from and pushes to "its" stack (by a hash of the thread) and only walks
+    // on to the others when that one is empty: sixteen callers on one stack spent most of their time retrying the CAS
+    // (0.8 M instead of 3.9 M queries/s at 1024 tickets in flight).
+    static constexpr uint32_t kFreeStacks = 32;
+    struct alignas(64) FreeStack {
+        std::atomic<uint64_t> head{0};
+    };
+    FreeStack free_stack[kFreeStacks];
     uint32_t* free_next = nullptr;            //   next slot + 1 of each free slot
-    uint32_t take_slot() {                    // kEmpty32 if none is free right now
-        uint64_t h = free_head.load(std::memory_order_acquire);
-        for (;;) {
-            const uint32_t top = (uint32_t)h;
-            if (!top) return 0xFFFFFFFFu;
-            const uint64_t nh = (((h >> 32) + 1) << 32) | free_next[top - 1];
-            if (free_head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return top - 1;
-        }
+    static uint32_t home_stack() {
+        static thread_local const uint32_t h =
+            (uint32_t)(std::hash<std::thread::id>()(std::this_thread::get_id()) * 0x9E3779B97F4A7C15ull >> 59);
+        return h & (kFreeStacks - 1u);
     }
-    void give_slot(uint32_t slot) {
-        uint64_t h = free_head.load(std::memory_order_acquire);
+    uint32_t take_slot() {                    // 0xFFFFFFFF if none is free right now
+        const uint32_t home = home_stack();
+        for (uint32_t i = 0; i < kFreeStacks; ++i) {
+            std::atomic<uint64_t>& head = free_stack[(home + i) & (kFreeStacks - 1u)].head;
+            uint64_t h = head.load(std::memory_order_acquire);
+            while ((uint32_t)h) {
+                const uint32_t top = (uint32_t)h;
+                const uint64_t nh = (((h >> 32) + 1) << 32) | free_next[top - 1];
+                if (head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return top - 1;
+            }
+        }
+        return 0xFFFFFFFFu;
+    }
+    void give_slot(uint32_t slot, uint32_t stack) {
+        std::atomic<uint64_t>& head = free_stack[stack & (kFreeStacks - 1u)].head;
+        uint64_t h = head.load(std::memory_order_acquire);
         for (;;) {
             free_next[slot] = (uint32_t)h;
             const uint64_t nh = (((h >> 32) + 1) << 32) | (slot + 1u);
-            if (free_head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return;
+            if (head.compare_exchange_weak(h, nh, std::memory_order_acq_rel, std::memory_order_acquire)) return;
         }
     }
     std::mutex launch_mu;
@@ -250,11 +269,8 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     s->slot_owner = new (std::nothrow) std::atomic<uint64_t>[ring];
     s->free_next = new (std::nothrow) uint32_t[ring];
     if (!s->slot_owner || !s->free_next) return fail(DANN_ENOMEM);
-    for (uint32_t i = 0; i < ring; ++i) {
-        s->slot_owner[i].store(0, std::memory_order_relaxed);
-        s->free_next[i] = i + 1 < ring ? i + 2 : 0;  // slot 0 on top
-    }
-    s->free_head.store(1, std::memory_order_release);
+    for (uint32_t i = 0; i < ring; ++i) s->slot_owner[i].store(0, std::memory_order_relaxed);
+    for (uint32_t i = ring; i-- > 0;) s->give_slot(i, i);  // slot i starts on stack i % kFreeStacks, low slots on top
     s->hv = sv;
     s->hv.h_queries = s->h_block + o_q;
     s->hv.h_pub = reinterpret_cast<const uint32_t*>(s->h_block + o_pub);
@@ -394,7 +410,7 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
     std::vector<uint8_t> q;
     if (st.status) q.assign(sv.h_queries + (size_t)slot * sv.qstride, sv.h_queries + (size_t)slot * sv.qstride + sv.qbytes);
     s->slot_owner[slot].store(0, std::memory_order_release);
-    s->give_slot(slot);
+    s->give_slot(slot, dann_server::home_stack());
     if (st.status) {
         // the resident waves carry a fixed LDS visited table: the rare query that outgrows it (and the spill pool) is
         // re-run through the launch path, which retries with larger tables
