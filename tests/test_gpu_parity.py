@@ -312,3 +312,22 @@ def test_team_single_queries_at_tiny_queues_follow_the_oracle():
             assert st["status"][0] == 0
             assert np.array_equal(gi[0], oi[q]) and np.array_equal(bits(gd[0]), bits(od[q])), (L, q)
             assert st["cmps"][0] == ost[q, 0] and st["hops"][0] == ost[q, 1], (L, q, st["cmps"][0], ost[q, 0])
+
+
+@pytest.mark.parametrize("R,nstart", [(63, 1), (64, 2), (17, 40), (5, 64)])
+def test_team_limits_of_degree_and_start_points(R, nstart):
+    """The edges of what a team takes: max_degree 63 fills the 64-dword adjacency request exactly (64 falls back to one
+    wave per query), 40 and 64 start points make hop 0 a two-pass gather."""
+    rng = np.random.default_rng(1000 + R + nstart)
+    n, dim = 3000, 128
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R, nstart=nstart)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:nstart], R)
+    queries = rand_vectors(rng, oracle.F32, 40, dim)
+    for L, k in ((3, 2), (30, 10), (100, 10)):
+        oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
+        for q0, nq in ((0, 1), (1, 1), (2, 38)):
+            gi, gd, st = gix.search(da.Knn(L, 1), queries[q0:q0 + nq], k)
+            assert not st["status"].any()
+            assert np.array_equal(gi, oi[q0:q0 + nq]) and np.array_equal(bits(gd), bits(od[q0:q0 + nq])), (L, q0)
+            assert np.array_equal(st["cmps"], ost[q0:q0 + nq, 0]) and np.array_equal(st["hops"], ost[q0:q0 + nq, 1]), (L, q0)
