@@ -510,7 +510,8 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     __syncthreads();  // hop 0 (the start points): distances ready -- the queue wave merges them and pops the first node
     for (;;) {
         bool started = false;
-        bool overtaken = false;
+        bool overtaken = false;  // (phase statistics only)
+        (void)overtaken;
         PH_T(pd0);
         if (hop > 0) {
             // ---- hop `hop`'s distances are ready
