@@ -356,6 +356,8 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
                 if (int32_t rc = relaunch_if_exited(idx, s)) return rc;
             std::this_thread::yield();
             if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
+                // (fatal for this server: the sequence number stays unpublished and the in-order ring cannot pass it --
+                // a resident kernel that takes no entry for 30 s is dead; dann_server_stop / start is the way out)
                 set_error("dann_search_submit: ring position %u was not taken by a worker within %u s", pos, kWaitLimitSeconds);
                 return DANN_EHIP;
             }
