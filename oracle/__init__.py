@@ -117,6 +117,8 @@ def lib():
     L.orc_gram_chain.argtypes = [vp, u32, u32, vp]
     L.orc_prune_pool.restype = i32
     L.orc_prune_pool.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp, vp, u32, i32, vp, vp]
+    L.orc_set_tie_rule.restype = None
+    L.orc_set_tie_rule.argtypes = [i32, u64]
     L.orc_insert.restype = i32
     L.orc_insert.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp]
     L.orc_multi_insert.restype = i32
@@ -398,6 +400,12 @@ def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_si
     return OrcBuildConfig(pruned_degree, max_degree, l_build, alpha, max_occlusion_size,
                           pruned_degree if max_backedges is None else max_backedges,
                           intra_batch_candidates, int(saturate_after_prune))
+
+
+def set_tie_rule(rule=0, seed=0):
+    """order of equal-distance candidates in RobustPrune's sort: 0 = the oracle's rule (pool position); 1..5 see
+    dann_oracle.cpp sort_pool -- only the tie-envelope measurement of tests/test_oracle_build.py uses them"""
+    lib().orc_set_tie_rule(rule, seed)
 
 
 def gram_chain(rows):

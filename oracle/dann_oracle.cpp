@@ -699,13 +699,53 @@ struct PNeighbor {
     uint32_t pos;
 };
 
-/* SortedNeighbors::new (internal/sorted_neighbors.rs:26-44) with the ORACLE TIE RULE. */
+/* SortedNeighbors::new (internal/sorted_neighbors.rs:26-44).  The reference sorts with select_nth_unstable_by +
+ * sort_unstable_by: the order of candidates at EQUAL distance is whatever Rust's unstable sort leaves (its source is
+ * not in this image).  The oracle's rule is "ties by pool position" (rule 0); the other rules exist to measure how far
+ * a tie order can move the reference's grid_insert counters (tests/test_oracle_build.py, tie envelope) -- the
+ * product and every parity test use rule 0:
+ *   0 pool position ascending (stable)   1 pool position descending   2 id ascending   3 id descending
+ *   4 a seeded shuffle of the tied entries (a fresh permutation per sort)
+ *   5 a hypothesis about small pools: when the whole pool is kept (max >= len) select_nth_unstable_by(len - 1) swaps
+ *     the FIRST maximum with the last element, and a prefix of <= 20 entries is sorted by insertion (stable on the
+ *     order after that swap); longer prefixes fall back to rule 0.  Public descriptions of Rust >= 1.81's sort, not
+ *     checked against its source. */
+static int g_tie_rule = 0;
+static uint64_t g_tie_state = 0x9E3779B97F4A7C15ull;
+void tie_rule_set(int32_t rule, uint64_t seed) {
+    g_tie_rule = rule;
+    g_tie_state = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+}
+static inline uint64_t tie_next() { /* splitmix64 */
+    uint64_t z = (g_tie_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 void sort_pool(std::vector<PNeighbor>& pool, size_t max) {
     for (size_t i = 0; i < pool.size(); ++i) pool[i].pos = (uint32_t)i;
-    std::stable_sort(pool.begin(), pool.end(), [](const PNeighbor& a, const PNeighbor& b) {
-        /* fast_distance: partial_cmp, NaN compares Equal (neighbor/mod.rs:150-154) */
-        return a.d < b.d;
-    });
+    /* fast_distance: partial_cmp, NaN compares Equal (neighbor/mod.rs:150-154) */
+    auto by_d = [](const PNeighbor& a, const PNeighbor& b) { return a.d < b.d; };
+    switch (g_tie_rule) {
+        case 1: std::reverse(pool.begin(), pool.end()); break;
+        case 2: std::stable_sort(pool.begin(), pool.end(), [](const PNeighbor& a, const PNeighbor& b) { return a.id < b.id; }); break;
+        case 3: std::stable_sort(pool.begin(), pool.end(), [](const PNeighbor& a, const PNeighbor& b) { return a.id > b.id; }); break;
+        case 4:
+            for (size_t i = pool.size(); i > 1; --i) std::swap(pool[i - 1], pool[tie_next() % i]);
+            break;
+        case 5:
+            if (max >= pool.size() && pool.size() >= 2 && pool.size() <= 21) {
+                size_t mx = 0;
+                for (size_t i = 1; i < pool.size(); ++i)
+                    if (pool[mx].d < pool[i].d) mx = i; /* acc kept unless acc < t: the first maximum */
+                std::swap(pool[mx], pool[pool.size() - 1]);
+                std::stable_sort(pool.begin(), pool.end() - 1, by_d);
+                return;
+            }
+            break;
+        default: break;
+    }
+    std::stable_sort(pool.begin(), pool.end(), by_d);
     if (pool.size() > max) pool.resize(max);
 }
 
@@ -1466,6 +1506,8 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
     std::copy(out.begin(), out.end(), out_neighbors);
     return (int32_t)out.size();
 }
+
+void orc_set_tie_rule(int32_t rule, uint64_t seed) { tie_rule_set(rule, seed); }
 
 /* counters: [0] query distances, [1] pair (prune) distances, [2] set_neighbors, [3] appends */
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters) {

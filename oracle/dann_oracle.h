@@ -165,6 +165,9 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
                        uint32_t* pool_ids, float* pool_dists, uint32_t pool_n, int32_t force_saturate,
                        uint32_t* out_neighbors, uint64_t* pair_evals);
 /* DiskANNIndex::insert for a row already stored at `slot` (index.rs:226-341). */
+/* tie order of RobustPrune's candidate sort (see sort_pool): 0 = the oracle's rule (pool position); 1..5 = alternative
+ * orders used only to measure the tie envelope of the reference's grid_insert goldens.  Process-global, not thread-safe. */
+void orc_set_tie_rule(int32_t rule, uint64_t seed);
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters);
 /* DiskANNIndex::multi_insert for rows already stored at slots[0..n)
  * (index.rs:815-1030, max_minibatch_par = 1). */

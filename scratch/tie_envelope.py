@@ -1,0 +1,47 @@
+# tie envelope of the reference's grid_insert lattice goldens: the oracle under alternative orders of equal-distance
+# prune candidates (oracle.set_tie_rule); writes profiles/r04_tie_envelope.json.  tests/test_oracle_build.py asserts it.
+import json, os, sys, re, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import oracle
+from test_oracle_build import _build, _files
+
+def run(f):
+    p = f["payload"]
+    ix, cnt = _build(f["source"], p)
+    tup = [int(cnt[2]), int(cnt[3])]
+    exact = 0
+    for sc in p["searches"]:
+        k, ids, dists, st = ix.search(np.array(sc["query"], np.float32), 10, sc["beam_width"], 10)
+        tup += [int(st[0]), int(st[1])]
+        exact += int([int(i) for i in ids[:k]] == [w[0] for w in sc["results"]] and int(st[0]) == sc["comparisons"] and int(st[1]) == sc["hops"])
+    return tup, exact
+
+t0=time.time()
+out = {}
+for f in _files(os.path.join(ROOT, 'tests', 'golden')):
+    p = f["payload"]
+    if p["grid_dims"] == 1: continue
+    name = f["test"].split("grid_insert/")[1]
+    ref = [p["insert_metrics"]["set_neighbors"], p["insert_metrics"]["append_neighbors"]]
+    for sc in p["searches"]: ref += [sc["comparisons"], sc["hops"]]
+    rows = {}
+    for rule in (0, 1, 2, 3, 5):
+        oracle.set_tie_rule(rule, 0)
+        rows[f"rule{rule}"] = run(f)
+    lo = None; hi = None; best_exact = 0; hits = 0
+    for seed in range(200):
+        oracle.set_tie_rule(4, seed + 1)
+        t, ex = run(f)
+        lo = t if lo is None else [min(a, b) for a, b in zip(lo, t)]
+        hi = t if hi is None else [max(a, b) for a, b in zip(hi, t)]
+        best_exact = max(best_exact, ex)
+        hits += int(t[:2] == ref[:2])
+    oracle.set_tie_rule(0, 0)
+    inside = [l <= r <= h for l, r, h in zip(lo, ref, hi)]
+    out[name] = dict(reference=ref, rules={k: dict(tuple=v[0], searches_exact=v[1]) for k, v in rows.items()},
+                     shuffle_min=lo, shuffle_max=hi, reference_inside=inside, shuffles_matching_both_counters=hits,
+                     best_searches_exact_over_shuffles=best_exact, n_searches=len(p["searches"]))
+    print(name, 'ref', ref[:2], 'r0', rows['rule0'][0][:2], 'r5', rows['rule5'][0][:2], 'lo', lo[:2], 'hi', hi[:2], 'inside', all(inside), 'hits', hits, flush=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)),'..','profiles','r04_tie_envelope.json'),'w'), indent=1)
+print('secs', time.time()-t0)

@@ -1,8 +1,9 @@
 """Oracle build path (insert / multi_insert / prune) against the reference's grid_insert
 golden files.  1-D lattices pin the build bit-for-bit (ids, distances, comparisons, hops,
 set/append counters); 3-D/4-D lattices are tie-heavy and the reference's own result
-depends on Rust's unstable sort (internal/sorted_neighbors.rs:36-40), so they are soft
-pins (counters within 5 %, nearest neighbour found)."""
+depends on Rust's unstable sort (internal/sorted_neighbors.rs:36-40): there the oracle's
+counters are recorded next to the reference's, and every counter of every golden is shown
+to lie inside the range that alternative tie orders span (the tie envelope)."""
 import json
 import os
 import re
@@ -58,21 +59,104 @@ def test_grid_insert_1d_exact(golden_dir):
     assert seen == 3
 
 
-def test_grid_insert_lattice_soft(golden_dir):
-    for f in _files(golden_dir):
-        p = f["payload"]
-        if p["grid_dims"] == 1:
-            continue
-        ix, cnt = _build(f["source"], p)
-        want_set = p["insert_metrics"]["set_neighbors"]
-        assert abs(int(cnt[2]) - want_set) <= max(3, 0.05 * want_set)
-        for sc in p["searches"]:
-            k, ids, dists, st = ix.search(np.array(sc["query"], np.float32), 10, sc["beam_width"], 10)
-            assert k == sc["num_results"]
-            # the exact nearest neighbour and its distance are tie-free
-            assert int(ids[0]) == sc["results"][0][0] and float(dists[0]) == sc["results"][0][1]
-            # same multiset of distances at the head of the list
-            assert sorted(float(d) for d in dists[:5]) == sorted(w[1] for w in sc["results"][:5])
+# (set_neighbors, append_neighbors) of the oracle under its own tie rule (pool position) next to the reference's, per
+# lattice golden -- measured, not a tolerance: append_neighbors is off by up to 12 % on the 3-D lattices.  The next test
+# shows that this is the freedom the reference's unstable sort has, not a different rule.
+ORACLE_VS_REFERENCE = {
+    "insert_3_5_batch_125/ibc_all": ([125, 83], [125, 81]),
+    "insert_3_5_batch_125/ibc_max_4": ([125, 83], [125, 74]),
+    "insert_3_5_batch_125/ibc_none": ([125, 83], [125, 76]),
+    "insert_3_5_batch_25/ibc_all": ([127, 142], [127, 132]),
+    "insert_3_5_batch_25/ibc_none": ([133, 139], [133, 131]),
+    "insert_3_5_single/ibc_none": ([205, 389], [206, 388]),
+    "insert_4_4_batch_25/ibc_all": ([292, 348], [293, 360]),
+    "insert_4_4_batch_25/ibc_none": ([376, 357], [374, 362]),
+    "insert_4_4_batch_256/ibc_all": ([257, 96], [257, 96]),
+    "insert_4_4_batch_256/ibc_max_4": ([272, 96], [272, 96]),
+    "insert_4_4_batch_256/ibc_none": ([272, 96], [272, 96]),
+    "insert_4_4_single/ibc_none": ([497, 1102], [503, 1096]),
+}
+
+
+def _lattice_files(golden_dir):
+    return [f for f in _files(golden_dir) if f["payload"]["grid_dims"] != 1]
+
+
+def _tuple(f):
+    """(set_neighbors, append_neighbors, then comparisons and hops of every post-build search) + exact searches"""
+    p = f["payload"]
+    ix, cnt = _build(f["source"], p)
+    tup = [int(cnt[2]), int(cnt[3])]
+    exact = 0
+    for sc in p["searches"]:
+        k, ids, dists, st = ix.search(np.array(sc["query"], np.float32), 10, sc["beam_width"], 10)
+        tup += [int(st[0]), int(st[1])]
+        assert k == sc["num_results"]
+        # the exact nearest neighbour and its distance are tie-free, and so is the multiset of distances at the head
+        assert int(ids[0]) == sc["results"][0][0] and float(dists[0]) == sc["results"][0][1]
+        assert sorted(float(d) for d in dists[:5]) == sorted(w[1] for w in sc["results"][:5])
+        exact += int([int(i) for i in ids[:k]] == [w[0] for w in sc["results"]])
+    return tup, exact
+
+
+def _reference_tuple(p):
+    ref = [p["insert_metrics"]["set_neighbors"], p["insert_metrics"]["append_neighbors"]]
+    for sc in p["searches"]:
+        ref += [sc["comparisons"], sc["hops"]]
+    return ref
+
+
+def test_grid_insert_lattice_counters_as_measured(golden_dir):
+    """the oracle's counters on the 12 tie-heavy lattice goldens are exactly the recorded ones (a regression pin of the
+    oracle) and the reference's are the recorded ones too (a pin of the table above)"""
+    oracle.set_tie_rule(0, 0)
+    seen = 0
+    for f in _lattice_files(golden_dir):
+        name = f["test"].split("grid_insert/")[1]
+        mine, ref = ORACLE_VS_REFERENCE[name]
+        tup, _ = _tuple(f)
+        assert tup[:2] == mine, name
+        assert _reference_tuple(f["payload"])[:2] == ref, name
+        seen += 1
+    assert seen == 12
+
+
+def test_grid_insert_lattice_tie_envelope(golden_dir):
+    """SortedNeighbors::new (internal/sorted_neighbors.rs:26-44) sorts with select_nth_unstable_by + sort_unstable_by:
+    the order of candidates at equal distance is unspecified, and on integer lattices nearly every prune has such ties.
+    For every lattice golden the oracle is re-run under other tie orders (pool position descending, id ascending /
+    descending, a hypothesis about Rust's small-slice path, 200 seeded shuffles): every counter the golden holds --
+    set_neighbors, append_neighbors, comparisons and hops of each post-build search -- lies inside the range those
+    orders span.  In particular the reference's 81 / 74 / 76 appends for the three intra-batch-candidate modes of the
+    all-at-once 5x5x5 batch (the oracle: 83 / 83 / 83, because position order is id order there) are three draws from a
+    60..83 range.  profiles/r04_tie_envelope.json holds the run (scratch/tie_envelope.py)."""
+    try:
+        for f in _lattice_files(golden_dir):
+            ref = _reference_tuple(f["payload"])
+            lo = hi = None
+            runs = [(r, 0) for r in (0, 1, 2, 3, 5)] + [(4, s + 1) for s in range(200)]
+            for rule, seed in runs:
+                oracle.set_tie_rule(rule, seed)
+                t, _ = _tuple(f)
+                lo = t if lo is None else [min(a, b) for a, b in zip(lo, t)]
+                hi = t if hi is None else [max(a, b) for a, b in zip(hi, t)]
+            assert all(l <= r <= h for l, r, h in zip(lo, ref, hi)), (f["test"], ref, lo, hi)
+    finally:
+        oracle.set_tie_rule(0, 0)
+
+
+def test_small_pool_hypothesis_reproduces_the_single_insert_3d_counters(golden_dir):
+    """Tie rule 5 (whole pool kept: first maximum swapped to the end, prefixes of <= 20 entries sorted by insertion --
+    public descriptions of Rust >= 1.81's select_nth_unstable / sort_unstable, not checked against their source)
+    reproduces both build counters of insert_3_5_single exactly where pool position is off by one in each.  Evidence
+    about where the residual differences come from (pools beyond 20 entries), nothing the product builds on."""
+    try:
+        oracle.set_tie_rule(5, 0)
+        f = [f for f in _lattice_files(golden_dir) if "insert_3_5_single" in f["test"]][0]
+        tup, _ = _tuple(f)
+        assert tup[:2] == _reference_tuple(f["payload"])[:2] == [206, 388]
+    finally:
+        oracle.set_tie_rule(0, 0)
 
 
 def test_prune_matches_bruteforce_rule():
