@@ -81,6 +81,8 @@ def parse():
                     help="file: load the built graph from it when present, else build and save it (profiling passes "
                          "under rocprofv3 --pmc skip the thousands of build dispatches this way)")
     ap.add_argument("--visited-bits", type=int, default=0)
+    ap.add_argument("--visited-format", type=int, default=0, choices=[0, 16, 32],
+                    help="experiment knob: width of a visited-table entry on every index of the run (0 = automatic)")
     ap.add_argument("--sq8-stride", type=int, default=256,
                     help="row stride of the SQ-8 store: 256 keeps the 128 code bytes of a row in one 128-byte line (the "
                          "L2 kernel never reads the compensation); 0 = payload rounded to 16 B (144: rows straddle lines)")
@@ -145,6 +147,13 @@ def main():
     import torch.distributed as dist
     import diskann_amd as da
     from diskann_amd import _ffi
+    if args.visited_format:  # A/B knob (results never depend on it)
+        _init = da.Provider.__init__
+
+        def _init_fmt(self, *a, **kw):
+            _init(self, *a, **kw)
+            self.set_visited_format(args.visited_format)
+        da.Provider.__init__ = _init_fmt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("DANN_LIB_PATH") or os.path.join(_HERE, "libdann_hip.s
 
 F32, F16, U8, I8, SQ8, PQ = 0, 1, 2, 3, 4, 5
 COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
-OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED, EINTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED, EINTERNAL, EBUSY = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
 BUILD_MFMA_BACKEDGE, BUILD_MFMA_POOL, BUILD_ROW_KERNEL_ONLY = 1, 2, 4
 
@@ -142,6 +143,7 @@ SYMBOLS = {
     "dann_kernel_time": (_i32, [_vp, _i32, _P(C.c_double), _P(_u64)]),
     "dann_kernel_time_reset": (_i32, [_vp]),
     "dann_set_visited_bits": (_i32, [_vp, _u32]),
+    "dann_set_visited_format": (_i32, [_vp, _u32]),
     "dann_set_max_concurrency": (_i32, [_vp, _u32]),
     "dann_comm_create_callbacks": (_i32, [_vp, _P(_vp)]),
     "dann_comm_rccl_unique_id": (_i32, [_vp]),

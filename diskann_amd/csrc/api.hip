@@ -349,6 +349,7 @@ int32_t dann_index_get_config(const dann_index* idx, dann_config* out) try {
 
 int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, const void* rows, uint64_t len) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (n == 0) return DANN_OK;
     if (!rows) return DANN_EINVAL;
     if (len != (uint64_t)n * idx->layer_bytes) {
@@ -374,6 +375,7 @@ int32_t dann_set_elements(dann_index* idx, uint32_t first_slot, uint32_t n, cons
 
 int32_t dann_set_elements_device(dann_index* idx, uint32_t first_slot, uint32_t n, const void* d_rows, uint64_t src_stride) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (n == 0) return DANN_OK;
     if (!d_rows) return DANN_EINVAL;
     if (src_stride < idx->layer_bytes) {
@@ -405,6 +407,7 @@ int32_t dann_index_device_pointers(const dann_index* idx, const void** d_rows, c
 
 int32_t dann_set_tags(dann_index* idx, uint32_t first_slot, uint32_t n, const uint8_t* tags) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (n == 0) return DANN_OK;
     if (!tags) return DANN_EINVAL;
     if (!idx->cfg.inline_tags) {
@@ -455,6 +458,7 @@ int32_t dann_get_element(const dann_index* idx, uint32_t slot, void* bytes, uint
 
 int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, uint32_t nrows) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (!base) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
     if (stride < idx->layer_bytes) return DANN_ELENGTH;
@@ -484,6 +488,7 @@ int32_t dann_upload_store(dann_index* idx, const void* base, uint64_t stride, ui
 
 int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (!pivots || !chunk_offsets) return DANN_EINVAL;
     if (idx->cfg.dtype != DT_PQ) {
         set_error("dann_set_pq_table: the index is not DANN_PQ");
@@ -551,6 +556,7 @@ int32_t dann_get_neighbors(const dann_index* idx, uint32_t slot, uint32_t* out, 
 
 int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     if (n > idx->cfg.max_degree) {
         set_error("adjacency list of length %u exceeds max degree %u", n, idx->cfg.max_degree);
@@ -568,6 +574,7 @@ int32_t dann_set_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, 
 
 int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* ids, uint32_t n) try {
     CHECK_IDX(idx);  // recursive mutex: the get / set calls below re-enter it
+    DANN_MUTATION(idx);
     if (n && !ids) return DANN_EINVAL;
     if (slot >= idx->nslots) return DANN_EBOUNDS;
     std::vector<uint32_t> cur(idx->cfg.max_degree);
@@ -582,6 +589,7 @@ int32_t dann_append_neighbors(dann_index* idx, uint32_t slot, const uint32_t* id
 
 int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t n, const uint32_t* lists) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (n == 0) return DANN_OK;
     if (!slots || !lists) return DANN_EINVAL;
     const uint32_t w = idx->cfg.max_degree + 1;
@@ -599,6 +607,7 @@ int32_t dann_set_neighbors_bulk(dann_index* idx, const uint32_t* slots, uint32_t
 
 int32_t dann_upload_graph(dann_index* idx, const uint32_t* adj, uint64_t nrows) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (!adj) return DANN_EINVAL;
     if (nrows > idx->nslots) return DANN_EBOUNDS;
     DANN_HIP(hipMemcpyAsync(idx->d_adj, adj, (size_t)nrows * (idx->cfg.max_degree + 1) * 4, hipMemcpyHostToDevice,
@@ -1473,6 +1482,7 @@ int32_t dann_save_graph(const dann_index* idx, const char* path) try {
 int32_t dann_load_graph(dann_index* idx, const char* path, uint32_t* out_start, uint64_t* out_num_start,
                         uint64_t* out_num_points) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (!path) return DANN_EINVAL;
     File in;
     in.f = fopen(path, "rb");
@@ -1556,6 +1566,7 @@ int32_t dann_save_vectors_bin(const dann_index* idx, const char* path, uint32_t 
 
 int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_slot, uint32_t* out_n) try {
     CHECK_IDX(idx);
+    DANN_MUTATION(idx);
     if (!path) return DANN_EINVAL;
     File in;
     in.f = fopen(path, "rb");
@@ -1603,6 +1614,12 @@ int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) try {
     // 0 = automatic; 6..15 = log2(entries); >= 64 = explicit entry count (rounded up to a multiple of 64)
     if (!idx || (bits != 0 && bits < 64 && (bits < 6 || bits > 15)) || bits > 32768) return DANN_EINVAL;
     idx->visited_bits = bits;
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_set_visited_format(dann_index* idx, uint32_t entry_bits) try {
+    if (!idx || (entry_bits != 0 && entry_bits != 16 && entry_bits != 32)) return DANN_EINVAL;
+    idx->visited_format = entry_bits;
     return DANN_OK;
 } DANN_CATCH_ALL
 

@@ -2226,6 +2226,7 @@ extern "C" {
 int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n) try {
     if (!idx) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -2271,6 +2272,7 @@ int32_t dann_insert_batch_commit(dann_index* idx, const dann_build_config* cfg, 
                                  const uint32_t* d_pending_all) try {
     if (!idx) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -2292,6 +2294,7 @@ int32_t dann_insert_batch_commit_part(dann_index* idx, const dann_build_config* 
     if (!idx || !count_out || world == 0 || rank >= world) return DANN_EINVAL;
     *count_out = 0;
     ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;
@@ -2314,6 +2317,7 @@ int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows,
     if (!idx || (count && !d_rows)) return DANN_EINVAL;
     if (count == 0) return DANN_OK;
     ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
     DeviceGuard guard(idx->device);
     hipLaunchKernelGGL(apply_rows_kernel, dim3(count), dim3(kWave), 0, idx->main.stream, idx->view(), d_rows, count);
     DANN_HIP(hipGetLastError());
@@ -2399,6 +2403,7 @@ int32_t dann_build(dann_index* idx, const dann_build_config* cfg, uint32_t first
                    uint32_t max_batch) try {
     if (!idx) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
     DeviceGuard guard(idx->device);
     int32_t rc = validate_cfg(idx, cfg);
     if (rc != DANN_OK) return rc;

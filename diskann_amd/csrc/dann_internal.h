@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/dann.h"
+#include "../../include/dann_debug.h"
 
 struct dann_index;
 
@@ -116,6 +117,12 @@ struct SearchArgs {
     uint32_t k = 0;
     uint32_t ht_entries = 0;     // per-query LDS visited-table entries (multiple of 64)
     uint32_t ht_prime = 0;       // probing modulus, set by search_with_retry: largest prime <= ht_entries
+    // 16-bit table entries (plain-mode kernels, chosen per launch by the host; search_kernel_impl.h, ht16_insert_open):
+    // the table holds 2 * ht_entries slots (a power of two), ht_prime is that slot count
+    uint32_t ht16 = 0;
+    uint32_t ht_idmask = 0;      // 2^m - 1, m = bits of the index's slot count
+    uint32_t ht_tb = 0;          // tag bits: m - log2(slots), or 0
+    uint32_t ht_kmax = 0;        // probes per id
     uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)
     float* out_dists = nullptr;
     dann_search_stats* stats = nullptr;
@@ -233,6 +240,7 @@ struct dann_index {
     uint32_t layer_bytes = 0;
     uint32_t nslots = 0;
     uint32_t visited_bits = 0;
+    uint32_t visited_format = 0;   // dann_set_visited_format: 0 = automatic, 32 / 16 = entry width of the LDS visited table
     uint32_t max_concurrency = 0;  // dann_set_max_concurrency: queries in flight per search call (0 = all of them)
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
@@ -261,7 +269,14 @@ struct dann_index {
     std::condition_variable ctx_cv;
     std::vector<dann::SearchCtx*> ctx_free;
     uint32_t ctx_created = 0;
-    dann_server* server = nullptr;  // dann_server_start / dann_search_submit
+    // dann_server_start / dann_search_submit.  submit / wait / poll take no lock: they pin the server (srv_users) for the
+    // duration of the call and dann_server_stop unpublishes the pointer, then waits for the pins to drain before it
+    // frees anything.  srv_outstanding = tickets submitted and not yet collected; `mutating` = mutations in progress:
+    // the two sides of the "no mutation while tickets are outstanding" rule (MutationScope, DANN_EBUSY).
+    std::atomic<dann_server*> server{nullptr};
+    std::atomic<uint32_t> srv_users{0};
+    std::atomic<int64_t> srv_outstanding{0};
+    std::atomic<uint32_t> mutating{0};
     dann::IndexView view() const;
 };
 
@@ -280,6 +295,30 @@ struct ExclusiveGuard {
     ExclusiveGuard(const ExclusiveGuard&) = delete;
     ExclusiveGuard& operator=(const ExclusiveGuard&) = delete;
 };
+// a mutation of the index (rows, tags, adjacency, build): refused with DANN_EBUSY while server tickets are outstanding,
+// and while it runs dann_search_submit refuses new tickets.  Both sides publish first and look second (sequentially
+// consistent): at least one of a racing pair sees the other.
+struct MutationScope {
+    dann_index* i;
+    bool ok;
+    explicit MutationScope(const dann_index* idx) : i(const_cast<dann_index*>(idx)) {
+        i->mutating.fetch_add(1, std::memory_order_seq_cst);
+        ok = i->srv_outstanding.load(std::memory_order_seq_cst) == 0;
+        if (!ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);
+    }
+    ~MutationScope() {
+        if (ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);
+    }
+    MutationScope(const MutationScope&) = delete;
+    MutationScope& operator=(const MutationScope&) = delete;
+};
+#define DANN_MUTATION(idx)                                                                                            \
+    ::dann::MutationScope _mut(idx);                                                                                  \
+    if (!_mut.ok) {                                                                                                   \
+        ::dann::set_error("the index has search-server tickets outstanding: collect them (dann_search_wait) or stop " \
+                          "the server before mutating the index");                                                   \
+        return DANN_EBUSY;                                                                                            \
+    }
 constexpr uint32_t kMaxSearchCtx = 16;
 // a search context for one concurrent call: from the pool, created on demand (at most kMaxSearchCtx), else waits
 struct CtxLease {

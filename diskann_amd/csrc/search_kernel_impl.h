@@ -41,6 +41,11 @@ struct SearchLds {
 };
 
 __host__ __device__ inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
+// entries of the queue image in LDS: the largest capacity the queue can have during the search
+__host__ __device__ inline uint32_t lds_queue_entries(const SearchArgs& a) {
+    const uint32_t q = a.l_value + a.ix.nstart;
+    return q > a.qcap_max ? q : a.qcap_max;
+}
 
 // bytes of the staged query: f32 vector (float rows), raw bytes (integer rows), lookup table (PQ rows)
 __host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
@@ -49,9 +54,11 @@ __host__ __device__ inline uint32_t query_lds_bytes(const IndexView& ix) {
     return ix.dim * 4u;
 }
 
-// The visited table comes last: every other region then sits at an offset that depends only on (cmax, queue slots,
-// query bytes) -- compile-time constants in the plain fixed-length instantiations, where the region pointers cost no
-// SGPRs and the LDS instructions carry immediate offsets.
+// The queue image and the visited table come last, in that order: every other region then sits at an offset that
+// depends only on (cmax, query bytes) -- compile-time constants in the plain fixed-length instantiations, where the
+// region pointers cost no SGPRs and the LDS instructions carry immediate offsets; the image is sized by the queue's
+// real capacity `qcap` (L + start points, or what AdaptiveL may grow it to), not by its register slots, so the table's
+// offset is the one run-time offset.  (Every byte counts: at 1 M x 128-byte rows the table caps the queries per CU.)
 __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint32_t cmax, uint32_t qcap,
                                                        uint32_t qbytes, bool team = false) {
     SearchLds l;
@@ -80,14 +87,13 @@ __host__ __device__ inline SearchLds search_lds_layout(uint32_t ht_entries, uint
     if (team) off += 512u;
     l.mail_off = off;  // teams: the mailbox the four waves of a team talk through (64 words, see kMb*)
     if (team) off += 256u;
+    l.beam_off = off;
+    off += round16(kMaxBeam * 4u);
     l.stage_off = off;  // the queue image, (id, distance bits) pairs: every merge scatters the register-resident queue
     off += round16(qcap * 8u);  // here and reloads it (one 8-byte LDS access per entry).  One buffer is enough: nothing
                                 // is read from it between the first scatter write and the reload (ranks come from
                                 // registers or were taken before), and one wave's LDS operations retire in order.
-    l.snew_off = off;      // the surviving new distances of one merge, sorted (slow path) / their slots (fast path)
-    off += 64u * 4u;
-    l.beam_off = off;
-    off += round16(kMaxBeam * 4u);
+    l.snew_off = l.cand_id_off;  // (unused: the slow merge keeps its sorted survivors in the candidates' own buffer)
     l.ht_off = off;        // 16-byte aligned (wiped with 16-byte stores)
     off += ht_entries * 4u;  // any multiple of 64
     l.total = off;
@@ -151,6 +157,89 @@ __device__ __forceinline__ bool ht_insert_open_slot(uint32_t* ht, uint32_t mod, 
     *slot = h;
     return isnew;
 }
+// ---- the visited table with 16-bit entries (SearchArgs::ht16) ------------------------------------------------------
+// Half the LDS per id, still an exact set.  Ids live below 2^m (m = bits of the slot count of the index); probe k of id
+// looks at x_k = id * (A + k * B2) mod 2^m -- A odd, B2 even: every multiplier is odd, so id -> x_k is a bijection of
+// [0, 2^m) for every k.  The table has 2^b slots: slot = x_k >> tb (tb = m - b, the top b bits of the product, i.e.
+// multiplicative hashing), and the entry stores (k << tb) | (x_k & (2^tb - 1)).  Slot and entry together give k and
+// x_k, hence the id: two different ids never look alike, whatever the probe they were placed by.  0xFFFF is "empty"
+// (k stays below 2^(16 - tb) - 1, so no entry is all ones).  An id that finds kmax occupied slots is "exhausted": the
+// caller freezes the table and sends it to the spill table in global memory (lookups keep probing kmax slots first).
+// Two slots share a dword and LDS has no 16-bit compare-and-swap: an insert swaps the whole dword and retries on the
+// same slot when the neighbour changed meanwhile.
+constexpr uint32_t kHt16A = 0x9E3779B1u, kHt16B2 = 0x3C6EF372u;
+enum : int { kHt16Present = 0, kHt16Inserted = 1, kHt16Exhausted = 2 };
+struct Ht16 {
+    uint32_t idmask, tb, kmax;
+};
+__device__ __forceinline__ int ht16_insert_open(uint32_t* htw, const Ht16& t, uint32_t id, bool active) {
+    const uint32_t tagmask = (1u << t.tb) - 1u;
+    uint32_t x = id * kHt16A;
+    uint32_t xm = x & t.idmask;
+    uint32_t slot = xm >> t.tb, val = xm & tagmask;
+    uint32_t* wp = htw + (slot >> 1);
+    uint32_t sh = (slot & 1u) << 4;
+    uint32_t w = *wp;  // (inactive lanes read some slot of the table too: no branch around the load)
+    uint32_t cur = (w >> sh) & 0xFFFFu;
+    const bool tryins = active && cur == 0xFFFFu;
+    uint32_t old = w;
+    if (tryins) old = atomicCAS(wp, w, w ^ ((0xFFFFu ^ val) << sh));
+    int res = (tryins && old == w) ? kHt16Inserted : kHt16Present;
+    bool pending = active && res != kHt16Inserted && cur != val;
+    if (ballot64(pending)) {
+        const uint32_t step = id * kHt16B2;
+        bool adv = !tryins;  // occupied by another id: next probe; lost the swap to the neighbour slot: the same slot again
+        uint32_t k = 0;
+        w = old;
+        while (pending) {
+            if (adv) {
+                ++k;
+                x += step;
+                if (k >= t.kmax) {
+                    res = kHt16Exhausted;
+                    break;
+                }
+                xm = x & t.idmask;
+                slot = xm >> t.tb;
+                val = (xm & tagmask) | (k << t.tb);
+                wp = htw + (slot >> 1);
+                sh = (slot & 1u) << 4;
+                w = *wp;
+            }
+            cur = (w >> sh) & 0xFFFFu;
+            if (cur == val) {
+                pending = false;  // present
+            } else if (cur == 0xFFFFu) {
+                old = atomicCAS(wp, w, w ^ ((0xFFFFu ^ val) << sh));
+                if (old == w) {
+                    res = kHt16Inserted;
+                    pending = false;
+                } else {
+                    w = old;
+                    adv = false;
+                }
+            } else {
+                adv = true;
+            }
+        }
+    }
+    return res;
+}
+// lookup in the frozen table: true when `id` is present
+__device__ __forceinline__ bool ht16_contains(const uint32_t* htw, const Ht16& t, uint32_t id) {
+    const uint32_t tagmask = (1u << t.tb) - 1u;
+    const uint16_t* h16 = reinterpret_cast<const uint16_t*>(htw);
+    uint32_t x = id * kHt16A;
+    const uint32_t step = id * kHt16B2;
+    for (uint32_t k = 0; k < t.kmax; ++k, x += step) {
+        const uint32_t xm = x & t.idmask;
+        const uint32_t cur = h16[xm >> t.tb];
+        if (cur == ((xm & tagmask) | (k << t.tb))) return true;
+        if (cur == 0xFFFFu) return false;
+    }
+    return false;
+}
+
 // Spill tables are handed from wave to wave inside a launch, possibly across XCDs (private L2s):
 // every probe is an agent-scope atomic, and the table is wiped with write-through (sc1) 16-byte
 // stores drained by s_waitcnt before the busy flag is released -- no release/acquire fences, which
@@ -279,22 +368,34 @@ __device__ __forceinline__ void mb_store(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
+// A mailbox wait that outlasts about a second is a protocol bug or a wave that was held up for that long (preemption
+// under oversubscription, a debugger): the team gives the query back -- status DANN_EINTERNAL through the words the
+// control wave's regular exit uses, release word set, this wave ends -- and the host re-runs it with one wave per query
+// (search_with_retry), instead of a trap that would take the host process down.  The queue wave, parked at the hop's
+// barrier, is released when the last helper has ended the same way or has seen the release word.
+__device__ __forceinline__ void team_abort(uint32_t* mail) {
+    mail[kMbDStatus] = (uint32_t)(-DANN_EINTERNAL);
+    mail[kMbDCmps] = 0u;
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(mail + kMbGo, kTeamExit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_endpgm();
+}
 // wait until *p != seen (another wave of the team writes it); returns the new value
-// (a wait that outlasts about a second is a protocol bug: abort the dispatch rather than hang the device)
-__device__ __forceinline__ uint32_t mb_wait_change(const uint32_t* p, uint32_t seen) {
+__device__ __forceinline__ uint32_t mb_wait_change(uint32_t* mail, const uint32_t* p, uint32_t seen) {
     uint32_t v, spins = 0;
     while ((v = mb_load(p)) == seen) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 24)) __builtin_trap();
+        if (++spins > (1u << 24)) team_abort(mail);
     }
     asm volatile("" ::: "memory");
     return v;
 }
-__device__ __forceinline__ void mb_wait_at_least(const uint32_t* p, uint32_t want) {
+__device__ __forceinline__ void mb_wait_at_least(uint32_t* mail, const uint32_t* p, uint32_t want) {
     uint32_t spins = 0;
     while (mb_load(p) < want) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 24)) __builtin_trap();
+        if (++spins > (1u << 24)) team_abort(mail);
     }
     asm volatile("" ::: "memory");
 }
@@ -429,7 +530,7 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     auto team_spec = [&]() {
         PH_T(pts0);
         // the visited wave refills the previous hop's buffer: the queue wave must hold those distances in registers
-        if (loaded_seen < hop) mb_wait_at_least(mail + kMbLoaded, hop);
+        if (loaded_seen < hop) mb_wait_at_least(mail, mail + kMbLoaded, hop);
         spec_sent = (pf_node != kEmpty && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
         if (lane == 0) {
             uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
@@ -494,7 +595,7 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     };
     auto read_pub = [&](uint32_t n) -> Pub {  // publication of pop n (waits for it)
         const uint32_t* w = mail + kMbPop + 8u * (n & 1u);
-        mb_wait_at_least(w, n);
+        mb_wait_at_least(mail, w, n);
         const uint4 lo = *reinterpret_cast<const uint4*>(w), hi = *reinterpret_cast<const uint4*>(w + 4);
         Pub r;
         r.found = uni(lo.y);
@@ -656,9 +757,9 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
     __syncthreads();  // the query is staged, the table wiped, the mailbox cleared
     uint32_t seen = 0;
     for (uint32_t hop = 0;; ++hop) {
-        seen = mb_wait_change(mail + kMbGo, seen);
+        seen = mb_wait_change(mail, mail + kMbGo, seen);
         if (seen == kTeamExit) break;
-        mb_wait_at_least(mail + kMbSpecSeq, hop + 1u);  // (the gather wave is started first)
+        mb_wait_at_least(mail, mail + kMbSpecSeq, hop + 1u);  // (the gather wave is started first)
         const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
         const uint32_t node = uni(w[1]), table_ids = uni(w[2]), out_buf = uni(w[3]);
         uint32_t ran = 0, kept = 0, fresh = 0;
@@ -740,7 +841,7 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qbytes = kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u;
-    const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, QS * kWave, qbytes, true);
+    const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, lds_queue_entries(a), qbytes, true);
     if (wave == 1u) {
         team_control_wave<DT, OP, NORM, QS, DIM>(a, smem, L, lane);
         return;
@@ -755,7 +856,7 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     // table of pointers) keeps every access an LDS instruction -- a selected pointer decays to a flat address, whose
     // loads also wait for the global-memory counter
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
-    const uint32_t* mail = reinterpret_cast<const uint32_t*>(smem + L.mail_off);
+    uint32_t* const mail = reinterpret_cast<uint32_t*>(smem + L.mail_off);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     __syncthreads();  // the query is staged
     const int g = lane / G, v = lane % G;
@@ -772,7 +873,7 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     }
     uint32_t seen = 0;
     for (;;) {
-        seen = mb_wait_change(mail + kMbGo, seen);
+        seen = mb_wait_change(mail, mail + kMbGo, seen);
         if (seen == kTeamExit) break;
         const uint32_t nc = (seen >> 20) & 0x7Fu, buf = (seen >> 27) & 1u;
         team_gather_share<DT, OP, NORM, DIM, 1, 4>(
@@ -785,11 +886,12 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
 
 enum : int { kModePlain = 0, kModeGeneral = 1, kModeFiltered = 2 };
 // TEAM > 1: this is the queue wave of a team (see team_control_wave)
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int TEAM = 1>
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int TEAM = 1, bool HT16 = false>
 __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint32_t slot, uint8_t* smem) {
     constexpr bool FILT = MODE == kModeFiltered;
     constexpr bool PLAIN = MODE == kModePlain;
     static_assert(TEAM == 1 || (PLAIN && DIM > 0), "teams serve the plain fixed-length searches");
+    static_assert(TEAM == 1 || !HT16, "teams keep the 32-bit visited table (their rollback works on its slots)");
     // synchronisation of this wave with itself (LDS written by some lanes, read by others): the workgroup barrier of a
     // one-wave workgroup, a counter drain when helper waves share the workgroup
     auto WS = [&]() {
@@ -817,7 +919,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t qbytes = DIM > 0 ? (kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u)
                                     : query_lds_bytes(ix);
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
-    const SearchLds L = search_lds_layout(a.ht_entries, cmax, QS * kWave, qbytes, TEAM > 1);
+    const SearchLds L = search_lds_layout(a.ht_entries, cmax, lds_queue_entries(a), qbytes, TEAM > 1);
     QT* qs = reinterpret_cast<QT*>(smem + L.q_off);
     uint32_t* ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     uint32_t* cand_id = reinterpret_cast<uint32_t*>(smem + L.cand_id_off);
@@ -826,7 +928,6 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
     uint2* stage = reinterpret_cast<uint2*>(smem + L.stage_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
-    float* snew = reinterpret_cast<float*>(smem + L.snew_off);
     constexpr uint32_t QCAPP = QS * kWave;  // padded queue capacity
     uint32_t* beam = reinterpret_cast<uint32_t*>(smem + L.beam_off);
     uint32_t* mail = reinterpret_cast<uint32_t*>(smem + L.mail_off);  // (teams)
@@ -858,7 +959,17 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         }
     }
     const uint32_t ht_size = a.ht_entries;
-    const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size
+    uint32_t status_early = 0;  // (HT16) an insert outside the hop found no slot: the query is re-run with a larger table
+    const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size (HT16: the number of 16-bit slots)
+    const Ht16 h16{a.ht_idmask, a.ht_tb, a.ht_kmax};
+    // insert into the open table outside the hop (start points, the second phase of a range search)
+    auto visit_open = [&](uint32_t id) {
+        if constexpr (HT16) {
+            if (ht16_insert_open(ht, h16, id, id < ix.nslots) == kHt16Exhausted) status_early = (uint32_t)(-DANN_EOVERFLOW);
+        } else {
+            ht_visit(ht, ht_mod, id, true);
+        }
+    };
     {   // wipe the visited table with 16-byte stores (ht_size is a multiple of 64, the table 16-byte aligned)
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
         for (uint32_t i = lane * 4u; i < ht_size; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
@@ -1230,6 +1341,8 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nd), jj));
             before += ((dj < nd) | ((dj == nd) & (jj > lane))) ? 1u : 0u;
         }
+        // (the sorted survivors go where the candidates came from: cbi's content is in registers by now)
+        float* const snew = reinterpret_cast<float*>(cbi);
         if (has) snew[before] = nd;
         WS();
         // old elements: shift = #{new <= d_e}  (upper bound in snew[0..nv))
@@ -1287,6 +1400,26 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // (provider.rs:448-454); survivors go to cand_id[0..nc)
     // accept_only (expand_beam_accept_only, labeled.rs:196-214,284-291): ids that do not match the filter
     // are skipped *before* the visited set sees them
+    auto claim_spill = [&]() {
+        if (spill) return;
+        uint32_t slice = kEmpty;
+        if (a.spill) {
+            // slices are recycled inside a launch: busy flag per slice, rotating start
+            if (lane == 0) {
+                uint32_t* busy = a.spill_next + 16;
+                uint32_t s = atomicAdd(a.spill_next, 1u) % a.spill_slices;
+                for (uint32_t t = 0; t < 2u * a.spill_slices; ++t) {
+                    if (atomicCAS(&busy[s], 0u, 1u) == 0u) {
+                        slice = s;
+                        break;
+                    }
+                    s = (s + 1 == a.spill_slices) ? 0u : s + 1;
+                }
+            }
+            slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
+        }
+        if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
+    };
     auto expand = [&](uint32_t nb, bool accept_only = false, bool node_in_reg = false) -> uint32_t {
         uint32_t nc = 0;
         for (uint32_t b = 0; b < nb; ++b) {
@@ -1301,25 +1434,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
                 // freeze the LDS table, claim a spill table (kept once claimed)
                 lds_open = false;
-                if (!spill) {
-                    uint32_t slice = kEmpty;
-                    if (a.spill) {
-                        // slices are recycled inside a launch: busy flag per slice, rotating start
-                        if (lane == 0) {
-                            uint32_t* busy = a.spill_next + 16;
-                            uint32_t s = atomicAdd(a.spill_next, 1u) % a.spill_slices;
-                            for (uint32_t t = 0; t < 2u * a.spill_slices; ++t) {
-                                if (atomicCAS(&busy[s], 0u, 1u) == 0u) {
-                                    slice = s;
-                                    break;
-                                }
-                                s = (s + 1 == a.spill_slices) ? 0u : s + 1;
-                            }
-                        }
-                        slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)slice);
-                    }
-                    if (slice < a.spill_slices) spill = a.spill + ((uint64_t)slice << a.spill_bits);
-                }
+                claim_spill();
             }
             if (!lds_open && (!spill || spill_count + len > spill_size - (spill_size >> 2))) {
                 status = (uint32_t)(-DANN_EOVERFLOW);
@@ -1331,11 +1446,28 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const bool inb = j < len;
                 const uint32_t id = hit ? (inb ? pf_val : kEmpty) : (inb ? arow[1 + j] : kEmpty);
                 bool isnew = false;
-                const bool act = inb && id != kEmpty && (!accept_only || fmatch(id));
+                // (HT16: the table holds ids below 2^m only; an id beyond the index is never a candidate anyway)
+                const bool act = inb && id != kEmpty && (!accept_only || fmatch(id)) && (!HT16 || id < ix.nslots);
                 if (lds_open) {
-                    isnew = ht_insert_open(ht, ht_mod, id, act);
+                    if constexpr (HT16) {
+                        const int r = ht16_insert_open(ht, h16, id, act);
+                        isnew = act && r == kHt16Inserted;
+                        const bool exh = act && r == kHt16Exhausted;
+                        if (ballot64(exh)) {  // (rare) no slot among this id's probes: freeze the table, the id goes to the spill table
+                            lds_open = false;
+                            claim_spill();
+                            if (!spill) {
+                                status = (uint32_t)(-DANN_EOVERFLOW);
+                                break;
+                            }
+                            if (exh) isnew = spill_insert(spill, spill_mask, spill_shift, id);
+                        }
+                    } else {
+                        isnew = ht_insert_open(ht, ht_mod, id, act);
+                    }
                 } else if (act) {  // frozen LDS table: lookup, then the spill table in global memory
-                    isnew = ht_visit(ht, ht_mod, id, false) == kAbsent && spill_insert(spill, spill_mask, spill_shift, id);
+                    if constexpr (HT16) isnew = !ht16_contains(ht, h16, id) && spill_insert(spill, spill_mask, spill_shift, id);
+                    else isnew = ht_visit(ht, ht_mod, id, false) == kAbsent && spill_insert(spill, spill_mask, spill_shift, id);
                 }
                 const bool keep = isnew && id < ix.nslots;
                 const uint64_t nm = ballot64(isnew), km = ballot64(keep);
@@ -1346,6 +1478,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             }
             PH_T(phv1);
             PH_ADD(7, phv0, phv1);
+            if (HT16 && status) break;
         }
         return nc;
     };
@@ -1355,8 +1488,9 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         const uint32_t ns = ix.nstart;
         for (uint32_t i = lane; i < ns; i += kWave) {
             cand_id[i] = ix.capacity + i;
-            ht_visit(ht, ht_mod, ix.capacity + i, true);
+            visit_open(ix.capacity + i);
         }
+        if (HT16 && ballot64(status_early != 0)) status = (uint32_t)(-DANN_EOVERFLOW);
         ht_count = ns;
         WS();
         // start points are created FROZEN (store.rs:766-772) and the host refuses to unpublish them; should one be
@@ -1717,7 +1851,8 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nf - i0) < (uint32_t)kWave ? (nf - i0) : (uint32_t)kWave;
                 if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nf) ht_visit(ht, ht_mod, u32_load(m_ids + i), true);
+                else if (i < nf) visit_open(u32_load(m_ids + i));
+                if (HT16 && ballot64(status_early != 0)) status = (uint32_t)(-DANN_EOVERFLOW);
                 ht_count += cnt;
             }
             WS();
@@ -1828,7 +1963,8 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nr - i0) < (uint32_t)kWave ? (nr - i0) : (uint32_t)kWave;
                 if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
-                else if (i < nr) ht_visit(ht, ht_mod, rids[i], true);
+                else if (i < nr) visit_open(rids[i]);
+                if (HT16 && ballot64(status_early != 0)) status = (uint32_t)(-DANN_EOVERFLOW);
                 ht_count += cnt;
             }
             WS();
@@ -2041,8 +2177,11 @@ __device__ void server_dispatch(const ServerView& sv) {
 // serve the submission ring of dann_server_start until told to stop.  Results do not depend on it.  Separate
 // instantiations (plain mode only): the loop around the body costs the one-wave-per-query launch 3-5 % when it is
 // compiled into the same kernel.
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP, int TEAM = 1>
-__global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a) {
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP, int TEAM = 1, bool HT16 = false>
+#ifndef DANN_SEARCH_KERNEL_ATTR
+#define DANN_SEARCH_KERNEL_ATTR
+#endif
+__global__ __launch_bounds__(kWave * TEAM) DANN_SEARCH_KERNEL_ATTR void beam_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if constexpr (TEAM > 1) {
         static_assert(LOOP == 0, "teams serve one-shot launches");
@@ -2052,13 +2191,13 @@ __global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a)
         }
         beam_search_one<DT, OP, NORM, QS, DIM, MODE, TEAM>(a, blockIdx.x, smem);
     } else if constexpr (LOOP == 0) {
-        beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, blockIdx.x, smem);
+        beam_search_one<DT, OP, NORM, QS, DIM, MODE, 1, HT16>(a, blockIdx.x, smem);
     } else if constexpr (LOOP == 1) {
         uint32_t slot = blockIdx.x;
         for (;;) {
             uint32_t nxt = 0;  // the ticket for the search after this one is drawn now: its round trip hides behind the search
             if (threadIdx.x == 0) nxt = atomicAdd(a.work_next, 1u);
-            beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, slot, smem);
+            beam_search_one<DT, OP, NORM, QS, DIM, MODE, 1, HT16>(a, slot, smem);
             __syncthreads();  // the next query reuses this wave's LDS
             slot = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
             if (slot >= a.nq) break;
@@ -2117,7 +2256,7 @@ __global__ __launch_bounds__(kWave * TEAM) void beam_search_kernel(SearchArgs a)
                 // the search reads the staged query back with plain loads: drop this CU's (stale) L1 copy of the buffer
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            beam_search_one<DT, OP, NORM, QS, DIM, MODE>(a, w, smem);
+            beam_search_one<DT, OP, NORM, QS, DIM, MODE, 1, HT16>(a, w, smem);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             // ---- result: this worker's device rows -> the host ring, then the completion word
@@ -2151,7 +2290,7 @@ inline bool plain_mode(const SearchArgs& a) {
 
 constexpr int kTeam = 4;  // wavefronts per query in the latency regime (SearchArgs::team)
 
-template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0, int TEAM = 1>
+template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0, int TEAM = 1, bool HT16 = false>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
     if constexpr (MODE == kModePlain && LOOP == 0 && TEAM == 1 && DIM > 0 && QS <= 4 && DT != DT_PQ) {
         if (a.team && !a.srv.ring && !a.grid && !regs_out)
@@ -2165,7 +2304,14 @@ int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* reg
         }
         if (a.grid && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, 1>(a, lds, stream, regs_out);
     }
-    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, LOOP, TEAM>;
+    if constexpr (MODE == kModePlain && TEAM == 1 && !HT16) {  // 16-bit visited-table entries (SearchArgs::ht16)
+        if (a.ht16 && !regs_out) return launch_one<DT, OP, NORM, QS, DIM, MODE, LOOP, TEAM, true>(a, lds, stream, regs_out);
+    }
+    if (a.ht16 && !HT16 && !regs_out) {
+        set_error("internal: 16-bit visited table requested for a kernel that has none");
+        return DANN_EINTERNAL;
+    }
+    auto kern = beam_search_kernel<DT, OP, NORM, QS, DIM, MODE, LOOP, TEAM, HT16>;
     if (regs_out) {  // query only: VGPRs of the instantiation this launch would use
         hipFuncAttributes attr;
         hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern));

@@ -50,8 +50,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    const uint32_t qcap = std::max(a.l_value + a.ix.nstart, a.qcap_max);
-    return search_lds_layout(a.ht_entries, cmax_of(a), qs_of(qcap) * kWave, query_lds_bytes(a.ix), a.team != 0).total;
+    return search_lds_layout(a.ht_entries, cmax_of(a), lds_queue_entries(a), query_lds_bytes(a.ix), a.team != 0).total;
 }
 
 // ---- sizing of the LDS visited table ---------------------------------------------------------
@@ -75,6 +74,86 @@ uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids, uint32_t useful_wa
     // beyond ~8 slots per id the probe chains are already one step long; a larger table only costs its wipe
     top = std::min<int64_t>(top, ((int64_t)cap_ids * 8 + 63) / 64 * 64);
     return (uint32_t)std::min<int64_t>(std::max<int64_t>(top, (int64_t)need), 32768);
+}
+
+uint32_t largest_prime_leq(uint32_t n);
+
+// ---- 16-bit table entries (SearchArgs::ht16; device side: ht16_insert_open) -----------------------------------------
+// Geometry of a table of `words` dwords = 2 * words slots (a power of two) for ids below the index's slot count:
+// m id bits, tb = m - log2(slots) tag bits (0 when the table has a slot per id), 16 - tb bits left for the probe number.
+struct Ht16Geom {
+    bool ok = false;
+    uint32_t idmask = 0, tb = 0, kmax = 0, slots = 0;
+};
+Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
+    Ht16Geom g;
+    const uint32_t slots = words * 2u;
+    if (words < 32u || (slots & (slots - 1u))) return g;
+    uint32_t m = 1, b = 0;
+    while (m < 32u && (1ull << m) < (uint64_t)nslots) ++m;
+    while ((1u << b) < slots) ++b;
+    if (m >= 32u) return g;
+    g.tb = m > b ? m - b : 0u;
+    if (g.tb > 13u) return g;  // fewer than 3 bits for the probe number: too few probes per id
+    g.idmask = (uint32_t)((1ull << m) - 1ull);
+    g.kmax = std::min<uint32_t>((1u << (16u - g.tb)) - 1u, 64u);
+    g.slots = slots;
+    g.ok = true;
+    return g;
+}
+// may this launch use 16-bit entries at all?  (plain-mode kernels, one wave per query)
+bool ht16_eligible(const SearchArgs& a) { return plain_mode(a) && !a.team; }
+
+// probing modulus / slot count and the 16-bit geometry of the table `a` has been given
+int32_t finish_visited_table(SearchArgs& a) {
+    if (a.ht16) {
+        const Ht16Geom g = ht16_geometry(a.ht_entries, a.ix.nslots);
+        if (!g.ok || !ht16_eligible(a)) {
+            set_error("internal: no 16-bit visited table of %u words for %u slots", a.ht_entries, a.ix.nslots);
+            return DANN_EINTERNAL;
+        }
+        a.ht_prime = g.slots;
+        a.ht_idmask = g.idmask;
+        a.ht_tb = g.tb;
+        a.ht_kmax = g.kmax;
+    } else {
+        a.ht_prime = largest_prime_leq(a.ht_entries);
+    }
+    return DANN_OK;
+}
+// ids the open table takes before it is frozen
+uint64_t visited_open_capacity(const SearchArgs& a) {
+    return a.ht16 ? (uint64_t)a.ht_entries * 2u * 3u / 4u : (uint64_t)largest_prime_leq(a.ht_entries) * 3u / 4u;
+}
+
+// sizes the table of an automatically sized launch: the 32-bit table at the top of its occupancy step, or -- where the
+// kernel has them and they buy a higher step -- 16-bit entries in a power-of-two table
+void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves, uint32_t format) {
+    a.ht16 = 0;
+    a.ht_entries = snap_visited_entries(a, cap_ids, useful_waves);
+    if (format == 32u || !ht16_eligible(a)) return;
+    auto waves_of = [&](uint32_t words) -> uint32_t {
+        SearchArgs t = a;
+        t.ht_entries = words;
+        const uint64_t granules = (search_lds_bytes(t) + kLdsGranule - 1) / kLdsGranule;
+        return granules > kLdsGranules ? 0u : std::min<uint32_t>(kLdsGranules / (uint32_t)granules, useful_waves);
+    };
+    const uint64_t need = std::max<uint64_t>((uint64_t)((double)cap_ids / 0.75), 512);
+    uint32_t words = 256;  // 512 slots
+    while (words < 32768u && (uint64_t)words * 2u < need) words *= 2u;
+    while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
+    if (!ht16_geometry(words, a.ix.nslots).ok) return;
+    const uint32_t w16 = waves_of(words), w32 = waves_of(a.ht_entries);
+    // Measured (profiles/r04a_visited16_sgpr_ab_*.log): where the 32-bit table already lets a dozen and more queries
+    // share a CU the search is bound by instruction issue, not by latency -- u8 rows at L = 26 went from 21 to 32
+    // queries per CU for -3 % (and +4 % where the SGPR count capped the gain at 24: the 16-bit probe is a few
+    // instructions longer); with few queries per CU (10 M x 128 f32 at L = 56: 11 -> 16) the extra residents pay.
+    if (format != 16u && (w16 <= w32 || w32 > 12u)) return;
+    if (w16 == 0 && format != 16u) return;
+    // a sparser table on the same step costs nothing but its wipe (cf. snap_visited_entries)
+    while (words < 32768u && (uint64_t)words * 4u <= (uint64_t)cap_ids * 8u && waves_of(words * 2u) == w16) words *= 2u;
+    a.ht16 = 1;
+    a.ht_entries = words;
 }
 
 // prior for a (L, beam) never seen on this index: comparisons per query ~= 4.3 R (L + W)^0.55 on
@@ -232,19 +311,31 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
         const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
         const uint32_t waves = tune_env(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
-        a.ht_entries = snap_visited_entries(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves);
+        choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
         if (getenv("DANN_DEBUG") && (cal.calls & (cal.calls - 1)) == 0)
-            fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u entries, %zu B LDS\n", a.l_value, a.beam_width,
-                    cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior", a.ht_entries,
-                    search_lds_bytes(a));
+            fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u %s, %zu B LDS\n", a.l_value, a.beam_width,
+                    cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior",
+                    a.ht16 ? a.ht_entries * 2u : a.ht_entries, a.ht16 ? "16-bit slots" : "entries", search_lds_bytes(a));
+    } else {
+        // explicit size (dann_set_visited_bits): 16-bit entries only on request (dann_set_visited_format)
+        a.ht16 = 0;
+        if (idx->visited_format == 16u && ht16_eligible(a)) {
+            uint32_t words = 32;
+            while (words < 32768u && words < a.ht_entries) words *= 2u;
+            while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
+            if (ht16_geometry(words, a.ix.nslots).ok) {
+                a.ht16 = 1;
+                a.ht_entries = words;
+            }
+        }
     }
     // the start points are inserted unconditionally and the first hop needs room before the freeze test can
     // trigger: the open table must hold nstart + W * R ids below its 75 % load limit, or ht_visit could probe a
     // full table forever (explicit dann_set_visited_bits sizes and small calibrated sizes are grown, never results)
     {
         const uint64_t floor_ids = (uint64_t)a.ix.nstart + (uint64_t)a.beam_width * a.ix.max_degree + 1;
-        while (a.ht_entries < 32768 && (uint64_t)largest_prime_leq(a.ht_entries) * 3 / 4 <= floor_ids) a.ht_entries *= 2;
-        if ((uint64_t)largest_prime_leq(a.ht_entries) * 3 / 4 <= floor_ids) {
+        while (a.ht_entries < 32768 && visited_open_capacity(a) <= floor_ids) a.ht_entries *= 2;
+        if (visited_open_capacity(a) <= floor_ids) {
             set_error("visited table: %u start points + beam %u x degree %u do not fit the largest LDS table", a.ix.nstart,
                       a.beam_width, a.ix.max_degree);
             return DANN_EINVAL;
@@ -273,7 +364,7 @@ int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     int32_t rc = prepare_launch(idx, ctx, a, a.srv.workers);
     if (rc != DANN_OK) return rc;
     a.fail_flag = nullptr;
-    a.ht_prime = largest_prime_leq(a.ht_entries);
+    if (int32_t frc = finish_visited_table(a)) return frc;
     return launch_search(a, ctx.stream);
 }
 
@@ -308,7 +399,7 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     // HIP events bracket exactly the beam-search launches, on the stream they run on
     float last_ms = 0.f;
     auto timed_launch = [&](SearchArgs& args) -> int32_t {
-        args.ht_prime = largest_prime_leq(args.ht_entries);
+        if (int32_t frc = finish_visited_table(args)) return frc;
 #ifdef DANN_PHASE_CYCLES
         args.phase_cycles = dann_phase_buffer();
 #endif

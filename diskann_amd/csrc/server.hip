@@ -94,7 +94,27 @@ struct dann_server {
     std::mutex launch_mu;
     bool launched = false;
     std::atomic<uint64_t> relaunches{0};
+    std::atomic<bool> stopping{false};  // dann_server_stop is draining the callers: every wait loop leaves
+    // a submit whose ring position was not taken for kWaitLimitSeconds: the resident kernel is dead or the ring is
+    // wedged.  The sequence number that submit drew can never be published, and the in-order ring cannot pass it: from
+    // here on every submit and wait fails at once (DANN_EHIP) instead of after its own timeout; stop / start recovers.
+    std::atomic<bool> poisoned{false};
 };
+
+namespace {
+// submit / wait / poll / stats hold one for the duration of the call (see dann_index::srv_users)
+struct ServerPin {
+    dann_index* i;
+    dann_server* s;
+    explicit ServerPin(dann_index* idx) : i(idx) {
+        i->srv_users.fetch_add(1, std::memory_order_seq_cst);
+        s = i->server.load(std::memory_order_seq_cst);
+    }
+    ~ServerPin() { i->srv_users.fetch_sub(1, std::memory_order_release); }
+    ServerPin(const ServerPin&) = delete;
+    ServerPin& operator=(const ServerPin&) = delete;
+};
+}  // namespace
 
 namespace {
 
@@ -180,7 +200,7 @@ extern "C" {
 int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     if (!idx || !cfg) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);  // start / stop are rare and exclude mutations; submit / wait take no lock at all
-    if (idx->server) {
+    if (idx->server.load()) {
         set_error("dann_server_start: a server is already running on this index");
         return DANN_EINVAL;
     }
@@ -280,33 +300,40 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     s->hv.h_done = reinterpret_cast<uint32_t*>(s->h_block + o_done);
     s->hv.h_ack = reinterpret_cast<uint32_t*>(s->h_block + o_ack);
     s->hv.h_ctl = reinterpret_cast<uint32_t*>(s->h_block + o_ctl);
-    idx->server = s;
-    // the first launch happens under the index's exclusive lock (no search is running)
+    // the first launch happens under the index's exclusive lock (no search is running) and before the server is
+    // published: no caller can see a server that failed to start
     int32_t rc;
     {
         std::lock_guard<std::mutex> lk(s->launch_mu);
         rc = launch_locked(idx, s);
     }
     if (rc != DANN_OK) {
-        idx->server = nullptr;
+        (void)hipStreamSynchronize(s->ctx.stream);
         return fail(rc);
     }
+    idx->srv_outstanding.store(0, std::memory_order_seq_cst);
+    idx->server.store(s, std::memory_order_seq_cst);
     return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_server_stop(dann_index* idx) try {
     if (!idx) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);
-    dann_server* s = idx->server;
+    // unpublish first: a caller that pins after this sees no server; the ones already inside are waited for below
+    dann_server* s = idx->server.exchange(nullptr, std::memory_order_seq_cst);
     if (!s) return DANN_OK;
     DeviceGuard guard(idx->device);
+    s->stopping.store(true, std::memory_order_seq_cst);
     {
         std::lock_guard<std::mutex> lk(s->launch_mu);
         __atomic_store_n(&s->hv.h_ctl[0], 1u, __ATOMIC_RELEASE);  // the dispatcher polls this word
         if (s->launched) (void)hipStreamSynchronize(s->ctx.stream);
         s->launched = false;
     }
-    idx->server = nullptr;
+    // callers still inside submit / wait / poll: their loops see `stopping` and return (DANN_EINVAL: the server is
+    // gone); nothing of the server is freed before the last of them has left
+    while (idx->srv_users.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
+    idx->srv_outstanding.store(0, std::memory_order_seq_cst);  // uncollected tickets die with the server
     s->ctx.destroy();
     if (s->h_block) (void)hipHostFree(s->h_block);
     if (s->d_block) (void)hipFree(s->d_block);
@@ -318,10 +345,29 @@ int32_t dann_server_stop(dann_index* idx) try {
 
 int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket) try {
     if (!idx || !query || !ticket) return DANN_EINVAL;
-    dann_server* s = idx->server;
+    ServerPin pin(idx);
+    dann_server* s = pin.s;
     if (!s) {
         set_error("dann_search_submit: no server on this index (dann_server_start)");
         return DANN_EINVAL;
+    }
+    auto gone = [&]() {
+        set_error("dann_search_submit: the server is being stopped");
+        return DANN_EINVAL;
+    };
+    auto dead = [&]() {
+        set_error("dann_search_submit: the server's ring is wedged (an earlier submit timed out): dann_server_stop / "
+                  "dann_server_start");
+        return DANN_EHIP;
+    };
+    if (s->poisoned.load(std::memory_order_acquire)) return dead();
+    // the "no mutation while tickets are outstanding" rule, this side: count the ticket, then look for a mutation
+    idx->srv_outstanding.fetch_add(1, std::memory_order_seq_cst);
+    auto uncount = [&]() { idx->srv_outstanding.fetch_sub(1, std::memory_order_seq_cst); };
+    if (idx->mutating.load(std::memory_order_seq_cst) != 0) {
+        uncount();
+        set_error("dann_search_submit: the index is being mutated");
+        return DANN_EBUSY;
     }
     const ServerView& sv = s->hv;
     std::chrono::steady_clock::time_point began{};
@@ -332,7 +378,10 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
             cpu_relax();
         } else {
             std::this_thread::yield();
+            if (s->stopping.load(std::memory_order_acquire)) return uncount(), gone();
+            if (s->poisoned.load(std::memory_order_acquire)) return uncount(), dead();
             if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
+                uncount();
                 set_error("dann_search_submit: no result slot was released within %u s (%u tickets outstanding: every ticket "
                           "must be waited for)", kWaitLimitSeconds, sv.ring);
                 return DANN_EOVERFLOW;
@@ -340,45 +389,83 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
         }
     }
     memcpy(const_cast<uint8_t*>(sv.h_queries) + (size_t)slot * sv.qstride, query, sv.qbytes);
+    // From here to the publication nothing may return without filling the ring position: the ring is consumed in order
+    // and a sequence number that never shows up would stall every later ticket of every caller.
     const uint64_t seq = s->next.fetch_add(1, std::memory_order_relaxed);
     const uint64_t t = (seq << 20) | slot;
     s->slot_owner[slot].store(t + 1, std::memory_order_release);
     // the ring position: free once a worker has taken the previous lap's entry -- which depends on nothing but the
-    // workers getting through older tickets (a relaunch included: this thread may be the one that has to do it)
+    // workers getting through older tickets (a relaunch included: this thread may be the one that has to do it; a
+    // relaunch that fails is tried again on the next round -- a transient HIP error must not cost the ring a position)
     const uint32_t pos = (uint32_t)(seq & (sv.ring - 1u));
     const uint32_t prev_tag = (seq >> sv.ring_shift) ? server_lap_tag(seq - sv.ring, sv.ring_shift) : 0u;
     began = {};
+    bool abandon = false;  // stop in progress: the position gets an entry without a query
     for (uint64_t spins = 0; __atomic_load_n(sv.h_ack + pos, __ATOMIC_ACQUIRE) != prev_tag; ++spins) {
         if (spins < 64) {
             cpu_relax();
         } else {
-            if ((spins & 63u) == 0)
-                if (int32_t rc = relaunch_if_exited(idx, s)) return rc;
+            if ((spins & 63u) == 0) (void)relaunch_if_exited(idx, s);
             std::this_thread::yield();
-            if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
-                // (fatal for this server: the sequence number stays unpublished and the in-order ring cannot pass it --
-                // a resident kernel that takes no entry for 30 s is dead; dann_server_stop / start is the way out)
-                set_error("dann_search_submit: ring position %u was not taken by a worker within %u s", pos, kWaitLimitSeconds);
+            if (s->stopping.load(std::memory_order_acquire)) {  // no worker will take anything any more: nothing to keep in order
+                abandon = true;
+                break;
+            }
+            if (s->poisoned.load(std::memory_order_acquire) || ((spins & 1023u) == 0 && wait_expired(spins, began))) {
+                // a resident kernel that takes no entry for 30 s is dead (or an earlier submit already found it so)
+                s->poisoned.store(true, std::memory_order_release);
+                s->slot_owner[slot].store(0, std::memory_order_release);
+                s->give_slot(slot, dann_server::home_stack());
+                uncount();
+                set_error("dann_search_submit: ring position %u was not taken by a worker within %u s; the server is "
+                          "unusable until dann_server_stop / dann_server_start", pos, kWaitLimitSeconds);
                 return DANN_EHIP;
             }
         }
     }
+    if (abandon) {
+        s->slot_owner[slot].store(0, std::memory_order_release);
+        s->give_slot(slot, dann_server::home_stack());
+        uncount();
+        return gone();
+    }
     __atomic_store_n(host_u32(sv.h_pub) + pos, (server_lap_tag(seq, sv.ring_shift) << 20) | slot, __ATOMIC_RELEASE);
     *ticket = t;
-    return relaunch_if_exited(idx, s);
+    // published: the ticket is live whatever happens now -- a kernel that left in the meantime is relaunched here or,
+    // if that fails, by dann_search_wait / dann_search_poll
+    (void)relaunch_if_exited(idx, s);
+    return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_search_poll(dann_index* idx, uint64_t ticket) try {
-    if (!idx || !idx->server) return DANN_EINVAL;
-    const ServerView& sv = idx->server->hv;
+    if (!idx) return DANN_EINVAL;
+    ServerPin pin(idx);
+    dann_server* s = pin.s;
+    if (!s) return DANN_EINVAL;
+    const ServerView& sv = s->hv;
     const uint32_t slot = (uint32_t)(ticket & 0xFFFFFu);
     if (slot >= sv.ring) return DANN_EINVAL;
-    return __atomic_load_n(sv.h_done + slot, __ATOMIC_ACQUIRE) == (uint32_t)(ticket >> 20) + 1u ? 1 : 0;
+    if (__atomic_load_n(sv.h_done + slot, __ATOMIC_ACQUIRE) == (uint32_t)(ticket >> 20) + 1u) return 1;
+    // not there yet: a caller that only polls must not wait for ever on a kernel that left on its idle timeout between
+    // the submit's last look and now
+    if (s->poisoned.load(std::memory_order_acquire)) {
+        set_error("dann_search_poll: the server's ring is wedged: dann_server_stop / dann_server_start");
+        return DANN_EHIP;
+    }
+    if (int32_t rc = relaunch_if_exited(idx, s)) return rc;
+    return 0;
 } DANN_CATCH_ALL
 
 int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
     if (!idx || !out_ids || !out_dists) return DANN_EINVAL;
-    dann_server* s = idx->server;
+    // (the pin is dropped before the rare re-run through dann_search_batch below: that call takes the index shared and
+    // must not hold up a dann_server_stop that holds it exclusively)
+    std::vector<uint8_t> q;
+    dann_search_stats st;
+    uint32_t k, l_value;
+    {
+    ServerPin pin(idx);
+    dann_server* s = pin.s;
     if (!s) {
         set_error("dann_search_wait: no server on this index");
         return DANN_EINVAL;
@@ -396,27 +483,33 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
         if (spins < 256) {
             cpu_relax();
         } else {
-            if ((spins & 63u) == 0)
-                if (int32_t rc = relaunch_if_exited(idx, s)) return rc;
+            if ((spins & 63u) == 0) (void)relaunch_if_exited(idx, s);  // (a failed relaunch is tried again; the limit below ends it)
             std::this_thread::yield();
-            if ((spins & 1023u) == 0 && wait_expired(spins, began)) {
-                set_error("dann_search_wait: no answer for ticket %llu within %u s", (unsigned long long)ticket, kWaitLimitSeconds);
+            if (s->stopping.load(std::memory_order_acquire)) {
+                set_error("dann_search_wait: the server is being stopped");
+                return DANN_EINVAL;
+            }
+            if (s->poisoned.load(std::memory_order_acquire) || ((spins & 1023u) == 0 && wait_expired(spins, began))) {
+                set_error("dann_search_wait: no answer for ticket %llu within %u s (or the server's ring is wedged): "
+                          "dann_server_stop / dann_server_start", (unsigned long long)ticket, kWaitLimitSeconds);
                 return DANN_EHIP;
             }
         }
     }
-    const uint32_t k = s->cfg.k;
+    k = s->cfg.k;
+    l_value = s->cfg.l_value;
     memcpy(out_ids, sv.h_res_ids + (size_t)slot * k, (size_t)k * 4);
     memcpy(out_dists, sv.h_res_d + (size_t)slot * k, (size_t)k * 4);
-    dann_search_stats st = sv.h_res_stats[slot];
-    std::vector<uint8_t> q;
+    st = sv.h_res_stats[slot];
     if (st.status) q.assign(sv.h_queries + (size_t)slot * sv.qstride, sv.h_queries + (size_t)slot * sv.qstride + sv.qbytes);
     s->slot_owner[slot].store(0, std::memory_order_release);
     s->give_slot(slot, dann_server::home_stack());
+    idx->srv_outstanding.fetch_sub(1, std::memory_order_seq_cst);
+    }
     if (st.status) {
         // the resident waves carry a fixed LDS visited table: the rare query that outgrows it (and the spill pool) is
         // re-run through the launch path, which retries with larger tables
-        int32_t rc = dann_search_batch(idx, q.data(), 1, s->cfg.l_value, 1, k, out_ids, out_dists, &st);
+        int32_t rc = dann_search_batch(idx, q.data(), 1, l_value, 1, k, out_ids, out_dists, &st);
         if (out_stats) *out_stats = st;
         return rc;
     }
@@ -425,9 +518,11 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
 } DANN_CATCH_ALL
 
 int32_t dann_server_stats(dann_index* idx, uint64_t* submitted, uint64_t* relaunches) try {
-    if (!idx || !idx->server) return DANN_EINVAL;
-    if (submitted) *submitted = idx->server->next.load(std::memory_order_relaxed);
-    if (relaunches) *relaunches = idx->server->relaunches.load(std::memory_order_relaxed);
+    if (!idx) return DANN_EINVAL;
+    ServerPin pin(idx);
+    if (!pin.s) return DANN_EINVAL;
+    if (submitted) *submitted = pin.s->next.load(std::memory_order_relaxed);
+    if (relaunches) *relaunches = pin.s->relaunches.load(std::memory_order_relaxed);
     return DANN_OK;
 } DANN_CATCH_ALL
 
@@ -440,9 +535,12 @@ int32_t dann_debug_concurrent_callers(dann_index* idx, const void* queries, uint
                                       uint32_t threads, uint32_t mode, uint32_t depth, uint32_t* out_ids, float* out_dists,
                                       float* out_latency_us, double* out_seconds) try {
     if (!idx || !queries || !out_ids || !out_dists || threads == 0 || nq == 0 || k == 0 || mode > 1) return DANN_EINVAL;
-    if (mode == 1 && (!idx->server || idx->server->cfg.k != k)) {
-        set_error("mode 1 needs a running server with the same k");
-        return DANN_EINVAL;
+    if (mode == 1) {
+        ServerPin pin(idx);
+        if (!pin.s || pin.s->cfg.k != k) {
+            set_error("mode 1 needs a running server with the same k");
+            return DANN_EINVAL;
+        }
     }
     if (depth == 0) depth = 1;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;

@@ -45,6 +45,7 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
+    std::string why;  // why the library is unusable (dlerror() is read once, when the load fails)
 };
 
 Rccl& rccl() {
@@ -54,14 +55,20 @@ Rccl& rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();
+            if (e) r.why = e;
         }
-        if (!r.lib) return;
+        if (!r.lib) {
+            if (r.why.empty()) r.why = "librccl.so not found";
+            return;
+        }
         r.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<int (*)(void**, int, dann_rccl_unique_id, int)>(dlsym(r.lib, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.lib, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+        if (!r.ok) r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
     });
     return r;
 }
@@ -112,9 +119,11 @@ struct dann_comm {
     dann_comm_ops ops{};
     void* nccl = nullptr;
     int device = 0;
+    bool in_sequence = false;  // this rank has entered a collective of the current call (see AbortOnError)
     std::shared_ptr<LocalGroup> group;
     // all-gather of `bytes` bytes per rank on device buffers, complete when it returns
     int32_t all_gather(const void* d_send, void* d_recv, uint64_t bytes, hipStream_t stream) {
+        in_sequence = true;
         if (world == 1 && kind != 1) {  // (a world-1 RCCL communicator still goes through ncclAllGather: pre-flight)
             if (d_send != d_recv) DANN_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, stream));
             DANN_HIP(hipStreamSynchronize(stream));
@@ -159,12 +168,16 @@ struct dann_comm {
 };
 
 namespace {
-// a rank that leaves a collective sequence with an error releases the ranks waiting for it (in-process communicators)
+// A rank that leaves a collective sequence with an error releases the ranks waiting for it (in-process communicators;
+// the group stays failed: its ranks are out of step for good).  An argument error reported before the first collective
+// of the call is the same on every rank (the arguments are) and nobody waits for anybody: the communicator stays usable.
 struct AbortOnError {
     dann_comm* c;
     int32_t rc = DANN_OK;
+    explicit AbortOnError(dann_comm* comm) : c(comm) { c->in_sequence = false; }
     ~AbortOnError() {
-        if (rc < 0) c->abort();
+        const bool argument = rc == DANN_EINVAL || rc == DANN_EBOUNDS || rc == DANN_ELENGTH || rc == DANN_EUNSUPPORTED;
+        if (rc < 0 && (c->in_sequence || !argument)) c->abort();
     }
 };
 }  // namespace
@@ -230,7 +243,7 @@ int32_t dann_comm_rccl_unique_id(dann_rccl_unique_id* out) try {
     if (!out) return DANN_EINVAL;
     Rccl& r = rccl();
     if (!r.ok) {
-        set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+        set_error("librccl could not be loaded (%s)", r.why.c_str());
         return DANN_EUNSUPPORTED;
     }
     int rc = r.GetUniqueId(out);
@@ -242,7 +255,7 @@ int32_t dann_comm_create_rccl(const dann_rccl_unique_id* id, uint32_t rank, uint
     if (!id || !out || world == 0 || rank >= world) return DANN_EINVAL;
     Rccl& r = rccl();
     if (!r.ok) {
-        set_error("librccl could not be loaded");
+        set_error("librccl could not be loaded (%s)", r.why.c_str());
         return DANN_EUNSUPPORTED;
     }
     if (device < 0) DANN_HIP(hipGetDevice(&device));
@@ -444,7 +457,7 @@ static int32_t build_sharded_impl(dann_index* idx, dann_comm* comm, const dann_b
 int32_t dann_build_sharded(dann_index* idx, dann_comm* comm, const dann_build_config* cfg, uint32_t first, uint32_t n,
                            float growth, uint32_t max_batch, uint64_t* stats) try {
     if (!comm) return DANN_EINVAL;
-    AbortOnError guard{comm};
+    AbortOnError guard(comm);
     try {
         guard.rc = build_sharded_impl(idx, comm, cfg, first, n, growth, max_batch, stats);
     } catch (...) {
@@ -519,7 +532,7 @@ static int32_t search_sharded_impl(dann_index* idx, dann_comm* comm, const void*
 int32_t dann_search_sharded(dann_index* idx, dann_comm* comm, const void* queries, uint32_t nq, uint32_t l_value,
                             uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists) try {
     if (!comm) return DANN_EINVAL;
-    AbortOnError guard{comm};
+    AbortOnError guard(comm);
     try {
         guard.rc = search_sharded_impl(idx, comm, queries, nq, l_value, beam_width, k, out_ids, out_dists);
     } catch (...) {

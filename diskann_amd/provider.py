@@ -426,6 +426,10 @@ class Provider:
     def set_visited_bits(self, bits):
         check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")
 
+    def set_visited_format(self, entry_bits):
+        """0 = automatic, 16 / 32 = width of a visited-table entry (never affects results)"""
+        check(_ffi.lib().dann_set_visited_format(self._h, entry_bits), "dann_set_visited_format")
+
     def set_elements_device(self, first_slot, device_ptr, n, src_stride=0):
         """n rows from device memory on the index's device (device to device; src_stride 0 = packed rows)"""
         check(_ffi.lib().dann_set_elements_device(self._h, int(first_slot), int(n), C.c_void_p(int(device_ptr)),

@@ -69,7 +69,8 @@ enum {
     DANN_ENOMEM = -6,
     DANN_EOVERFLOW = -7, /* per-query scratch (visited table / record) exhausted      */
     DANN_EUNSUPPORTED = -8,
-    DANN_EINTERNAL = -9  /* a consistency check inside a kernel failed (a bug, never an input)  */
+    DANN_EINTERNAL = -9, /* a consistency check inside a kernel failed (a bug, never an input)  */
+    DANN_EBUSY = -10     /* a mutation while search-server tickets are outstanding, or a submit during a mutation */
 } /* dann_status */;
 
 typedef struct dann_index dann_index; /* == diskann_inmem::Provider<Full<T>, _> + DiskANNIndex */
@@ -399,10 +400,6 @@ int32_t dann_sq8_train(int32_t device, const float* data, uint64_t n, uint32_t d
 int32_t dann_sq8_compress(int32_t device, const float* x, uint32_t n, uint32_t dim, const float* shift, float scale,
                           void* out);
 
-/* diagnostic: bandwidth (GB/s) of a plain streaming read of `bytes` bytes of HBM on `device` (16-byte loads, four in
- * flight per lane), averaged over `reps` launches -- the achievable line to hold next to the 8 TB/s peak */
-int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t reps, double* gbps);
-
 /* build-path options (never change the resulting graph).  The matrix-core path evaluates the pair similarities a
  * RobustPrune asks for (prune.rs:196-232) as the lower triangle of one Gram matrix per candidate list
  * (v_mfma_f32_32x32x2_f32; three kernels: list / sort, Gram tiles, sweep), with a bit-exact re-evaluation of every
@@ -424,12 +421,6 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
  * an exact re-evaluation by the row kernel (the rest were answered from a Gram).  n <= 10 entries are written. */
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
-/* diagnostic: the Gram block of the MFMA prunes (gram_tiles_kernel) for n <= 256 rows of dtype
- * DANN_F32 / DANN_F16: out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain
- * over k = 0 .. dim-1 of row_i[k] * row_j[k] (f16 rows widened exactly); out_nrm[i] = |row_i|^2 accumulated in f64 */
-int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
-                              float* out_gram, float* out_nrm);
-
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
 #define DANN_ABI_VERSION 3
 int32_t dann_abi_version(void);
@@ -445,6 +436,11 @@ int32_t dann_kernel_time_reset(dann_index* idx);
 /* tuning knob: per-query LDS visited-table size. 0 = auto from L and degree; 6..15 = log2(entries);
  * 64..32768 = explicit entry count (rounded up to a multiple of 64). Never affects results. */
 int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits);
+/* tuning knob: width of a visited-table entry.  0 (default) = automatic: 16-bit entries -- an exact set all the same:
+ * slot and entry together determine the id -- where they let more queries share a compute unit, 32-bit entries
+ * otherwise; 32 / 16 = always that width (16 applies to the plain searches and falls back to 32 where the index has
+ * too many slots for the table).  Never affects results. */
+int32_t dann_set_visited_format(dann_index* idx, uint32_t entry_bits);
 /* queries in flight per search call.  0 (default) = every query of the call gets its own wavefront at once;
  * N > 0 = N persistent wavefronts take the call's queries one after the other from a shared counter -- what a
  * server does that keeps N searches in flight (the reference: N tokio workers calling DiskANNIndex::search on a
@@ -518,10 +514,16 @@ int32_t dann_multi_search_batch(dann_multi* m, const void* queries, uint32_t nq,
  * exactly once, in any order and by any thread; at most `ring` tickets can be outstanding (a further submit waits for a
  * dann_search_wait to return a result slot; collecting tickets late never holds up another caller's submission).
  * Submit / wait / poll may be called from any number of threads concurrently and take no lock on the index; results are
- * identical to dann_search_batch.  Mutations of the index (set / insert / build) must not run while tickets are
- * outstanding.  The resident kernel leaves after idle_timeout_us without a submission (default 100 ms) and is
- * relaunched by the next submission: a device-wide synchronisation elsewhere in the process waits at most that
- * long on an idle server.  Row lengths must be a multiple of 16 bytes; L + start points <= 256. */
+ * identical to dann_search_batch.  Mutations of the index (set / insert / build / load) are refused with DANN_EBUSY
+ * while tickets are outstanding (submitted and not yet collected by dann_search_wait), and a submit during a mutation
+ * is refused with DANN_EBUSY.  dann_server_stop may be called while other threads are inside submit / wait / poll:
+ * it unpublishes the server, those calls return DANN_EINVAL ("the server is being stopped"), and nothing is freed
+ * before the last of them has left; uncollected tickets die with the server.  A submit whose ring position no worker
+ * takes within 30 s means the resident kernel is dead: from then on every submit / wait on this server fails at once
+ * with DANN_EHIP until dann_server_stop + dann_server_start.  The resident kernel leaves after idle_timeout_us
+ * without a submission (default 100 ms) and is relaunched by the next submit, wait or poll: a device-wide
+ * synchronisation elsewhere in the process waits at most that long on an idle server.  Row lengths must be a multiple
+ * of 16 bytes; L + start points <= 256. */
 typedef struct {
     uint32_t l_value;
     uint32_t k;
@@ -538,12 +540,6 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
                          dann_search_stats* out_stats);
 /* tickets issued so far, relaunches of the resident kernel after an idle exit */
 int32_t dann_server_stats(dann_index* idx, uint64_t* submitted, uint64_t* relaunches);
-/* measurement harness: `threads` host threads issue single-query calls on the shared index, thread t serving queries
- * t, t + threads, ...: mode 0 = dann_search_batch(nq = 1) per call, mode 1 = submit / wait with up to `depth` tickets
- * outstanding per thread (1 = synchronous).  out_latency_us (nq, optional): submit -> result, host clock. */
-int32_t dann_debug_concurrent_callers(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t k,
-                                      uint32_t threads, uint32_t mode, uint32_t depth, uint32_t* out_ids,
-                                      float* out_dists, float* out_latency_us, double* out_seconds);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ def test_library_exports_every_declared_symbol():
     import diskann_amd as da
     from diskann_amd import _ffi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hdr = open(os.path.join(root, "include", "dann.h")).read()
+    # the drop-in boundary (dann.h) + the measurement hooks (dann_debug.h, not part of the boundary)
+    hdr = open(os.path.join(root, "include", "dann.h")).read() + open(os.path.join(root, "include", "dann_debug.h")).read()
     declared = set(re.findall(r"\b(dann_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     L = da.lib()

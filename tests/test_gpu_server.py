@@ -145,3 +145,98 @@ def test_host_pointer_search_pipeline_equals_one_pass():
         assert np.array_equal(st["cmps"][s0:s0 + 300], sst["cmps"])
     oi, od, _, _ = oix.search_batch(q[:500], L, 1, k)
     assert np.array_equal(ids[:500], oi)
+
+
+def test_mutations_are_refused_while_tickets_are_outstanding():
+    """dann.h: mutations of the index are refused with DANN_EBUSY while tickets are outstanding; once every ticket has
+    been collected they go through (the server stays up), and the results after the mutation follow the new rows."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 4000, 128, 32, 23)
+    q = rand_vectors(rng, oracle.F32, 64, 128)
+    L, k = 32, 10
+    gix.server_start(L, k, workers=32)
+    try:
+        tickets = [gix.submit(q[i]) for i in range(8)]
+        new_row = rand_vectors(rng, oracle.F32, 1, 128)
+        for call in (lambda: gix.set_elements(5, new_row),
+                     lambda: gix.set_neighbors(5, np.array([1, 2, 3], np.uint32)),
+                     lambda: gix.upload_graph(oix.adj)):
+            with pytest.raises(da.DannError) as e:
+                call()
+            assert e.value.status == da._ffi.EBUSY
+        oi, od, _, _ = oix.search_batch(q, L, 1, k)
+        for i, t in enumerate(tickets):
+            ids, d, st = gix.wait(t)
+            assert np.array_equal(ids, oi[i]) and np.array_equal(bits(d), bits(od[i]))
+        gix.set_elements(5, new_row)          # nothing outstanding any more: accepted, server still resident
+        oix.set_rows(5, new_row)
+        oi, od, _, _ = oix.search_batch(q, L, 1, k)
+        ids, d, _, _ = gix.concurrent_callers(q, L, k, threads=2, mode=1, depth=4)
+        assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od))
+    finally:
+        gix.server_stop()
+
+
+def test_stop_while_callers_are_inside_wait_and_submit():
+    """dann_server_stop racing with threads inside submit / wait / poll: the calls return an error (the server is gone)
+    or a correct result, nothing crashes or hangs, and a new server starts on the same index afterwards."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 6000, 128, 32, 29)
+    q = rand_vectors(rng, oracle.F32, 512, 128)
+    L, k = 48, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    for rnd in range(3):
+        gix.server_start(L, k, workers=32, ring=64)
+        stop_now = threading.Event()
+        bad = []
+
+        def caller(t):
+            i = t
+            while not stop_now.is_set() or i < 64:
+                try:
+                    tk = gix.submit(q[i % len(q)])
+                    while not gix.poll(tk):
+                        pass
+                    ids, d, st = gix.wait(tk)
+                    if not (np.array_equal(ids, oi[i % len(q)]) and np.array_equal(bits(d), bits(od[i % len(q)]))):
+                        bad.append(i)
+                except da.DannError as e:   # the server went away under the call
+                    if e.status not in (da._ffi.EINVAL,):
+                        bad.append((i, e.status))
+                    return
+                i += 8
+        th = [threading.Thread(target=caller, args=(t,)) for t in range(8)]
+        [t.start() for t in th]
+        time.sleep(0.02 * (rnd + 1))
+        stop_now.set()
+        gix.server_stop()
+        [t.join(timeout=60) for t in th]
+        assert not any(t.is_alive() for t in th)
+        assert not bad, bad[:5]
+    gix.server_start(L, k, workers=16)
+    try:
+        ids, d, st = gix.wait(gix.submit(q[3]))
+        assert np.array_equal(ids, oi[3])
+    finally:
+        gix.server_stop()
+
+
+def test_poll_alone_brings_an_exited_kernel_back():
+    """A caller that only polls (dann.h allows looping on poll before wait) must not spin for ever when the resident
+    kernel left on its idle timeout right after the submit: poll relaunches it."""
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 3000, 128, 32, 31)
+    q = rand_vectors(rng, oracle.F32, 40, 128)
+    L, k = 24, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    gix.server_start(L, k, workers=16, ring=64, idle_timeout_us=2000)
+    try:
+        for i in range(40):
+            time.sleep(0.004)               # > idle timeout: the kernel has usually left when the submit arrives
+            tk = gix.submit(q[i])
+            t0 = time.time()
+            while not gix.poll(tk):
+                assert time.time() - t0 < 20, "poll never saw the result"
+            ids, d, st = gix.wait(tk)
+            assert np.array_equal(ids, oi[i]) and np.array_equal(bits(d), bits(od[i]))
+        _, rel = gix.server_stats()
+        assert rel >= 5, rel
+    finally:
+        gix.server_stop()
