@@ -165,6 +165,8 @@ struct SearchArgs {
     uint32_t* work_next = nullptr;   //    this counter (zeroed before the launch): dann_set_max_concurrency
     ServerView srv;                  // srv.ring != 0: the launch is the persistent server (grid = workers + 1 waves)
     uint32_t team = 0;               // 1: several wavefronts per query (latency regime; plain fixed-length searches only)
+    uint32_t pair = 0;               // 1: two queries per wavefront (search_pair_impl.h; 128-byte integer rows, L + start
+                                     //    points <= 32, degree <= 32); ht_entries = table words of ONE query then
 };
 
 // Everything one in-flight search call needs besides the (read-only) index: its own stream and events, the retry

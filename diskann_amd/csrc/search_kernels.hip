@@ -31,6 +31,7 @@
 // HBM traffic per query = cmps * row bytes + hops * adjacency row; everything else stays
 // in registers/LDS.
 #include "search_kernel_impl.h"
+#include "search_pair_impl.h"
 
 namespace dann {
 #ifdef DANN_PHASE_CYCLES
@@ -50,6 +51,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
+    if (a.pair) return 2u * (size_t)pair_lds_layout(a.ht_entries).half_bytes;
     return search_lds_layout(a.ht_entries, cmax_of(a), lds_queue_entries(a), query_lds_bytes(a.ix), a.team != 0).total;
 }
 
@@ -285,6 +287,22 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !tune_env(4)) ? 1u : 0u;
         if (tune_env(8)) a.tune |= kTuneNoSpeculation;
     }
+    // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  Launches beyond the
+    // latency regime only; DANN_TUNE_OFF bit 16 / DANN_PAIR_MIN_QUERIES: development switches.
+    a.pair = 0;
+    {
+        static const uint32_t pair_min = [] {
+            const char* e = getenv("DANN_PAIR_MIN_QUERIES");
+            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
+        }();
+        const uint32_t floor_q = pair_min != 0xFFFFFFFFu ? pair_min : 4u * idx->num_cus + 1u;
+        SearchArgs t = a;
+        t.team = 0;
+        if (a.nq >= floor_q && inflight >= floor_q && idx->visited_format != 32u && pair_shape(t) && !tune_env(16)) {
+            a.pair = 1;
+            a.team = 0;
+        }
+    }
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = calib_key(a);
     // calibration state of this (L, beam, mode) -- shared by concurrent callers: read and written under stat_mu
@@ -311,14 +329,29 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
         const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
         const uint32_t waves = tune_env(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
-        choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
+        if (a.pair) {  // one 16-bit table per query: the power of two that holds the 90th percentile at 75 % load
+            const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
+            uint32_t words = 256;
+            while (words < 8192u && (uint64_t)words * 2u * 3u / 4u < cap) words *= 2u;
+            while (words < 8192u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
+            if (ht16_geometry(words, a.ix.nslots).ok) {
+                a.ht16 = 1;
+                a.ht_entries = words;
+            } else {
+                a.pair = 0;
+            }
+        }
+        if (!a.pair) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
         if (getenv("DANN_DEBUG") && (cal.calls & (cal.calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u %s, %zu B LDS\n", a.l_value, a.beam_width,
                     cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior",
-                    a.ht16 ? a.ht_entries * 2u : a.ht_entries, a.ht16 ? "16-bit slots" : "entries", search_lds_bytes(a));
+                    a.ht16 ? a.ht_entries * 2u : a.ht_entries,
+                    a.pair ? "16-bit slots per query, two queries per wavefront" : a.ht16 ? "16-bit slots" : "entries",
+                    search_lds_bytes(a));
     } else {
         // explicit size (dann_set_visited_bits): 16-bit entries only on request (dann_set_visited_format)
         a.ht16 = 0;
+        if (a.pair && idx->visited_format != 16u) a.pair = 0;  // (the pair kernel has 16-bit tables only)
         if (idx->visited_format == 16u && ht16_eligible(a)) {
             uint32_t words = 32;
             while (words < 32768u && words < a.ht_entries) words *= 2u;
@@ -328,6 +361,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                 a.ht_entries = words;
             }
         }
+        if (a.pair && !a.ht16) a.pair = 0;
     }
     // the start points are inserted unconditionally and the first hop needs room before the freeze test can
     // trigger: the open table must hold nstart + W * R ids below its 75 % load limit, or ht_visit could probe a
@@ -463,6 +497,9 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
         if (h == 0) return DANN_OK;
         if (a.team) {
             a.team = 0;  // a team never spills its visited table: the same table, one wave per query (which does)
+        } else if (a.pair) {
+            a.pair = 0;  // re-runs go through beam_search_kernel: the table of one query doubled
+            a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
         } else {
             if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status
             a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);

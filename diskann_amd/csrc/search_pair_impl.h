@@ -1,0 +1,441 @@
+// Two queries per wavefront: the beam search of 128-byte integer rows (u8 / i8 / SQ-8 codes) in the throughput regime.
+//
+// Why.  With one wavefront per query these rows are bound by instruction issue, not by memory: 585 wave-instructions per
+// hop, half of them scalar or branch, for seven memory instructions (profiles/r03_final_u8_insts_1.csv), and more
+// resident queries per CU buy nothing (profiles/r04a_visited16_sgpr_ab_int.log: 21 -> 32 per CU, -3 %).  A query with
+// L + start points <= 32 and max_degree <= 32 needs 32 lanes for everything except the row gather: the queue is one
+// entry per lane, an adjacency row one id per lane.  So a wavefront carries two queries, one per half (lanes 0-31 /
+// 32-63), and every instruction of the hop's bookkeeping -- pop, adjacency row, visited filter, compaction, merge --
+// is issued once for both.  The row gather keeps its shape (8 lanes per 128-byte row, 4 rows per lane group in
+// flight): 16 candidates per half and pass, both halves in every pass.
+//
+// What stays exactly as in beam_search_one (search_kernel_impl.h), which remains the statement of the algorithm and
+// serves every other configuration: the queue rule (rank merge == sequential NeighborPriorityQueue::insert,
+// queue.rs:130-171), pop order (queue.rs:297-313), adjacency clamp (neighbors.rs:146-148), the exact visited set
+// (glue.rs:542-549; here always the 16-bit table, frozen at 75 % load and continued in a spill table in global
+// memory), counters and the result rule (provider.rs:933-944).  Values that are wave-uniform there are uniform per
+// half here: they live in pairs of scalars (x0 for lanes 0-31, x1 for lanes 32-63) and are turned into a vector
+// operand by one select where a lane needs "its" value.
+//
+// Eligibility (pair_eligible): plain Knn search (beam width 1, no filter, no tags, no record), integer rows of 128
+// bytes, L + start points <= 32, max_degree <= 32, a 16-bit table geometry for the index, a launch beyond the latency
+// regime.  Everything else takes beam_search_kernel.  A query that exhausts table and spill pool reports
+// DANN_EOVERFLOW and is re-run by search_with_retry through beam_search_kernel with a larger table.
+#pragma once
+#include "search_kernel_impl.h"
+
+namespace dann {
+namespace {
+
+constexpr uint32_t kPairHalf = 32;
+// LDS of one half: candidates (ids, distances), the scatter buffer of the merge ((id, distance) pairs), the queue's
+// distances in order (what the lower-bound searches read), the survivors' distances of one merge, a sink for the
+// stores of lanes that have nothing to store, the visited table
+struct PairLds {
+    uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, sd_off, sink_off, ht_off, half_bytes;
+};
+__host__ __device__ inline PairLds pair_lds_layout(uint32_t ht_words) {
+    PairLds l;
+    l.cand_id_off = 0;
+    l.cand_d_off = 128;
+    l.stage_off = 256;
+    l.qimg_off = 512;  // 64 keys: the upper 32 stay "beyond the queue" (the lower-bound search needs no bound check)
+    l.sd_off = 768;
+    l.sink_off = 896;
+    l.ht_off = 912;  // 16-byte aligned
+    l.half_bytes = l.ht_off + ht_words * 4u;
+    return l;
+}
+
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// Insert into the open 16-bit table, written without a per-lane branch: the hop is bound by the scalar unit (every
+// `if` on a lane condition costs an exec-mask save / branch / restore there), so the probe is one straight body that
+// all lanes run until the last one is done -- a lane with nothing to insert swaps the dword for itself.  Same probe
+// sequence, same table contents as ht16_insert_open.  Returns 1 = inserted (the id was new), 2 = no slot among its
+// probes (the caller freezes the table), 0 = already present / inactive.
+__device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& t, uint32_t id, bool active) {
+    const uint32_t tagmask = (1u << t.tb) - 1u;
+    uint32_t x = id * kHt16A;
+    const uint32_t step = id * kHt16B2;
+    uint32_t k = 0, res = 0;
+    bool pending = active;
+    do {
+        const uint32_t xm = x & t.idmask;
+        const uint32_t slot = xm >> t.tb, val = (xm & tagmask) | (k << t.tb);
+        uint32_t* const wp = htw + (slot >> 1);
+        const uint32_t sh = (slot & 1u) << 4;
+        const uint32_t w = *wp;
+        const uint32_t cur = (w >> sh) & 0xFFFFu;
+        const bool present = cur == val, empty = cur == 0xFFFFu;
+        const bool tryins = pending & empty;
+        const uint32_t neww = tryins ? (w ^ ((0xFFFFu ^ val) << sh)) : w;
+        const uint32_t old = atomicCAS(wp, w, neww);  // (a lost swap -- the neighbour slot changed -- reads the dword again)
+        const bool inserted = tryins & (old == w);
+        res = inserted ? 1u : res;
+        const bool next = pending & !present & !empty;  // the slot holds another id: next probe
+        k += next ? 1u : 0u;
+        x += next ? step : 0u;
+        const bool exh = next & (k >= t.kmax);
+        res = exh ? 2u : res;
+        pending = pending & !present & !inserted & !exh;
+    } while (ballot64(pending));
+    return res;
+}
+
+template <int DT, int OP, bool NORM>
+__global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
+    static_assert(DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8, "integer rows");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr bool SIGNED = DT == DT_I8;
+    const IndexView& ix = a.ix;
+    const uint32_t lane = threadIdx.x, li = lane & 31u;
+    const bool up = lane >= kPairHalf;     // this lane serves the second query
+    const uint32_t g4 = (lane >> 3) & 3u;  // lane group within the half
+    const int v = (int)(lane & 7u);
+    const uint32_t R = ix.max_degree, ns = ix.nstart, qcap = a.l_value + ns;  // qcap <= 32
+    const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    constexpr uint32_t kOverflow = (uint32_t)(-DANN_EOVERFLOW);
+
+    // ---- the two queries of this wavefront (the upper half of the last wavefront of an odd batch idles) --------------
+    const uint32_t slot = 2u * blockIdx.x + (up ? 1u : 0u);
+    const bool exists = slot < a.nq;
+    const uint32_t slot_c = exists ? slot : a.nq - 1u;
+    const uint32_t qi = a.qmap ? a.qmap[slot_c] : slot_c;
+
+    const PairLds L = pair_lds_layout(a.ht_entries);
+    uint8_t* const hbase = smem + (up ? L.half_bytes : 0u);
+    uint32_t* const cand_id = reinterpret_cast<uint32_t*>(hbase + L.cand_id_off);
+    float* const cand_d = reinterpret_cast<float*>(hbase + L.cand_d_off);
+    uint2* const stage = reinterpret_cast<uint2*>(hbase + L.stage_off);
+    // distances in these two are order-preserving integer keys (ordered_bits): the rank arithmetic of the merge is
+    // integer compares feeding add-with-carry, no lane-mask logic on the scalar unit
+    uint32_t* const qimg = reinterpret_cast<uint32_t*>(hbase + L.qimg_off);
+    uint32_t* const sd = reinterpret_cast<uint32_t*>(hbase + L.sd_off);
+    uint8_t* const sink = hbase + L.sink_off;
+    uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
+    const Ht16 h16{a.ht_idmask, a.ht_tb, a.ht_kmax};
+    const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
+    {
+        const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+        for (uint32_t i = li * 4u; i < a.ht_entries; i += kPairHalf * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
+        cand_id[li] = 0u;
+        qimg[li] = kEmpty;
+        qimg[kPairHalf + li] = kEmpty;
+    }
+    // the lane's 16 query bytes and the query's squared norm stay in registers (as in the fixed-length integer path)
+    const uint8_t* const qsrc = reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
+    uint4 xqi;
+    {
+        const uint32_t* qw = reinterpret_cast<const uint32_t*>(qsrc + 16 * v);  // (SQ-8 queries are 4-byte aligned only)
+        xqi = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+    }
+    const int xx_pre = group_norm_int_pre<SIGNED>(xqi);
+
+    // ---- state.  Queue: entry p of a half in its lane p.  What is wave-uniform in beam_search_one is uniform per half
+    // here and kept in vector registers (every lane holds the value of its half): no scalar selects, no scalar pairs.
+    uint32_t qid = kEmpty;
+    float qd = 0.0f;
+    uint32_t sizev = 0, cmpsv = 0, hopsv = 0, htcv = ns, spcv = 0, stv = 0, ncv = 0;
+    bool alivev = exists, openv = true;
+    uint32_t* spv = nullptr;  // the half's spill table once its LDS table is frozen
+    const uint32_t spill_size = 1u << a.spill_bits, spill_mask = spill_size - 1u, spill_shift = 32u - a.spill_bits;
+    const uint32_t spill_limit = spill_size - (spill_size >> 2);
+    // (cold) claims a table of the spill pool for the half whose first lane is `first_lane`; null if none is free
+    auto claim_spill = [&](uint32_t first_lane) -> uint32_t* {
+        uint32_t slice = kEmpty;
+        if (a.spill) {
+            if (lane == first_lane) {
+                uint32_t* busy = a.spill_next + 16;
+                uint32_t s = atomicAdd(a.spill_next, 1u) % a.spill_slices;
+                for (uint32_t t = 0; t < 2u * a.spill_slices; ++t) {
+                    if (atomicCAS(&busy[s], 0u, 1u) == 0u) {
+                        slice = s;
+                        break;
+                    }
+                    s = (s + 1 == a.spill_slices) ? 0u : s + 1;
+                }
+            }
+            slice = rl_u32(slice, (int)first_lane);
+        }
+        return slice < a.spill_slices ? a.spill + ((uint64_t)slice << a.spill_bits) : nullptr;
+    };
+    // (cold) freezes the table of every half with a lane in `want`: new ids go to a spill table from here on; a half
+    // that gets none gives up (DANN_EOVERFLOW: the host re-runs the query with one wavefront and a larger table)
+    auto freeze = [&](bool want) {
+        const uint64_t fm = ballot64(want);
+        uint32_t* p0 = nullptr;
+        uint32_t* p1 = nullptr;
+        if ((uint32_t)fm) p0 = claim_spill(0u);
+        if ((uint32_t)(fm >> 32)) p1 = claim_spill(kPairHalf);
+        const bool mine = up ? ((uint32_t)(fm >> 32) != 0u) : ((uint32_t)fm != 0u);
+        if (mine) {
+            openv = false;
+            if (!spv) spv = up ? p1 : p0;
+            if (!spv) stv = kOverflow;
+        }
+    };
+
+    // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958), the candidates of "hop 0" ----
+    {
+        const bool on = (li < ns) & alivev;
+        const uint32_t id = ix.capacity + li;
+        if (li < ns) cand_id[li] = id;
+        __syncthreads();  // the tables are wiped
+        if (ballot64(ht16_insert_flat(ht, h16, id, on) == 2u)) stv = kOverflow;  // (a table of >= 64 slots: never)
+        ncv = alivev ? ns : 0u;
+    }
+    __syncthreads();
+
+    uint32_t pfnv = kEmpty;  // the node whose adjacency row was requested ahead (pf_len / pf_val), per half
+    uint32_t pf_len = 0, pf_val = kEmpty;
+    for (;;) {
+        // ---- distances of cand_id[0 .. nc) of both halves: 4 lane groups per half, every row of the hop requested before
+        // the first one is evaluated (one memory round trip per hop: 4 rows per lane group when neither half has more than
+        // 16 candidates, else 8).  The sums end up in lanes 0-3 of a group: lane u stores the result of row u.
+        {
+            const uint32_t nc0 = rl_u32(ncv, 0), nc1 = rl_u32(ncv, (int)kPairHalf);
+            const uint32_t ncmax = nc0 > nc1 ? nc0 : nc1;
+            auto gather = [&](auto tag) {
+                constexpr int U = decltype(tag)::value;
+                const uint8_t* rows[U];
+                float out[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t ci = (uint32_t)u * 4u + g4;
+                    const uint32_t raw = cand_id[ci];            // (read first, select after: no load under a branch)
+                    const uint32_t id = ci < ncv ? raw : 0u;     // unused slots evaluate row 0
+                    rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
+                }
+                group_distance_int_pre<OP, SIGNED, U>(xqi, xx_pre, rows, v, out);
+#pragma unroll
+                for (int h = 0; h < U / 4; ++h) {
+                    float val = out[4 * h];
+                    const uint8_t* row = rows[4 * h];
+#pragma unroll
+                    for (int u = 1; u < 4; ++u) {
+                        val = v == u ? out[4 * h + u] : val;
+                        if constexpr (DT == DT_SQ8 && OP != OP_L2) row = v == u ? rows[4 * h + u] : row;
+                    }
+                    const uint32_t ci = (uint32_t)(4 * h + v) * 4u + g4;
+                    const bool ok = (v < 4) & (ci < ncv);
+                    float* dst = ok ? cand_d + (ci & 31u) : reinterpret_cast<float*>(sink);
+                    *dst = finish_distance<DT, OP, NORM>(val, qsrc, row, ix.dim, sqp);
+                }
+            };
+            if (ncmax > 16u) gather(std::integral_constant<int, 8>());
+            else if (ncmax) gather(std::integral_constant<int, 4>());
+            cmpsv += ncv;
+        }
+        __syncthreads();
+
+        // ---- merge the candidates into the queues (see merge_regs in beam_search_one for the rule and its proof):
+        // a surviving candidate j lands at #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)}, an old
+        // entry e moves up by #{surviving j: d_j <= d_e}.  The survivors' distances go to LDS in emission order; every
+        // lane walks them (broadcast reads), the lower bounds come from a binary search in the queue's distances.
+        {
+            const bool has = li < ncv;
+            const float nd = cand_d[li];
+            const uint32_t nid = cand_id[li];
+            const uint32_t oknd = ordered_bits(nd), okq = ordered_bits(qd);
+            // a full queue rejects what is worse than its last entry (queue.rs:142-146)
+            const uint32_t okw = qimg[(sizev - 1u) & 63u];
+            const bool nvalid = has & (nd == nd) & !((sizev == qcap) & (okw < oknd));
+            const uint64_t km = ballot64(nvalid);
+            if (km) {
+                const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
+                const uint32_t nvv = (uint32_t)__popc(up ? k1 : k0);
+                const uint32_t nvmax = max((uint32_t)__popc(k0), (uint32_t)__popc(k1));
+                const uint32_t cj = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
+                sd[li] = kEmpty;  // (keys beyond a half's survivors: larger than every distance)
+                *(nvalid ? sd + cj : reinterpret_cast<uint32_t*>(sink)) = oknd;
+                __syncthreads();
+                uint32_t before = 0, shift = 0;
+#pragma nounroll
+                for (uint32_t t = 0; t < nvmax; ++t) {
+                    const uint32_t okj = sd[t];
+                    before += okj < oknd + (t > cj ? 1u : 0u) ? 1u : 0u;  // d_j < d, or equal and emitted later
+                    shift += okj <= okq ? 1u : 0u;                        // (entries at or beyond the size are never scattered)
+                }
+                uint32_t lb = 0;  // #{old e: d_e < d}
+#pragma unroll
+                for (uint32_t step = kPairHalf; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
+                const uint32_t pos_new = lb + before, np = li + shift;
+                uint2* const sink2 = reinterpret_cast<uint2*>(sink);
+                *(((li < sizev) & (np < qcap)) ? stage + (np & 31u) : sink2) = make_uint2(qid, __builtin_bit_cast(uint32_t, qd));
+                *((nvalid & (pos_new < qcap)) ? stage + (pos_new & 31u) : sink2) = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
+                const uint32_t total = sizev + nvv;
+                sizev = total < qcap ? total : qcap;
+                __syncthreads();
+                const uint2 e = stage[li];
+                const bool in = li < sizev;
+                qid = in ? e.x : qid;
+                qd = in ? __builtin_bit_cast(float, e.y) : qd;
+                qimg[li] = in ? ordered_bits(qd) : kEmpty;
+            }
+        }
+
+        // ---- pop: the closest unexpanded entry of each queue (queue.rs:297-313); a half without one has finished -------
+        uint32_t nextv;  // the next unexpanded entry after it: the node the following hop expands unless a new candidate
+                         // gets in front of it (kEmpty: none)
+        uint32_t nodev;
+        {
+            const uint64_t um = ballot64((li < sizev) & !(qid & kVisitedBit) & alivev & (stv == 0u));
+            if (!um) break;
+            const uint32_t mybits = up ? (uint32_t)(um >> 32) : (uint32_t)um;
+            alivev = mybits != 0u;
+            const uint32_t hb = up ? kPairHalf : 0u;
+            const uint32_t l1 = (uint32_t)__builtin_ctz(mybits | 0x80000000u);
+            const uint32_t rest = mybits & (mybits - 1u);
+            const uint32_t l2 = (uint32_t)__builtin_ctz(rest | 0x80000000u);
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l1) << 2), (int)qid);
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l2) << 2), (int)qid);
+            nodev = alivev ? n1 : 0u;
+            nextv = (alivev & (rest != 0u)) ? n2 : kEmpty;
+            qid |= (alivev & (li == l1)) ? kVisitedBit : 0u;
+            hopsv += alivev ? 1u : 0u;
+        }
+
+        // ---- expand: adjacency row (requested a hop ahead when the prediction held), visited filter, compaction ---------
+        {
+            const bool miss = alivev & (nodev != pfnv);
+            uint32_t lenl = pf_len, vall = pf_val;
+            if (ballot64(miss)) {  // some half has to read its row now (both do: a half that had it reads the same again)
+                const uint32_t* arow = ix.adj + (uint64_t)nodev * ix.adj_stride;
+                lenl = arow[0];
+                vall = arow[1u + (li < R ? li : R - 1u)];
+            }
+            const uint32_t len = lenl < R ? lenl : R;  // Neighbors::get clamps (neighbors.rs:146-148)
+            // the open table takes ids up to 75 % of its slots; then it is frozen and new ids go to a spill table
+            const bool live = alivev & (stv == 0u);
+            if (ballot64(live & (openv ? (htcv + len > ht_limit) : (spcv + len > spill_limit)))) {
+                freeze(live & openv & (htcv + len > ht_limit));
+                if (alivev & !openv & (!spv | (spcv + len > spill_limit))) stv = kOverflow;
+            }
+            const bool inb = alivev & (stv == 0u) & (li < len);
+            const uint32_t id = inb ? vall : kEmpty;
+            // (the 16-bit table holds ids below 2^m only; an id beyond the index is never a candidate anyway)
+            const bool act = inb & (id != kEmpty) & (id < ix.nslots);
+            const uint32_t r = ht16_insert_flat(ht, h16, id, act & openv);
+            bool isnew = r == 1u;
+            const bool exh = r == 2u;
+            if (ballot64(exh | (act & !openv))) {  // (rare) no slot among an id's probes, or a frozen table
+                if (ballot64(exh)) {
+                    freeze(exh);  // that half's table is frozen; the id goes to its spill table
+                    if (exh && spv) isnew = spill_insert(spv, spill_mask, spill_shift, id);
+                }
+                if (act && !openv && !exh && spv && !stv && !isnew)
+                    isnew = !ht16_contains(ht, h16, id) && spill_insert(spv, spill_mask, spill_shift, id);
+            }
+            const uint64_t km = ballot64(isnew);
+            const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
+            *(isnew ? cand_id + (rank & 31u) : reinterpret_cast<uint32_t*>(sink)) = id;
+            const uint32_t cnt = (uint32_t)__popc(up ? k1 : k0);
+            ncv = stv ? 0u : cnt;
+            htcv += openv ? ncv : 0u;
+            spcv += openv ? 0u : ncv;
+        }
+        // ---- request the adjacency row of the predicted next node; it lands while the rows are evaluated --------------
+        {
+            pfnv = nextv;
+            const uint32_t* prow = ix.adj + (uint64_t)(pfnv != kEmpty ? pfnv : 0u) * ix.adj_stride;
+            pf_len = prow[0];
+            pf_val = prow[1u + (li < R ? li : R - 1u)];
+        }
+        __syncthreads();
+    }
+
+    // ---- spill tables go back clean ------------------------------------------------------------------------------------
+    if (ballot64(spv != nullptr)) {
+        __syncthreads();
+        if (spv) {
+            const u32x4 e = {kEmpty, kEmpty, kEmpty, kEmpty};
+            for (uint32_t i = li * 4u; i < spill_size; i += kPairHalf * 4u) {
+                uint32_t* p = spv + i;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (spv && li == 0u) atomicExch(a.spill_next + 16 + (uint32_t)((spv - a.spill) >> a.spill_bits), 0u);
+    }
+    // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----------------------------------
+    {
+        const uint32_t id = qid & ~kVisitedBit;
+        const bool res = exists & (li < sizev) & (id < ix.capacity);
+        const uint64_t rm = ballot64(res);
+        const uint32_t r0 = (uint32_t)rm, r1 = (uint32_t)(rm >> 32);
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi(r1, up ? 0u : __builtin_amdgcn_mbcnt_lo(r0, 0u));
+        const uint32_t wv = (uint32_t)__popc(up ? r1 : r0);
+        const uint32_t written = wv < a.k ? wv : a.k;
+        if (a.out_ids && exists) {
+            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+            float* od = a.out_dists + (uint64_t)qi * a.k;
+            if (res && r < a.k) {
+                oi[r] = id;
+                od[r] = qd;
+            }
+            for (uint32_t t = written + li; t < a.k; t += kPairHalf) {
+                oi[t] = kEmpty;
+                od[t] = __builtin_inff();
+            }
+        }
+        if (li == 0u && exists) {
+            if (a.stats) {
+                dann_search_stats st;
+                st.cmps = cmpsv;
+                st.hops = hopsv;
+                // Translate::post_process counts a push only while the buffer still has room afterwards
+                // (provider.rs:933-944, search_output_buffer.rs:107-124): k - 1 when the buffer of length k fills
+                st.result_count = (a.k && written == a.k) ? a.k - 1u : written;
+                st.written = written;
+                st.status = stv;
+                a.stats[qi] = st;
+            }
+            if (stv && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// what the pair kernel serves (host side; the table geometry is checked by the caller)
+inline bool pair_shape(const SearchArgs& a) {
+    const int dt = a.ix.dtype;
+    return plain_mode(a) && !a.team && !a.grid && !a.srv.ring && !a.rec_ids && !a.range_ids && !a.qslots && a.out_ids &&
+           (dt == DT_U8 || dt == DT_I8 || dt == DT_SQ8) && a.ix.dim == 128u && a.l_value + a.ix.nstart <= kPairHalf &&
+           a.ix.max_degree <= kPairHalf && a.ix.nstart >= 1u && a.ix.row_stride % 16u == 0u;
+}
+
+template <int DT>
+int32_t launch_pair_dt(const SearchArgs& a, size_t lds, hipStream_t stream) {
+    int op;
+    bool norm;
+    if (!resolve_metric(a.ix.dtype, a.ix.metric, &op, &norm)) {
+        set_error("metric %d is not defined for dtype %d", a.ix.metric, a.ix.dtype);
+        return DANN_EUNSUPPORTED;
+    }
+    const uint32_t grid = (a.nq + 1u) / 2u;
+    auto go = [&](auto kern) -> int32_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave), lds, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "pair_search_kernel launch");
+        return DANN_OK;
+    };
+    if (op == OP_L2) {
+        if constexpr (DT == DT_SQ8) {
+            if (norm) return go(pair_search_kernel<DT, OP_L2, true>);
+        }
+        return go(pair_search_kernel<DT, OP_L2, false>);
+    }
+    if (op == OP_IP) return go(pair_search_kernel<DT, OP_IP, false>);
+    if constexpr (DT != DT_SQ8) return go(pair_search_kernel<DT, OP_COS, false>);
+    return DANN_EUNSUPPORTED;
+}
+
+}  // namespace
+}  // namespace dann

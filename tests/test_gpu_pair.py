@@ -1,0 +1,112 @@
+"""Two queries per wavefront (search_pair_impl.h: the throughput path of 128-byte integer rows with L + start points <= 32
+and max_degree <= 32).  Everything it returns -- ids, distances, comparisons, hops, written, result_count -- must equal the
+oracle's and beam_search_kernel's; odd batch sizes leave the upper half of the last wavefront idle; tiny explicit tables
+drive queries through the frozen-table / spill path and, beyond it, through the re-run with one wavefront per query."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import bits, make_pair, rand_vectors, random_graph
+
+pytestmark = pytest.mark.gpu
+da = pytest.importorskip("diskann_amd")
+
+
+@pytest.fixture(autouse=True)
+def _pairs_from_the_first_query(monkeypatch):
+    monkeypatch.setenv("DANN_PAIR_MIN_QUERIES", "1")  # (by default only launches beyond the latency regime are paired)
+
+
+def _check(gix, oix, queries, L, k, tag):
+    oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
+    gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)
+    assert not gst["status"].any(), tag
+    assert np.array_equal(oi, gi), tag
+    assert np.array_equal(bits(od), bits(gd)), tag
+    assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"]), tag
+    assert np.array_equal(oc, gst["written"]) and np.array_equal(ost[:, 2], gst["result_count"]), tag
+
+
+CASES = [
+    (oracle.U8, oracle.L2, 32, 1),
+    (oracle.U8, oracle.COSINE, 32, 1),
+    (oracle.U8, oracle.INNER_PRODUCT, 24, 2),
+    (oracle.I8, oracle.L2, 32, 1),
+    (oracle.I8, oracle.INNER_PRODUCT, 17, 3),
+    (oracle.I8, oracle.COSINE, 8, 1),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,R,nstart", CASES)
+def test_pair_kernel_equals_the_oracle(dtype, metric, R, nstart):
+    rng = np.random.default_rng(500 + R + nstart)
+    n, dim = 6000, 128
+    data = rand_vectors(rng, dtype, n, dim)
+    adj = random_graph(rng, n, R, nstart=nstart, min_len=0 if R == 8 else None)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:nstart], R)
+    for nq in (1, 2, 7, 64, 333):   # odd sizes: the last wavefront carries one query
+        queries = rand_vectors(rng, dtype, nq, dim)
+        for L, k in ((1, 1), (5, 5), (10, 10), (26, 10), (32 - nstart, 10), (20, 40)):
+            _check(gix, oix, queries, L, k, (nq, L, k))
+
+
+def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits(monkeypatch):
+    """L + start points = 33, degree 33, other row lengths: not the pair kernel's -- same results either way"""
+    rng = np.random.default_rng(9)
+    n = 4000
+    for dtype, dim, R, L in ((oracle.U8, 128, 32, 32), (oracle.U8, 128, 33, 20), (oracle.U8, 100, 32, 20),
+                             (oracle.F32, 128, 32, 20)):
+        data = rand_vectors(rng, dtype, n, dim)
+        adj = random_graph(rng, n, R)
+        oix, gix = make_pair(dtype, oracle.L2, data, adj, data[:1], R)
+        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L))
+
+
+def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query(monkeypatch):
+    """explicit tables of 64 .. 1024 words per query: frozen after a few hops, continued in the spill pool (20 000
+    queries recycle its 512 tables many times), and a query that outgrows even that is re-run with one wave"""
+    rng = np.random.default_rng(21)
+    n, dim, R, nq = 20000, 128, 32, 20000
+    data = rand_vectors(rng, oracle.U8, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.U8, oracle.L2, data, adj, data[:1], R)
+    queries = rand_vectors(rng, oracle.U8, nq, dim)
+    monkeypatch.setenv("DANN_TUNE_OFF", "20")      # one wave per query, no teams
+    ri, rd, rst = gix.search(da.Knn(30), queries, 10)
+    monkeypatch.delenv("DANN_TUNE_OFF")
+    gix.set_visited_format(16)
+    for words in (0, 64, 256, 1024):
+        gix.set_visited_bits(words)
+        for rep in range(2):
+            gi, gd, gst = gix.search(da.Knn(30), queries, 10)
+            assert not gst["status"].any(), words
+            assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd)), words
+            assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), words
+    gix.set_visited_bits(0)
+    gix.set_visited_format(0)
+    oi, od, oc, ost = oix.search_batch(queries[:300], 30, 1, 10)
+    assert np.array_equal(ri[:300], oi) and np.array_equal(ost[:, 0], rst["cmps"][:300])
+    assert rst["cmps"].mean() > 300
+
+
+@pytest.mark.parametrize("metric,stride", [(oracle.L2, 0), (oracle.L2, 256), (oracle.INNER_PRODUCT, 0),
+                                           (oracle.COSINE_NORMALIZED, 256)])
+def test_pair_kernel_sq8_rows(metric, stride):
+    """SQ-8 codes (132-byte rows at a 144- or 256-byte stride, compensated epilogues) through the pair kernel"""
+    from test_gpu_quant import _sq_setup
+    rng = np.random.default_rng(77 + metric)
+    n, dim, R = 5000, 128, 32
+    data, shift, scale = _sq_setup(rng, n, dim)
+    codes = da.sq8_compress(data, shift, scale)
+    snorm = float(np.float32((shift.astype(np.float32) ** 2).sum(dtype=np.float32)))
+    adj = random_graph(rng, n, R)
+    oix = oracle.Index(oracle.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm)
+    oix.set_rows(0, codes)
+    oix.adj[:] = adj
+    gix = da.Provider(da.SQ8, metric, dim, n, R, codes[:1], sq_scale=scale, sq_shift_norm_sq=snorm, row_stride=stride)
+    gix.set_elements(0, codes)
+    gix.upload_graph(adj)
+    for nq in (3, 40, 257):
+        queries = da.sq8_compress(rng.normal(0.3, 0.5, (nq, dim)).astype(np.float32), shift, scale)
+        for L, k in ((8, 5), (26, 10), (31, 10)):
+            _check(gix, oix, queries, L, k, (nq, L, k))
