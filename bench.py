@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
-    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8", "build768"],
+    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8", "pq",
+                                                   "build768", "cpu-distance"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
                          "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
                          "u8 search kernel")
@@ -74,6 +75,9 @@ def parse():
                     help="only the headline workload (used under rocprofv3 so that every launch of the "
                          "beam-search kernel is the timed one)")
     ap.add_argument("--pq-chunks", type=int, default=16)
+    ap.add_argument("--replicated-build", action="store_true",
+                    help="with --gpus N > 1: every rank builds its own replica with dann_build (no exchange); default "
+                         "is the library's sharded build over RCCL (dann_build_sharded)")
     ap.add_argument("--sharded-build", action="store_true",
                     help="N>1: build with diskann_amd.sharding.build_sharded (batch partitioned across ranks, RCCL "
                          "all-gather of the pending adjacency rows) instead of one independent build per rank")
@@ -142,6 +146,9 @@ def maybe_spawn(args):
 
 def main():
     args = parse()
+    if args.only == "cpu-distance":  # host only
+        print(json.dumps(_strict({"cpu_distance_kernels": cpu_distance_microbench()})), flush=True)
+        return
     maybe_spawn(args)
     import torch
     import torch.distributed as dist
@@ -184,7 +191,7 @@ def main():
     if args.only == "build768":
         print(json.dumps(_strict({"build_large": build_large_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
-    if args.only in ("gather", "sq8", "u8"):
+    if args.only in ("gather", "sq8", "u8", "pq"):
         print(json.dumps(_strict({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
     if args.only in ("large", "large768", "large768f16"):
@@ -226,19 +233,44 @@ def main():
     if args.graph_cache and os.path.exists(args.graph_cache):
         prov.load_graph(args.graph_cache)
         nb = 0
-    elif args.sharded_build and world > 1:
+    elif world > 1 and not args.replicated_build:
+        # The reference's multi_insert has one exchange step (index.rs:911-1024); with several ranks the benchmark index is
+        # built by the library's own sharded build: dann_comm_create_rccl (the unique id travels over torch.distributed),
+        # candidates per rank, ncclAllGather of the pending rows, owner-partitioned prunes, second all-gather of the
+        # rewritten rows -- every replica byte-identical to a single-GPU dann_build.  Should the communicator fail on
+        # this node the run falls back to replicated builds and says so (build_exchange.error).
         from diskann_amd.sharding import build_sharded
-        build_stats = {}
-        nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world, stats=build_stats)
-        # the replicas must be byte-identical: compare a digest of every rank's adjacency
         import hashlib
-        dig = np.frombuffer(hashlib.sha256(prov.download_graph().tobytes()).digest()[:8], dtype=np.int64).copy()
-        mine_d = torch.from_numpy(dig).to(torch.device("cpu") if one_dev else dev)
-        all_d = torch.empty(world, dtype=torch.int64, device=mine_d.device)
-        dist.all_gather_into_tensor(all_d, mine_d)
-        if len(set(all_d.cpu().tolist())) != 1:
-            raise SystemExit("sharded build: the replicas' graphs differ")
-        build_stats["replicas_identical"] = True
+        build_stats = {}
+        try:
+            nb = build_sharded(prov, cfg, 0, args.n, args.growth, args.max_batch, rank, world, stats=build_stats)
+            ok_local = 1
+        except Exception as e:  # noqa: BLE001
+            build_stats = {"error": str(e)[:300]}
+            ok_local = 0
+        flag = torch.tensor([ok_local], dtype=torch.int32, device=torch.device("cpu") if one_dev else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            log(f"[rank {rank}] sharded build failed on some rank ({build_stats.get('error', 'another rank')}): "
+                "replicated builds instead")
+            err = build_stats.get("error", "failed on another rank")
+            prov.close()
+            prov = da.Provider(da.F32, da.L2, args.dim, args.n, args.max_degree, start, device=local)
+            prov.set_elements(0, base_h)
+            nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
+            build_stats = {"error": err, "fallback": "replicated dann_build per rank"}
+        else:
+            # the replicas must be byte-identical: compare a digest of every rank's adjacency
+            dig = np.frombuffer(hashlib.sha256(prov.download_graph().tobytes()).digest()[:8], dtype=np.int64).copy()
+            mine_d = torch.from_numpy(dig).to(torch.device("cpu") if one_dev else dev)
+            all_d = torch.empty(world, dtype=torch.int64, device=mine_d.device)
+            dist.all_gather_into_tensor(all_d, mine_d)
+            if len(set(all_d.cpu().tolist())) != 1:
+                raise SystemExit("sharded build: the replicas' graphs differ")
+            build_stats["digest_identical_across_ranks"] = True
+            build_stats["replicas_identical"] = True
+            build_stats["rccl_ranks"] = 0 if one_dev else world
+            build_stats["communicator"] = "gloo callback (one-device test hook)" if one_dev else "RCCL (dann_comm_create_rccl)"
     else:
         nb = prov.build(cfg, 0, args.n, args.growth, args.max_batch)
         if args.graph_cache and rank == 0:
@@ -392,8 +424,8 @@ def main():
                 "workload": f"batched beam search over a {args.n}x{args.dim} f32 index resident in HBM, "
                             f"{args.nq} queries/step/GPU, k=10, L={chosen}, beam_width={W}",
                 "index": f"Vamana R={args.max_degree} (pruned {args.pruned_degree}), l_build={args.l_build}, "
-                         f"alpha=1.2, built on GPU by " + (f"sharding.build_sharded over {world} ranks" if build_stats
-                                                           is not None else "dann_build") +
+                         f"alpha=1.2, built on GPU by " + (f"dann_build_sharded over {world} ranks" if build_stats
+                                                           is not None and "error" not in build_stats else "dann_build") +
                          f" (growth {args.growth}, max_batch {args.max_batch})",
                 "recall_at_10": round(rec, 4),
                 "L": chosen,
@@ -618,6 +650,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, oix_head, qh_all, chosen, W, k, evaluate.last_ids)
             if not args.no_extras:
                 out["other_configs"].update(cpu_small_regimes(oix_head, qh_all, chosen, W, k))
+                try:  # the CPU distance kernels beside other_configs.distance_kernel (the GPU gather kernel)
+                    out["other_configs"]["cpu_distance_kernels"] = cpu_distance_microbench(full=False)
+                except Exception as e:  # noqa: BLE001
+                    out["other_configs"]["cpu_distance_kernels"] = {"error": str(e)[:200]}
             del oix_head
         # the same kernel on a working set far beyond the 256 MiB Infinity Cache (the honest HBM fraction)
         if args.large != "none" and not args.no_extras and world == 1:
@@ -633,6 +669,11 @@ def main():
                 except Exception as e:
                     out[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
+        for key in ("roofline_large_d768", "roofline_large_d768_f16"):  # north_star: MFMA utilisation of the build
+            b = out.get(key, {}).get("build") if isinstance(out.get(key), dict) else None
+            if b and b.get("used"):
+                out.setdefault("mfma", {})[key.replace("roofline_large_", "build_1Mx")] = {
+                    k2: b[k2] for k2 in ("kernel", "TFLOP_s", "peak", "frac", "share_of_prune_pairs", "build_seconds")}
         if isinstance(out.get("roofline_large"), dict) and "frac" in out["roofline_large"]:
             # the HBM-side fraction of the same kernel: the 6.4 GB index, 25 x the Infinity Cache
             out["roofline"]["hbm_side_frac"] = out["roofline_large"]["frac"]
@@ -799,7 +840,7 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                                                 C.c_void_p(cand.data_ptr()), L, k, C.c_void_p(d_out.data_ptr()),
                                                 C.c_void_p(d_outd.data_ptr())), "dann_rerank_batch_device")
     chosen, rec = None, 0.0
-    for L in [16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]:
+    for L in ([args.L] if args.L else [16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]):
         run_rr(L)
         rec = recall_at_k(d_out.cpu().numpy().view(np.uint32), gt, k)
         chosen = L
@@ -809,12 +850,21 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
     for _ in range(2):
         run_rr(chosen)
     torch.cuda.synchronize()
+    prov.kernel_time_reset()
     t0 = time.perf_counter()
     for _ in range(10):
         run_rr(chosen)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
-    alg = (int(st[:, 0].sum()) * nch + int(st[:, 1].sum()) * (args.max_degree + 1) * 4 + args.nq * chosen * dim * 4)
+    kms, kn = prov.kernel_time(0)
+    search_ms = kms / max(kn, 1)
+    alg_search = int(st[:, 0].sum()) * nch + int(st[:, 1].sum()) * (args.max_degree + 1) * 4
+    alg = alg_search + args.nq * chosen * dim * 4
+    # what bounds the lookup-table search: not HBM.  Per query the wave builds a 256 x chunks table in LDS from the
+    # pivots (chunks x 256 x (dim / chunks) multiply-adds, pivots L2-resident) and then does one dependent LDS lookup
+    # per chunk and candidate; the code rows are 16-byte gathers of which a 64-byte sector is fetched.
+    lut_flop = 2.0 * 256 * dim * args.nq
+    lds_lookups = int(st[:, 0].sum()) * nch
     import oracle
     try:
         osample = oracle_sample(prov, oracle.PQ, oracle.L2, dim, args.n, args.max_degree, codes_h[medoid:medoid + 1], codes_h,
@@ -822,8 +872,18 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
     except Exception as e:  # noqa: BLE001
         osample = {"error": str(e)[:200]}
     return {"oracle_sample": osample, "chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
-            "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()),
+            "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()), "mean_hops": float(st[:, 1].mean()),
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
+            "search_kernel": {"kernel": "beam_search_kernel<DT_PQ>", "avg_kernel_ms": search_ms, "qps_search_only": args.nq / (search_ms * 1e-3),
+                              "algorithmic_bytes_per_launch": alg_search,
+                              "algorithmic_GBps": alg_search / (search_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": alg_search / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "bound": "LDS / latency, not HBM: 16-byte code rows (a 64-byte sector each), a 16 KB lookup "
+                                       "table per query in LDS, one dependent LDS lookup per chunk and candidate",
+                              "lds_lookups_per_launch": lds_lookups,
+                              "lds_lookups_per_s": lds_lookups / (search_ms * 1e-3),
+                              "lut_build_flop_per_launch": lut_flop},
+            "rerank_share_of_time": max(0.0, 1.0 - search_ms * 1e-3 / dt),
             "train_seconds_kmeanspp_plus_10_lloyds_131072_rows": round(t_train, 3),
             "compress_seconds_incl_pcie": round(t_comp, 3)}
 
@@ -852,6 +912,29 @@ def _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build,
     prov.build(cfg, 0, n, args.growth, max_batch)
     torch.cuda.synchronize()
     return prov, base, queries, start, time.time() - t0
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (= the f32 vector rate)
+
+
+def build_mfma_info(prov, n, dim, row_bytes, t_build):
+    """The matrix-core share of an index build just finished on `prov` (north_star: "MFMA only for the dense ... case at
+    index-build time ... MFMA utilisation against gfx950 peak"): flop from the library's work counter (Gram entries
+    computed x dim x 2), time from HIP events around every gram_tiles_kernel launch on the build stream
+    (dann_kernel_time, which = 5)."""
+    c = [int(x) for x in prov.build_counters()]
+    ms, launches = prov.kernel_time(5)
+    if not launches:
+        return {"kernel": "gram_tiles_kernel", "used": False,
+                "note": "rows below 1 KiB keep the row kernels (measured faster there, DESIGN 3.4)"}
+    flop = 2.0 * c[7] * dim
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "gram_tiles_kernel (v_mfma_f32_32x32x2_f32)", "used": True, "launches": int(launches),
+            "total_ms": ms, "flop": flop, "TFLOP_s": tf, "peak": F32_MFMA_PEAK_TFLOPS, "frac": tf / F32_MFMA_PEAK_TFLOPS,
+            "share_of_prune_pairs": (c[8] - c[9]) / max(1, c[8] - c[9] + c[4]),
+            "pairs_asked_by_the_sweeps": c[8], "of_those_re_evaluated_exactly": c[9], "row_kernel_pairs": c[4],
+            "gram_rows": c[6], "gram_entries": c[7], "build_seconds": t_build, "points_per_s": n / t_build,
+            "insert_search_comparisons": c[2], "insert_search_algorithmic_bytes": c[2] * row_bytes}
 
 
 def _sweep(torch, lib, _ffi, prov, queries, nq, k, W, gt, ngt, sweep, target):
@@ -925,6 +1008,7 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     else:
         queries32 = queries
     esz, tname, odt = (2, "f16", oracle.F16) if f16 else (4, "f32", oracle.F32)
+    mfma = build_mfma_info(prov, n, dim, dim * esz, t_build)
     sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]
     if args.L:  # profiling passes: fixed L, no ground truth
         gt = np.zeros((ngt, k), np.int64)
@@ -958,6 +1042,7 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
         "kernel": "beam_search_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": avg_ms,
         "working_set_bytes": n * row_bytes + (n + 1) * adj_bytes,
+        "build": mfma,
     }
     if stream_read_gbps:
         res["measured_stream_read_GBps"] = stream_read_gbps
@@ -1184,6 +1269,15 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
     base, queries = make_data(torch, dev, args.n, args.dim, args.nq, args.dist, 0xD15CA11, 0xD15CA12)
     mean = base.double().mean(0).float()
     medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
+    if args.only == "pq":  # PQ codes walk the f32 index's graph: build that first
+        full = da.Provider(da.F32, da.L2, args.dim, args.n, args.max_degree, base[medoid:medoid + 1].cpu().numpy(), device=local)
+        full.set_elements(0, base.cpu().numpy())
+        full.build(da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE),
+                   0, args.n, args.growth, args.max_batch)
+        gt = ground_truth(torch, base, queries, k)
+        if args.L:  # profiling pass: fixed L
+            args.target_recall = -1.0
+        return pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, full)
     if args.only == "sq8":
         g = torch.Generator(device=dev)
         g.manual_seed(11)
@@ -1238,6 +1332,34 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
             "mean_hops": float(st[:, 1].mean()), "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": ms / nl,
             "achieved_GBps": alg / (ms / nl * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms / nl * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "qps": args.nq / (ms / nl * 1e-3)}
+
+
+def cpu_distance_microbench(full=True):
+    """The CPU side of SURVEY.md 8(d) / BASELINE.md 3: the reference's distance micro-benchmark
+    (diskann-benchmark-simd/src/lib.rs:716-771, examples/simd.json: ONE query x 50 rows x 5000 loops, dims 100 / 128 /
+    384 / 768) with this repository's AVX2 restatement of the V3 kernels, plus the cache-defeating variant that is the
+    fair partner of the GPU gather kernel: rows of a table far beyond the caches (1 GiB; 512 MiB in the short form)
+    visited in a random order, one thread and all host cores.  `full=False`: the two dims of the benchmark
+    configurations, f32 only (about 15 s)."""
+    import oracle
+    cores, quota_note = host_cores()
+    dims = (100, 128, 384, 768) if full else (128, 768)
+    dts = (("f32", oracle.F32, 4), ("f16", oracle.F16, 2), ("u8", oracle.U8, 1)) if full else (("f32", oracle.F32, 4),)
+    rows = []
+    for name, dt, esz in dts:
+        for dim in dims:
+            r = oracle.bench_distance(dt, oracle.L2, dim, 50, 5000, False, 1)
+            e = {"rows": name, "dim": dim, "metric": "L2", "simd_shape_ns_per_distance_T1": 1e9 / r}
+            nrows = max(1 << 16, ((1 << 30) if full else (1 << 29)) // (dim * esz))
+            for T in (1, cores):
+                r = oracle.bench_distance(dt, oracle.L2, dim, nrows, 1, True, T)
+                e[f"random_rows_Mdist_per_s_T{T}"] = r / 1e6
+                e[f"random_rows_GBps_T{T}"] = r * dim * esz / 1e9
+            e["random_rows_table_bytes"] = nrows * dim * esz
+            rows.append(e)
+    return {"shape": "diskann-benchmark-simd: 1 query x 50 rows x 5000 loops (L1-resident), and the same kernels over a "
+                     "1 GiB table in random row order", "kernels": "oracle AVX2 + FMA (f32, f16: bitwise the V3 kernels), "
+                     "auto-vectorised integer loop (u8)", "cores": cores, "note": quota_note.strip(), "results": rows}
 
 
 def host_cores():

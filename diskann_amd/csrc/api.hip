@@ -1596,7 +1596,11 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
 // ---- diagnostics -----------------------------------------------------------------------------
 int32_t dann_abi_version(void) { return DANN_ABI_VERSION; }
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches) try {
-    if (!idx || which < 0 || which > 4) return DANN_EINVAL;
+    if (!idx || which < 0 || which > 5) return DANN_EINVAL;
+    if (which == 5) {  // the build's MFMA Gram tiles: events on the build stream, resolved here
+        ::dann::ExclusiveGuard lock(idx);
+        return build_tile_clock(idx, total_ms, launches);
+    }
     std::lock_guard<std::mutex> lk(idx->stat_mu);
     if (total_ms) *total_ms = idx->clocks[which].total_ms;
     if (launches) *launches = idx->clocks[which].launches;
@@ -1605,6 +1609,10 @@ int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms,
 
 int32_t dann_kernel_time_reset(dann_index* idx) try {
     if (!idx) return DANN_EINVAL;
+    {
+        ::dann::ExclusiveGuard lock(idx);
+        build_tile_clock_reset(idx);
+    }
     std::lock_guard<std::mutex> lk(idx->stat_mu);
     for (auto& c : idx->clocks) c = KernelClock();
     return DANN_OK;

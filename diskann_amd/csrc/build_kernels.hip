@@ -1737,6 +1737,44 @@ struct BuildScratch {
     // MFMA pool prune: sorted pools, Gram blocks and norms of one batch slice (grow-only)
     DevBuf g_sid, g_sd, g_sn, g_loc, g_gram, g_nrm;
     size_t g_sorted_elems = 0, g_items = 0, g_gram_elems = 0, g_nrm_elems = 0;
+    // HIP-event time of the gram_tiles_kernel launches (dann_kernel_time, which = 5): pairs of events around every
+    // launch on the build stream, resolved without ever making the build wait (a pair is read once it has completed,
+    // or when the ring comes round to it -- hundreds of launches later)
+    static constexpr uint32_t kTileEvents = 64;
+    hipEvent_t tile_ev[2 * kTileEvents] = {};
+    uint32_t tile_head = 0, tile_tail = 0;  // pairs [tail, head) are pending
+    double tile_ms = 0.0;
+    uint64_t tile_launches = 0;
+    void tile_drain(bool all) {
+        while (tile_tail != tile_head) {
+            hipEvent_t e0 = tile_ev[2 * (tile_tail % kTileEvents)], e1 = tile_ev[2 * (tile_tail % kTileEvents) + 1];
+            if (!all && tile_head - tile_tail < kTileEvents && hipEventQuery(e1) != hipSuccess) break;
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+                tile_ms += ms;
+                tile_launches += 1;
+            }
+            ++tile_tail;
+        }
+    }
+    int32_t tile_begin(hipStream_t st) {
+        tile_drain(false);
+        hipEvent_t& e0 = tile_ev[2 * (tile_head % kTileEvents)];
+        hipEvent_t& e1 = tile_ev[2 * (tile_head % kTileEvents) + 1];
+        if (!e0) DANN_HIP(hipEventCreate(&e0));
+        if (!e1) DANN_HIP(hipEventCreate(&e1));
+        DANN_HIP(hipEventRecord(e0, st));
+        return DANN_OK;
+    }
+    int32_t tile_end(hipStream_t st) {
+        DANN_HIP(hipEventRecord(tile_ev[2 * (tile_head % kTileEvents) + 1], st));
+        ++tile_head;
+        return DANN_OK;
+    }
+    ~BuildScratch() {
+        for (hipEvent_t e : tile_ev)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
 
 int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uint32_t degree) {
@@ -1907,8 +1945,10 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         ta.gram = s.g_gram.as<float>();
         ta.nrm = s.g_nrm.as<float>();
         ta.counters = pc.counters;
+        if (int32_t trc = s.tile_begin(st)) return trc;
         rc = launch_gram_tiles(ta, m, st);
         if (rc != DANN_OK) return rc;
+        if (int32_t trc = s.tile_end(st)) return trc;
         SweepArgs sw;
         sw.p = pa;
         sw.sid = so.sid;
@@ -2123,8 +2163,10 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 ta.gram = s.g_gram.as<float>();
                 ta.nrm = s.g_nrm.as<float>();
                 ta.counters = pc.counters;
+                if (int32_t trc = s.tile_begin(st)) return trc;
                 rc = launch_gram_tiles(ta, nshort, st);
                 if (rc != DANN_OK) return rc;
+                if (int32_t trc = s.tile_end(st)) return trc;
                 SweepArgs sw;
                 sw.p = PoolArgs{};
                 sw.p.ix = ix;
@@ -2380,6 +2422,28 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags) try {
     idx->build_flags = flags;
     return DANN_OK;
 } DANN_CATCH_ALL
+
+}  // extern "C"
+// dann_kernel_time(which = 5): the gram_tiles_kernel launches of this index's builds (all pending events resolved)
+int32_t dann::build_tile_clock(const dann_index* idx, double* total_ms, uint64_t* launches) {
+    if (total_ms) *total_ms = 0.0;
+    if (launches) *launches = 0;
+    if (!idx->build_scratch) return DANN_OK;
+    BuildScratch& s = *static_cast<BuildScratch*>(idx->build_scratch);
+    DeviceGuard guard(idx->device);
+    s.tile_drain(true);
+    if (total_ms) *total_ms = s.tile_ms;
+    if (launches) *launches = s.tile_launches;
+    return DANN_OK;
+}
+void dann::build_tile_clock_reset(const dann_index* idx) {
+    if (!idx->build_scratch) return;
+    BuildScratch& s = *static_cast<BuildScratch*>(idx->build_scratch);
+    s.tile_drain(true);
+    s.tile_ms = 0.0;
+    s.tile_launches = 0;
+}
+extern "C" {
 
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n) try {
     if (!idx || (n && !out)) return DANN_EINVAL;

@@ -219,6 +219,10 @@ struct VisitedCalib {
     uint32_t waves = 0;  // occupancy the kernel's VGPRs allow (queries per CU); the table never costs more than that
 };
 
+// HIP-event time of the MFMA Gram-tile launches of the build path (build_kernels.hip; dann_kernel_time which = 5)
+int32_t build_tile_clock(const dann_index* idx, double* total_ms, uint64_t* launches);
+void build_tile_clock_reset(const dann_index* idx);
+
 int32_t launch_expand_beam(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_ids,
                            const uint64_t* d_offsets, uint64_t max_len, float* d_out, hipStream_t stream);
 int32_t launch_rerank(const IndexView& ix, const void* d_queries, uint32_t nq, const uint32_t* d_cand, uint32_t stride,

@@ -41,8 +41,9 @@ __host__ __device__ inline PairLds pair_lds_layout(uint32_t ht_words) {
     l.stage_off = 256;
     l.qimg_off = 512;  // 64 keys: the upper 32 stay "beyond the queue" (the lower-bound search needs no bound check)
     l.sd_off = 768;
-    l.sink_off = 896;
-    l.ht_off = 912;  // 16-byte aligned
+    l.sink_off = 896;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
+                       // 8-byte stores of the merge's scatter sink into [sd, sink): the survivors' keys are dead by then
+    l.ht_off = 1024;
     l.half_bytes = l.ht_off + ht_words * 4u;
     return l;
 }
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     // integer compares feeding add-with-carry, no lane-mask logic on the scalar unit
     uint32_t* const qimg = reinterpret_cast<uint32_t*>(hbase + L.qimg_off);
     uint32_t* const sd = reinterpret_cast<uint32_t*>(hbase + L.sd_off);
-    uint8_t* const sink = hbase + L.sink_off;
+    uint32_t* const sink = reinterpret_cast<uint32_t*>(hbase + L.sink_off) + li;  // this lane's own sink
+    uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
     const Ht16 h16{a.ht_idmask, a.ht_tb, a.ht_kmax};
     const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                 const uint32_t nvmax = max((uint32_t)__popc(k0), (uint32_t)__popc(k1));
                 const uint32_t cj = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
                 sd[li] = kEmpty;  // (keys beyond a half's survivors: larger than every distance)
-                *(nvalid ? sd + cj : reinterpret_cast<uint32_t*>(sink)) = oknd;
+                *(nvalid ? sd + cj : sink) = oknd;
                 __syncthreads();
                 uint32_t before = 0, shift = 0;
 #pragma nounroll
@@ -261,7 +263,6 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
 #pragma unroll
                 for (uint32_t step = kPairHalf; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
                 const uint32_t pos_new = lb + before, np = li + shift;
-                uint2* const sink2 = reinterpret_cast<uint2*>(sink);
                 *(((li < sizev) & (np < qcap)) ? stage + (np & 31u) : sink2) = make_uint2(qid, __builtin_bit_cast(uint32_t, qd));
                 *((nvalid & (pos_new < qcap)) ? stage + (pos_new & 31u) : sink2) = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
                 const uint32_t total = sizev + nvv;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
             const uint64_t km = ballot64(isnew);
             const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
-            *(isnew ? cand_id + (rank & 31u) : reinterpret_cast<uint32_t*>(sink)) = id;
+            *(isnew ? cand_id + (rank & 31u) : sink) = id;
             const uint32_t cnt = (uint32_t)__popc(up ? k1 : k0);
             ncv = stv ? 0u : cnt;
             htcv += openv ? ncv : 0u;

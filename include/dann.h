@@ -430,7 +430,9 @@ int32_t dann_abi_version(void);
 int32_t dann_last_error(char* buf, uint64_t len);
 /* HIP-event time (ms) and launch count of the named kernel since the last reset.
  * which: 0 = beam search, 1 = gather distance, 2 = prune, 3 = back-edge,
- * 4 = beam-search retry launches (their time is also part of 0; `launches` counts re-run queries) */
+ * 4 = beam-search retry launches (their time is also part of 0; `launches` counts re-run queries),
+ * 5 = gram_tiles_kernel, the matrix-core kernel of the build's prunes (with dann_build_counters()[7] x dim x 2 flop:
+ *     the MFMA rate of the build) */
 int32_t dann_kernel_time(const dann_index* idx, int32_t which, double* total_ms, uint64_t* launches);
 int32_t dann_kernel_time_reset(dann_index* idx);
 /* tuning knob: per-query LDS visited-table size. 0 = auto from L and degree; 6..15 = log2(entries);

@@ -117,6 +117,8 @@ def lib():
     L.orc_gram_chain.argtypes = [vp, u32, u32, vp]
     L.orc_prune_pool.restype = i32
     L.orc_prune_pool.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp, vp, u32, i32, vp, vp]
+    L.orc_bench_distance.restype = f64
+    L.orc_bench_distance.argtypes = [i32, i32, u32, u64, u32, i32, u32, u64, vp]
     L.orc_set_tie_rule.restype = None
     L.orc_set_tie_rule.argtypes = [i32, u64]
     L.orc_insert.restype = i32
@@ -400,6 +402,15 @@ def build_config(pruned_degree, max_degree, l_build, alpha=1.2, max_occlusion_si
     return OrcBuildConfig(pruned_degree, max_degree, l_build, alpha, max_occlusion_size,
                           pruned_degree if max_backedges is None else max_backedges,
                           intra_batch_candidates, int(saturate_after_prune))
+
+
+def bench_distance(dtype, metric, dim, nrows, loops, random_order=False, threads=1, seed=1):
+    """distances per second of the CPU kernels, diskann-benchmark-simd shape (see dann_oracle.cpp orc_bench_distance)"""
+    cs = C.c_double(0.0)
+    r = lib().orc_bench_distance(dtype, metric, dim, nrows, loops, int(bool(random_order)), threads, seed, C.byref(cs))
+    if r < 0:
+        raise ValueError("orc_bench_distance: unsupported dtype / metric")
+    return float(r)
 
 
 def set_tie_rule(rule=0, seed=0):

@@ -1509,6 +1509,104 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
 
 void orc_set_tie_rule(int32_t rule, uint64_t seed) { tie_rule_set(rule, seed); }
 
+/* ---- CPU distance micro-benchmark (bench.py cpu_distance_kernels; never used by a test as a checker) -----------------
+ * The shape of diskann-benchmark-simd (src/lib.rs:716-771, examples/simd.json): ONE query against `nrows` contiguous
+ * rows, `loops` times over -- everything stays in L1/L2, the number is the kernel's arithmetic rate.  random_order != 0
+ * is the cache-defeating variant the GPU gather kernel is held against: the rows of a table far larger than the caches
+ * are visited in a random order (one dependent-free load stream, hardware prefetchers useless).  f32 / f16 rows run the
+ * AVX2 + FMA kernels of this file (bit-identical to the scalar emulation of the reference's V3 kernels); u8 / i8 rows a
+ * plain integer loop the compiler vectorises.  `threads` workers share the table, each with its own query and order.
+ * Returns distances per second over all threads (best of 3 timed passes); *checksum keeps the work observable. */
+}  // extern "C"
+template <bool SIGNED, bool L2>
+static int32_t int_rows_op(const uint8_t* a, const uint8_t* b, size_t n) {
+    int32_t s = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t x = SIGNED ? (int32_t)(int8_t)a[i] : (int32_t)a[i], y = SIGNED ? (int32_t)(int8_t)b[i] : (int32_t)b[i];
+        s += L2 ? (x - y) * (x - y) : x * y;
+    }
+    return s;
+}
+extern "C" {
+double orc_bench_distance(int32_t dtype, int32_t metric, uint32_t dim, uint64_t nrows, uint32_t loops, int32_t random_order,
+                          uint32_t threads, uint64_t seed, double* checksum) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_U8 || dtype == ORC_I8) || dim == 0 || nrows == 0 || loops == 0)
+        return -1.0;
+    if (!(metric == ORC_L2 || metric == ORC_INNER_PRODUCT)) return -1.0;
+    if (threads == 0) threads = 1;
+    const size_t esz = elem_size(dtype), rb = (size_t)dim * esz;
+    std::vector<uint8_t> table(nrows * rb + 64);
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    if (dtype == ORC_F32) {
+        float* t = reinterpret_cast<float*>(table.data());
+        for (size_t i = 0; i < nrows * dim; ++i) t[i] = (float)((int32_t)(next() >> 40) - (1 << 23)) * (1.0f / (1 << 23));
+    } else if (dtype == ORC_F16) {
+        uint16_t* t = reinterpret_cast<uint16_t*>(table.data());
+        for (size_t i = 0; i < nrows * dim; ++i) t[i] = orc_f32_to_f16((float)((int32_t)(next() >> 40) - (1 << 23)) * (1.0f / (1 << 23)));
+    } else {
+        for (size_t i = 0; i < nrows * rb; i += 8) {
+            const uint64_t r = next();
+            std::memcpy(table.data() + i, &r, std::min<size_t>(8, nrows * rb - i));
+        }
+    }
+    std::vector<double> rate(threads, 0.0), sums(threads, 0.0);
+    auto work = [&](uint32_t tid) {
+        std::vector<float> q32(dim);
+        std::vector<uint8_t> q(rb);
+        uint64_t y = (seed + 77 * (tid + 1)) * 0xD1B54A32D192ED03ull + 1;
+        auto nx = [&]() {
+            y ^= y << 13;
+            y ^= y >> 7;
+            y ^= y << 17;
+            return y;
+        };
+        for (uint32_t i = 0; i < dim; ++i) q32[i] = (float)((int32_t)(nx() >> 40) - (1 << 23)) * (1.0f / (1 << 23));
+        if (dtype == ORC_F32) std::memcpy(q.data(), q32.data(), rb);
+        else if (dtype == ORC_F16) for (uint32_t i = 0; i < dim; ++i) reinterpret_cast<uint16_t*>(q.data())[i] = orc_f32_to_f16(q32[i]);
+        else for (size_t i = 0; i < rb; ++i) q[i] = (uint8_t)nx();
+        std::vector<uint32_t> order;
+        if (random_order) {
+            order.resize(nrows);
+            for (uint64_t i = 0; i < nrows; ++i) order[i] = (uint32_t)i;
+            for (uint64_t i = nrows; i > 1; --i) std::swap(order[i - 1], order[nx() % i]);
+        }
+        double best = 0.0, acc = 0.0;
+        for (int pass = 0; pass < 4; ++pass) { /* pass 0 warms */
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t l = 0; l < loops; ++l)
+                for (uint64_t r = 0; r < nrows; ++r) {
+                    const uint8_t* row = table.data() + (random_order ? (size_t)order[r] : (size_t)r) * rb;
+                    float d;
+                    if (dtype == ORC_U8) d = (float)(metric == ORC_L2 ? int_rows_op<false, true>(q.data(), row, dim) : int_rows_op<false, false>(q.data(), row, dim));
+                    else if (dtype == ORC_I8) d = (float)(metric == ORC_L2 ? int_rows_op<true, true>(q.data(), row, dim) : int_rows_op<true, false>(q.data(), row, dim));
+                    else d = query_raw_fast(dtype, metric, q32.data(), q.data(), row, dim);
+                    acc += d;
+                }
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (pass > 0) best = std::max(best, (double)nrows * loops / secs);
+        }
+        rate[tid] = best;
+        sums[tid] = acc;
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    double total = 0.0, cs = 0.0;
+    for (uint32_t t = 0; t < threads; ++t) {
+        total += rate[t];
+        cs += sums[t];
+    }
+    if (checksum) *checksum = cs;
+    return total;
+}
+
 /* counters: [0] query distances, [1] pair (prune) distances, [2] set_neighbors, [3] appends */
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters) {
     if (!ix || !cfg || slot >= ix->capacity) return -1;

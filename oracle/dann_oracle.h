@@ -168,6 +168,9 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
 /* tie order of RobustPrune's candidate sort (see sort_pool): 0 = the oracle's rule (pool position); 1..5 = alternative
  * orders used only to measure the tie envelope of the reference's grid_insert goldens.  Process-global, not thread-safe. */
 void orc_set_tie_rule(int32_t rule, uint64_t seed);
+/* CPU distance micro-benchmark in the shape of diskann-benchmark-simd (see dann_oracle.cpp); distances per second */
+double orc_bench_distance(int32_t dtype, int32_t metric, uint32_t dim, uint64_t nrows, uint32_t loops, int32_t random_order,
+                          uint32_t threads, uint64_t seed, double* checksum);
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters);
 /* DiskANNIndex::multi_insert for rows already stored at slots[0..n)
  * (index.rs:815-1030, max_minibatch_par = 1). */

@@ -139,6 +139,10 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    # with several ranks the benchmark index comes from the library's sharded build (here over the callback
+    # communicator: both ranks share one device): exchange statistics in the line, replicas byte-identical
+    ex = out["config"]["build_exchange"]
+    assert "error" not in ex and ex["digest_identical_across_ranks"] is True and ex["rounds"] > 0 and ex["bytes_gathered"] > 0
     s = out["other_configs"]["strong_scaling_shared_set"]
     assert s["ranks"] == 2 and s["queries"] == 1001 and s["identical_to_single_rank"] is True
     # a launcher whose WORLD_SIZE disagrees with --gpus is an error, not a silent 1-rank run
