@@ -871,8 +871,19 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                                 queries.cpu().numpy(), chosen, W, k, pq_pivots=pivots_h, pq_offsets=bounds)
     except Exception as e:  # noqa: BLE001
         osample = {"error": str(e)[:200]}
+    traffic = None
+    try:  # fabric traffic of the search kernel from the committed PMC pass (rocprofv3 cannot run inside bench.py)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pq_latest.json")))
+        wl = pm["workload"]
+        if (wl["nq"], wl["L"], wl["n"], wl["dim"], wl["chunks"]) == (args.nq, chosen, args.n, dim, nch):
+            traffic = {"fabric_bytes_per_launch": pm["fabric_bytes_per_launch_corrected"],
+                       "traffic_over_algorithmic": pm["fabric_bytes_per_launch_corrected"] / alg_search,
+                       "l2_hit_rate": pm["l2_hit_rate"], "source": "profiles/pmc_pq_latest.json"}
+    except (OSError, KeyError, ValueError):
+        pass
     return {"oracle_sample": osample, "chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
             "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()), "mean_hops": float(st[:, 1].mean()),
+            "search_kernel_traffic": traffic,
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
             "search_kernel": {"kernel": "beam_search_kernel<DT_PQ>", "avg_kernel_ms": search_ms, "qps_search_only": args.nq / (search_ms * 1e-3),
                               "algorithmic_bytes_per_launch": alg_search,
