@@ -95,6 +95,10 @@ def parse():
                          "MI355X holds (config 5's row shape): data generated on the device chunk by chunk, built by "
                          "dann_build, recall on a 1 000-query exact (f64) ground truth, a 256-query replay through the CPU "
                          "oracle on the bytes the searches touch")
+    ap.add_argument("--build-blobs", type=int, default=0, help="--only build768: number of blobs (0 = n / 3906, at least 256)")
+    ap.add_argument("--build-centres", default="auto", choices=["auto", "iid", "hier"],
+                    help="--only build768: blob centres i.i.d. U(0,1)^dim, or hierarchical (256 topic centres, the blobs "
+                         "of a topic on a shared 8-d subspace around it); auto = hier beyond 4096 blobs")
     ap.add_argument("--sweep", action="store_true", help="print the whole recall/QPS sweep to stderr")
     ap.add_argument("--query-sets", type=int, default=4,
                     help="distinct query sets of --nq queries each; timed step i searches set i %% query_sets")
@@ -1103,13 +1107,28 @@ def build_large_variant(args, torch, da, lib, _ffi, dev, local):
     n, dim, R, pruned, lb = (int(x) for x in f[:5])
     f16 = len(f) > 5 and f[5] == "f16"
     esz, tname, dt, odt = (2, "f16", da.F16, oracle.F16) if f16 else (4, "f32", da.F32, oracle.F32)
-    nblobs = max(256, n // 3906)
+    nblobs = args.build_blobs or max(256, n // 3906)
     chunk = 1 << 20
     k, nq, ngt = 10, min(args.nq, 20000), 1000
     g0 = torch.Generator(device=dev)
     g0.manual_seed(0xD15CA11)
-    centers = torch.rand((nblobs, dim), generator=g0, device=dev, dtype=torch.float32)
-    basis = torch.randn((16, dim), generator=g0, device=dev, dtype=torch.float32) / 4.0
+    hier = args.build_centres == "hier" or (args.build_centres == "auto" and nblobs > 4096)
+    if hier:
+        # Tens of thousands of i.i.d. centres in U(0,1)^768 are all nearly equidistant (concentration of measure): no
+        # graph walk finds the query's blob among them, which is a property of that generator, not of embeddings -- text
+        # embeddings cluster hierarchically.  256 topic centres as before; the blobs of a topic sit around it on a shared
+        # 8-dimensional subspace with the spread of a blob's own points, so neighbouring blobs overlap and a walk moves
+        # between them as it moves inside one.
+        ntop = 256
+        top = torch.rand((ntop, dim), generator=g0, device=dev, dtype=torch.float32)
+        cbasis = torch.randn((8, dim), generator=g0, device=dev, dtype=torch.float32) / 4.0
+        basis = torch.randn((16, dim), generator=g0, device=dev, dtype=torch.float32) / 4.0
+        tlab = torch.randint(0, ntop, (nblobs,), generator=g0, device=dev)
+        w = torch.randn((nblobs, 8), generator=g0, device=dev, dtype=torch.float32)
+        centers = top[tlab] + 0.5 * (w @ cbasis)
+    else:
+        centers = torch.rand((nblobs, dim), generator=g0, device=dev, dtype=torch.float32)
+        basis = torch.randn((16, dim), generator=g0, device=dev, dtype=torch.float32) / 4.0
 
     def draw(m, gen):
         lab = torch.randint(0, nblobs, (m,), generator=gen, device=dev)
@@ -1176,7 +1195,9 @@ def build_large_variant(args, torch, da, lib, _ffi, dev, local):
     res = {
         "workload": f"dann_build of a {n}x{dim} {tname} index (Vamana R={R}, pruned {pruned}, l_build={lb}, alpha 1.2, growth "
                     f"{args.growth}, max_batch {max_batch}) on one GPU: {n * row_b / 1e9:.1f} GB rows + {(n + 1) * adj_b / 1e9:.1f} GB "
-                    f"adjacency resident in HBM; data: the benchmark mixture, {nblobs} blobs, generated on the device",
+                    f"adjacency resident in HBM; data: the benchmark mixture, {nblobs} blobs ("
+                    + ("256 topics, blob centres on a shared 8-d subspace around their topic" if hier else "i.i.d. centres")
+                    + "), generated on the device",
         "build_seconds": t_build, "points_per_second": n / t_build, "batches": nb, "data_seconds": t_data,
         "insert_search": {"cmps": c[2], "hops": c[3], "algorithmic_bytes": c[2] * row_b + c[3] * adj_b},
         "prune": {"row_kernel_pair_distances": c[4], "list_distances": c[5], "gram_rows": c[6], "gram_entries": c[7],

@@ -62,6 +62,25 @@ struct DeviceGuard {
 };
 
 // time one launch on the index stream with HIP events (the stream the kernel runs on)
+// a block of a context's arena, carved into 256-byte aligned pieces
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+struct ArenaPtr {
+    void* p;
+    ArenaPtr(void* base, size_t off) : p(reinterpret_cast<uint8_t*>(base) + off) {}
+    ArenaPtr() : p(nullptr) {}
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
 template <class F>
 static int32_t timed(dann_index* idx, int which, F&& f) {
     DANN_HIP(hipEventRecord(idx->main.ev0, idx->main.stream));
@@ -1024,7 +1043,7 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
                                 float initial_slack, float range_slack, uint32_t max_returned, uint32_t out_cap,
                                 uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                 uint32_t* out_second_round) try {
-    CHECK_IDX(idx);
+    CHECK_IDX_SHARED(idx);  // read-only: concurrent callers run side by side, each on its own context
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
         set_error("l_value and beam width cannot be zero");
@@ -1053,15 +1072,16 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     cap = std::max<uint64_t>(cap, 1);
     if (int32_t prc = pq_ready(idx)) return prc;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
-    DevBuf bq, bi, bd, bs, bri, brd, bsec;
-    DANN_HIP(bq.alloc((size_t)nq * qb + 16));
-    DANN_HIP(bi.alloc((size_t)nq * out_cap * 4));
-    DANN_HIP(bd.alloc((size_t)nq * out_cap * 4));
-    DANN_HIP(bs.alloc((size_t)nq * sizeof(dann_search_stats)));
-    DANN_HIP(bri.alloc((size_t)nq * cap * 4));
-    DANN_HIP(brd.alloc((size_t)nq * cap * 4));
-    DANN_HIP(bsec.alloc((size_t)nq * 4));
-    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, idx->main.stream));
+    // scratch of this call: one block of the context's grow-only arena (no hipMalloc / hipFree per call: a hipFree
+    // synchronises the whole device and would serialise concurrent callers)
+    Carve cv;
+    const size_t o_q = cv.take((size_t)nq * qb + 16), o_i = cv.take((size_t)nq * out_cap * 4),
+                 o_d = cv.take((size_t)nq * out_cap * 4), o_s = cv.take((size_t)nq * sizeof(dann_search_stats)),
+                 o_ri = cv.take((size_t)nq * cap * 4), o_rd = cv.take((size_t)nq * cap * 4), o_sec = cv.take((size_t)nq * 4);
+    if (int32_t grc = grow_stage(ctx, 4, cv.off)) return grc;
+    const ArenaPtr bq{ctx.stage[4], o_q}, bi{ctx.stage[4], o_i}, bd{ctx.stage[4], o_d}, bs{ctx.stage[4], o_s},
+        bri{ctx.stage[4], o_ri}, brd{ctx.stage[4], o_rd}, bsec{ctx.stage[4], o_sec};
+    DANN_HIP(hipMemcpyAsync(bq.p, queries, (size_t)nq * qb, hipMemcpyHostToDevice, ctx.stream));
     SearchArgs a;
     a.ix = idx->view();
     a.queries = bq.p;
@@ -1093,16 +1113,16 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
     a.spill = nullptr;
     a.spill_next = nullptr;
     a.spill_slices = a.spill_bits = 0;
-    int32_t rc = search_with_retry(idx, idx->main, a);
+    int32_t rc = search_with_retry(idx, ctx, a);
     if (rc != DANN_OK) return rc;
     std::vector<dann_search_stats> stats(nq);
-    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->main.stream));
-    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(out_ids, bi.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, ctx.stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, bd.p, (size_t)nq * out_cap * 4, hipMemcpyDeviceToHost, ctx.stream));
     DANN_HIP(hipMemcpyAsync(stats.data(), bs.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
-                            idx->main.stream));
+                            ctx.stream));
     if (out_second_round)
-        DANN_HIP(hipMemcpyAsync(out_second_round, bsec.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->main.stream));
-    DANN_HIP(hipStreamSynchronize(idx->main.stream));
+        DANN_HIP(hipMemcpyAsync(out_second_round, bsec.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx.stream));
+    DANN_HIP(hipStreamSynchronize(ctx.stream));
     if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
     for (uint32_t i = 0; i < nq; ++i)
         if (stats[i].status) {
@@ -1143,7 +1163,7 @@ struct FilteredCall {
 };
 }  // namespace
 
-static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
+static int32_t filtered_search(dann_index* idx, SearchCtx& ctx, const FilteredCall& c) {
     const dann_filter* f = c.filter;
     if (!f || !f->bits || (f->mode != DANN_FILTER_INLINE && f->mode != DANN_FILTER_MULTIHOP)) {
         set_error("filter: mode must be DANN_FILTER_INLINE or DANN_FILTER_MULTIHOP and bits non-null");
@@ -1173,7 +1193,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
                   (unsigned long long)f->stride_words, (unsigned long long)words);
         return DANN_EINVAL;
     }
-    hipStream_t st = idx->main.stream;
+    hipStream_t st = ctx.stream;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
     const bool inl = f->mode == DANN_FILTER_INLINE;
     SearchArgs a;
@@ -1185,7 +1205,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
     a.filter_mode = f->mode;
     a.filter_stride = f->stride_words;
     // AdaptiveL: table of new L for every (visited, matched) the decision can see
-    DevBuf btab;
+    std::vector<uint32_t> tab;  // (outlives the asynchronous upload below: the arena is sized after it)
     const uint32_t cmax = std::max<uint32_t>((c.beam * idx->cfg.max_degree + 63u) & ~63u, (idx->cfg.num_start_points + 63u) & ~63u);
     if (f->adaptive_samples) {
         const uint64_t stride = (uint64_t)f->adaptive_samples + cmax;
@@ -1193,7 +1213,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
             set_error("AdaptiveL sample_count %u is too large for the decision table", f->adaptive_samples);
             return DANN_EUNSUPPORTED;
         }
-        std::vector<uint32_t> tab(stride * cmax);
+        tab.resize(stride * cmax);
         uint32_t lmax = 0;
         for (uint32_t dv = 0; dv < cmax; ++dv)
             for (uint64_t m = 0; m < stride; ++m) {
@@ -1202,11 +1222,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
                 tab[dv * stride + m] = nl;
                 lmax = std::max(lmax, nl);
             }
-        DANN_HIP(btab.alloc(tab.size() * 4));
-        DANN_HIP(hipMemcpyAsync(btab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
-        DANN_HIP(hipStreamSynchronize(st));  // tab is a local
         a.ad_samples = f->adaptive_samples;
-        a.ad_table = btab.as<uint32_t>();
         a.ad_stride = (uint32_t)stride;
         a.qcap_max = std::max(lmax, c.l_value + idx->cfg.num_start_points);
     }
@@ -1227,18 +1243,26 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
     }
     const uint64_t per_query = (uint64_t)m_cap * 8 + (uint64_t)key_cap * 8 + rcap * 8 + 64;
     const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c.nq, (1ull << 30) / per_query));
-    DevBuf bq, bi, bd, bs, bf, bmi, bmd, bk, bri, brd, bsec;
-    DANN_HIP(bq.alloc((size_t)chunk * qb + 16));
-    DANN_HIP(bi.alloc((size_t)chunk * c.k * 4));
-    DANN_HIP(bd.alloc((size_t)chunk * c.k * 4));
-    DANN_HIP(bs.alloc((size_t)chunk * sizeof(dann_search_stats)));
+    // scratch of this call: one block of the context's grow-only arena (see dann_range_search_batch)
     const size_t fwords = f->stride_words ? (size_t)f->stride_words * c.nq : (size_t)words;
-    DANN_HIP(bf.alloc(fwords * 4));
+    Carve cv;
+    const size_t o_q = cv.take((size_t)chunk * qb + 16), o_i = cv.take((size_t)chunk * c.k * 4),
+                 o_d = cv.take((size_t)chunk * c.k * 4), o_s = cv.take((size_t)chunk * sizeof(dann_search_stats)),
+                 o_f = cv.take(fwords * 4), o_tab = cv.take(tab.size() * 4),
+                 o_mi = cv.take(inl ? (size_t)chunk * m_cap * 4 : 0), o_md = cv.take(inl ? (size_t)chunk * m_cap * 4 : 0),
+                 o_k = cv.take(inl ? (size_t)chunk * key_cap * 8 : 0),
+                 o_ri = cv.take(c.range ? (size_t)chunk * rcap * 4 : 0), o_rd = cv.take(c.range ? (size_t)chunk * rcap * 4 : 0),
+                 o_sec = cv.take(c.range ? (size_t)chunk * 4 : 0);
+    if (int32_t grc = grow_stage(ctx, 4, cv.off)) return grc;
+    void* const ar = ctx.stage[4];
+    const ArenaPtr bq{ar, o_q}, bi{ar, o_i}, bd{ar, o_d}, bs{ar, o_s}, bf{ar, o_f}, btab{ar, o_tab}, bmi{ar, o_mi}, bmd{ar, o_md},
+        bk{ar, o_k}, bri{ar, o_ri}, brd{ar, o_rd}, bsec{ar, o_sec};
     DANN_HIP(hipMemcpyAsync(bf.p, f->bits, fwords * 4, hipMemcpyHostToDevice, st));
+    if (!tab.empty()) {
+        DANN_HIP(hipMemcpyAsync(btab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+        a.ad_table = btab.as<uint32_t>();
+    }
     if (inl) {
-        DANN_HIP(bmi.alloc((size_t)chunk * m_cap * 4));
-        DANN_HIP(bmd.alloc((size_t)chunk * m_cap * 4));
-        DANN_HIP(bk.alloc((size_t)chunk * key_cap * 8));
         a.m_ids = bmi.as<uint32_t>();
         a.m_d = bmd.as<float>();
         a.m_keys = bk.as<unsigned long long>();
@@ -1246,9 +1270,6 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
         a.key_cap = key_cap;
     }
     if (c.range) {
-        DANN_HIP(bri.alloc((size_t)chunk * rcap * 4));
-        DANN_HIP(brd.alloc((size_t)chunk * rcap * 4));
-        DANN_HIP(bsec.alloc((size_t)chunk * 4));
         a.range_ids = bri.as<uint32_t>();
         a.range_d = brd.as<float>();
         a.range_second = bsec.as<uint32_t>();
@@ -1270,7 +1291,7 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
         DANN_HIP(hipMemcpyAsync(bq.p, (const uint8_t*)c.queries + (size_t)off * qb, (size_t)n * qb, hipMemcpyHostToDevice, st));
         a.nq = n;
         a.filter = bf.as<uint32_t>() + (size_t)off * f->stride_words;
-        int32_t rc = search_with_retry(idx, idx->main, a);
+        int32_t rc = search_with_retry(idx, ctx, a);
         if (rc != DANN_OK) return rc;
         DANN_HIP(hipMemcpyAsync(c.out_ids + (size_t)off * c.k, bi.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
         DANN_HIP(hipMemcpyAsync(c.out_dists + (size_t)off * c.k, bd.p, (size_t)n * c.k * 4, hipMemcpyDeviceToHost, st));
@@ -1292,11 +1313,11 @@ static int32_t filtered_search(dann_index* idx, const FilteredCall& c) {
 int32_t dann_filtered_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value,
                                    uint32_t beam_width, uint32_t k, const dann_filter* filter, uint32_t* out_ids,
                                    float* out_dists, dann_search_stats* out_stats) try {
-    CHECK_IDX(idx);
+    CHECK_IDX_SHARED(idx);
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
     FilteredCall c{queries, nq, l_value, beam_width, k, filter, out_ids, out_dists, out_stats};
-    return filtered_search(idx, c);
+    return filtered_search(idx, ctx, c);
 } DANN_CATCH_ALL
 
 int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
@@ -1305,7 +1326,7 @@ int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, u
                                          uint32_t max_returned, uint32_t out_cap, const dann_filter* filter,
                                          uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                          uint32_t* out_second_round) try {
-    CHECK_IDX(idx);
+    CHECK_IDX_SHARED(idx);
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
         set_error("l_value and beam width cannot be zero");
@@ -1338,7 +1359,7 @@ int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, u
     c.has_inner = has_inner_radius;
     c.max_returned = max_returned;
     c.out_second = out_second_round;
-    return filtered_search(idx, c);
+    return filtered_search(idx, ctx, c);
 } DANN_CATCH_ALL
 
 int32_t dann_rerank_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, const uint32_t* d_cand_ids,

@@ -183,8 +183,10 @@ struct SearchCtx {
     uint32_t spill_slices = 0, spill_bits = 0;
     uint32_t* h_flag = nullptr;  // pinned, device-visible: set by a query that exhausts its scratch
     // grow-only device staging for the host-pointer search entry (no hipMalloc / hipFree per call)
-    void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[4] = {0, 0, 0, 0};
+    // [0] queries, [1] outputs, [2] stats, [3] second query buffer of the chunked pipeline, [4] the scratch arena of the
+    // range / filtered searches (one block, carved per call)
+    void* stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[5] = {0, 0, 0, 0, 0};
     void* h_stage = nullptr;     // pinned host staging (small batches: one H2D + one D2H per call; large: chunk ring)
     size_t h_stage_bytes = 0;
     hipStream_t copy_stream = nullptr;  // second stream of the chunked host-pointer pipeline

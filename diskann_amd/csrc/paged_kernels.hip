@@ -395,10 +395,14 @@ int32_t dann_paged_begin(dann_index* idx, const void* queries, uint32_t nq, uint
         set_error("paged search is not defined for DANN_PQ rows");
         return DANN_EUNSUPPORTED;
     }
-    ::dann::ExclusiveGuard lock(idx);
+    // read-only on the index: sessions of different callers run side by side, each call on a leased context
+    std::shared_lock<std::shared_mutex> rd(idx->rw);
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != idx->device) DANN_HIP(hipSetDevice(idx->device));
+    ::dann::CtxLease lease(idx);
+    if (lease.status != DANN_OK) return lease.status;
+    hipStream_t stream = lease.ctx->stream;
     dann_paged* s = new dann_paged();
     s->idx = idx;
     const uint32_t nslots = idx->nslots;
@@ -455,8 +459,8 @@ int32_t dann_paged_begin(dann_index* idx, const void* queries, uint32_t nq, uint
     a.out_n = nullptr;
     a.stats = (dann_search_stats*)s->stats.p;
     a.init = 1;
-    int32_t rc = launch_paged(a, idx->main.stream);
-    if (rc == DANN_OK && (e = hipStreamSynchronize(idx->main.stream)) != hipSuccess) rc = hip_fail(e, "paged begin");
+    int32_t rc = launch_paged(a, stream);
+    if (rc == DANN_OK && (e = hipStreamSynchronize(stream)) != hipSuccess) rc = hip_fail(e, "paged begin");
     if (rc != DANN_OK) {
         delete s;
         return rc;
@@ -477,10 +481,13 @@ int32_t dann_paged_next(dann_paged* s, uint32_t k, uint32_t* out_ids, float* out
         return DANN_EINVAL;
     }
     dann_index* idx = s->idx;
-    ::dann::ExclusiveGuard lock(idx);
+    std::shared_lock<std::shared_mutex> rd(idx->rw);
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != idx->device) DANN_HIP(hipSetDevice(idx->device));
+    ::dann::CtxLease lease(idx);
+    if (lease.status != DANN_OK) return lease.status;
+    hipStream_t stream = lease.ctx->stream;
     const uint32_t nq = s->a.nq;
     if (s->out_k < k) {
         if (s->out_ids.p) (void)hipFree(s->out_ids.p);
@@ -496,16 +503,16 @@ int32_t dann_paged_next(dann_paged* s, uint32_t k, uint32_t* out_ids, float* out
     s->a.out_ids = (uint32_t*)s->out_ids.p;
     s->a.out_d = (float*)s->out_d.p;
     s->a.out_n = (uint32_t*)s->out_n.p;
-    int32_t rc = launch_paged(s->a, idx->main.stream);
+    int32_t rc = launch_paged(s->a, stream);
     if (rc != DANN_OK) return rc;
     std::vector<dann_search_stats> st(nq);
     std::vector<uint32_t> counts(nq);
-    DANN_HIP(hipMemcpyAsync(out_ids, s->out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->main.stream));
-    DANN_HIP(hipMemcpyAsync(out_dists, s->out_d.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->main.stream));
-    DANN_HIP(hipMemcpyAsync(counts.data(), s->out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->main.stream));
+    DANN_HIP(hipMemcpyAsync(out_ids, s->out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+    DANN_HIP(hipMemcpyAsync(out_dists, s->out_d.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+    DANN_HIP(hipMemcpyAsync(counts.data(), s->out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
     DANN_HIP(hipMemcpyAsync(st.data(), s->stats.p, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost,
-                            idx->main.stream));
-    DANN_HIP(hipStreamSynchronize(idx->main.stream));
+                            stream));
+    DANN_HIP(hipStreamSynchronize(stream));
     if (out_counts) memcpy(out_counts, counts.data(), (size_t)nq * 4);
     for (uint32_t i = 0; i < nq; ++i)
         if (st[i].status) {

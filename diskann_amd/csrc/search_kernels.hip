@@ -287,15 +287,17 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !tune_env(4)) ? 1u : 0u;
         if (tune_env(8)) a.tune |= kTuneNoSpeculation;
     }
-    // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  Launches beyond the
-    // latency regime only; DANN_TUNE_OFF bit 16 / DANN_PAIR_MIN_QUERIES: development switches.
+    // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  A pair-hop is longer
+    // than a hop of one query, so the pairing pays once the chip is full: measured on 1 M u8 rows at L = 26
+    // (scratch/pair_latency.py, kernel us, pair / one wave per query): 4 096 queries 292 / 260, 6 144: 301 / 346,
+    // 16 384: 497 / 585, 65 536: 1 423 / 1 801.  DANN_TUNE_OFF bit 16 / DANN_PAIR_MIN_QUERIES: development switches.
     a.pair = 0;
     {
         static const uint32_t pair_min = [] {
             const char* e = getenv("DANN_PAIR_MIN_QUERIES");
             return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
         }();
-        const uint32_t floor_q = pair_min != 0xFFFFFFFFu ? pair_min : 4u * idx->num_cus + 1u;
+        const uint32_t floor_q = pair_min != 0xFFFFFFFFu ? pair_min : 20u * idx->num_cus;
         SearchArgs t = a;
         t.team = 0;
         if (a.nq >= floor_q && inflight >= floor_q && idx->visited_format != 32u && pair_shape(t) && !tune_env(16)) {

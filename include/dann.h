@@ -12,12 +12,13 @@
  * 682-756): opaque handles, caller-owned buffers passed as pointer + length, `int32_t`
  * status (>= 0 ok, < 0 one of DANN_E*), no exceptions or aborts cross the boundary,
  * a thread-local message is available from dann_last_error().  Entry points are
- * thread-safe.  Threading model (the reference: N workers on one shared `&DiskANNIndex`): dann_search_batch,
- * dann_search_batch_device and the server entry points (dann_search_submit / wait) take the index shared -- calls
- * from different threads run side by side on the device, each on its own stream; everything that mutates the
- * index, and the remaining search entry points (range / filtered / paged / record / rerank, the fine-grained seam),
- * take it exclusively and wait for the searches in flight (the GPU index is an immutable snapshot between mutations;
- * the reference's EBR / tag machinery stays on the host).
+ * thread-safe.  Threading model (the reference: N workers on one shared `&DiskANNIndex`, for every search kind):
+ * dann_search_batch(_device), dann_range_search_batch, dann_filtered_search_batch, dann_filtered_range_search_batch,
+ * dann_paged_begin / dann_paged_next take the index shared -- calls from different threads run side by side on the
+ * device, each on its own stream and scratch (a pool of search contexts) -- and the server entry points
+ * (dann_search_submit / wait / poll) take no lock at all; everything that mutates the index, and the fine-grained
+ * seam and the record / rerank entry points, take it exclusively and wait for the searches in flight (the GPU index
+ * is an immutable snapshot between mutations; the reference's EBR / tag machinery stays on the host).
  *
  * All "host" pointers are plain host memory; `_device` variants take HIP device
  * pointers that live on the index's device.

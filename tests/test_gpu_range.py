@@ -72,3 +72,50 @@ def test_range_parameter_errors():
         with pytest.raises(da.DannError) as e:
             p.range_search(q, **kw)
         assert e.value.status == da._ffi.EINVAL
+
+
+def test_range_searches_of_concurrent_callers_overlap():
+    """The reference's callers are N workers on one shared index for every search kind
+    (diskann-benchmark-core/src/search/api.rs:399-436).  Range searches take the index shared and run on leased
+    contexts: 8 threads finish the same calls in well under the serial time, every result equal to the oracle's."""
+    import threading
+    import time
+    rng = np.random.default_rng(99)
+    n, dim, R = 20000, 128, 32
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], R)
+    nthreads, calls, per_call = 8, 25, 4   # few queries per call, long searches: a call is latency on the device
+    queries = rand_vectors(rng, oracle.F32, nthreads * per_call, dim)
+    d0 = np.array([oracle.distance(oracle.F32, oracle.L2, queries[0], data[i]) for i in range(300)])
+    radius = float(np.quantile(d0, 0.02))
+    Lr = 250
+    want = [oix.range_search(queries[q], Lr, radius, 1, None, 1.0, 1.0, 0, out_cap=2000) for q in range(len(queries))]
+
+    def work(t, out):
+        q = queries[t * per_call:(t + 1) * per_call]
+        for _ in range(calls):
+            out[t] = gix.range_search(q, Lr, radius, 1, None, 1.0, 1.0, 0, out_cap=2000)
+    res = [None] * nthreads
+    work(0, res)  # warm: contexts, calibration
+    t0 = time.perf_counter()
+    for t in range(nthreads):
+        work(t, res)
+    serial = time.perf_counter() - t0
+    serial_res = list(res)
+    res = [None] * nthreads
+    th = [threading.Thread(target=work, args=(t, res)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    conc = time.perf_counter() - t0
+    for got in (serial_res, res):
+        for t in range(nthreads):
+            gi, gd, gst, gsec = got[t]
+            for j in range(per_call):
+                oi, od, ost = want[t * per_call + j]
+                k = oi.size
+                assert int(gst["result_count"][j]) == k
+                assert np.array_equal(gi[j, :k], oi) and np.array_equal(bits(gd[j, :k]), bits(od))
+                assert int(gst["cmps"][j]) == int(ost[0]) and int(gst["hops"][j]) == int(ost[1])
+    assert conc < 0.5 * serial, (serial, conc)
