@@ -423,7 +423,7 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */
-#define DANN_ABI_VERSION 3
+#define DANN_ABI_VERSION 4
 int32_t dann_abi_version(void);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
