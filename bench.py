@@ -1327,6 +1327,8 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
         qrows = ((queries - lo) * (255.0 / (hi - lo))).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
         prov = da.Provider(da.U8, da.L2, args.dim, args.n, args.max_degree, rows[medoid:medoid + 1], device=local)
         row_bytes = args.dim
+    if args.visited_bits:  # experiment knob: explicit LDS visited-table size (never affects results)
+        prov.set_visited_bits(args.visited_bits)
     prov.set_elements(0, rows)
     prov.build(da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE),
                0, args.n, args.growth, args.max_batch)

@@ -118,10 +118,10 @@ struct SearchArgs {
     uint32_t ht_entries = 0;     // per-query LDS visited-table entries (multiple of 64)
     uint32_t ht_prime = 0;       // probing modulus, set by search_with_retry: largest prime <= ht_entries
     // 16-bit table entries (plain-mode kernels, chosen per launch by the host; search_kernel_impl.h, ht16_insert_open):
-    // the table holds 2 * ht_entries slots (a power of two), ht_prime is that slot count
+    // the table holds 2 * ht_entries slots, ht_prime is that slot count
     uint32_t ht16 = 0;
-    uint32_t ht_idmask = 0;      // 2^m - 1, m = bits of the index's slot count
-    uint32_t ht_tb = 0;          // tag bits: m - log2(slots), or 0
+    uint32_t ht_shift = 0;       // 32 - m, m = bits of the index's slot count
+    uint32_t ht_tb = 0;          // tag bits: 2^tb >= ceil(2^m / slots)
     uint32_t ht_kmax = 0;        // probes per id
     uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)
     float* out_dists = nullptr;

@@ -160,23 +160,27 @@ __device__ __forceinline__ bool ht_insert_open_slot(uint32_t* ht, uint32_t mod, 
 // ---- the visited table with 16-bit entries (SearchArgs::ht16) ------------------------------------------------------
 // Half the LDS per id, still an exact set.  Ids live below 2^m (m = bits of the slot count of the index); probe k of id
 // looks at x_k = id * (A + k * B2) mod 2^m -- A odd, B2 even: every multiplier is odd, so id -> x_k is a bijection of
-// [0, 2^m) for every k.  The table has 2^b slots: slot = x_k >> tb (tb = m - b, the top b bits of the product, i.e.
-// multiplicative hashing), and the entry stores (k << tb) | (x_k & (2^tb - 1)).  Slot and entry together give k and
-// x_k, hence the id: two different ids never look alike, whatever the probe they were placed by.  0xFFFF is "empty"
-// (k stays below 2^(16 - tb) - 1, so no entry is all ones).  An id that finds kmax occupied slots is "exhausted": the
+// [0, 2^m) for every k.  The table has S slots (any even number): slot = floor(x_k * S / 2^m) (multiplicative hashing
+// onto [0, S)), so the x_k of one slot are a contiguous range of at most ceil(2^m / S) <= 2^tb values, and the entry
+// stores (k << tb) | (x_k & (2^tb - 1)): within one slot the low tb bits tell the x_k apart.  Slot and entry together
+// give k and x_k, hence the id: two different ids never look alike, whatever the probe they were placed by.  0xFFFF is
+// "empty" (k stays below 2^(16 - tb) - 1, so no entry is all ones).  An id that finds kmax occupied slots is "exhausted": the
 // caller freezes the table and sends it to the spill table in global memory (lookups keep probing kmax slots first).
 // Two slots share a dword and LDS has no 16-bit compare-and-swap: an insert swaps the whole dword and retries on the
 // same slot when the neighbour changed meanwhile.
 constexpr uint32_t kHt16A = 0x9E3779B1u, kHt16B2 = 0x3C6EF372u;
 enum : int { kHt16Present = 0, kHt16Inserted = 1, kHt16Exhausted = 2 };
 struct Ht16 {
-    uint32_t idmask, tb, kmax;
+    uint32_t shift, slots, tb, kmax;  // shift = 32 - m: x << shift is x_k as a 32-bit fraction of 2^m
 };
+__device__ __forceinline__ uint32_t ht16_slot(const Ht16& t, uint32_t x) { return __umulhi(x << t.shift, t.slots); }
+__device__ __forceinline__ uint32_t ht16_tag(const Ht16& t, uint32_t x, uint32_t tagmask) {
+    return ((x << t.shift) >> t.shift) & tagmask;
+}
 __device__ __forceinline__ int ht16_insert_open(uint32_t* htw, const Ht16& t, uint32_t id, bool active) {
     const uint32_t tagmask = (1u << t.tb) - 1u;
     uint32_t x = id * kHt16A;
-    uint32_t xm = x & t.idmask;
-    uint32_t slot = xm >> t.tb, val = xm & tagmask;
+    uint32_t slot = ht16_slot(t, x), val = ht16_tag(t, x, tagmask);
     uint32_t* wp = htw + (slot >> 1);
     uint32_t sh = (slot & 1u) << 4;
     uint32_t w = *wp;  // (inactive lanes read some slot of the table too: no branch around the load)
@@ -199,9 +203,8 @@ __device__ __forceinline__ int ht16_insert_open(uint32_t* htw, const Ht16& t, ui
                     res = kHt16Exhausted;
                     break;
                 }
-                xm = x & t.idmask;
-                slot = xm >> t.tb;
-                val = (xm & tagmask) | (k << t.tb);
+                slot = ht16_slot(t, x);
+                val = ht16_tag(t, x, tagmask) | (k << t.tb);
                 wp = htw + (slot >> 1);
                 sh = (slot & 1u) << 4;
                 w = *wp;
@@ -232,9 +235,8 @@ __device__ __forceinline__ bool ht16_contains(const uint32_t* htw, const Ht16& t
     uint32_t x = id * kHt16A;
     const uint32_t step = id * kHt16B2;
     for (uint32_t k = 0; k < t.kmax; ++k, x += step) {
-        const uint32_t xm = x & t.idmask;
-        const uint32_t cur = h16[xm >> t.tb];
-        if (cur == ((xm & tagmask) | (k << t.tb))) return true;
+        const uint32_t cur = h16[ht16_slot(t, x)];
+        if (cur == (ht16_tag(t, x, tagmask) | (k << t.tb))) return true;
         if (cur == 0xFFFFu) return false;
     }
     return false;
@@ -961,7 +963,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t ht_size = a.ht_entries;
     uint32_t status_early = 0;  // (HT16) an insert outside the hop found no slot: the query is re-run with a larger table
     const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size (HT16: the number of 16-bit slots)
-    const Ht16 h16{a.ht_idmask, a.ht_tb, a.ht_kmax};
+    const Ht16 h16{a.ht_shift, a.ht_prime, a.ht_tb, a.ht_kmax};
     // insert into the open table outside the hop (start points, the second phase of a range search)
     auto visit_open = [&](uint32_t id) {
         if constexpr (HT16) {

@@ -81,24 +81,27 @@ uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids, uint32_t useful_wa
 uint32_t largest_prime_leq(uint32_t n);
 
 // ---- 16-bit table entries (SearchArgs::ht16; device side: ht16_insert_open) -----------------------------------------
-// Geometry of a table of `words` dwords = 2 * words slots (a power of two) for ids below the index's slot count:
-// m id bits, tb = m - log2(slots) tag bits (0 when the table has a slot per id), 16 - tb bits left for the probe number.
+// Geometry of a table of `words` dwords = 2 * words slots (any even count) for ids below the index's slot count: m id
+// bits; the ids of one slot are at most ceil(2^m / slots) consecutive values, told apart by tb tag bits; 16 - tb bits
+// are left for the probe number.
 struct Ht16Geom {
     bool ok = false;
-    uint32_t idmask = 0, tb = 0, kmax = 0, slots = 0;
+    uint32_t shift = 0, tb = 0, kmax = 0, slots = 0;
 };
 Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
     Ht16Geom g;
     const uint32_t slots = words * 2u;
-    if (words < 32u || (slots & (slots - 1u))) return g;
-    uint32_t m = 1, b = 0;
+    if (words < 32u || slots > 65536u * 2u) return g;
+    uint32_t m = 1;
     while (m < 32u && (1ull << m) < (uint64_t)nslots) ++m;
-    while ((1u << b) < slots) ++b;
     if (m >= 32u) return g;
-    g.tb = m > b ? m - b : 0u;
-    if (g.tb > 13u) return g;  // fewer than 3 bits for the probe number: too few probes per id
-    g.idmask = (uint32_t)((1ull << m) - 1ull);
-    g.kmax = std::min<uint32_t>((1u << (16u - g.tb)) - 1u, 64u);
+    const uint64_t per_slot = ((1ull << m) + slots - 1) / slots;  // ids of one slot: at most this many consecutive values
+    uint32_t tb = 0;
+    while ((1ull << tb) < per_slot) ++tb;
+    if (tb > 13u) return g;  // fewer than 3 bits for the probe number: too few probes per id
+    g.tb = tb;
+    g.shift = 32u - m;
+    g.kmax = std::min<uint32_t>((1u << (16u - tb)) - 1u, 64u);
     g.slots = slots;
     g.ok = true;
     return g;
@@ -115,7 +118,7 @@ int32_t finish_visited_table(SearchArgs& a) {
             return DANN_EINTERNAL;
         }
         a.ht_prime = g.slots;
-        a.ht_idmask = g.idmask;
+        a.ht_shift = g.shift;
         a.ht_tb = g.tb;
         a.ht_kmax = g.kmax;
     } else {
@@ -129,7 +132,7 @@ uint64_t visited_open_capacity(const SearchArgs& a) {
 }
 
 // sizes the table of an automatically sized launch: the 32-bit table at the top of its occupancy step, or -- where the
-// kernel has them and they buy a higher step -- 16-bit entries in a power-of-two table
+// kernel has them and they buy a higher step -- 16-bit entries, also at the top of their step
 void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves, uint32_t format) {
     a.ht16 = 0;
     a.ht_entries = snap_visited_entries(a, cap_ids, useful_waves);
@@ -141,9 +144,8 @@ void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves
         return granules > kLdsGranules ? 0u : std::min<uint32_t>(kLdsGranules / (uint32_t)granules, useful_waves);
     };
     const uint64_t need = std::max<uint64_t>((uint64_t)((double)cap_ids / 0.75), 512);
-    uint32_t words = 256;  // 512 slots
-    while (words < 32768u && (uint64_t)words * 2u < need) words *= 2u;
-    while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
+    uint32_t words = (uint32_t)std::min<uint64_t>(((need + 1) / 2 + 63) / 64 * 64, 32768);  // multiples of 64 words
+    while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words = std::min<uint32_t>(words * 2u, 32768u);
     if (!ht16_geometry(words, a.ix.nslots).ok) return;
     const uint32_t w16 = waves_of(words), w32 = waves_of(a.ht_entries);
     // Measured (profiles/r04a_visited16_sgpr_ab_*.log): where the 32-bit table already lets a dozen and more queries
@@ -153,7 +155,9 @@ void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves
     if (format != 16u && (w16 <= w32 || w32 > 12u)) return;
     if (w16 == 0 && format != 16u) return;
     // a sparser table on the same step costs nothing but its wipe (cf. snap_visited_entries)
-    while (words < 32768u && (uint64_t)words * 4u <= (uint64_t)cap_ids * 8u && waves_of(words * 2u) == w16) words *= 2u;
+    while (words + 64u <= 32768u && (uint64_t)(words + 64u) * 2u <= (uint64_t)cap_ids * 8u && waves_of(words + 64u) == w16 &&
+           ht16_geometry(words + 64u, a.ix.nslots).ok)
+        words += 64u;
     a.ht16 = 1;
     a.ht_entries = words;
 }
@@ -331,12 +335,21 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
         const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
         const uint32_t waves = tune_env(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
-        if (a.pair) {  // one 16-bit table per query: the power of two that holds the 90th percentile at 75 % load
+        if (a.pair) {
+            // one 16-bit table per query: the largest table of the first LDS step (1 280-byte granules per wavefront = two
+            // queries) whose open capacity -- 75 % of its slots -- holds the 90th percentile of the comparisons with a
+            // tenth to spare: the step decides how many wavefronts share a CU, and the pair kernel lives on that
+            // (profiles/r04m: 16 / 8 / 4 wavefronts per CU -> 2.09 / 2.94 / 5.27 ms)
             const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
-            uint32_t words = 256;
-            while (words < 8192u && (uint64_t)words * 2u * 3u / 4u < cap) words *= 2u;
-            while (words < 8192u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
-            if (ht16_geometry(words, a.ix.nslots).ok) {
+            const uint32_t fixed = pair_lds_layout(0).half_bytes;
+            uint32_t words = 0;
+            for (uint32_t g = 2; g <= kLdsGranules && !words; ++g) {
+                const uint32_t half = g * kLdsGranule / 2u;
+                if (half <= fixed) continue;
+                const uint32_t w = std::min<uint32_t>((half - fixed) / 4u / 4u * 4u, 16384u);
+                if ((uint64_t)w * 2u * 3u / 4u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+            }
+            if (words) {
                 a.ht16 = 1;
                 a.ht_entries = words;
             } else {
@@ -355,9 +368,8 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         a.ht16 = 0;
         if (a.pair && idx->visited_format != 16u) a.pair = 0;  // (the pair kernel has 16-bit tables only)
         if (idx->visited_format == 16u && ht16_eligible(a)) {
-            uint32_t words = 32;
-            while (words < 32768u && words < a.ht_entries) words *= 2u;
-            while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words *= 2u;
+            uint32_t words = std::max<uint32_t>((a.ht_entries + 63u) / 64u * 64u, 64u);
+            while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words = std::min<uint32_t>(words * 2u, 32768u);
             if (ht16_geometry(words, a.ix.nslots).ok) {
                 a.ht16 = 1;
                 a.ht_entries = words;

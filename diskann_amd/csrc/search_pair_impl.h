@@ -38,12 +38,12 @@ __host__ __device__ inline PairLds pair_lds_layout(uint32_t ht_words) {
     PairLds l;
     l.cand_id_off = 0;
     l.cand_d_off = 128;
-    l.stage_off = 256;
-    l.qimg_off = 512;  // 64 keys: the upper 32 stay "beyond the queue" (the lower-bound search needs no bound check)
-    l.sd_off = 768;
-    l.sink_off = 896;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
+    l.stage_off = 0;   // the scatter buffer of a merge takes the candidates' place: they are in registers by then
+    l.qimg_off = 256;  // 64 keys: the upper 32 stay "beyond the queue" (the lower-bound search needs no bound check)
+    l.sd_off = 512;
+    l.sink_off = 640;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
                        // 8-byte stores of the merge's scatter sink into [sd, sink): the survivors' keys are dead by then
-    l.ht_off = 1024;
+    l.ht_off = 768;
     l.half_bytes = l.ht_off + ht_words * 4u;
     return l;
 }
@@ -62,8 +62,7 @@ __device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& 
     uint32_t k = 0, res = 0;
     bool pending = active;
     do {
-        const uint32_t xm = x & t.idmask;
-        const uint32_t slot = xm >> t.tb, val = (xm & tagmask) | (k << t.tb);
+        const uint32_t slot = ht16_slot(t, x), val = ht16_tag(t, x, tagmask) | (k << t.tb);
         uint32_t* const wp = htw + (slot >> 1);
         const uint32_t sh = (slot & 1u) << 4;
         const uint32_t w = *wp;
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint32_t* const sink = reinterpret_cast<uint32_t*>(hbase + L.sink_off) + li;  // this lane's own sink
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
-    const Ht16 h16{a.ht_idmask, a.ht_tb, a.ht_kmax};
+    const Ht16 h16{a.ht_shift, a.ht_prime, a.ht_tb, a.ht_kmax};
     const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
@@ -239,6 +238,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
             const bool has = li < ncv;
             const float nd = cand_d[li];
             const uint32_t nid = cand_id[li];
+            asm volatile("" ::: "memory");  // (the scatter below is written over the candidates' buffers)
             const uint32_t oknd = ordered_bits(nd), okq = ordered_bits(qd);
             // a full queue rejects what is worse than its last entry (queue.rs:142-146)
             const uint32_t okw = qimg[(sizev - 1u) & 63u];

@@ -1,9 +1,10 @@
 """CPU model of the 16-bit visited table (search_kernel_impl.h: ht16_insert_open / ht16_contains, search_kernels.hip:
 ht16_geometry).  The device code stores 16 bits per id and still has to be an exact set -- NotInMut is a
 hashbrown::HashSet (diskann/src/graph/glue.rs:524-561).  The argument: probe k of id looks at x_k = id * (A + k * B2)
-mod 2^m with an odd multiplier, a bijection of [0, 2^m); slot = top bits of x_k, entry = (k, low bits of x_k): slot and
-entry give back x_k and k, hence the id.  This file checks that argument on the same constants and the same geometry
-rule, and replays inserts against a Python set."""
+mod 2^m with an odd multiplier, a bijection of [0, 2^m); slot = floor(x_k * S / 2^m) for a table of S slots (any even
+count), so the x_k of one slot are at most ceil(2^m / S) consecutive values and their low tb bits tell them apart;
+entry = (k, low tb bits of x_k): slot and entry give back x_k and k, hence the id.  This file checks that argument on
+the same constants and the same geometry rule, and replays inserts against a Python set."""
 import numpy as np
 
 A, B2 = 0x9E3779B1, 0x3C6EF372
@@ -11,15 +12,17 @@ A, B2 = 0x9E3779B1, 0x3C6EF372
 
 def geometry(words, nslots):
     slots = words * 2
-    if words < 32 or slots & (slots - 1):
+    if words < 32 or slots > 131072:
         return None
     m = 1
     while m < 32 and (1 << m) < nslots:
         m += 1
-    b = slots.bit_length() - 1
     if m >= 32:
         return None
-    tb = max(m - b, 0)
+    per_slot = ((1 << m) + slots - 1) // slots
+    tb = 0
+    while (1 << tb) < per_slot:
+        tb += 1
     if tb > 13:
         return None
     return dict(idmask=(1 << m) - 1, tb=tb, kmax=min((1 << (16 - tb)) - 1, 64), slots=slots, m=m)
@@ -27,11 +30,12 @@ def geometry(words, nslots):
 
 def probe(g, ident, k):
     x = (ident * (A + k * B2)) & 0xFFFFFFFF & g["idmask"]
-    return x >> g["tb"], (x & ((1 << g["tb"]) - 1)) | (k << g["tb"])
+    return (x * g["slots"]) >> g["m"], (x & ((1 << g["tb"]) - 1)) | (k << g["tb"])
 
 
 def test_slot_and_entry_determine_the_id():
-    for words, nslots in ((32, 100), (64, 4001), (256, 70000), (1024, 1 << 20), (2048, 1_000_001), (4096, 10_000_001)):
+    for words, nslots in ((32, 100), (64, 4001), (256, 70000), (1024, 1 << 20), (2048, 1_000_001), (4096, 10_000_001),
+                          (928, 1_000_001), (768, 1_000_001), (1504, 10_000_001), (36, 4001)):
         g = geometry(words, nslots)
         assert g is not None
         ids = np.arange(min(nslots, 1 << 18), dtype=np.uint64)
@@ -41,7 +45,7 @@ def test_slot_and_entry_determine_the_id():
         seen = {}
         for k in range(min(g["kmax"], 6)):
             x = (ids * np.uint64((A + k * B2) & 0xFFFFFFFF)) & np.uint64(g["idmask"])
-            slot = x >> np.uint64(g["tb"])
+            slot = (x * np.uint64(g["slots"])) >> np.uint64(g["m"])
             entry = (x & np.uint64((1 << g["tb"]) - 1)) | np.uint64(k << g["tb"])
             assert entry.max() < 0xFFFF, "0xFFFF is the empty mark"
             assert slot.max() < g["slots"]
@@ -53,7 +57,7 @@ def test_slot_and_entry_determine_the_id():
 
 
 def test_geometry_limits():
-    assert geometry(48, 100) is None            # not a power of two
+    assert geometry(48, 100) is not None        # any even slot count
     assert geometry(16, 100) is None
     assert geometry(1024, 100_000_001) is None  # 27 id bits over 2^11 slots: no room for a probe number
     g = geometry(8192, 100_000_001)             # 2^14 slots: 13 tag bits, 7 probes
@@ -67,7 +71,7 @@ def test_geometry_limits():
 def test_replay_against_a_set():
     """insert / lookup exactly as the device does (first empty slot among the probes, exhausted after kmax)"""
     rng = np.random.default_rng(7)
-    for words, nslots, fill in ((64, 5001, 96), (256, 1 << 20, 380), (256, 3_000_000, 384)):
+    for words, nslots, fill in ((64, 5001, 96), (256, 1 << 20, 380), (256, 3_000_000, 384), (928, 1_000_001, 1390)):
         g = geometry(words, nslots)
         table = {}
         truth, exhausted = set(), set()
