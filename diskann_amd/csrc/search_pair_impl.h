@@ -192,8 +192,8 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint32_t pf_len = 0, pf_val = kEmpty;
     for (;;) {
         // ---- distances of cand_id[0 .. nc) of both halves: 4 lane groups per half, every row of the hop requested before
-        // the first one is evaluated (one memory round trip per hop: 4 rows per lane group when neither half has more than
-        // 16 candidates, else 8).  The sums end up in lanes 0-3 of a group: lane u stores the result of row u.
+        // the first one is evaluated (one memory round trip per hop: 4, 6 or 8 rows per lane group, by the larger of
+        // the halves' candidate counts).  The sums end up in lanes 0-3 of a group: lane u stores the result of row u.
         {
             const uint32_t nc0 = rl_u32(ncv, 0), nc1 = rl_u32(ncv, (int)kPairHalf);
             const uint32_t ncmax = nc0 > nc1 ? nc0 : nc1;
@@ -210,21 +210,22 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                 }
                 group_distance_int_pre<OP, SIGNED, U>(xqi, xx_pre, rows, v, out);
 #pragma unroll
-                for (int h = 0; h < U / 4; ++h) {
+                for (int h = 0; h < (U + 3) / 4; ++h) {
                     float val = out[4 * h];
                     const uint8_t* row = rows[4 * h];
 #pragma unroll
-                    for (int u = 1; u < 4; ++u) {
+                    for (int u = 1; u < 4 && 4 * h + u < U; ++u) {
                         val = v == u ? out[4 * h + u] : val;
                         if constexpr (DT == DT_SQ8 && OP != OP_L2) row = v == u ? rows[4 * h + u] : row;
                     }
                     const uint32_t ci = (uint32_t)(4 * h + v) * 4u + g4;
-                    const bool ok = (v < 4) & (ci < ncv);
+                    const bool ok = (v < 4) & (4 * h + v < U) & (ci < ncv);
                     float* dst = ok ? cand_d + (ci & 31u) : reinterpret_cast<float*>(sink);
                     *dst = finish_distance<DT, OP, NORM>(val, qsrc, row, ix.dim, sqp);
                 }
             };
-            if (ncmax > 16u) gather(std::integral_constant<int, 8>());
+            if (ncmax > 24u) gather(std::integral_constant<int, 8>());
+            else if (ncmax > 16u) gather(std::integral_constant<int, 6>());
             else if (ncmax) gather(std::integral_constant<int, 4>());
             cmpsv += ncv;
         }
