@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 D=/tmp/prof_${TAG}_$WL
 rm -rf $D && mkdir -p $D
-case $WL in gather) FLT=expand_beam;; *) FLT=beam_search;; esac
+case $WL in gather) FLT=expand_beam;; *) FLT=search_kernel;; esac
 python $R/bench.py --only $WL "$@" > $OUT/${TAG}_${WL}.json 2> $OUT/${TAG}_${WL}.err
 L=$(python -c "import json;d=json.loads(open('$OUT/${TAG}_${WL}.json').read().strip().splitlines()[-1]);v=list(d.values())[0];print(v.get('L',0))")
 LARG=""; if [ "$L" != "0" ]; then LARG="--L $L"; fi
