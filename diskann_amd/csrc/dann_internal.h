@@ -10,6 +10,8 @@
 #include <new>
 #include <shared_mutex>
 #include <string>
+#include <thread>
+#include <functional>
 #include <unordered_map>
 #include <vector>
 
@@ -239,6 +241,34 @@ int32_t launch_distance_raw(const IndexView& ix, const void* d_x, const void* d_
 
 struct dann_server;  // persistent search server (server.hip)
 
+namespace dann {
+// A counter many threads bump at millions of operations per second (the per-query path of the search server): one cell
+// per cache line, a thread uses "its" cell; only the rare readers (dann_server_stop, a mutation's busy test) sum them.
+// With sixteen callers on ONE atomic the server's throughput halved (4.5 -> 2.2 M queries/s at 64 tickets in flight per
+// thread).  All operations are sequentially consistent: the publish-then-look handshakes built on it rely on that.
+struct ShardedCounter {
+    static constexpr uint32_t kCells = 32;
+    struct alignas(64) Cell {
+        std::atomic<int64_t> v{0};
+    };
+    Cell cell[kCells];
+    static uint32_t home() {
+        static thread_local const uint32_t h = (uint32_t)(std::hash<std::thread::id>()(std::this_thread::get_id()) *
+                                                          0x9E3779B97F4A7C15ull >> 59);
+        return h & (kCells - 1u);
+    }
+    void add(int64_t d) { cell[home()].v.fetch_add(d, std::memory_order_seq_cst); }
+    int64_t sum() const {
+        int64_t s = 0;
+        for (const Cell& c : cell) s += c.v.load(std::memory_order_seq_cst);
+        return s;
+    }
+    void reset() {
+        for (Cell& c : cell) c.v.store(0, std::memory_order_seq_cst);
+    }
+};
+}  // namespace dann
+
 struct dann_index {
     dann_config cfg;
     int device = 0;
@@ -282,8 +312,8 @@ struct dann_index {
     // frees anything.  srv_outstanding = tickets submitted and not yet collected; `mutating` = mutations in progress:
     // the two sides of the "no mutation while tickets are outstanding" rule (MutationScope, DANN_EBUSY).
     std::atomic<dann_server*> server{nullptr};
-    std::atomic<uint32_t> srv_users{0};
-    std::atomic<int64_t> srv_outstanding{0};
+    dann::ShardedCounter srv_users;
+    dann::ShardedCounter srv_outstanding;
     std::atomic<uint32_t> mutating{0};
     dann::IndexView view() const;
 };
@@ -311,7 +341,7 @@ struct MutationScope {
     bool ok;
     explicit MutationScope(const dann_index* idx) : i(const_cast<dann_index*>(idx)) {
         i->mutating.fetch_add(1, std::memory_order_seq_cst);
-        ok = i->srv_outstanding.load(std::memory_order_seq_cst) == 0;
+        ok = i->srv_outstanding.sum() == 0;
         if (!ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);
     }
     ~MutationScope() {

@@ -107,10 +107,10 @@ struct ServerPin {
     dann_index* i;
     dann_server* s;
     explicit ServerPin(dann_index* idx) : i(idx) {
-        i->srv_users.fetch_add(1, std::memory_order_seq_cst);
+        i->srv_users.add(1);
         s = i->server.load(std::memory_order_seq_cst);
     }
-    ~ServerPin() { i->srv_users.fetch_sub(1, std::memory_order_release); }
+    ~ServerPin() { i->srv_users.add(-1); }
     ServerPin(const ServerPin&) = delete;
     ServerPin& operator=(const ServerPin&) = delete;
 };
@@ -311,7 +311,7 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
         (void)hipStreamSynchronize(s->ctx.stream);
         return fail(rc);
     }
-    idx->srv_outstanding.store(0, std::memory_order_seq_cst);
+    idx->srv_outstanding.reset();
     idx->server.store(s, std::memory_order_seq_cst);
     return DANN_OK;
 } DANN_CATCH_ALL
@@ -332,8 +332,8 @@ int32_t dann_server_stop(dann_index* idx) try {
     }
     // callers still inside submit / wait / poll: their loops see `stopping` and return (DANN_EINVAL: the server is
     // gone); nothing of the server is freed before the last of them has left
-    while (idx->srv_users.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
-    idx->srv_outstanding.store(0, std::memory_order_seq_cst);  // uncollected tickets die with the server
+    while (idx->srv_users.sum() != 0) std::this_thread::yield();
+    idx->srv_outstanding.reset();  // uncollected tickets die with the server
     s->ctx.destroy();
     if (s->h_block) (void)hipHostFree(s->h_block);
     if (s->d_block) (void)hipFree(s->d_block);
@@ -362,8 +362,8 @@ int32_t dann_search_submit(dann_index* idx, const void* query, uint64_t* ticket)
     };
     if (s->poisoned.load(std::memory_order_acquire)) return dead();
     // the "no mutation while tickets are outstanding" rule, this side: count the ticket, then look for a mutation
-    idx->srv_outstanding.fetch_add(1, std::memory_order_seq_cst);
-    auto uncount = [&]() { idx->srv_outstanding.fetch_sub(1, std::memory_order_seq_cst); };
+    idx->srv_outstanding.add(1);
+    auto uncount = [&]() { idx->srv_outstanding.add(-1); };
     if (idx->mutating.load(std::memory_order_seq_cst) != 0) {
         uncount();
         set_error("dann_search_submit: the index is being mutated");
@@ -504,7 +504,7 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
     if (st.status) q.assign(sv.h_queries + (size_t)slot * sv.qstride, sv.h_queries + (size_t)slot * sv.qstride + sv.qbytes);
     s->slot_owner[slot].store(0, std::memory_order_release);
     s->give_slot(slot, dann_server::home_stack());
-    idx->srv_outstanding.fetch_sub(1, std::memory_order_seq_cst);
+    idx->srv_outstanding.add(-1);
     }
     if (st.status) {
         // the resident waves carry a fixed LDS visited table: the rare query that outgrows it (and the spill pool) is
