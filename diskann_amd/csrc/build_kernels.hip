@@ -1234,6 +1234,7 @@ struct TileArgs {
     float* gram;          // n x ng x mg, entry (p, q) valid for q < p (and on the diagonal blocks)
     float* nrm;           // n x ng
     unsigned long long* counters;  // PruneCfg::counters: [2] += rows, [3] += tiles * 1024 (x dim x 2 = MFMA flop)
+    const uint32_t* order = nullptr;  // optional: workgroup b works on item order[b] (longest lists first)
 };
 
 constexpr int kTileRowBlocks = 8;  // ng <= 256: wave w of the 8-wave workgroup owns row block w
@@ -1283,29 +1284,55 @@ __device__ __forceinline__ float4 tile_fetch4<__half>(const uint8_t* row, uint32
     return q;
 }
 
-// one 32-column slab of NT tiles that share the row-block operand: every operand of the slab is read from LDS up front
-// (the compiler is free to interleave), then 16 NT independent-accumulator MFMAs stream into the matrix pipe
+// one 32-column slab of NT tiles that share the row-block operand.  The operands come from LDS in chunks of CK k-pairs, the
+// next chunk requested before the MFMAs of the current one are issued.  The scheduling barriers pin that order: left to
+// itself the compiler puts every read directly in front of its MFMAs (read, wait, two MFMAs, read, wait, ...), and all 16
+// (1 + NT) operands up front would be 64 registers.
 template <int NT>
-__device__ __forceinline__ void tile_slab(const float* pa, const float* pc, f32x16 (&acc)[kTileColBlocks]) {
-    float av[16], bv[NT][16];
+__device__ __forceinline__ void tile_slab(const float* pa, const float* pc, f32x16 (&acc)[NT]) {
+    constexpr int CK = NT == 3 ? 2 : 4, NC = 16 / CK;
+    float av[2][CK], bv[2][NT][CK];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        av[kk] = pa[2 * kk];
+    for (int j = 0; j < CK; ++j) {
+        av[0][j] = pa[2 * j];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t][kk] = pc[t * 32 * 33 + 2 * kk];
+        for (int t = 0; t < NT; ++t) bv[0][t][j] = pc[t * 32 * 33 + 2 * j];
     }
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[t][kk], acc[t], 0, 0, 0);
+            for (int j = 0; j < CK; ++j) {
+                av[(c + 1) & 1][j] = pa[2 * (CK * (c + 1) + j)];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[(c + 1) & 1][t][j] = pc[t * 32 * 33 + 2 * (CK * (c + 1) + j)];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CK; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j], bv[c & 1][t][j], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-template <typename RT>
-__global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
+// rows of one LDS slab: the fill writes whole passes of 64 rows
+__host__ __device__ inline uint32_t tile_slab_rows(uint32_t ng) { return (ng + 63u) & ~63u; }
+
+template <typename RT, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float* slab = reinterpret_cast<float*>(smem);  // ng rows x 33 floats
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, item = blockIdx.x;
+    // two slabs of 32 columns (rows x 33 floats each): slab k + 1 is written while the MFMAs of slab k are in the pipe --
+    // one barrier per slab, and the only phase of a workgroup without MFMA work is the first fill
+    const uint32_t slab_floats = tile_slab_rows(a.ng) * 33u;
+    float* const slab0 = reinterpret_cast<float*>(smem);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, item = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform for the compiler too
+    // row block of this wave.  Row block b has min(b, 2) + 1 tiles, and wave w sits on SIMD w % 4: in item order the light
+    // row blocks of every workgroup would share a SIMD.  Odd workgroups take them in reverse (two workgroups per CU).
+    const uint32_t rb = (blockIdx.x & 1u) ? (uint32_t)(kTileRowBlocks - 1) - wave : wave;
     const uint32_t N = a.sn[item];
     const uint32_t nrows = N < a.ng ? N : a.ng, ncols = N < a.mg ? N : a.mg;
     if (nrows == 0) return;
@@ -1316,84 +1343,96 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
     // (a load under a per-lane condition gets its own s_waitcnt and the prefetch degenerates to one request in flight):
     // rows that do not exist or cannot be retrieved point at row 0 and are zeroed when the slab is written.
     const uint32_t lr = tid >> 3, c4 = (tid & 7u) << 2;
-    const uint8_t* rowp[kTilePasses];
-    bool rowok[kTilePasses];
+    // (register diet: 48 accumulators + 16 prefetch registers leave little under the 128 of two workgroups per CU -- a
+    // row is kept as its id, kEmpty for a zero row, and its address is formed at the request)
+    uint32_t rowid[kTilePasses];
     double nsq[kTilePasses];
 #pragma unroll
     for (int p = 0; p < kTilePasses; ++p) {
         const uint32_t r = ((uint32_t)p << 6) + lr;
         const uint32_t id = r < nrows ? ids[r] : kEmpty;
-        rowok[p] = id < a.ix.nslots;  // ids the sweep excludes anyway (not retrievable) read as zero rows
-        rowp[p] = a.ix.rows + (uint64_t)(rowok[p] ? id : 0u) * a.ix.row_stride + (size_t)c4 * sizeof(RT);
+        rowid[p] = id < a.ix.nslots ? id : kEmpty;  // ids the sweep excludes anyway (not retrievable) read as zero rows
         nsq[p] = 0.0;
     }
+    const uint8_t* const rows_c4 = a.ix.rows + (size_t)c4 * sizeof(RT);
+    auto row_ptr = [&](int p) -> const uint8_t* {
+        return rows_c4 + (uint64_t)(rowid[p] != kEmpty ? rowid[p] : 0u) * a.ix.row_stride;
+    };
     float4 nxt[kTilePasses];
     const uint32_t dim_full = dim & ~31u;  // slabs below this are complete: one 4-element request per thread and row
-    // tiles of this wave: row block `wave`, column blocks 0 .. min(wave, TC - 1)
-    const uint32_t nt = wave < TR ? ((wave < TC ? wave : TC - 1u) + 1u) : 0u;
-    f32x16 acc[kTileColBlocks];
-#pragma unroll
-    for (int t = 0; t < kTileColBlocks; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // tiles of this wave: row block `rb`, column blocks 0 .. min(rb, TC - 1)
+    const uint32_t nt = rb < TR ? ((rb < TC ? rb : TC - 1u) + 1u) : 0u;
     const uint32_t l31 = lane & 31u, hi = lane >> 5;
-    const uint32_t fill_rows = TR << 5;
-    const float* pa = slab + ((wave << 5) + l31) * 33u + hi;
-    const float* pc = slab + l31 * 33u + hi;
-    auto write_slab = [&]() {
+    const uint32_t fill_passes = (TR + 1u) >> 1;  // whole passes (wave-uniform): rows past the item's last are zero rows
+    const uint32_t pa_off = ((rb << 5) + l31) * 33u + hi, pc_off = l31 * 33u + hi;
+    auto write_slab = [&](float* slab) {
 #pragma unroll
         for (int p = 0; p < kTilePasses; ++p) {
-            const uint32_t r = ((uint32_t)p << 6) + lr;
-            if (r < fill_rows) {
+            if ((uint32_t)p < fill_passes) {
                 float4 q = nxt[p];
-                if (!rowok[p]) q = float4{0.f, 0.f, 0.f, 0.f};
-                float* dst = slab + r * 33u + c4;
+                if (rowid[p] == kEmpty) q = float4{0.f, 0.f, 0.f, 0.f};
+                float* dst = slab + (((uint32_t)p << 6) + lr) * 33u + c4;
                 dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
                 nsq[p] += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
             }
         }
     };
-    auto mfma_slab = [&]() {
-        if (nt == 3u) tile_slab<3>(pa, pc, acc);
-        else if (nt == 2u) tile_slab<2>(pa, pc, acc);
-        else if (nt == 1u) tile_slab<1>(pa, pc, acc);
-    };
-    if (dim_full) {
-        // steady state: one basic block of requests per slab -- all kTilePasses of them, unconditionally (passes beyond
-        // the item's rows re-read row 0 from cache): a request under a branch, even a uniform one, is fenced by its own
-        // s_waitcnt.  The last iteration re-requests its own slab instead of branching around the prefetch.
+    float* const g = a.gram + (uint64_t)item * a.ng * a.mg;
+    // The whole slab loop is instantiated per tile count of the wave (0 .. 3).  A branch on the count inside the loop makes
+    // the accumulators a three-way merge in every iteration: the compiler then keeps two copies of all 48 of them (and
+    // moves one into the other every slab), which is what drove this kernel into scratch until round 4.
+    auto run = [&](auto ntc) {
+        constexpr int NT = decltype(ntc)::value;
+        f32x16 acc[NT > 0 ? NT : 1];
 #pragma unroll
-        for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p]);
-        for (uint32_t k0 = 0; k0 < dim_full; k0 += 32u) {
-            write_slab();
+        for (int t = 0; t < (NT > 0 ? NT : 1); ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        uint32_t cur = 0;  // the slab the next MFMAs read: slab0 + cur * slab_floats
+        if (dim_full) {
+            // steady state: one basic block of requests per slab -- all kTilePasses of them, unconditionally (passes
+            // beyond the item's rows re-read row 0 from cache): a request under a branch, even a uniform one, is fenced
+            // by its own s_waitcnt.  The last iteration re-requests its own slab instead of branching around the prefetch.
+#pragma unroll
+            for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(row_ptr(p));
+            write_slab(slab0);
             __syncthreads();
-            const uint32_t kn = k0 + 32u < dim_full ? k0 + 32u : k0;
+            for (uint32_t k0 = 0; k0 < dim_full; k0 += 32u) {
+                const bool more = k0 + 32u < dim_full;
+                const uint32_t kn = more ? k0 + 32u : k0;
 #pragma unroll
-            for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(rowp[p] + (size_t)kn * sizeof(RT));
-            mfma_slab();
-            __syncthreads();
-        }
-    }
-    if (dim_full < dim) {  // the last, partial slab (dim % 32 != 0): element-wise requests, once per item
-#pragma unroll
-        for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_fetch4<RT>(rowp[p] - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
-        write_slab();
-        __syncthreads();
-        mfma_slab();
-        __syncthreads();
-    }
-    // C layout of v_mfma_f32_32x32x2_f32: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    float* g = a.gram + (uint64_t)item * a.ng * a.mg;
-#pragma unroll
-    for (int t = 0; t < kTileColBlocks; ++t) {
-        if ((uint32_t)t < nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t i = (wave << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
-                g[(uint64_t)i * a.mg + ((uint32_t)t << 5) + l31] = acc[t][r];  // i < 32 TR <= ng, column < 32 TC <= mg
+                for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(row_ptr(p) + (size_t)kn * sizeof(RT));
+                __builtin_amdgcn_sched_barrier(0);  // the requests go out before the MFMAs, not behind them
+                if constexpr (NT > 0) tile_slab<NT>(slab0 + cur * slab_floats + pa_off, slab0 + cur * slab_floats + pc_off, acc);
+                cur ^= 1u;
+                if (more) write_slab(slab0 + cur * slab_floats);  // nobody reads this one before the barrier
+                __syncthreads();
             }
         }
-    }
+        if (dim_full < dim) {  // the last, partial slab (dim % 32 != 0): element-wise requests, once per item
+#pragma unroll
+            for (int p = 0; p < kTilePasses; ++p)
+                nxt[p] = tile_fetch4<RT>(row_ptr(p) - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
+            write_slab(slab0 + cur * slab_floats);  // every wave is past the barrier behind the last MFMAs
+            __syncthreads();
+            if constexpr (NT > 0) tile_slab<NT>(slab0 + cur * slab_floats + pa_off, slab0 + cur * slab_floats + pc_off, acc);
+        }
+        // C layout of v_mfma_f32_32x32x2_f32: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+        if constexpr (NT > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t i = (rb << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
+                    g[(uint64_t)i * a.mg + ((uint32_t)t << 5) + l31] = acc[t][r];  // i < 32 TR <= ng, column < 32 TC <= mg
+                }
+            }
+        }
+    };
+    if (nt == 3u) run(std::integral_constant<int, 3>{});
+    else if (nt == 2u) run(std::integral_constant<int, 2>{});
+    else if (nt == 1u) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
     // squared norms: the 8 threads of a row hold f64 partial sums
     float* nr = a.nrm + (uint64_t)item * a.ng;
 #pragma unroll
@@ -1413,6 +1452,36 @@ __global__ __launch_bounds__(512, 4) void gram_tiles_kernel(TileArgs a) {
     }
 }
 
+// Longest lists first: a sweep is a serial walk over its list, and a launch in item order ends with a few long lists on an
+// otherwise idle chip (1 M x 768, 16 384 pools per launch: 6 of 13 wavefront slots per CU occupied on average).  The
+// workgroups of the Gram and sweep kernels take their items in descending order of list length instead -- a counting
+// sort by length, one workgroup (the order among equal lengths is whatever the atomics give: no result depends on it).
+constexpr uint32_t kOrderBins = kMaxPool + 1u;
+__global__ __launch_bounds__(1024) void lpt_order_kernel(const uint32_t* sn, uint32_t m, uint32_t* order) {
+    __shared__ uint32_t hist[kOrderBins];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < kOrderBins; i += 1024u) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024u) atomicAdd(&hist[sn[i] < kMaxPool ? sn[i] : kMaxPool], 1u);
+    __syncthreads();
+    if (tid < 64u) {  // exclusive scan from the longest bin down: 64 bins per step
+        uint32_t acc = 0;
+        for (int base = (int)kOrderBins - 1; base >= 0; base -= 64) {
+            const int b = base - (int)tid;
+            const uint32_t c = b >= 0 ? hist[b] : 0u;
+            uint32_t inc = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if ((int)tid >= o) inc += t;
+            }
+            if (b >= 0) hist[b] = acc + inc - c;
+            acc += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024u) order[atomicAdd(&hist[sn[i] < kMaxPool ? sn[i] : kMaxPool], 1u)] = i;
+}
+
 struct SweepArgs {
     PoolArgs p;
     const uint32_t* sid;
@@ -1428,13 +1497,14 @@ struct SweepArgs {
     uint32_t* prunes = nullptr;      // [0] += 1 per pruned list (BackArgs::counters + 1)
     uint32_t* mfma_prunes = nullptr; // optional statistic
     uint32_t one_by_one = 0;         // development switch (DANN_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
+    const uint32_t* order = nullptr; // optional: workgroup b works on item order[b] (longest lists first)
 };
 
 template <int DT, int OP, bool NORM>
 __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const PoolArgs& a = sa.p;
-    const uint32_t lane = threadIdx.x, wi = blockIdx.x, item = a.pos0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x, wi = sa.order ? sa.order[blockIdx.x] : blockIdx.x, item = a.pos0 + wi;
     const uint32_t N = sa.sn[wi];
     if (N == 0) {  // pool prune: overflow (reported by pool_sort_kernel) or an empty pool; back-edges: nothing to prune
         if (lane == 0 && !sa.out_loc) a.out[(uint64_t)wi * a.out_stride] = 0;
@@ -1668,10 +1738,27 @@ DANN_LAUNCHER(SweepLauncher, pool_sweep_kernel, SweepArgs)
 DANN_LAUNCHER(BackListLauncher, backedge_list_kernel, BackListArgs)
 
 int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) {
-    const size_t lds = (size_t)a.ng * 33u * 4u;
-    if (a.ix.dtype == DT_F32) hipLaunchKernelGGL(gram_tiles_kernel<float>, dim3(grid), dim3(512), lds, stream, a);
-    else if (a.ix.dtype == DT_F16) hipLaunchKernelGGL(gram_tiles_kernel<__half>, dim3(grid), dim3(512), lds, stream, a);
-    else return DANN_EUNSUPPORTED;
+    const size_t lds = 2u * (size_t)tile_slab_rows(a.ng) * 33u * 4u;  // two slabs
+    if (a.ix.dtype != DT_F32 && a.ix.dtype != DT_F16) return DANN_EUNSUPPORTED;
+    // DANN_GRAM_WAVES (development switch): 2 = a register budget of 256 (one workgroup per CU), default 4 (two per CU)
+    static const int occ = [] {
+        const char* e = getenv("DANN_GRAM_WAVES");
+        return e && atoi(e) == 2 ? 2 : 4;
+    }();
+    const bool f32 = a.ix.dtype == DT_F32;
+    const void* fn = occ == 2 ? (f32 ? (const void*)gram_tiles_kernel<float, 2> : (const void*)gram_tiles_kernel<__half, 2>)
+                              : (f32 ? (const void*)gram_tiles_kernel<float, 4> : (const void*)gram_tiles_kernel<__half, 4>);
+    if (lds > 64u * 1024u) {  // beyond the default limit of dynamic LDS
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute");
+    }
+    if (occ == 2) {
+        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 2>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 2>), dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 4>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 4>), dim3(grid), dim3(512), lds, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gram_tiles_kernel launch");
     return DANN_OK;
@@ -1762,7 +1849,7 @@ struct BuildScratch {
     DevBuf counters;  // 8 x u64, see PruneCfg::counters (accumulate until dann_build_counters_reset)
     size_t sort_tmp_bytes = 0;
     // MFMA pool prune: sorted pools, Gram blocks and norms of one batch slice (grow-only)
-    DevBuf g_sid, g_sd, g_sn, g_loc, g_gram, g_nrm;
+    DevBuf g_sid, g_sd, g_sn, g_loc, g_gram, g_nrm, g_order;
     size_t g_sorted_elems = 0, g_items = 0, g_gram_elems = 0, g_nrm_elems = 0;
     // HIP-event time of the gram_tiles_kernel launches (dann_kernel_time, which = 5): pairs of events around every
     // launch on the build stream, resolved without ever making the build wait (a pair is read once it has completed,
@@ -1798,9 +1885,18 @@ struct BuildScratch {
         ++tile_head;
         return DANN_OK;
     }
+    // second stream of a commit: the few long back-edge lists of a batch (one wavefront each, a serial prune of hundreds
+    // of candidates) run beside the short lists instead of holding the chip for themselves
+    hipStream_t side = nullptr;
+    int32_t side_stream(hipStream_t* out) {
+        if (!side) DANN_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        *out = side;
+        return DANN_OK;
+    }
     ~BuildScratch() {
         for (hipEvent_t e : tile_ev)
             if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -1851,6 +1947,7 @@ int32_t ensure_gram_scratch(BuildScratch& s, size_t items, uint32_t pcap, uint32
         s.g_items = 0;
         DANN_HIP(s.g_sn.alloc(items * 4));
         DANN_HIP(s.g_loc.alloc(items * 4));
+        DANN_HIP(s.g_order.alloc(items * 4));
         s.g_items = items;
     }
     if (s.g_gram_elems < gram_elems) {
@@ -1867,6 +1964,14 @@ int32_t ensure_gram_scratch(BuildScratch& s, size_t items, uint32_t pcap, uint32
 }
 
 }  // namespace
+
+// the order of the Gram / sweep workgroups of one slice (lpt_order_kernel); DANN_BUILD_ITEM_ORDER: development switch
+static const uint32_t* longest_first(BuildScratch& s, const uint32_t* sn, uint32_t m, hipStream_t st) {
+    static const bool off = getenv("DANN_BUILD_ITEM_ORDER") != nullptr;
+    if (off || m < 2u) return nullptr;
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, sn, m, s.g_order.as<uint32_t>());
+    return s.g_order.as<uint32_t>();
+}
 
 // ---- one multi_insert batch in two phases, everything on the index stream -------------------------
 // Phase 1 (candidate generation, index.rs:349-434): insert-time search + RobustPrune for the batch
@@ -1972,6 +2077,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         ta.gram = s.g_gram.as<float>();
         ta.nrm = s.g_nrm.as<float>();
         ta.counters = pc.counters;
+        ta.order = longest_first(s, so.sn, m, st);
         if (int32_t trc = s.tile_begin(st)) return trc;
         rc = launch_gram_tiles(ta, m, st);
         if (rc != DANN_OK) return rc;
@@ -1990,6 +2096,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.c1 = gram_c1_chained(ix.dim);
         sw.c2 = gram_c2_for_dim(ix.dim);
         sw.one_by_one = sweep_one_by_one();
+        sw.order = ta.order;
         rc = dispatch_float<SweepLauncher>(ix, sw, m, ((lds + 15u) & ~(size_t)15u) + kSweepRowsLds, st);
         if (rc != DANN_OK) return rc;
         pool_gram = true;
@@ -2159,7 +2266,38 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         uint32_t h_counts[3] = {0, 0, 0};
         DANN_HIP(hipMemcpyAsync(h_counts, meta + 10, 12, hipMemcpyDeviceToHost, st));
         DANN_HIP(hipStreamSynchronize(st));
-        // (2) short lists
+        // (2) long lists first, on the side stream: every list belongs to another target row and a prune reads vector rows
+        //     and its own list only, so the two classes do not depend on each other.  A launch of these is as long as its
+        //     longest list (1 M x 768: 1.7 ms on average, 170 ms of a 2.4 s build, with a handful of CUs busy).
+        hipStream_t side = nullptr;
+        bool side_busy = false;
+        struct SideGuard {  // an error return below must not leave the side stream working on this scratch
+            hipStream_t& s;
+            bool& busy;
+            ~SideGuard() {
+                if (busy) (void)hipStreamSynchronize(s);
+            }
+        } side_guard{side, side_busy};
+        if (h_counts[1]) {
+            BackArgs bl = ba;
+            bl.work = work + ba.nseg;
+            bl.nseg = h_counts[1];
+            bl.pcap = next_pow2(h_counts[2]);
+            if (bl.pcap > kMaxPool) {
+                set_error("a node received back-edges for a list of %u entries in one batch (cap %u): lower max_batch",
+                          h_counts[2], kMaxPool);
+                return DANN_EOVERFLOW;
+            }
+            hipStream_t run_on = st;
+            if (h_counts[0] && !getenv("DANN_BUILD_ONE_STREAM")) {
+                if (int32_t src = s.side_stream(&side)) return src;
+                run_on = side;
+                side_busy = true;
+            }
+            rc = dispatch<BackLauncher>(ix, bl, bl.nseg, pool_lds_layout(bl.pcap, pc.pruned_degree).total, run_on);
+            if (rc != DANN_OK) return rc;
+        }
+        // (3) short lists
         if (h_counts[0]) {
             BackArgs bs = ba;
             bs.work = work;
@@ -2190,6 +2328,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 ta.gram = s.g_gram.as<float>();
                 ta.nrm = s.g_nrm.as<float>();
                 ta.counters = pc.counters;
+                ta.order = longest_first(s, la.sn, nshort, st);
                 if (int32_t trc = s.tile_begin(st)) return trc;
                 rc = launch_gram_tiles(ta, nshort, st);
                 if (rc != DANN_OK) return rc;
@@ -2212,6 +2351,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.c1 = gram_c1_chained(ix.dim);
                 sw.c2 = gram_c2_for_dim(ix.dim);
                 sw.one_by_one = sweep_one_by_one();
+                sw.order = ta.order;
                 sw.out_loc = la.loc;
                 sw.prunes = meta + 5;       // BackArgs::counters[1]
                 sw.mfma_prunes = meta + 8;
@@ -2224,19 +2364,9 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 if (rc != DANN_OK) return rc;
             }
         }
-        // (3) long lists
-        if (h_counts[1]) {
-            BackArgs bl = ba;
-            bl.work = work + ba.nseg;
-            bl.nseg = h_counts[1];
-            bl.pcap = next_pow2(h_counts[2]);
-            if (bl.pcap > kMaxPool) {
-                set_error("a node received back-edges for a list of %u entries in one batch (cap %u): lower max_batch",
-                          h_counts[2], kMaxPool);
-                return DANN_EOVERFLOW;
-            }
-            rc = dispatch<BackLauncher>(ix, bl, bl.nseg, pool_lds_layout(bl.pcap, pc.pruned_degree).total, st);
-            if (rc != DANN_OK) return rc;
+        if (side_busy) {  // both classes of lists are written before the rows are exported / the counters are read
+            side_busy = false;
+            DANN_HIP(hipStreamSynchronize(side));
         }
         if (world > 1u) {  // the rows this rank owns and has just rewritten, for the other replicas
             const uint32_t cnt = h_counts[0] + h_counts[1];

@@ -51,3 +51,5 @@ print(f"mfma={mfma} metric={metric} ", end="")
 print(f"n={n} dim={dim} R={R}/{pruned} l_build={lb} max_batch={mb}: build {dt:.3f}s ({n / dt:,.0f} pts/s) batches {nb}; "
       f"search {ks[0][0]:.0f} ms ({ks[0][1]}), prune {ks[2][0]:.0f} ms ({ks[2][1]}), backedge {ks[3][0]:.0f} ms ({ks[3][1]}); "
       f"other {dt * 1e3 - sum(k[0] for k in ks):.0f} ms", flush=True)
+tms, tl = p.kernel_time(5)
+print(f"gram_tiles {tms:.1f} ms over {tl} launches: {2 * c[7] * dim / max(tms, 1e-9) / 1e9:.1f} TFLOP/s", flush=True)
