@@ -1135,11 +1135,14 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
 // Pool prune (phase 1 of multi_insert: robust_prune_with, index.rs:2476-2532) on the matrix cores, three kernels:
 //   pool_sort_kernel   one wave per inserted point: pool + intra-batch extras -> SortedNeighbors::new, the sorted
 //                      (id, distance) list goes to global memory;
-//   gram_tiles_kernel  one 4-wave workgroup per point: the lower-triangular 32 x 32 tiles of
+//   gram_tiles_kernel  one 8-wave workgroup per point: the lower-triangular 32 x 32 tiles of
 //                      G = C[0..ng) x C[0..mg)^T (the selected candidates come from the front of the sorted pool, and the
-//                      sweep only ever asks for pairs (i, j) with j < i) with v_mfma_f32_32x32x2_f32, rows streamed
-//                      through 32-column LDS slabs, the next slab's global loads in flight under the MFMAs; nothing
-//                      else lives in this kernel, so several workgroups per CU keep the matrix pipes fed;
+//                      sweep only ever asks for pairs (i, j) with j < i) with v_mfma_f32_32x32x2_f32, the tiles dealt out
+//                      to the waves one at a time; rows streamed through two 32-column LDS slabs (the next slab's global
+//                      loads in flight under the MFMAs, written to the other slab behind them, one barrier per slab);
+//                      nothing else lives in this kernel: 128 registers, no scratch, two workgroups per CU (three for
+//                      the short back-edge lists).  1 M x 768: 70 % of the matrix pipes' cycles in the 16 384-point
+//                      launches (profiles/r04q_gram_tiles_pmc_*.csv), 91 TFLOP/s over the whole build;
 //   pool_sweep_kernel  one wave per point at full occupancy: the sweep of prune::robust_prune with look-ups in G
 //                      (global memory, L2 / Infinity-Cache resident) and the bit-exact row kernel where the error
 //                      interval does not decide or the pair lies outside the block.
@@ -1284,36 +1287,48 @@ __device__ __forceinline__ float4 tile_fetch4<__half>(const uint8_t* row, uint32
     return q;
 }
 
-// one 32-column slab of NT tiles that share the row-block operand.  The operands come from LDS in chunks of CK k-pairs, the
-// next chunk requested before the MFMAs of the current one are issued.  The scheduling barriers pin that order: left to
-// itself the compiler puts every read directly in front of its MFMAs (read, wait, two MFMAs, read, wait, ...), and all 16
-// (1 + NT) operands up front would be 64 registers.
+// one 32-column slab of the NT tiles of a wave (tile t: row-block operand at ao[t], column-block operand at bo[t], float
+// offsets into the slab).  The operands come from LDS in chunks of CK k-pairs, the next chunk requested before the MFMAs of
+// the current one are issued.  The scheduling barriers pin that order: left to itself the compiler puts every read directly
+// in front of its MFMAs (read, wait, two MFMAs, read, wait, ...), and all operands of a slab up front would be 96 registers.
 template <int NT>
-__device__ __forceinline__ void tile_slab(const float* pa, const float* pc, f32x16 (&acc)[NT]) {
+__device__ __forceinline__ void tile_slab(const float* lane_base, const uint32_t (&sa)[3], const uint32_t (&sb)[3],
+                                          f32x16 (&acc)[NT]) {
     constexpr int CK = NT == 3 ? 2 : 4, NC = 16 / CK;
-    float av[2][CK], bv[2][NT][CK];
+    float av[2][NT][CK], bv[2][NT][CK];
+    // operand addresses: one per-lane base plus wave-uniform offsets (formed here, per slab: six address registers kept
+    // across the loop are six registers too many next to 48 accumulators)
+    const float* ao[NT];
+    const float* bo[NT];
 #pragma unroll
-    for (int j = 0; j < CK; ++j) {
-        av[0][j] = pa[2 * j];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bv[0][t][j] = pc[t * 32 * 33 + 2 * j];
+    for (int t = 0; t < NT; ++t) {
+        ao[t] = lane_base + sa[t];
+        bo[t] = lane_base + sb[t];
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            av[0][t][j] = ao[t][2 * j];
+            bv[0][t][j] = bo[t][2 * j];
+        }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + 1 < NC) {
 #pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                av[(c + 1) & 1][j] = pa[2 * (CK * (c + 1) + j)];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bv[(c + 1) & 1][t][j] = pc[t * 32 * 33 + 2 * (CK * (c + 1) + j)];
-            }
+                for (int j = 0; j < CK; ++j) {
+                    av[(c + 1) & 1][t][j] = ao[t][2 * (CK * (c + 1) + j)];
+                    bv[(c + 1) & 1][t][j] = bo[t][2 * (CK * (c + 1) + j)];
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < CK; ++j)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j], bv[c & 1][t][j], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][t][j], bv[c & 1][t][j], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1321,8 +1336,11 @@ __device__ __forceinline__ void tile_slab(const float* pa, const float* pc, f32x
 // rows of one LDS slab: the fill writes whole passes of 64 rows
 __host__ __device__ inline uint32_t tile_slab_rows(uint32_t ng) { return (ng + 63u) & ~63u; }
 
-template <typename RT, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArgs a) {
+// MAXNT: the most tiles a wave of this launch can own (ceil(T / 8) for the launch's ng x mg).  Launches of short lists
+// (back-edge lists: 96 rows, six tiles) are compiled without the 32- and 48-accumulator paths and fit three workgroups
+// per CU instead of two.
+template <typename RT, int MAXNT>
+__global__ __launch_bounds__(512, MAXNT == 1 ? 6 : 4) void gram_tiles_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // two slabs of 32 columns (rows x 33 floats each): slab k + 1 is written while the MFMAs of slab k are in the pipe --
     // one barrier per slab, and the only phase of a workgroup without MFMA work is the first fill
@@ -1330,9 +1348,9 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
     float* const slab0 = reinterpret_cast<float*>(smem);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, item = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform for the compiler too
-    // row block of this wave.  Row block b has min(b, 2) + 1 tiles, and wave w sits on SIMD w % 4: in item order the light
-    // row blocks of every workgroup would share a SIMD.  Odd workgroups take them in reverse (two workgroups per CU).
-    const uint32_t rb = (blockIdx.x & 1u) ? (uint32_t)(kTileRowBlocks - 1) - wave : wave;
+    // Wave w sits on SIMD w % 4, and two workgroups share a CU: odd workgroups count their waves in reverse, so that the
+    // waves with one tile more than the others are not on the same SIMDs in both.
+    const uint32_t wv = (blockIdx.x & 1u) ? (uint32_t)(kTileRowBlocks - 1) - wave : wave;
     const uint32_t N = a.sn[item];
     const uint32_t nrows = N < a.ng ? N : a.ng, ncols = N < a.mg ? N : a.mg;
     if (nrows == 0) return;
@@ -1360,11 +1378,31 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
     };
     float4 nxt[kTilePasses];
     const uint32_t dim_full = dim & ~31u;  // slabs below this are complete: one 4-element request per thread and row
-    // tiles of this wave: row block `rb`, column blocks 0 .. min(rb, TC - 1)
-    const uint32_t nt = rb < TR ? ((rb < TC ? rb : TC - 1u) + 1u) : 0u;
+    // The tiles of the item -- row block b has min(b, TC - 1) + 1 of them, column blocks 0 .. min(b, TC - 1) -- in row-major
+    // order q = 0 .. T - 1; wave wv takes q = wv, wv + 8, wv + 16: at most one tile more than any other wave (a wave per
+    // row block, as until round 4, leaves 1 + 2 + 3 + 3 + 3 tiles on five waves of a 160-row item: the SIMD with two of
+    // them sets the pace of every slab).
     const uint32_t l31 = lane & 31u, hi = lane >> 5;
+    uint32_t T = 0;
+    for (uint32_t b = 0; b < TR; ++b) T += (b < TC ? b : TC - 1u) + 1u;
+    const uint32_t nt = T > wv ? (T - wv + 7u) >> 3 : 0u;  // <= 3: T <= 21
+    uint32_t trb[3] = {0, 0, 0}, tcb[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        uint32_t q = wv + 8u * (uint32_t)t, b = 0;
+        if ((uint32_t)t < nt) {
+            for (;;) {
+                const uint32_t c = (b < TC ? b : TC - 1u) + 1u;
+                if (q < c) break;
+                q -= c;
+                ++b;
+            }
+            trb[t] = b;
+            tcb[t] = q;
+        }
+    }
+    const float* const lane_base = slab0 + l31 * 33u + hi;
     const uint32_t fill_passes = (TR + 1u) >> 1;  // whole passes (wave-uniform): rows past the item's last are zero rows
-    const uint32_t pa_off = ((rb << 5) + l31) * 33u + hi, pc_off = l31 * 33u + hi;
     auto write_slab = [&](float* slab) {
 #pragma unroll
         for (int p = 0; p < kTilePasses; ++p) {
@@ -1403,7 +1441,12 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
 #pragma unroll
                 for (int p = 0; p < kTilePasses; ++p) nxt[p] = tile_load4<RT>(row_ptr(p) + (size_t)kn * sizeof(RT));
                 __builtin_amdgcn_sched_barrier(0);  // the requests go out before the MFMAs, not behind them
-                if constexpr (NT > 0) tile_slab<NT>(slab0 + cur * slab_floats + pa_off, slab0 + cur * slab_floats + pc_off, acc);
+                if constexpr (NT > 0) {
+                    const uint32_t so = cur * slab_floats;
+                    const uint32_t sa[3] = {so + trb[0] * 1056u, so + trb[1] * 1056u, so + trb[2] * 1056u};
+                    const uint32_t sb[3] = {so + tcb[0] * 1056u, so + tcb[1] * 1056u, so + tcb[2] * 1056u};
+                    tile_slab<NT>(lane_base, sa, sb, acc);
+                }
                 cur ^= 1u;
                 if (more) write_slab(slab0 + cur * slab_floats);  // nobody reads this one before the barrier
                 __syncthreads();
@@ -1415,7 +1458,12 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
                 nxt[p] = tile_fetch4<RT>(row_ptr(p) - (size_t)c4 * sizeof(RT), dim_full + c4, dim);
             write_slab(slab0 + cur * slab_floats);  // every wave is past the barrier behind the last MFMAs
             __syncthreads();
-            if constexpr (NT > 0) tile_slab<NT>(slab0 + cur * slab_floats + pa_off, slab0 + cur * slab_floats + pc_off, acc);
+            if constexpr (NT > 0) {
+                const uint32_t so = cur * slab_floats;
+                const uint32_t sa[3] = {so + trb[0] * 1056u, so + trb[1] * 1056u, so + trb[2] * 1056u};
+                const uint32_t sb[3] = {so + tcb[0] * 1056u, so + tcb[1] * 1056u, so + tcb[2] * 1056u};
+                tile_slab<NT>(lane_base, sa, sb, acc);
+            }
         }
         // C layout of v_mfma_f32_32x32x2_f32: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
         if constexpr (NT > 0) {
@@ -1423,15 +1471,15 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const uint32_t i = (rb << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
-                    g[(uint64_t)i * a.mg + ((uint32_t)t << 5) + l31] = acc[t][r];  // i < 32 TR <= ng, column < 32 TC <= mg
+                    const uint32_t i = (trb[t] << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
+                    g[(uint64_t)i * a.mg + (tcb[t] << 5) + l31] = acc[t][r];  // i < 32 TR <= ng, column < 32 TC <= mg
                 }
             }
         }
     };
-    if (nt == 3u) run(std::integral_constant<int, 3>{});
-    else if (nt == 2u) run(std::integral_constant<int, 2>{});
-    else if (nt == 1u) run(std::integral_constant<int, 1>{});
+    if (MAXNT >= 3 && nt == 3u) run(std::integral_constant<int, 3>{});
+    else if (MAXNT >= 2 && nt == 2u) run(std::integral_constant<int, 2>{});
+    else if (nt >= 1u) run(std::integral_constant<int, 1>{});
     else run(std::integral_constant<int, 0>{});
     // squared norms: the 8 threads of a row hold f64 partial sums
     float* nr = a.nrm + (uint64_t)item * a.ng;
@@ -1445,10 +1493,8 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void gram_tiles_kernel(TileArg
         if ((tid & 7u) == 0 && r < nrows) nr[r] = (float)v;
     }
     if (tid == 0 && a.counters) {
-        uint32_t tiles = 0;
-        for (uint32_t rb = 0; rb < TR; ++rb) tiles += (rb < TC ? rb : TC - 1u) + 1u;
         atomicAdd(&a.counters[2], (unsigned long long)nrows);
-        atomicAdd(&a.counters[3], (unsigned long long)tiles * 1024ull);
+        atomicAdd(&a.counters[3], (unsigned long long)T * 1024ull);
     }
 }
 
@@ -1740,24 +1786,25 @@ DANN_LAUNCHER(BackListLauncher, backedge_list_kernel, BackListArgs)
 int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) {
     const size_t lds = 2u * (size_t)tile_slab_rows(a.ng) * 33u * 4u;  // two slabs
     if (a.ix.dtype != DT_F32 && a.ix.dtype != DT_F16) return DANN_EUNSUPPORTED;
-    // DANN_GRAM_WAVES (development switch): 2 = a register budget of 256 (one workgroup per CU), default 4 (two per CU)
-    static const int occ = [] {
-        const char* e = getenv("DANN_GRAM_WAVES");
-        return e && atoi(e) == 2 ? 2 : 4;
-    }();
+    // the most tiles a wave of this launch can own: T tiles of a full item over eight waves
+    const uint32_t tr = a.ng >> 5, tc = a.mg >> 5;
+    uint32_t tmax = 0;
+    for (uint32_t b2 = 0; b2 < tr; ++b2) tmax += (b2 < tc ? b2 : tc - 1u) + 1u;
+    static const bool wide_only = getenv("DANN_GRAM_ONE_KERNEL") != nullptr;  // development switch
+    const bool narrow = tmax <= 8u && !wide_only;
     const bool f32 = a.ix.dtype == DT_F32;
-    const void* fn = occ == 2 ? (f32 ? (const void*)gram_tiles_kernel<float, 2> : (const void*)gram_tiles_kernel<__half, 2>)
-                              : (f32 ? (const void*)gram_tiles_kernel<float, 4> : (const void*)gram_tiles_kernel<__half, 4>);
+    const void* fn = narrow ? (f32 ? (const void*)gram_tiles_kernel<float, 1> : (const void*)gram_tiles_kernel<__half, 1>)
+                            : (f32 ? (const void*)gram_tiles_kernel<float, 3> : (const void*)gram_tiles_kernel<__half, 3>);
     if (lds > 64u * 1024u) {  // beyond the default limit of dynamic LDS
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute");
     }
-    if (occ == 2) {
-        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 2>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 2>), dim3(grid), dim3(512), lds, stream, a);
+    if (narrow) {
+        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 1>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 1>), dim3(grid), dim3(512), lds, stream, a);
     } else {
-        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 4>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 4>), dim3(grid), dim3(512), lds, stream, a);
+        if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 3>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((gram_tiles_kernel<__half, 3>), dim3(grid), dim3(512), lds, stream, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gram_tiles_kernel launch");

@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04s}; O=$R/gpurun_out/$T; mkdir -p $O
 A=${2:-"1000000 768 64 56 128 16384"}
 cd /tmp
 for i in 1 2; do
-  for V in "X=0" "DANN_GRAM_WAVES=2"; do
+  for V in "X=0" "DANN_GRAM_ONE_KERNEL=1"; do
     echo "$V:" $(env $V timeout 200 python $R/scratch/build_phases.py $A 2>/dev/null | grep -o "build [0-9.]*s\|gram_tiles.*" | tr '\n' ' ')
   done
 done 2>&1 | tee $O/ab.txt
 (cd $R && timeout 900 python -m pytest tests/test_gpu_build.py -x -q 2>&1 | tail -3) | tee $O/pytest_build.log
-(cd $R && DANN_GRAM_WAVES=2 timeout 900 python -m pytest tests/test_gpu_build.py -x -q 2>&1 | tail -3) | tee $O/pytest_build_w2.log
+(cd $R && DANN_GRAM_ONE_KERNEL=1 timeout 900 python -m pytest tests/test_gpu_build.py -x -q 2>&1 | tail -3) | tee $O/pytest_build_w2.log
