@@ -2015,7 +2015,7 @@ int32_t ensure_gram_scratch(BuildScratch& s, size_t items, uint32_t pcap, uint32
 // the order of the Gram / sweep workgroups of one slice (lpt_order_kernel); DANN_BUILD_ITEM_ORDER: development switch
 static const uint32_t* longest_first(BuildScratch& s, const uint32_t* sn, uint32_t m, hipStream_t st) {
     static const bool off = getenv("DANN_BUILD_ITEM_ORDER") != nullptr;
-    if (off || m < 2u) return nullptr;
+    if (off || m < 4096u) return nullptr;  // (a launch that does not fill the chip twice has no tail to shorten)
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, sn, m, s.g_order.as<uint32_t>());
     return s.g_order.as<uint32_t>();
 }
@@ -2315,7 +2315,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         DANN_HIP(hipStreamSynchronize(st));
         // (2) long lists first, on the side stream: every list belongs to another target row and a prune reads vector rows
         //     and its own list only, so the two classes do not depend on each other.  A launch of these is as long as its
-        //     longest list (1 M x 768: 1.7 ms on average, 170 ms of a 2.4 s build, with a handful of CUs busy).
+        //     longest list (1 M x 768: 1.7 ms on average, 170 ms of a 2.4 s build, with a handful of CUs busy: some fifty
+        //     hubs per 16 384-point batch, the longest with ~2 000 back-edges -- far beyond the 256 rows of a Gram block).
         hipStream_t side = nullptr;
         bool side_busy = false;
         struct SideGuard {  // an error return below must not leave the side stream working on this scratch
