@@ -107,6 +107,10 @@ struct ServerView {
     uint32_t idle_timeout_us = 100000;   // the kernel leaves after this long without a new submission (a later submit
                                          // relaunches it): a device-wide synchronisation elsewhere in the process must
                                          // not wait for ever on an idle server
+    uint32_t max_resident_us = 200000;   // ... nor on a busy one: the kernel also leaves (drains and is relaunched by the
+                                         // next submit / wait / poll) once it has been resident this long.  hipFree is a
+                                         // device-wide synchronisation: without the bound, destroying another index while
+                                         // callers keep this server busy would block until they pause
 };
 
 struct SearchArgs {

@@ -2139,7 +2139,9 @@ __device__ void server_dispatch(const ServerView& sv) {
     const uint32_t lane = threadIdx.x;
     unsigned long long avail = __hip_atomic_load(sv.d_avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long long last = wall_clock64();
+    const long long born = last;
     const long long idle_ticks = (long long)sv.idle_timeout_us * (long long)sv.ticks_per_us;
+    const long long resident_ticks = (long long)sv.max_resident_us * (long long)sv.ticks_per_us;
     uint32_t backoff = 1;
     // second bound, should the wall clock not advance: an idle iteration costs at least a PCIe round trip (~1 us)
     uint32_t idle_iters = 0;
@@ -2156,11 +2158,14 @@ __device__ void server_dispatch(const ServerView& sv) {
             last = wall_clock64();
             backoff = 1;
             idle_iters = 0;
-            continue;
+            if (last - born <= resident_ticks) continue;
+            // resident for max_resident_us under a steady stream of tickets: leave as on the idle timeout -- the workers
+            // serve what has been counted into `avail`, later tickets wait in the ring for the relaunch
         }
         const bool stop = sys_load_u32(sv.h_ctl) != 0u;
         const bool idle = wall_clock64() - last > idle_ticks || ++idle_iters > max_idle_iters;
-        if (stop || idle) {
+        const bool old = wall_clock64() - born > resident_ticks;
+        if (stop || idle || old) {
             if (lane == 0) {
                 sys_store_u32(sv.h_ctl + 1, 1u);  // tells the host to relaunch on the next submission
                 __hip_atomic_store(sv.d_stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

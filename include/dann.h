@@ -524,8 +524,9 @@ int32_t dann_multi_search_batch(dann_multi* m, const void* queries, uint32_t nq,
  * before the last of them has left; uncollected tickets die with the server.  A submit whose ring position no worker
  * takes within 30 s means the resident kernel is dead: from then on every submit / wait on this server fails at once
  * with DANN_EHIP until dann_server_stop + dann_server_start.  The resident kernel leaves after idle_timeout_us
- * without a submission (default 100 ms) and is relaunched by the next submit, wait or poll: a device-wide
- * synchronisation elsewhere in the process waits at most that long on an idle server.  Row lengths must be a multiple
+ * without a submission (default 100 ms), and after 200 ms of residence under a steady stream of submissions, and is
+ * relaunched by the next submit, wait or poll: a device-wide synchronisation elsewhere in the process (every hipFree is
+ * one -- dann_index_destroy of another index, for instance) waits at most that long on this server.  Row lengths must be a multiple
  * of 16 bytes; L + start points <= 256. */
 typedef struct {
     uint32_t l_value;
