@@ -2337,7 +2337,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 return DANN_EOVERFLOW;
             }
             hipStream_t run_on = st;
-            if (h_counts[0] && !getenv("DANN_BUILD_ONE_STREAM")) {
+            static const bool one_stream = getenv("DANN_BUILD_ONE_STREAM") != nullptr;  // development switch
+            if (h_counts[0] && !one_stream) {
                 if (int32_t src = s.side_stream(&side)) return src;
                 run_on = side;
                 side_busy = true;
