@@ -1790,8 +1790,7 @@ int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) 
     const uint32_t tr = a.ng >> 5, tc = a.mg >> 5;
     uint32_t tmax = 0;
     for (uint32_t b2 = 0; b2 < tr; ++b2) tmax += (b2 < tc ? b2 : tc - 1u) + 1u;
-    static const bool wide_only = getenv("DANN_GRAM_ONE_KERNEL") != nullptr;  // development switch
-    const bool narrow = tmax <= 8u && !wide_only;
+    const bool narrow = tmax <= 8u;
     const bool f32 = a.ix.dtype == DT_F32;
     const void* fn = narrow ? (f32 ? (const void*)gram_tiles_kernel<float, 1> : (const void*)gram_tiles_kernel<__half, 1>)
                             : (f32 ? (const void*)gram_tiles_kernel<float, 3> : (const void*)gram_tiles_kernel<__half, 3>);
@@ -2012,10 +2011,9 @@ int32_t ensure_gram_scratch(BuildScratch& s, size_t items, uint32_t pcap, uint32
 
 }  // namespace
 
-// the order of the Gram / sweep workgroups of one slice (lpt_order_kernel); DANN_BUILD_ITEM_ORDER: development switch
+// the order of the Gram / sweep workgroups of one slice (lpt_order_kernel)
 static const uint32_t* longest_first(BuildScratch& s, const uint32_t* sn, uint32_t m, hipStream_t st) {
-    static const bool off = getenv("DANN_BUILD_ITEM_ORDER") != nullptr;
-    if (off || m < 4096u) return nullptr;  // (a launch that does not fill the chip twice has no tail to shorten)
+    if (m < 4096u) return nullptr;  // (a launch that does not fill the chip twice has no tail to shorten)
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, sn, m, s.g_order.as<uint32_t>());
     return s.g_order.as<uint32_t>();
 }
@@ -2337,8 +2335,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 return DANN_EOVERFLOW;
             }
             hipStream_t run_on = st;
-            static const bool one_stream = getenv("DANN_BUILD_ONE_STREAM") != nullptr;  // development switch
-            if (h_counts[0] && !one_stream) {
+            if (h_counts[0]) {  // (with no short lists there is nothing to run beside)
                 if (int32_t src = s.side_stream(&side)) return src;
                 run_on = side;
                 side_busy = true;

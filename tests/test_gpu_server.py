@@ -240,3 +240,44 @@ def test_poll_alone_brings_an_exited_kernel_back():
         assert rel >= 5, rel
     finally:
         gix.server_stop()
+
+
+def test_resident_kernel_leaves_under_load_and_results_stay_exact(monkeypatch):
+    """The resident kernel leaves not only when it is idle but also after max_resident_us of residence under a steady
+    stream of tickets (a hipFree elsewhere in the process is a device-wide synchronisation and would otherwise wait for
+    the callers to pause).  With the bound lowered to 1 ms, thousands of tickets from eight native threads cross dozens
+    of drain / relaunch cycles: every result is still the oracle's, no ticket is lost, and another index can be created
+    and destroyed (hipMalloc / hipFree) by a second thread while the server is kept busy."""
+    monkeypatch.setenv("DANN_SERVER_MAX_RESIDENT_US", "1000")
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 6000, 128, 32, 37)
+    q = rand_vectors(rng, oracle.F32, 6000, 128)
+    L, k = 32, 10
+    oi, od, _, _ = oix.search_batch(q, L, 1, k)
+    gix.server_start(L, k, workers=256, ring=1024)
+    try:
+        done = threading.Event()
+        churn = []
+
+        def other_index():  # device-wide synchronisations from another thread, while the callers keep the server busy
+            r2 = np.random.default_rng(5)
+            while not done.is_set():
+                t0 = time.time()
+                o = da.Provider(oracle.F32, oracle.L2, 64, 2000, 8, r2.random((1, 64), dtype=np.float32))
+                o.set_elements(0, r2.random((2000, 64), dtype=np.float32))
+                o.close()
+                churn.append(time.time() - t0)
+        th = threading.Thread(target=other_index)
+        th.start()
+        try:
+            for _ in range(5):
+                ids, d, lat, _ = gix.concurrent_callers(q, L, k, threads=8, mode=1, depth=16)
+                assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od))
+        finally:
+            done.set()
+            th.join(timeout=60)
+        assert not th.is_alive()
+        sub, rel = gix.server_stats()
+        assert sub >= 5 * len(q) and rel >= 3, (sub, rel)    # the kernel did leave and come back under load
+        assert churn and max(churn) < 5.0, max(churn)         # and nobody waited for the callers to pause
+    finally:
+        gix.server_stop()
