@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the DANN_BUILD_ONE_STREAM / DANN_BUILD_ITEM_ORDER / DANN_GRAM_ONE_KERNEL switches this A/B used were removed from the library after the
+# measurement (results: profiles/r04q_*); check out commit 1e8b133 to repeat it.
 # 1 M x 768 f32 build wall clock: default vs a development switch given as $2 (env assignment), three runs each;
 # then the build tests and a kernel trace of the default
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04r}; SW=${2:-DANN_BUILD_ITEM_ORDER=0}; O=$R/gpurun_out/$T; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the DANN_BUILD_ONE_STREAM / DANN_BUILD_ITEM_ORDER / DANN_GRAM_ONE_KERNEL switches this A/B used were removed from the library after the
+# measurement (results: profiles/r04q_*); check out commit 1e8b133 to repeat it.
 # 1 M x 768 f32 build: (a) long back-edge lists on the side stream vs one stream, wall clock, three runs each;
 # (b) kernel trace; (c) instruction / wave-state counters of the prune kernels (pool_sweep, gram_tiles, backedge)
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04q}; O=$R/gpurun_out/$T; mkdir -p $O

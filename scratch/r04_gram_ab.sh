@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the DANN_BUILD_ONE_STREAM / DANN_BUILD_ITEM_ORDER / DANN_GRAM_ONE_KERNEL switches this A/B used were removed from the library after the
+# measurement (results: profiles/r04q_*); check out commit 1e8b133 to repeat it.
 # gram_tiles variants on the 1 M x 768 build: wall clock + HIP-event time of the tile launches, and the build tests
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04s}; O=$R/gpurun_out/$T; mkdir -p $O
 A=${2:-"1000000 768 64 56 128 16384"}
