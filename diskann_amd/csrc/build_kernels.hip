@@ -74,6 +74,29 @@ __host__ __device__ inline PoolLds pool_lds_layout(uint32_t pcap, uint32_t degre
     return l;
 }
 
+// What pool_sweep_kernel's batched sweep keeps in LDS: the sorted list (ids, distances), its sweep state and the norms of the
+// Gram rows -- not the unsorted pool and the sort keys of the kernels that build the list (3 KB of 7.9 KB at 256 slots: with
+// them the sweep ran 12 lists per CU, without them 16).  Same field names, so sweep_gram_batched reads either layout.
+__host__ __device__ inline PoolLds sweep_lds_layout(uint32_t pcap, uint32_t degree) {
+    PoolLds l;
+    uint32_t off = 0;
+    l.keys_off = off;  // the norms of the Gram rows (at most 256 rows)
+    off += (pcap < 256u ? pcap : 256u) * 4u;
+    l.pid_off = l.pd_off = 0;  // (not part of this layout)
+    l.sid_off = off;
+    off += pcap * 4u;
+    l.sd_off = off;
+    off += pcap * 4u;
+    l.occ_off = off;
+    off += pcap * 4u;
+    l.last_off = off;
+    off += ((pcap * 2u) + 15u) & ~15u;
+    l.sel_off = off;
+    off += ((degree + 1u) * 4u + 15u) & ~15u;
+    l.total = off;
+    return l;
+}
+
 __device__ __forceinline__ uint64_t sort_key(float d, uint32_t pos) {
     uint32_t u = __builtin_bit_cast(uint32_t, d + 0.0f);  // -0.0 -> +0.0: `<` treats them as equal
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -1544,7 +1567,18 @@ struct SweepArgs {
     uint32_t* mfma_prunes = nullptr; // optional statistic
     uint32_t one_by_one = 0;         // development switch (DANN_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
     const uint32_t* order = nullptr; // optional: workgroup b works on item order[b] (longest lists first)
+    uint32_t compact_lds = 0;        // sweep_lds_layout instead of pool_lds_layout (the batched sweep only)
 };
+
+// the batched sweep (sweep_gram_batched) serves this launch: one lane per selected entry, at most 128 Gram columns
+inline bool sweep_is_batched(const PruneCfg& cfg, uint32_t mg, uint32_t one_by_one) {
+    return cfg.pruned_degree <= (uint32_t)kWave && mg <= 128u && !one_by_one;
+}
+inline size_t sweep_lds_bytes(const SweepArgs& sw) {
+    const uint32_t pool = sw.compact_lds ? sweep_lds_layout(sw.p.pcap, sw.p.cfg.pruned_degree).total
+                                         : pool_lds_layout(sw.p.pcap, sw.p.cfg.pruned_degree).total;
+    return (((size_t)pool + 15u) & ~(size_t)15u) + kSweepRowsLds;
+}
 
 template <int DT, int OP, bool NORM>
 __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
@@ -1556,7 +1590,7 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
         if (lane == 0 && !sa.out_loc) a.out[(uint64_t)wi * a.out_stride] = 0;
         return;
     }
-    const PoolLds L = pool_lds_layout(a.pcap, a.cfg.pruned_degree);
+    const PoolLds L = sa.compact_lds ? sweep_lds_layout(a.pcap, a.cfg.pruned_degree) : pool_lds_layout(a.pcap, a.cfg.pruned_degree);
     uint32_t* sid = reinterpret_cast<uint32_t*>(smem + L.sid_off);
     float* sd = reinterpret_cast<float*>(smem + L.sd_off);
     float* occ = reinterpret_cast<float*>(smem + L.occ_off);
@@ -1575,7 +1609,7 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
     uint32_t* out = sa.out_loc ? a.ix.adj + (uint64_t)location * a.ix.adj_stride : a.out + (uint64_t)wi * a.out_stride;
     const GramCtx gc{sa.gram + (uint64_t)wi * sa.ng * sa.mg, sa.nrm + (uint64_t)wi * sa.ng, sa.mg,
                      nr, nc, true, sa.escale, sa.c1, sa.c2, false, true};
-    if (a.cfg.pruned_degree <= (uint32_t)kWave && sa.mg <= 128u && !sa.one_by_one)
+    if (sa.compact_lds)
         sweep_gram_batched<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc,
                                          reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u)));
     else
@@ -2142,7 +2176,8 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.c2 = gram_c2_for_dim(ix.dim);
         sw.one_by_one = sweep_one_by_one();
         sw.order = ta.order;
-        rc = dispatch_float<SweepLauncher>(ix, sw, m, ((lds + 15u) & ~(size_t)15u) + kSweepRowsLds, st);
+        sw.compact_lds = sweep_is_batched(pc, mg, sw.one_by_one) ? 1u : 0u;
+        rc = dispatch_float<SweepLauncher>(ix, sw, m, sweep_lds_bytes(sw), st);
         if (rc != DANN_OK) return rc;
         pool_gram = true;
     }
@@ -2401,7 +2436,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.out_loc = la.loc;
                 sw.prunes = meta + 5;       // BackArgs::counters[1]
                 sw.mfma_prunes = meta + 8;
-                rc = dispatch_float<SweepLauncher>(ix, sw, nshort, ((lds_pool + 15u) & ~(size_t)15u) + kSweepRowsLds, st);
+                sw.compact_lds = sweep_is_batched(pc, mg, sw.one_by_one) ? 1u : 0u;
+                rc = dispatch_float<SweepLauncher>(ix, sw, nshort, sweep_lds_bytes(sw), st);
                 if (rc != DANN_OK) return rc;
                 gram = true;
             }
