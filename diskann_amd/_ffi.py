@@ -171,7 +171,17 @@ SYMBOLS = {
     "dann_server_stats": (_i32, [_vp, _P(_u64), _P(_u64)]),
     "dann_debug_concurrent_callers": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp,
                                              _P(C.c_double)]),
+    "dann_debug_set": (_i32, [_vp, _i32, C.c_double]),
+    "dann_debug_get": (_i32, [_vp, _i32, _P(C.c_double)]),
+    "dann_debug_search_families": (_i32, [_vp, _P(_u64), _P(C.c_double)]),
+    "dann_debug_family_name": (C.c_char_p, [_i32]),
 }
+
+# dann_debug.h: development switches (dann_debug_set) and kernel families (dann_debug_search_families)
+DBG_KEYS = {"tune_off": 0, "tune_on": 1, "pair_min_queries": 2, "team_max_queries": 3, "host_pipeline": 4,
+            "sweep_one_by_one": 5, "pool_gram": 6, "gram_cols": 7, "gram_escale": 8, "backedge_gram_rows": 9,
+            "server_max_resident_us": 10, "verbose": 11}
+FAMILIES = ("one_wave", "team", "pair", "persistent", "server", "pq_lut")
 
 _lib = None
 

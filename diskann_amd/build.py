@@ -26,7 +26,19 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
+
+
+def _depfile_deps(dep):
+    """prerequisites recorded by `hipcc -MD -MF` for one object (None if there is no usable depfile yet)"""
+    try:
+        text = open(dep).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    return [d for d in text.split(":", 1)[1].split() if not d.startswith("/opt/") and not d.startswith("/usr/")]
 
 
 def build(force=False, verbose=False):
@@ -38,12 +50,13 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + headers):
+        deps = _depfile_deps(obj[:-2] + ".d")  # the headers this unit really includes; without a depfile: all of them
+        if force or _stale(obj, [src] + (deps if deps is not None else headers)):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+        cmd = [_hipcc(), *FLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -267,6 +267,7 @@ int32_t dann_index_create(const dann_config* cfg, const void* start_rows, uint64
     if (!idx) return DANN_ENOMEM;
     idx->cfg = *cfg;
     idx->layer_bytes = lb;
+    for (auto& d : idx->dbg) d.store(__builtin_nan(""), std::memory_order_relaxed);
     if (idx->cfg.row_stride == 0) idx->cfg.row_stride = (lb + 15u) & ~15u;
     if (idx->cfg.row_stride < lb || (idx->cfg.row_stride & 15u)) {
         set_error("row_stride %u must be >= %u and a multiple of 16", idx->cfg.row_stride, lb);
@@ -925,10 +926,7 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
-    static const bool pipeline_off = [] {
-        const char* e = getenv("DANN_HOST_PIPELINE");
-        return e && atoi(e) == 0;
-    }();
+    const bool pipeline_off = idx->dbg_u32(DANN_DBG_HOST_PIPELINE, 1u) == 0u;
     const bool chunked = nq >= 2 * kHostChunk && !pipeline_off;
     const uint32_t cq = chunked ? kHostChunk : nq;  // queries per device pass
     // device staging owned by the context (grow-only): [0] queries, [1] ids | dists | stats in one block; the
@@ -1636,8 +1634,37 @@ int32_t dann_kernel_time_reset(dann_index* idx) try {
     }
     std::lock_guard<std::mutex> lk(idx->stat_mu);
     for (auto& c : idx->clocks) c = KernelClock();
+    for (auto& c : idx->families) c = KernelClock();
     return DANN_OK;
 } DANN_CATCH_ALL
+
+// ---- development switches and the per-family launch counters (include/dann_debug.h) ----------------------------------
+int32_t dann_debug_set(dann_index* idx, int32_t key, double value) try {
+    if (!idx || key < 0 || key >= DANN_DBG_COUNT) return DANN_EINVAL;
+    idx->dbg[key].store(value, std::memory_order_relaxed);
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value) try {
+    if (!idx || !value || key < 0 || key >= DANN_DBG_COUNT) return DANN_EINVAL;
+    *value = idx->dbg[key].load(std::memory_order_relaxed);
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+int32_t dann_debug_search_families(const dann_index* idx, uint64_t* out_launches, double* out_ms) try {
+    if (!idx) return DANN_EINVAL;
+    std::lock_guard<std::mutex> lk(idx->stat_mu);
+    for (int f = 0; f < DANN_FAMILY_COUNT; ++f) {
+        if (out_launches) out_launches[f] = idx->families[f].launches;
+        if (out_ms) out_ms[f] = idx->families[f].total_ms;
+    }
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+const char* dann_debug_family_name(int32_t family) {
+    static const char* const names[DANN_FAMILY_COUNT] = {"one_wave", "team", "pair", "persistent", "server", "pq_lut"};
+    return family >= 0 && family < DANN_FAMILY_COUNT ? names[family] : nullptr;
+}
 
 int32_t dann_set_visited_bits(dann_index* idx, uint32_t bits) try {
     // 0 = automatic; 6..15 = log2(entries); >= 64 = explicit entry count (rounded up to a multiple of 64)

@@ -665,7 +665,7 @@ struct GramCtx {
     const float* nrm;    // |row p|^2, p < nrows
     uint32_t ld, nrows, ncols;
     bool by_sorted;      // rows are indexed by sorted pool order (pool prune) or by pool position (back-edge lists)
-    float escale;        // 1.0; tests widen the error interval (DANN_GRAM_ESCALE) to drive every decision through the exact path
+    float escale;        // 1.0; tests widen the error interval (DANN_DBG_GRAM_ESCALE) to drive every decision through the exact path
     float c1, c2;        // error interval E = c1 (|x|^2 + |y|^2) + c2 |d'| of this Gram's arithmetic
     bool count_rows;     // add this list to the Gram row / flop counters (the tiles kernel counts its own)
     bool prefetch;       // g lives in global memory: touch the next candidates' rows ahead of their look-ups
@@ -1565,7 +1565,7 @@ struct SweepArgs {
     const uint32_t* out_loc = nullptr;
     uint32_t* prunes = nullptr;      // [0] += 1 per pruned list (BackArgs::counters + 1)
     uint32_t* mfma_prunes = nullptr; // optional statistic
-    uint32_t one_by_one = 0;         // development switch (DANN_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
+    uint32_t one_by_one = 0;         // development switch (DANN_DBG_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
     const uint32_t* order = nullptr; // optional: workgroup b works on item order[b] (longest lists first)
     uint32_t compact_lds = 0;        // sweep_lds_layout instead of pool_lds_layout (the batched sweep only)
 };
@@ -1850,16 +1850,10 @@ uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-uint32_t sweep_one_by_one() {
-    const char* e = getenv("DANN_SWEEP_ONE_BY_ONE");
-    return e && atoi(e) != 0 ? 1u : 0u;
-}
-
-// development switch: DANN_POOL_GRAM=0 keeps the row kernel for the pool prune of large rows (A/B runs)
-bool pool_gram_default() {
-    const char* e = getenv("DANN_POOL_GRAM");
-    return !e || atoi(e) != 0;
-}
+// development switches (dann_debug_set): DANN_DBG_SWEEP_ONE_BY_ONE; DANN_DBG_POOL_GRAM = 0 keeps the row kernel for the
+// pool prune of large rows (A/B runs)
+uint32_t sweep_one_by_one(const dann_index* idx) { return idx->dbg_u32(DANN_DBG_SWEEP_ONE_BY_ONE, 0u) ? 1u : 0u; }
+bool pool_gram_default(const dann_index* idx) { return idx->dbg_u32(DANN_DBG_POOL_GRAM, 1u) != 0u; }
 
 PruneCfg to_prune_cfg(const dann_build_config& c) {
     PruneCfg p;
@@ -2155,10 +2149,9 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
     const bool floatrows = (ix.dtype == DT_F32 || ix.dtype == DT_F16) && ix.metric != M_COSINE;
     const bool want_pool_gram = floatrows && ((idx->build_flags & DANN_BUILD_MFMA_POOL) ||
                                               (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u &&
-                                               pool_gram_default()));
+                                               pool_gram_default(idx)));
     if (want_pool_gram) {
-        const char* ce = getenv("DANN_GRAM_COLS");  // tuning hook: columns of the Gram block (32 / 64 / 96)
-        uint32_t mg = ce ? (uint32_t)atoi(ce) : 96u;
+        uint32_t mg = idx->dbg_u32(DANN_DBG_GRAM_COLS, 96u);  // tuning hook: columns of the Gram block (32 / 64 / 96)
         mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
         const uint32_t ng = std::max<uint32_t>(mg, std::min<uint32_t>(32u * kTileRowBlocks, (h_recmax + nex + 31u) & ~31u));
         rc = ensure_gram_scratch(s, m, pa.pcap, ng, mg);
@@ -2194,11 +2187,10 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         sw.nrm = ta.nrm;
         sw.ng = ng;
         sw.mg = mg;
-        const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
-        sw.escale = es ? (float)atof(es) : 1.0f;
+        sw.escale = (float)idx->dbg_value(DANN_DBG_GRAM_ESCALE, 1.0);  // test hook
         sw.c1 = gram_c1_chained(ix.dim);
         sw.c2 = gram_c2_for_dim(ix.dim);
-        sw.one_by_one = sweep_one_by_one();
+        sw.one_by_one = sweep_one_by_one(idx);
         sw.order = ta.order;
         sw.compact_lds = sweep_is_batched(pc, mg, sw.one_by_one) ? 1u : 0u;
         rc = dispatch_float<SweepLauncher>(ix, sw, m, sweep_lds_bytes(sw), st);
@@ -2332,12 +2324,12 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                                 (!(idx->build_flags & DANN_BUILD_ROW_KERNEL_ONLY) && ix.layer_bytes >= 1024u));
         // Gram rows per list: degree + 8 rounded up (96 at R = 64) covers the lists of a steady-state batch; the tiles kernel
         // could take up to 256, but sizing every list's LDS pool and Gram stride for the rare hub costs more than the hubs
-        // save (1 M x 768: 3.18 s at 256 against 2.81 s; DANN_BACKEDGE_GRAM_ROWS raises it for experiments).  Longer
+        // save (1 M x 768: 3.18 s at 256 against 2.81 s; DANN_DBG_BACKEDGE_GRAM_ROWS raises it for experiments).  Longer
         // lists stay on the row kernel.
         uint32_t pg = std::min<uint32_t>(128u, (ix.max_degree + 8u + 31u) & ~31u);
         if (want_gram) {
-            if (const char* e = getenv("DANN_BACKEDGE_GRAM_ROWS"))
-                pg = std::min<uint32_t>(32u * kTileRowBlocks, std::max<uint32_t>(pg, ((uint32_t)atoi(e) + 31u) & ~31u));
+            if (const uint32_t e = idx->dbg_u32(DANN_DBG_BACKEDGE_GRAM_ROWS, 0u))
+                pg = std::min<uint32_t>(32u * kTileRowBlocks, std::max<uint32_t>(pg, (e + 31u) & ~31u));
         }
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
@@ -2454,11 +2446,10 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.nrm = ta.nrm;
                 sw.ng = pg;
                 sw.mg = mg;
-                const char* es = getenv("DANN_GRAM_ESCALE");  // test hook
-                sw.escale = es ? (float)atof(es) : 1.0f;
+                sw.escale = (float)idx->dbg_value(DANN_DBG_GRAM_ESCALE, 1.0);  // test hook
                 sw.c1 = gram_c1_chained(ix.dim);
                 sw.c2 = gram_c2_for_dim(ix.dim);
-                sw.one_by_one = sweep_one_by_one();
+                sw.one_by_one = sweep_one_by_one(idx);
                 sw.order = ta.order;
                 sw.out_loc = la.loc;
                 sw.prunes = meta + 5;       // BackArgs::counters[1]

@@ -295,6 +295,21 @@ struct dann_index {
     void* build_scratch = nullptr;            // owned by build_kernels.hip
     void (*build_scratch_free)(void*) = nullptr;
     dann::KernelClock clocks[5];  // 4 = beam-search retry launches (ms already in [0]; launches = re-run queries); stat_mu
+    dann::KernelClock families[DANN_FAMILY_COUNT];  // beam-search launches per kernel family (dann_debug.h); stat_mu
+    // development switches (dann_debug_set; NaN = default).  Plain doubles written by the test / bench thread before
+    // the calls they are meant for: relaxed atomics keep concurrent searches well-defined.
+    std::atomic<double> dbg[DANN_DBG_COUNT];
+    double dbg_value(int key, double dflt) const {
+        const double v = dbg[key].load(std::memory_order_relaxed);
+        return v == v ? v : dflt;
+    }
+    uint32_t dbg_u32(int key, uint32_t dflt) const {
+        const double v = dbg[key].load(std::memory_order_relaxed);
+        return v == v ? (v <= 0.0 ? 0u : v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v) : dflt;
+    }
+    bool tune_off(uint32_t bit) const { return (dbg_u32(DANN_DBG_TUNE_OFF, 0u) & bit) != 0; }
+    bool tune_on(uint32_t bit) const { return (dbg_u32(DANN_DBG_TUNE_ON, 0u) & bit) != 0; }
+    bool verbose() const { return dbg_u32(DANN_DBG_VERBOSE, 0u) != 0; }
     std::vector<uint64_t> ext_ids;  // slot -> external id (empty = identity for dynamic slots)
     std::vector<uint8_t> h_tags;    // inline_tags: host mirror of the tag bytes (the reference's Store::tags, store.rs:150)
     // Locking.  `rw` is the index: shared by the Knn search entry points (dann_search_batch(_device), the server),

@@ -2402,6 +2402,20 @@ int32_t launch_dt(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t st
     return DANN_EUNSUPPORTED;
 }
 
+// does a team instantiation exist for this launch?  (launch_one: plain mode, a fixed-length kernel -- 128-element rows
+// of the metric's specialised form --, at most 256 queue entries, not PQ rows; launch_dt's case analysis)
+inline bool team_shape(const SearchArgs& a) {
+    int op;
+    bool norm;
+    const int dt = a.ix.dtype;
+    if (!plain_mode(a) || dt == DT_PQ || a.ix.dim != 128u || !resolve_metric(dt, a.ix.metric, &op, &norm)) return false;
+    if (std::max(a.l_value + a.ix.nstart, a.qcap_max) > 256u) return false;
+    const bool ints = dt == DT_U8 || dt == DT_I8 || dt == DT_SQ8;
+    if (op == OP_L2) return true;
+    if (op == OP_IP) return ints;  // (float rows: inner product and CosineNormalized run the generic-length kernel)
+    return dt == DT_U8 || dt == DT_I8;
+}
+
 uint32_t cmax_of(const SearchArgs& a) {
     uint32_t c1 = (a.beam_width * a.ix.max_degree + 63u) & ~63u, c2 = (a.ix.nstart + 63u) & ~63u;
     return c1 > c2 ? c1 : c2;

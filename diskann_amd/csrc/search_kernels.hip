@@ -194,10 +194,13 @@ __global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uin
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// development switches: DANN_TUNE_OFF=<bits> disables 1 = row prefetch in latency mode, 2 = latency-mode table sizing
-static bool tune_env(uint32_t bit) {
-    const char* e = getenv("DANN_TUNE_OFF");
-    return e && ((uint32_t)strtoul(e, nullptr, 0) & bit) != 0;
+// which kernel family a launch with these arguments runs (include/dann_debug.h)
+int search_family(const SearchArgs& a) {
+    if (a.srv.ring) return DANN_FAMILY_SERVER;
+    if (a.pair) return DANN_FAMILY_PAIR;
+    if (a.team) return DANN_FAMILY_TEAM;
+    if (a.grid) return DANN_FAMILY_PERSISTENT;
+    return DANN_FAMILY_ONE_WAVE;
 }
 
 int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
@@ -280,31 +283,26 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // latency regime with at most one query per SIMD: a team of four wavefronts per query -- queue, control, visited
     // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches only (the launch falls back to one wave
     // per query where no team instantiation exists).  Decided before the table is sized: teams carry more LDS.
-    // DANN_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_TEAM_MAX_QUERIES: development switches.
+    // DANN_DBG_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_DBG_TEAM_MAX_QUERIES: development switches
+    // (dann_debug_set; read on every call).
     {
-        static const uint32_t team_max = [] {
-            const char* e = getenv("DANN_TEAM_MAX_QUERIES");
-            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
-        }();
-        const uint32_t limit = std::min<uint32_t>(team_max, 4u * idx->num_cus);
+        const uint32_t limit = idx->dbg_u32(DANN_DBG_TEAM_MAX_QUERIES, 4u * idx->num_cus);
         a.team = (inflight <= limit && !a.grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && plain_mode(a) &&
-                  a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !tune_env(4)) ? 1u : 0u;
-        if (tune_env(8)) a.tune |= kTuneNoSpeculation;
+                  a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !idx->tune_off(4) &&
+                  team_shape(a)) ? 1u : 0u;
+        if (idx->tune_off(8)) a.tune |= kTuneNoSpeculation;
     }
     // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  A pair-hop is longer
     // than a hop of one query, so the pairing pays once the chip is full: measured on 1 M u8 rows at L = 26
     // (scratch/pair_latency.py, kernel us, pair / one wave per query): 4 096 queries 292 / 260, 6 144: 301 / 346,
-    // 16 384: 497 / 585, 65 536: 1 423 / 1 801.  DANN_TUNE_OFF bit 16 / DANN_PAIR_MIN_QUERIES: development switches.
+    // 16 384: 497 / 585, 65 536: 1 423 / 1 801.  DANN_DBG_TUNE_OFF bit 16 / DANN_DBG_PAIR_MIN_QUERIES: development
+    // switches (dann_debug_set; read on every call).
     a.pair = 0;
     {
-        static const uint32_t pair_min = [] {
-            const char* e = getenv("DANN_PAIR_MIN_QUERIES");
-            return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu;
-        }();
-        const uint32_t floor_q = pair_min != 0xFFFFFFFFu ? pair_min : 20u * idx->num_cus;
+        const uint32_t floor_q = idx->dbg_u32(DANN_DBG_PAIR_MIN_QUERIES, 20u * idx->num_cus);
         SearchArgs t = a;
         t.team = 0;
-        if (a.nq >= floor_q && inflight >= floor_q && idx->visited_format != 32u && pair_shape(t) && !tune_env(16)) {
+        if (a.nq >= floor_q && inflight >= floor_q && idx->visited_format != 32u && pair_shape(t) && !idx->tune_off(16)) {
             a.pair = 1;
             a.team = 0;
         }
@@ -329,12 +327,12 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                 std::lock_guard<std::mutex> lk(idx->stat_mu);
                 idx->calib[key].waves = cal.waves;
             }
-            if (getenv("DANN_DEBUG")) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal.waves);
+            if (idx->verbose()) fprintf(stderr, "[dann] search kernel: %d VGPRs -> %u queries per CU\n", regs, cal.waves);
         }
         // a launch with fewer queries than the chip has wave slots leaves LDS idle: give each query the share of a CU
         // it will actually have (a sparse table keeps the slowest lane's probe chain short -- the latency regime)
         const uint32_t per_cu = std::max<uint32_t>(1u, (inflight + idx->num_cus - 1) / idx->num_cus);
-        const uint32_t waves = tune_env(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
+        const uint32_t waves = idx->tune_off(2) ? cal.waves : std::min<uint32_t>(cal.waves, per_cu);
         if (a.pair) {
             // one 16-bit table per query: the largest table of the first LDS step (1 280-byte granules per wavefront = two
             // queries) whose open capacity -- 75 % of its slots -- holds the 90th percentile of the comparisons with a
@@ -357,7 +355,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             }
         }
         if (!a.pair) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
-        if (getenv("DANN_DEBUG") && (cal.calls & (cal.calls - 1)) == 0)
+        if (idx->verbose() && (cal.calls & (cal.calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u %s, %zu B LDS\n", a.l_value, a.beam_width,
                     cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior",
                     a.ht16 ? a.ht_entries * 2u : a.ht_entries,
@@ -393,11 +391,9 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // predicted next hop are requested a hop ahead.  Measured on 1 M x 128 f32, L = 26 (scratch/prefetch_ab.py, kernel
     // time with / without): 64 queries 131 / 144 us, 256: 146 / 161, 512: 164 / 175, 1024: 200 / 189, 2048: 304 / 246 --
     // from about three queries per CU on, the requests of mispredicted hops cost more than the early ones gain.
-    if (inflight <= 3u * idx->num_cus && !tune_env(1)) a.tune |= kTuneRowPrefetch;
-    {   // development switch DANN_TUNE_ON bit 1: the row prefetch in the throughput regime too (A/B on large indexes)
-        const char* e = getenv("DANN_TUNE_ON");
-        if (e && (strtoul(e, nullptr, 0) & 1u)) a.tune |= kTuneRowPrefetch;
-    }
+    if (inflight <= 3u * idx->num_cus && !idx->tune_off(1)) a.tune |= kTuneRowPrefetch;
+    // development switch DANN_DBG_TUNE_ON bit 1: the row prefetch in the throughput regime too (A/B on large indexes)
+    if (idx->tune_on(1)) a.tune |= kTuneRowPrefetch;
     return DANN_OK;
 }
 
@@ -413,7 +409,12 @@ int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     if (rc != DANN_OK) return rc;
     a.fail_flag = nullptr;
     if (int32_t frc = finish_visited_table(a)) return frc;
-    return launch_search(a, ctx.stream);
+    rc = launch_search(a, ctx.stream);
+    if (rc == DANN_OK) {
+        std::lock_guard<std::mutex> lk(idx->stat_mu);
+        idx->families[DANN_FAMILY_SERVER].launches += 1;
+    }
+    return rc;
 }
 
 int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
@@ -461,6 +462,9 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
         last_ms = ms;
         std::lock_guard<std::mutex> lk(idx->stat_mu);
         idx->clocks[0].total_ms += ms;
+        KernelClock& fam = idx->families[search_family(args)];
+        fam.total_ms += ms;
+        fam.launches += 1;
         return DANN_OK;
     };
     int32_t rc = timed_launch(a);

@@ -283,8 +283,8 @@ int32_t dann_server_start(dann_index* idx, const dann_server_config* cfg) try {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, idx->device) == hipSuccess && khz >= 1000)
         sv.ticks_per_us = (uint32_t)(khz / 1000);
     sv.idle_timeout_us = cfg->idle_timeout_us ? cfg->idle_timeout_us : 100000u;
-    if (const char* e = getenv("DANN_SERVER_MAX_RESIDENT_US"))  // development switch (tests: relaunches under load)
-        sv.max_resident_us = std::max<uint32_t>(100u, (uint32_t)strtoul(e, nullptr, 0));
+    // development switch (dann_debug_set; tests: relaunches under load)
+    sv.max_resident_us = std::max<uint32_t>(100u, idx->dbg_u32(DANN_DBG_SERVER_MAX_RESIDENT_US, sv.max_resident_us));
     s->d_out_ids = reinterpret_cast<uint32_t*>(db + d_ids);
     s->d_out_d = reinterpret_cast<float*>(db + d_d);
     s->d_stats = reinterpret_cast<dann_search_stats*>(db + d_st);

@@ -9,6 +9,8 @@ buffers through the C ABI of include/dann.h.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -107,6 +109,12 @@ class Provider:
             piv = np.ascontiguousarray(pq_pivots, dtype=np.float32)
             assert piv.shape == (256, self.dim)
             check(_ffi.lib().dann_set_pq_table(self._h, _p(piv), _p(pq_offsets)), "dann_set_pq_table")
+        # developer convenience for A/B scripts (scratch/, profiles/): DANN_<SWITCH>=<value> in the environment of the
+        # *Python* process is applied to every Provider it creates; the library itself reads no environment variable
+        for name in _ffi.DBG_KEYS:
+            env = os.environ.get("DANN_" + name.upper())
+            if env not in (None, ""):
+                self.debug_set(**{name: float(int(env, 0)) if name.startswith("tune") else float(env)})
 
     def close(self):
         if getattr(self, "_h", None):
@@ -422,6 +430,27 @@ class Provider:
 
     def kernel_time_reset(self):
         check(_ffi.lib().dann_kernel_time_reset(self._h), "dann_kernel_time_reset")
+
+    def debug_set(self, **switches):
+        """development switches of include/dann_debug.h (per index, read on every call, never change a result):
+        debug_set(pair_min_queries=1, tune_off=4); None restores a default"""
+        for name, value in switches.items():
+            v = float("nan") if value is None else float(value)
+            check(_ffi.lib().dann_debug_set(self._h, _ffi.DBG_KEYS[name], v), "dann_debug_set")
+
+    def search_families(self):
+        """{family: (launches, HIP-event ms)} of the beam-search launches since the last kernel_time_reset()"""
+        n = len(_ffi.FAMILIES)
+        cnt, ms = (C.c_uint64 * n)(), (C.c_double * n)()
+        check(_ffi.lib().dann_debug_search_families(self._h, cnt, ms), "dann_debug_search_families")
+        return {f: (int(cnt[i]), float(ms[i])) for i, f in enumerate(_ffi.FAMILIES)}
+
+    def last_family(self, fn):
+        """runs fn() and returns (its result, the set of kernel families that served searches meanwhile)"""
+        before = self.search_families()
+        out = fn()
+        after = self.search_families()
+        return out, {f for f in after if after[f][0] > before[f][0]}
 
     def set_visited_bits(self, bits):
         check(_ffi.lib().dann_set_visited_bits(self._h, bits), "dann_set_visited_bits")

@@ -29,6 +29,46 @@ int32_t dann_debug_concurrent_callers(dann_index* idx, const void* queries, uint
                                       uint32_t threads, uint32_t mode, uint32_t depth, uint32_t* out_ids,
                                       float* out_dists, float* out_latency_us, double* out_seconds);
 
+/* ---- development switches (per index; none of them ever changes a result) ------------------------------------------
+ * The library used to read these from DANN_* environment variables, some of them cached at the first call of the
+ * process; they are per-index settings now, read on every call.  value = NaN restores the default. */
+enum {
+    DANN_DBG_TUNE_OFF = 0,               /* bit mask: 1 row prefetch in latency mode, 2 latency-mode table sizing, 4 teams of
+                                            wavefronts, 8 the teams' speculative expansion, 16 two queries per wavefront,
+                                            32 the lookup-table kernel of PQ rows (default 0) */
+    DANN_DBG_TUNE_ON = 1,                /* bit mask: 1 row prefetch in the throughput regime too (default 0) */
+    DANN_DBG_PAIR_MIN_QUERIES = 2,       /* launches of at least this many queries take two queries per wavefront
+                                            (default 20 x compute units) */
+    DANN_DBG_TEAM_MAX_QUERIES = 3,       /* launches of at most this many queries take a team per query (default 4 x CUs) */
+    DANN_DBG_HOST_PIPELINE = 4,          /* 0: dann_search_batch never chunks its host buffers (default 1) */
+    DANN_DBG_SWEEP_ONE_BY_ONE = 5,       /* 1: the MFMA prune's sweep decides one candidate at a time (default 0) */
+    DANN_DBG_POOL_GRAM = 6,              /* 0: the pool prune of rows >= 1 KiB stays on the row kernel (default 1) */
+    DANN_DBG_GRAM_COLS = 7,              /* columns of the Gram block: 32 / 64 / 96 (default 96) */
+    DANN_DBG_GRAM_ESCALE = 8,            /* test hook: widens the error interval of the Gram distances (default 1.0) */
+    DANN_DBG_BACKEDGE_GRAM_ROWS = 9,     /* Gram rows per back-edge list (default degree + 8 rounded up to 32) */
+    DANN_DBG_SERVER_MAX_RESIDENT_US = 10,/* residency bound of the server kernel, read by dann_server_start (default 200000) */
+    DANN_DBG_VERBOSE = 11,               /* 1: launch sizing decisions on stderr (default 0) */
+    DANN_DBG_COUNT = 12
+};
+int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
+int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);
+
+/* which beam-search kernel family served the launches of this index since the last dann_kernel_time_reset: launches
+ * and HIP-event milliseconds per family (tests assert that the kernel they claim to test is the one that ran; bench.py
+ * names the family of every timed leg).  out_launches / out_ms: DANN_FAMILY_COUNT entries each (either may be null). */
+enum {
+    DANN_FAMILY_ONE_WAVE = 0,    /* beam_search_kernel, one wavefront per query */
+    DANN_FAMILY_TEAM = 1,        /* beam_search_kernel, four wavefronts per query (latency regime) */
+    DANN_FAMILY_PAIR = 2,        /* pair_search_kernel, two queries per wavefront (128-byte integer rows) */
+    DANN_FAMILY_PERSISTENT = 3,  /* beam_search_kernel, persistent wavefronts sharing a batch (dann_set_max_concurrency) */
+    DANN_FAMILY_SERVER = 4,      /* the resident server kernel */
+    DANN_FAMILY_PQ_LUT = 5,      /* pq_search_kernel, lookup table in registers (PQ rows) */
+    DANN_FAMILY_COUNT = 6
+};
+int32_t dann_debug_search_families(const dann_index* idx, uint64_t* out_launches, double* out_ms);
+/* family name for logs ("one_wave", "team", "pair", "persistent", "server", "pq_lut"); null for an unknown family */
+const char* dann_debug_family_name(int32_t family);
+
 #ifdef __cplusplus
 }
 #endif

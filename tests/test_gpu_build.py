@@ -260,7 +260,7 @@ def test_build_splits_batches_that_need_an_oversized_bootstrap():
     (oracle.INNER_PRODUCT, 96, 28, 32),        # PruneKind::Occluding
     (oracle.COSINE_NORMALIZED, 64, 20, 24),    # 1 - <x, y> on unit vectors
 ])
-def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeypatch):
+def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg):
     """dann_build with the MFMA back-edge and pool prunes == the oracle's multi_insert, adjacency byte for byte (tie-free
     data); the same again with the error interval widened 10^6 x, which drives every comparison through the exact
     re-check."""
@@ -278,10 +278,9 @@ def test_mfma_backedge_build_identical_to_oracle(metric, dim, R, maxdeg, monkeyp
     oix.set_rows(0, data)
     for s0, b in batch_schedule(0, n, growth, max_batch):
         oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
-    for escale in (None, "1e6"):
-        if escale:
-            monkeypatch.setenv("DANN_GRAM_ESCALE", escale)
+    for escale in (None, 1e6):
         gix = da.Provider(oracle.F32, metric, dim, n, maxdeg, start)
+        gix.debug_set(gram_escale=escale)   # 1e6: every decision falls into the widened interval -> the exact path
         gix.set_elements(0, data)
         gix.set_build_options(da.BUILD_MFMA_BACKEDGE | da.BUILD_MFMA_POOL)
         gix.build(gcfg, 0, n, growth, max_batch)
@@ -353,7 +352,7 @@ def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
 
 @pytest.mark.parametrize("dtype,metric,dim", [(oracle.F16, oracle.L2, 96), (oracle.F16, oracle.INNER_PRODUCT, 100),
                                               (oracle.F32, oracle.L2, 260)])
-def test_mfma_pool_prune_f16_and_default_policy_identical_to_oracle(dtype, metric, dim, monkeypatch):
+def test_mfma_pool_prune_f16_and_default_policy_identical_to_oracle(dtype, metric, dim):
     """The three-kernel pool prune on f16 rows (widened exactly while the Gram slabs are filled; exact re-checks by the
     reference's f16 x f16 pair kernel) and as the default policy for rows of 1 KiB and more (dim 260 f32): adjacency ==
     the oracle's multi_insert, also with every decision forced through the exact path, and most pair distances the
@@ -371,10 +370,9 @@ def test_mfma_pool_prune_f16_and_default_policy_identical_to_oracle(dtype, metri
     oix.set_rows(0, data)
     for s0, b in batch_schedule(0, n, growth, max_batch):
         oix.multi_insert(ocfg, np.arange(s0, s0 + b, dtype=np.uint32))
-    for escale in (None, "1e6"):
-        if escale:
-            monkeypatch.setenv("DANN_GRAM_ESCALE", escale)
+    for escale in (None, 1e6):
         gix = da.Provider(dtype, metric, dim, n, maxdeg, start)
+        gix.debug_set(gram_escale=escale)
         gix.set_elements(0, data)
         if dim * data.itemsize < 1024:
             gix.set_build_options(da.BUILD_MFMA_POOL)   # small rows: opt in; rows >= 1 KiB take the path by default

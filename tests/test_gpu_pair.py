@@ -14,12 +14,22 @@ da = pytest.importorskip("diskann_amd")
 
 @pytest.fixture(autouse=True)
 def _pairs_from_the_first_query(monkeypatch):
-    monkeypatch.setenv("DANN_PAIR_MIN_QUERIES", "1")  # (by default only launches beyond the latency regime are paired)
+    """by default only launches beyond the latency regime are paired (20 x compute units queries): every Provider of
+    this file pairs from the first query on (dann_debug_set, read by the library on every call)"""
+    orig = da.Provider.__init__
+
+    def init(self, *a, **kw):
+        orig(self, *a, **kw)
+        self.debug_set(pair_min_queries=1)
+
+    monkeypatch.setattr(da.Provider, "__init__", init)
 
 
-def _check(gix, oix, queries, L, k, tag):
+def _check(gix, oix, queries, L, k, tag, family="pair"):
+    """the search equals the oracle's -- and was served by the kernel family this file is about"""
     oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
-    gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)
+    (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))
+    assert fam == {family}, (fam, tag)
     assert not gst["status"].any(), tag
     assert np.array_equal(oi, gi), tag
     assert np.array_equal(bits(od), bits(gd)), tag
@@ -50,7 +60,7 @@ def test_pair_kernel_equals_the_oracle(dtype, metric, R, nstart):
             _check(gix, oix, queries, L, k, (nq, L, k))
 
 
-def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits(monkeypatch):
+def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits():
     """L + start points = 33, degree 33, other row lengths: not the pair kernel's -- same results either way"""
     rng = np.random.default_rng(9)
     n = 4000
@@ -59,10 +69,13 @@ def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits(monkeyp
         data = rand_vectors(rng, dtype, n, dim)
         adj = random_graph(rng, n, R)
         oix, gix = make_pair(dtype, oracle.L2, data, adj, data[:1], R)
-        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L))
+        # (50 queries: the latency regime -- a team per query where a team instantiation exists, i.e. 128-element rows)
+        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L), family="team" if dim == 128 else "one_wave")
+        gix.debug_set(tune_off=4)
+        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L), family="one_wave")
 
 
-def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query(monkeypatch):
+def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query():
     """explicit tables of 64 .. 1024 words per query: frozen after a few hops, continued in the spill pool (20 000
     queries recycle its 512 tables many times), and a query that outgrows even that is re-run with one wave"""
     rng = np.random.default_rng(21)
@@ -71,14 +84,17 @@ def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query
     adj = random_graph(rng, n, R)
     oix, gix = make_pair(oracle.U8, oracle.L2, data, adj, data[:1], R)
     queries = rand_vectors(rng, oracle.U8, nq, dim)
-    monkeypatch.setenv("DANN_TUNE_OFF", "20")      # one wave per query, no teams
-    ri, rd, rst = gix.search(da.Knn(30), queries, 10)
-    monkeypatch.delenv("DANN_TUNE_OFF")
+    gix.debug_set(tune_off=20)      # one wave per query, no teams
+    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(30), queries, 10))
+    assert fam == {"one_wave"}, fam
+    gix.debug_set(tune_off=None)
     gix.set_visited_format(16)
     for words in (0, 64, 256, 1024):
         gix.set_visited_bits(words)
         for rep in range(2):
-            gi, gd, gst = gix.search(da.Knn(30), queries, 10)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(30), queries, 10))
+            # (tiny tables: queries that outgrow table + spill pool are re-run with one wavefront per query)
+            assert "pair" in fam and fam <= {"pair", "one_wave"}, (fam, words)
             assert not gst["status"].any(), words
             assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd)), words
             assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), words
@@ -110,3 +126,20 @@ def test_pair_kernel_sq8_rows(metric, stride):
         queries = da.sq8_compress(rng.normal(0.3, 0.5, (nq, dim)).astype(np.float32), shift, scale)
         for L, k in ((8, 5), (26, 10), (31, 10)):
             _check(gix, oix, queries, L, k, (nq, L, k))
+
+
+def test_default_threshold_pairs_exactly_from_twenty_queries_per_compute_unit():
+    """without the test switch: launches of 20 x CUs queries and more are paired, one query fewer is not -- and both
+    sides of the threshold return the oracle's results (the last wavefront of the odd batch carries one query)"""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    floor = 20 * cus
+    rng = np.random.default_rng(1234)
+    n, dim, R = 8000, 128, 32
+    data = rand_vectors(rng, oracle.I8, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.I8, oracle.L2, data, adj, data[:1], R)
+    gix.debug_set(pair_min_queries=None)
+    queries = rand_vectors(rng, oracle.I8, floor + 1, dim)
+    for nq, family in ((floor - 1, "one_wave"), (floor, "pair"), (floor + 1, "pair")):
+        _check(gix, oix, queries[:nq], 26, 10, nq, family=family)

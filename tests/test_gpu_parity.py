@@ -262,11 +262,11 @@ def test_spill_tables_recycled_under_load():
 
 @pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.F16, oracle.L2), (oracle.U8, oracle.L2),
                                           (oracle.I8, oracle.INNER_PRODUCT), (oracle.U8, oracle.COSINE)])
-def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric, monkeypatch):
+def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric):
     """Latency regime: launches with few queries give every query a team of four wavefronts (queue / control / visited
     filter / row gather, talking through an LDS mailbox; the control wave decides the next expansion before the merge,
     the visited wave filters the predicted one after that speculatively -- inserts that are taken back when the prediction
-    fails).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query launch's (DANN_TUNE_OFF bit 4
+    fails).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query launch's (debug_set(tune_off=...): bit 4
     switches the teams off, bit 8 the speculation), with several start points and for every queue size the team
     instantiations cover (L + start points <= 256) and beyond; a small explicit visited table makes a team give the query
     back (a team never spills) and the host re-run it with one wave."""
@@ -280,13 +280,18 @@ def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric, mon
         queries = rand_vectors(rng, dtype, nq, dim)
         for L, k in ((1, 1), (10, 10), (26, 10), (64, 10), (125, 20), (253, 50), (300, 10)):
             oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
-            monkeypatch.delenv("DANN_TUNE_OFF", raising=False)
-            gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)        # teams + speculative expansion of the predicted node
-            monkeypatch.setenv("DANN_TUNE_OFF", "8")
-            ni, nd, nst = gix.search(da.Knn(L, 1), queries, k)        # teams, no speculation
-            monkeypatch.setenv("DANN_TUNE_OFF", "4")
-            si, sd, sst = gix.search(da.Knn(L, 1), queries, k)        # one wave per query
-            monkeypatch.delenv("DANN_TUNE_OFF", raising=False)
+            gix.debug_set(tune_off=0)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))  # teams + speculative
+            # expansion of the predicted node (a 256-entry table makes some teams give their query back: re-run, one wave)
+            teamed = L + nstart <= 256   # beyond 256 queue entries no team instantiation exists: one wave per query
+            assert ("team" in fam) == teamed and (len(fam) == 1 or vbits), (fam, nq, L)
+            gix.debug_set(tune_off=8)
+            (ni, nd, nst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))  # teams, no speculation
+            assert ("team" in fam) == teamed, (fam, nq, L)
+            gix.debug_set(tune_off=4)
+            (si, sd, sst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))  # one wave per query
+            assert fam == {"one_wave"}, (fam, nq, L)
+            gix.debug_set(tune_off=None)
             for ids, d, st in ((gi, gd, gst), (ni, nd, nst), (si, sd, sst)):
                 assert np.array_equal(oi, ids), (nq, L)
                 assert np.array_equal(bits(od), bits(d)), (nq, L)

@@ -242,14 +242,14 @@ def test_poll_alone_brings_an_exited_kernel_back():
         gix.server_stop()
 
 
-def test_resident_kernel_leaves_under_load_and_results_stay_exact(monkeypatch):
+def test_resident_kernel_leaves_under_load_and_results_stay_exact():
     """The resident kernel leaves not only when it is idle but also after max_resident_us of residence under a steady
     stream of tickets (a hipFree elsewhere in the process is a device-wide synchronisation and would otherwise wait for
     the callers to pause).  With the bound lowered to 1 ms, thousands of tickets from eight native threads cross dozens
     of drain / relaunch cycles: every result is still the oracle's, no ticket is lost, and another index can be created
     and destroyed (hipMalloc / hipFree) by a second thread while the server is kept busy."""
-    monkeypatch.setenv("DANN_SERVER_MAX_RESIDENT_US", "1000")
     rng, oix, gix = _index(oracle.F32, oracle.L2, 6000, 128, 32, 37)
+    gix.debug_set(server_max_resident_us=1000)   # (read by server_start)
     q = rand_vectors(rng, oracle.F32, 6000, 128)
     L, k = 32, 10
     oi, od, _, _ = oix.search_batch(q, L, 1, k)

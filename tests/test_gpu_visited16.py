@@ -1,7 +1,8 @@
 """16-bit visited-table entries (dann_set_visited_format; search_kernel_impl.h: ht16_insert_open): an exact set at half
 the LDS -- every result, distance and counter must equal the oracle's and the 32-bit table's, also when ids run out of
 probes (they go to the spill table) and when the table is frozen and handed on to the spill pool under load.
-tests/test_visited16_model.py holds the CPU argument; `DANN_TEST_VISITED_FORMAT=16 DANN_TUNE_OFF=4 pytest -m gpu` runs
+tests/test_visited16_model.py holds the CPU argument; `DANN_TEST_VISITED_FORMAT=16 DANN_TUNE_OFF=4 pytest -m gpu` (read by
+tests/conftest.py and the Python Provider, not by the library) runs
 the whole suite on this table."""
 import numpy as np
 import pytest
@@ -15,7 +16,14 @@ da = pytest.importorskip("diskann_amd")
 
 @pytest.fixture(autouse=True)
 def _one_wave_per_query(monkeypatch):
-    monkeypatch.setenv("DANN_TUNE_OFF", "4")  # small launches would go to teams (32-bit tables only)
+    """small launches would go to teams (32-bit tables only): every Provider of this file has them switched off"""
+    orig = da.Provider.__init__
+
+    def init(self, *a, **kw):
+        orig(self, *a, **kw)
+        self.debug_set(tune_off=4)
+
+    monkeypatch.setattr(da.Provider, "__init__", init)
 
 
 CASES = [
@@ -43,7 +51,8 @@ def test_search_parity_with_16_bit_entries(dtype, metric, dim, R, stride):
         gix.set_visited_bits(vbits)
         for L, k in ((1, 1), (10, 10), (26, 10), (64, 10), (200, 10), (300, 50)):
             oi, od, oc, ost = oix.search_batch(queries, L, 1, k)
-            gi, gd, gst = gix.search(da.Knn(L, 1), queries, k)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))
+            assert fam == {"one_wave"}, (fam, fmt, vbits, L)
             assert not gst["status"].any(), (fmt, vbits, L)
             assert np.array_equal(oi, gi), (fmt, vbits, L)
             assert np.array_equal(bits(od), bits(gd)), (fmt, vbits, L)
