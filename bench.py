@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--nq-shared", type=int, default=10000, help="size of the shared query set (the protocol's nq)")
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
+    ap.add_argument("--no-pq-pack", action="store_true", help="PQ leg: search the plain rows (no dann_pq_pack_neighbors)")
     ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8", "pq",
                                                    "build768", "cpu-distance"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
@@ -861,6 +862,11 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                        pq_pivots=pivots_h, pq_offsets=bounds)
     prov.set_elements(0, codes_h)
     prov.upload_graph(full_prov.download_graph())
+    t_pack = None
+    if not args.no_pq_pack:  # opt-in search layout: adjacency + the neighbours' code rows in one 64-byte-aligned row
+        t_pack = time.perf_counter()
+        prov.pq_pack_neighbors()
+        t_pack = time.perf_counter() - t_pack
     d_st = torch.empty((args.nq, 5), dtype=torch.int32, device=dev)
     d_out = torch.empty((args.nq, k), dtype=torch.int32, device=dev)
     d_outd = torch.empty((args.nq, k), dtype=torch.float32, device=dev)
@@ -935,6 +941,9 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                               "lds_lookups_per_s": lds_lookups / (search_ms * 1e-3),
                               "lut_build_flop_per_launch": lut_flop},
             "rerank_share_of_time": max(0.0, 1.0 - search_ms * 1e-3 / dt),
+            "packed_neighbor_codes": None if t_pack is None else {
+                "seconds": round(t_pack, 4), "bytes": (args.n + 1) * ((((args.max_degree + 1) * 4 + 15) // 16 * 16 +
+                                                                       16 * args.max_degree + 63) // 64 * 64)},
             "train_seconds_kmeanspp_plus_10_lloyds_131072_rows": round(t_train, 3),
             "compress_seconds_incl_pcie": round(t_comp, 3)}
 

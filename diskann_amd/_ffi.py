@@ -129,6 +129,7 @@ SYMBOLS = {
     "dann_save_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _u32]),
     "dann_load_vectors_bin": (_i32, [_vp, C.c_char_p, _u32, _P(_u32)]),
     "dann_set_pq_table": (_i32, [_vp, _vp, _vp]),
+    "dann_pq_pack_neighbors": (_i32, [_vp]),
     "dann_sq8_train": (_i32, [_i32, _vp, _u64, _u32, C.c_double, _vp, _vp, _vp]),
     "dann_sq8_compress": (_i32, [_i32, _vp, _u32, _u32, _vp, _f32, _vp]),
     "dann_pq_build_lut": (_i32, [_i32, _i32, _vp, _vp, _u32, _u32, _vp, _u32, _vp]),

@@ -196,6 +196,9 @@ dann::IndexView dann_index::view() const {
     v.pq_pivots = d_pq_pivots;
     v.pq_offsets = d_pq_offsets;
     v.pq_chunks = cfg.pq_chunks;
+    v.pq_pack = pq_pack_valid ? d_pq_pack : nullptr;
+    v.pq_pack_stride = pq_pack_stride;
+    v.pq_pack_codes = pq_pack_codes;
     v.tag_off = cfg.inline_tags ? layer_bytes : 0u;
     return v;
 }
@@ -346,6 +349,7 @@ int32_t dann_index_destroy(dann_index* idx) try {
     if (idx->d_adj) (void)hipFree(idx->d_adj);
     if (idx->d_pq_pivots) (void)hipFree(idx->d_pq_pivots);
     if (idx->d_pq_offsets) (void)hipFree(idx->d_pq_offsets);
+    if (idx->d_pq_pack) (void)hipFree(idx->d_pq_pack);
     if (idx->build_scratch && idx->build_scratch_free) idx->build_scratch_free(idx->build_scratch);
     delete idx;
     return DANN_OK;
@@ -529,6 +533,39 @@ int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* 
     DANN_HIP(hipMemcpyAsync(idx->d_pq_pivots, pivots, (size_t)256 * dim * 4, hipMemcpyHostToDevice, idx->main.stream));
     DANN_HIP(hipMemcpyAsync(idx->d_pq_offsets, chunk_offsets, (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, idx->main.stream));
     DANN_HIP(hipStreamSynchronize(idx->main.stream));
+    return DANN_OK;
+} DANN_CATCH_ALL
+
+// ---- packed search layout of PQ indexes ----------------------------------------------------------------------------
+int32_t dann_pq_pack_neighbors(dann_index* idx) try {
+    CHECK_IDX(idx);
+    if (idx->cfg.dtype != DT_PQ || idx->cfg.pq_chunks > 16u || idx->cfg.inline_tags) {
+        set_error("dann_pq_pack_neighbors: a DANN_PQ index of at most 16 chunks without inline tags");
+        return DANN_EUNSUPPORTED;
+    }
+    if (idx->srv_outstanding.sum() != 0) {
+        set_error("the index has search-server tickets outstanding");
+        return DANN_EBUSY;
+    }
+    const uint32_t R = idx->cfg.max_degree;
+    const uint32_t codes_off = ((R + 1u) * 4u + 15u) & ~15u;
+    const uint32_t stride = (codes_off + 16u * R + 63u) & ~63u;
+    const size_t bytes = (size_t)idx->nslots * stride;
+    if (idx->pq_pack_bytes < bytes) {
+        if (idx->d_pq_pack) (void)hipFree(idx->d_pq_pack);
+        idx->d_pq_pack = nullptr;
+        idx->pq_pack_bytes = 0;
+        idx->pq_pack_valid = false;
+        DANN_HIP(hipMalloc((void**)&idx->d_pq_pack, bytes));
+        idx->pq_pack_bytes = bytes;
+    }
+    idx->pq_pack_stride = stride;
+    idx->pq_pack_codes = codes_off;
+    idx->pq_pack_valid = false;
+    int32_t rc = launch_pq_pack(idx->view(), idx->d_pq_pack, stride, codes_off, idx->main.stream);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));
+    idx->pq_pack_valid = true;
     return DANN_OK;
 } DANN_CATCH_ALL
 

@@ -71,6 +71,11 @@ struct IndexView {
     const float* pq_pivots;
     const uint32_t* pq_offsets;
     uint32_t pq_chunks;
+    // PQ rows, packed search layout (dann_pq_pack_neighbors; null = none): node i's row at pq_pack + i * pq_pack_stride =
+    // [u32 len][u32 x max_degree neighbour ids][pad to 16][16-byte code row of each neighbour], 64-byte aligned
+    const uint8_t* pq_pack;
+    uint32_t pq_pack_stride;
+    uint32_t pq_pack_codes;  // byte offset of the code rows within a packed row
     // inline concurrency tags (dann_config::inline_tags): byte offset of a row's tag (== layer_bytes), 0 = none.
     // A slot is readable iff tag >= 254 (Tag::can_read, diskann-inmem/src/tag.rs:86-133).
     uint32_t tag_off;
@@ -171,6 +176,8 @@ struct SearchArgs {
     uint32_t* work_next = nullptr;   //    this counter (zeroed before the launch): dann_set_max_concurrency
     ServerView srv;                  // srv.ring != 0: the launch is the persistent server (grid = workers + 1 waves)
     uint32_t team = 0;               // 1: several wavefronts per query (latency regime; plain fixed-length searches only)
+    uint32_t pqlut = 0;              // 1: PQ rows through pq_search_kernel (search_pq_impl.h: lookup table in registers, 16-bit
+                                     //    visited table; plain Knn, <= 16 chunks, L + start points <= 256)
     uint32_t pair = 0;               // 1: two queries per wavefront (search_pair_impl.h; 128-byte integer rows, L + start
                                      //    points <= 32, degree <= 32); ht_entries = table words of ONE query then
 };
@@ -212,6 +219,7 @@ DANN_DECL_LAUNCH(i8);
 DANN_DECL_LAUNCH(sq8);
 DANN_DECL_LAUNCH(pq);
 #undef DANN_DECL_LAUNCH
+int32_t launch_search_pqlut(const SearchArgs& a, size_t lds, hipStream_t stream);  // search_pqlut.hip (SearchArgs::pqlut)
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a);
 // enqueue the persistent server kernel (a.srv filled in) on ctx.stream; returns without waiting
@@ -237,6 +245,8 @@ int32_t launch_rerank(const IndexView& ix, const void* d_queries, uint32_t nq, c
                       uint32_t k, uint32_t* d_out_ids, float* d_out_d, hipStream_t stream);
 int32_t launch_distance_pairs(const IndexView& ix, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, float* d_out,
                               hipStream_t stream);
+// dann_pq_pack_neighbors: writes the packed rows (adjacency + neighbours' code rows) of every slot of the index
+int32_t launch_pq_pack(const IndexView& ix, uint8_t* d_pack, uint32_t stride, uint32_t codes_off, hipStream_t stream);
 // raw rows x[i] vs y[i] (pair kernel numerics), n pairs of `bytes` each
 int32_t launch_distance_raw(const IndexView& ix, const void* d_x, const void* d_y, uint64_t stride, uint32_t n,
                             float* d_out, hipStream_t stream);
@@ -291,6 +301,11 @@ struct dann_index {
     uint64_t build_counters[4] = {0, 0, 0, 0};
     float* d_pq_pivots = nullptr;
     uint32_t* d_pq_offsets = nullptr;
+    // dann_pq_pack_neighbors: adjacency + neighbours' code rows per node; dropped (valid = false) by every mutation
+    uint8_t* d_pq_pack = nullptr;
+    size_t pq_pack_bytes = 0;
+    uint32_t pq_pack_stride = 0, pq_pack_codes = 0;
+    bool pq_pack_valid = false;
     std::unordered_map<uint64_t, dann::VisitedCalib> calib;  // guarded by stat_mu
     void* build_scratch = nullptr;            // owned by build_kernels.hip
     void (*build_scratch_free)(void*) = nullptr;
@@ -362,6 +377,7 @@ struct MutationScope {
         i->mutating.fetch_add(1, std::memory_order_seq_cst);
         ok = i->srv_outstanding.sum() == 0;
         if (!ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);
+        else i->pq_pack_valid = false;  // (the caller holds the index exclusively) derived layouts die with the mutation
     }
     ~MutationScope() {
         if (ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);

@@ -803,7 +803,7 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                     // adjacency rows, should a candidate be expanded straight away
                     if (touch && keep) {
                         const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
-                        const uint32_t last = ix.layer_bytes - 4u;
+                        const uint32_t last = ix.layer_bytes >= 4u ? ix.layer_bytes - 4u : 0u;  // (PQ rows of fewer than four chunks)
                         const uint8_t* p1 = prow + (128u < last ? 128u : last);
                         const uint8_t* p2 = prow + (256u < last ? 256u : last);
                         const uint8_t* p3 = prow + (384u < last ? 384u : last);
@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     auto touch_row = [&](uint32_t id, bool on) {
         if (on) {
             const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
-            const uint32_t last = ix.layer_bytes - 4u;
+            const uint32_t last = ix.layer_bytes >= 4u ? ix.layer_bytes - 4u : 0u;  // (PQ rows of fewer than four chunks)
             const uint8_t* p1 = prow + (128u < last ? 128u : last);
             const uint8_t* p2 = prow + (256u < last ? 256u : last);
             const uint8_t* p3 = prow + (384u < last ? 384u : last);

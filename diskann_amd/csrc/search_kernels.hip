@@ -32,6 +32,7 @@
 // in registers/LDS.
 #include "search_kernel_impl.h"
 #include "search_pair_impl.h"
+#include "search_pq_impl.h"
 
 namespace dann {
 #ifdef DANN_PHASE_CYCLES
@@ -52,6 +53,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 
 size_t search_lds_bytes(const SearchArgs& a) {
     if (a.pair) return 2u * (size_t)pair_lds_layout(a.ht_entries).half_bytes;
+    if (a.pqlut) return pq_lds_layout(pq_lut_qs(a), a.ht_entries).total;
     return search_lds_layout(a.ht_entries, cmax_of(a), lds_queue_entries(a), query_lds_bytes(a.ix), a.team != 0).total;
 }
 
@@ -198,6 +200,7 @@ __global__ void cmps_hist_kernel(const dann_search_stats* stats, uint32_t n, uin
 int search_family(const SearchArgs& a) {
     if (a.srv.ring) return DANN_FAMILY_SERVER;
     if (a.pair) return DANN_FAMILY_PAIR;
+    if (a.pqlut) return DANN_FAMILY_PQ_LUT;
     if (a.team) return DANN_FAMILY_TEAM;
     if (a.grid) return DANN_FAMILY_PERSISTENT;
     return DANN_FAMILY_ONE_WAVE;
@@ -224,6 +227,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
         set_error("per-query LDS footprint %zu B exceeds 160 KiB (visited table %u entries)", lds, a.ht_entries);
         return DANN_EOVERFLOW;
     }
+    if (a.pqlut && !regs_out) return launch_search_pqlut(a, lds, stream);
     switch (a.ix.dtype) {
         case DT_F32: return launch_search_f32(a, qcap, lds, stream, regs_out);
         case DT_F16: return launch_search_f16(a, qcap, lds, stream, regs_out);
@@ -307,6 +311,9 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             a.team = 0;
         }
     }
+    // PQ rows of at most 16 chunks, plain Knn search: the lookup table in registers (search_pq_impl.h).
+    // DANN_DBG_TUNE_OFF bit 32: development switch.
+    a.pqlut = (pq_lut_shape(a) && idx->visited_format != 32u && !idx->tune_off(32)) ? 1u : 0u;
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = calib_key(a);
     // calibration state of this (L, beam, mode) -- shared by concurrent callers: read and written under stat_mu
@@ -316,6 +323,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             std::lock_guard<std::mutex> lk(idx->stat_mu);
             cal = idx->calib[key];
         }
+        if (a.pqlut) cal.waves = 16u;  // (pq_search_kernel is compiled for four wavefronts per SIMD)
         if (!cal.waves) {  // queries per CU the registers of this instantiation allow (512 VGPRs per SIMD lane)
             int regs = 0;
             a.ht_entries = 256;
@@ -354,18 +362,37 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                 a.pair = 0;
             }
         }
-        if (!a.pair) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
+        if (a.pqlut) {
+            // one 16-bit table: registers cap the CU at 16 queries = 8 LDS granules each; the table takes what is left of
+            // them (a sparse table costs nothing but its wipe), or -- a larger 90th percentile of comparisons -- the
+            // first step whose open capacity holds it with a tenth to spare
+            const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
+            const uint32_t fixed = pq_lds_layout(pq_lut_qs(a), 0).total;
+            uint32_t words = 0;
+            for (uint32_t g = kLdsGranules / 16u; g <= kLdsGranules && !words; ++g) {
+                if (g * kLdsGranule <= fixed) continue;
+                const uint32_t w = std::min<uint32_t>((g * kLdsGranule - fixed) / 4u / 64u * 64u, 32768u);
+                if ((uint64_t)w * 2u * 3u / 4u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+            }
+            if (words) {
+                a.ht16 = 1;
+                a.ht_entries = words;
+            } else {
+                a.pqlut = 0;
+            }
+        }
+        if (!a.pair && !a.pqlut) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
         if (idx->verbose() && (cal.calls & (cal.calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u %s, %zu B LDS\n", a.l_value, a.beam_width,
                     cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior",
                     a.ht16 ? a.ht_entries * 2u : a.ht_entries,
-                    a.pair ? "16-bit slots per query, two queries per wavefront" : a.ht16 ? "16-bit slots" : "entries",
+                    a.pair ? "16-bit slots per query, two queries per wavefront" : a.pqlut ? "16-bit slots, PQ table in registers" : a.ht16 ? "16-bit slots" : "entries",
                     search_lds_bytes(a));
     } else {
         // explicit size (dann_set_visited_bits): 16-bit entries only on request (dann_set_visited_format)
         a.ht16 = 0;
         if (a.pair && idx->visited_format != 16u) a.pair = 0;  // (the pair kernel has 16-bit tables only)
-        if (idx->visited_format == 16u && ht16_eligible(a)) {
+        if ((idx->visited_format == 16u || a.pqlut) && ht16_eligible(a)) {
             uint32_t words = std::max<uint32_t>((a.ht_entries + 63u) / 64u * 64u, 64u);
             while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words = std::min<uint32_t>(words * 2u, 32768u);
             if (ht16_geometry(words, a.ix.nslots).ok) {
@@ -374,6 +401,9 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             }
         }
         if (a.pair && !a.ht16) a.pair = 0;
+        if (a.pqlut && !a.ht16) a.pqlut = 0;
+        // (the two special kernels carry their own LDS layout: a table they cannot hold goes to beam_search_kernel)
+        if ((a.pair || a.pqlut) && search_lds_bytes(a) > 160 * 1024) a.pair = a.pqlut = 0;
     }
     // the start points are inserted unconditionally and the first hop needs room before the freeze test can
     // trigger: the open table must hold nstart + W * R ids below its 75 % load limit, or ht_visit could probe a
@@ -515,8 +545,8 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
         if (h == 0) return DANN_OK;
         if (a.team) {
             a.team = 0;  // a team never spills its visited table: the same table, one wave per query (which does)
-        } else if (a.pair) {
-            a.pair = 0;  // re-runs go through beam_search_kernel: the table of one query doubled
+        } else if (a.pair || a.pqlut) {
+            a.pair = a.pqlut = 0;  // re-runs go through beam_search_kernel: the table of one query doubled
             a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
         } else {
             if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status

@@ -52,10 +52,13 @@ __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int l) { return (uint32_t
 
 // Insert into the open 16-bit table, written without a per-lane branch: the hop is bound by the scalar unit (every
 // `if` on a lane condition costs an exec-mask save / branch / restore there), so the probe is one straight body that
-// all lanes run until the last one is done -- a lane with nothing to insert swaps the dword for itself.  Same probe
+// all lanes run until the last one is done -- a lane with nothing to insert swaps a dword of its own for itself.  Same probe
 // sequence, same table contents as ht16_insert_open.  Returns 1 = inserted (the id was new), 2 = no slot among its
 // probes (the caller freezes the table), 0 = already present / inactive.
-__device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& t, uint32_t id, bool active) {
+// `own`: a dword of LDS that belongs to this lane alone -- a lane that has nothing (more) to insert swaps THAT word for
+// itself: compare-and-swaps of many lanes on one address (the lanes beyond a list's length all carry the same id) are
+// served one after the other, like a bank conflict.
+__device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& t, uint32_t id, bool active, uint32_t* own) {
     const uint32_t tagmask = (1u << t.tb) - 1u;
     uint32_t x = id * kHt16A;
     const uint32_t step = id * kHt16B2;
@@ -63,7 +66,7 @@ __device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& 
     bool pending = active;
     do {
         const uint32_t slot = ht16_slot(t, x), val = ht16_tag(t, x, tagmask) | (k << t.tb);
-        uint32_t* const wp = htw + (slot >> 1);
+        uint32_t* const wp = pending ? htw + (slot >> 1) : own;
         const uint32_t sh = (slot & 1u) << 4;
         const uint32_t w = *wp;
         const uint32_t cur = (w >> sh) & 0xFFFFu;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
         const uint32_t id = ix.capacity + li;
         if (li < ns) cand_id[li] = id;
         __syncthreads();  // the tables are wiped
-        if (ballot64(ht16_insert_flat(ht, h16, id, on) == 2u)) stv = kOverflow;  // (a table of >= 64 slots: never)
+        if (ballot64(ht16_insert_flat(ht, h16, id, on, sink) == 2u)) stv = kOverflow;  // (a table of >= 64 slots: never)
         ncv = alivev ? ns : 0u;
     }
     __syncthreads();
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
             const uint32_t id = inb ? vall : kEmpty;
             // (the 16-bit table holds ids below 2^m only; an id beyond the index is never a candidate anyway)
             const bool act = inb & (id != kEmpty) & (id < ix.nslots);
-            const uint32_t r = ht16_insert_flat(ht, h16, id, act & openv);
+            const uint32_t r = ht16_insert_flat(ht, h16, id, act & openv, sink);
             bool isnew = r == 1u;
             const bool exh = r == 2u;
             if (ballot64(exh | (act & !openv))) {  // (rare) no slot among an id's probes, or a frozen table

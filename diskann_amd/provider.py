@@ -431,6 +431,11 @@ class Provider:
     def kernel_time_reset(self):
         check(_ffi.lib().dann_kernel_time_reset(self._h), "dann_kernel_time_reset")
 
+    def pq_pack_neighbors(self):
+        """opt-in search layout of a PQ index: adjacency + the neighbours' code rows per node (dann_pq_pack_neighbors);
+        dropped by any later mutation, never changes a result"""
+        check(_ffi.lib().dann_pq_pack_neighbors(self._h), "dann_pq_pack_neighbors")
+
     def debug_set(self, **switches):
         """development switches of include/dann_debug.h (per index, read on every call, never change a result):
         debug_set(pair_min_queries=1, tune_off=4); None restores a default"""
