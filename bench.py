@@ -691,6 +691,10 @@ def main():
             # the HBM-side fraction of the same kernel: the 6.4 GB index, 25 x the Infinity Cache
             out["roofline"]["hbm_side_frac"] = out["roofline_large"]["frac"]
             out["roofline"]["hbm_side_workload"] = out["roofline_large"]["workload"]
+            # what of that HBM provably served (first-touch bytes), and the distance kernel on rows read once per launch
+            out["roofline"]["hbm_side"] = {
+                "beam_search_first_touch": out["roofline_large"].get("hbm_side"),
+                "distance_kernel_rows_read_once": out["roofline_large"].get("hbm_side_distance_kernel")}
         print(json.dumps(_strict(out)), flush=True)
     if world > 1:
         dist.barrier()
@@ -1138,6 +1142,57 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
                             "distances_cmps_hops_identical": bool(
                                 np.array_equal(gd, od.view(np.uint32)) and
                                 np.array_equal(gst[:, 0], ost[:, 0]) and np.array_equal(gst[:, 1], ost[:, 1]))}
+    # ---- what part of the launch's reads HBM must have served.  The fabric-side counters (FETCH_SIZE = TCC_EA0_RDREQ,
+    # TCC_EA0_RDREQ_DRAM) count requests the L2 sends towards memory and cannot tell an Infinity-Cache hit from a DRAM
+    # access, so the split is made from the algorithm: the rows a launch reads for the FIRST time must come from DRAM (the
+    # 256 MiB cache cannot hold them from the launch before: the index is 25 x its size), re-reads may come from anywhere.
+    # Distinct rows = the union over all queries of the neighbours of the nodes they expanded (every neighbour of an
+    # expanded node is evaluated by that query once); distinct adjacency rows = the expanded nodes.
+    try:
+        rid, _, rn, _ = prov.search_record_queries(queries.cpu().numpy(), L)
+        rid_t = torch.from_numpy(rid.view(np.int32)).to(dev)
+        valid = torch.arange(rid.shape[1], device=dev)[None, :] < torch.from_numpy(rn.astype(np.int64)).to(dev)[:, None]
+        expanded = torch.unique(rid_t[valid])
+        del rid_t, valid
+        adj_t = torch.from_numpy(adj.view(np.int32)).to(dev)
+        rows_of = adj_t[expanded.long()]
+        lens = rows_of[:, 0].clamp(max=R)
+        nb = rows_of[:, 1:]
+        keep = torch.arange(R, device=dev)[None, :] < lens[:, None]
+        distinct_rows = int(torch.unique(nb[keep]).numel()) + 1  # (+ the start point)
+        distinct_adj = int(expanded.numel())
+        del adj_t, rows_of, nb, keep
+        compulsory = distinct_rows * row_bytes + distinct_adj * adj_bytes
+        res["hbm_side"] = {
+            "distinct_rows_per_launch": distinct_rows, "distinct_adjacency_rows_per_launch": distinct_adj,
+            "first_touch_bytes_per_launch": compulsory, "share_of_algorithmic_bytes": compulsory / alg,
+            "dram_rate_at_least_GBps": compulsory / (avg_ms * 1e-3) / 1e9,
+            "note": "first-touch bytes must come from DRAM; the other reads of the launch (the same rows again, by other "
+                    "queries) are served by L2 / Infinity Cache / DRAM in a mix no counter of this rocprofv3 separates"}
+    except Exception as e:  # noqa: BLE001
+        res["hbm_side"] = {"error": str(e)[:200]}
+    # ---- and the distance kernel where nothing CAN be cached: ExpandBeam::expand_beam batched (expand_beam_kernel) over
+    # row ids drawn WITHOUT repetition from the whole store -- every row is read once per launch
+    try:
+        gq = 20000
+        gl = max(1, min(256, n // gq))
+        gids = np.random.default_rng(7).permutation(n)[:gq * gl].astype(np.uint32)
+        goff = np.arange(gq + 1, dtype=np.uint64) * gl
+        qh_g = queries[:gq].cpu().numpy()
+        prov.expand_beam_batch(qh_g, gids, goff)
+        prov.kernel_time_reset()
+        for _ in range(3):
+            prov.expand_beam_batch(qh_g, gids, goff)
+        gms, gn = prov.kernel_time(1)
+        gbytes = gq * gl * row_bytes
+        grate = gbytes / (gms / max(gn, 1) * 1e-3) / 1e9
+        res["hbm_side_distance_kernel"] = {
+            "kernel": "expand_beam_kernel", "rows_per_launch": gq * gl, "every_row_read_once": True,
+            "bytes_per_launch": gbytes, "avg_kernel_ms": gms / max(gn, 1), "achieved_GBps": grate,
+            "frac_of_hbm_peak": grate / HBM_PEAK_GBS,
+            **({"frac_of_measured_stream_read": grate / stream_read_gbps} if stream_read_gbps else {})}
+    except Exception as e:  # noqa: BLE001
+        res["hbm_side_distance_kernel"] = {"error": str(e)[:200]}
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_large_latest.json")))
         if pm["workload"] == spec and pm["L"] == L and pm["nq"] == nq:

@@ -925,6 +925,23 @@ static int32_t grow_stage(SearchCtx& ctx, int i, size_t need) {
     return DANN_OK;
 }
 
+// The scratch arena of the range / filtered searches (stage[4]) stays resident between calls only up to this size: a
+// call with per-query filter bitmaps on a large index can need gigabytes, and an index that nearly fills HBM would
+// miss them in its next build or search (the pool keeps up to 16 contexts).  Beyond it the block is released when the
+// call returns (a hipFree synchronises the device: the price of a call that large, not of every call).
+constexpr size_t kArenaKeepBytes = (size_t)256 << 20;
+struct ArenaTrim {
+    SearchCtx& ctx;
+    ~ArenaTrim() {
+        if (ctx.stage_bytes[4] > kArenaKeepBytes) {
+            (void)hipStreamSynchronize(ctx.stream);
+            (void)hipFree(ctx.stage[4]);
+            ctx.stage[4] = nullptr;
+            ctx.stage_bytes[4] = 0;
+        }
+    }
+};
+
 int32_t dann_search_batch_device(dann_index* idx, const void* d_queries, uint32_t nq, uint32_t l_value,
                                  uint32_t beam_width, uint32_t k, uint32_t* d_out_ids, float* d_out_dists,
                                  dann_search_stats* d_out_stats) try {
@@ -1079,6 +1096,7 @@ int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t n
                                 uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                 uint32_t* out_second_round) try {
     CHECK_IDX_SHARED(idx);  // read-only: concurrent callers run side by side, each on its own context
+    ArenaTrim _trim{ctx};
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
         set_error("l_value and beam width cannot be zero");
@@ -1349,6 +1367,7 @@ int32_t dann_filtered_search_batch(dann_index* idx, const void* queries, uint32_
                                    uint32_t beam_width, uint32_t k, const dann_filter* filter, uint32_t* out_ids,
                                    float* out_dists, dann_search_stats* out_stats) try {
     CHECK_IDX_SHARED(idx);
+    ArenaTrim _trim{ctx};
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
     FilteredCall c{queries, nq, l_value, beam_width, k, filter, out_ids, out_dists, out_stats};
@@ -1362,6 +1381,7 @@ int32_t dann_filtered_range_search_batch(dann_index* idx, const void* queries, u
                                          uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats,
                                          uint32_t* out_second_round) try {
     CHECK_IDX_SHARED(idx);
+    ArenaTrim _trim{ctx};
     // RangeSearchError (range_search.rs:30-45, 93-131)
     if (starting_l == 0 || beam_width == 0) {
         set_error("l_value and beam width cannot be zero");

@@ -374,6 +374,10 @@ struct MutationScope {
     dann_index* i;
     bool ok;
     explicit MutationScope(const dann_index* idx) : i(const_cast<dann_index*>(idx)) {
+        if (i->srv_outstanding.sum() != 0) {  // refused without ever raising `mutating`: no submit bounces on our account
+            ok = false;
+            return;
+        }
         i->mutating.fetch_add(1, std::memory_order_seq_cst);
         ok = i->srv_outstanding.sum() == 0;
         if (!ok) i->mutating.fetch_sub(1, std::memory_order_seq_cst);
@@ -385,13 +389,15 @@ struct MutationScope {
     MutationScope(const MutationScope&) = delete;
     MutationScope& operator=(const MutationScope&) = delete;
 };
+void server_quiesce(dann_index* idx);  // server.hip: the resident kernel leaves and is waited for (relaunched by the next submit)
 #define DANN_MUTATION(idx)                                                                                            \
     ::dann::MutationScope _mut(idx);                                                                                  \
     if (!_mut.ok) {                                                                                                   \
         ::dann::set_error("the index has search-server tickets outstanding: collect them (dann_search_wait) or stop " \
                           "the server before mutating the index");                                                   \
         return DANN_EBUSY;                                                                                            \
-    }
+    }                                                                                                                 \
+    ::dann::server_quiesce(const_cast<dann_index*>(static_cast<const dann_index*>(idx)))
 constexpr uint32_t kMaxSearchCtx = 16;
 // a search context for one concurrent call: from the pool, created on demand (at most kMaxSearchCtx), else waits
 struct CtxLease {

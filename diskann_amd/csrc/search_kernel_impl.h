@@ -160,69 +160,64 @@ __device__ __forceinline__ bool ht_insert_open_slot(uint32_t* ht, uint32_t mod, 
 // ---- the visited table with 16-bit entries (SearchArgs::ht16) ------------------------------------------------------
 // Half the LDS per id, still an exact set.  Ids live below 2^m (m = bits of the slot count of the index); probe k of id
 // looks at x_k = id * (A + k * B2) mod 2^m -- A odd, B2 even: every multiplier is odd, so id -> x_k is a bijection of
-// [0, 2^m) for every k.  The table has S slots (any even number): slot = floor(x_k * S / 2^m) (multiplicative hashing
-// onto [0, S)), so the x_k of one slot are a contiguous range of at most ceil(2^m / S) <= 2^tb values, and the entry
-// stores (k << tb) | (x_k & (2^tb - 1)): within one slot the low tb bits tell the x_k apart.  Slot and entry together
-// give k and x_k, hence the id: two different ids never look alike, whatever the probe they were placed by.  0xFFFF is
-// "empty" (k stays below 2^(16 - tb) - 1, so no entry is all ones).  An id that finds kmax occupied slots is "exhausted": the
-// caller freezes the table and sends it to the spill table in global memory (lookups keep probing kmax slots first).
-// Two slots share a dword and LDS has no 16-bit compare-and-swap: an insert swaps the whole dword and retries on the
-// same slot when the neighbour changed meanwhile.
+// [0, 2^m) for every k.  The table is W dwords = W buckets of two 16-bit entries (any W): bucket = floor(x_k * W / 2^m)
+// (multiplicative hashing onto [0, W)), so the x_k of one bucket are a contiguous range of at most ceil(2^m / W) <= 2^tb
+// values, and an entry stores (k << tb) | (x_k & (2^tb - 1)): within one bucket the low tb bits tell the x_k apart.
+// Bucket and entry together give k and x_k, hence the id: two different ids never look alike, whatever the probe they
+// were placed by and whichever half of the bucket they sit in.  0xFFFF is "empty" (k stays below 2^(16 - tb) - 1, so no
+// entry is all ones).  An insert takes the first empty half (low, then high) of the first probed bucket that has one;
+// entries are never removed, so a bucket's high half is never occupied while its low half is empty, and a lookup may
+// stop at the first bucket with an empty half.  (Round 5: a probe used to look at ONE 16-bit slot; with two per probe a
+// wavefront's inserts of a hop need 1.7 trips through the probe loop instead of 2.9 at the tables' load.)  An id that
+// finds kmax full buckets is "exhausted": the caller freezes the table and sends it to the spill table in global
+// memory (lookups keep probing kmax buckets first).  LDS has no 16-bit compare-and-swap: an insert swaps the whole
+// dword and retries on the same bucket when the other half changed meanwhile.
 constexpr uint32_t kHt16A = 0x9E3779B1u, kHt16B2 = 0x3C6EF372u;
 enum : int { kHt16Present = 0, kHt16Inserted = 1, kHt16Exhausted = 2 };
 struct Ht16 {
-    uint32_t shift, slots, tb, kmax;  // shift = 32 - m: x << shift is x_k as a 32-bit fraction of 2^m
+    uint32_t shift, buckets, tb, kmax;  // shift = 32 - m: x << shift is x_k as a 32-bit fraction of 2^m
 };
-__device__ __forceinline__ uint32_t ht16_slot(const Ht16& t, uint32_t x) { return __umulhi(x << t.shift, t.slots); }
+// (SearchArgs::ht_prime holds the number of 16-bit entries = 2 * buckets)
+__device__ __forceinline__ Ht16 ht16_of(const SearchArgs& a) { return Ht16{a.ht_shift, a.ht_prime >> 1, a.ht_tb, a.ht_kmax}; }
+__device__ __forceinline__ uint32_t ht16_bucket(const Ht16& t, uint32_t x) { return __umulhi(x << t.shift, t.buckets); }
 __device__ __forceinline__ uint32_t ht16_tag(const Ht16& t, uint32_t x, uint32_t tagmask) {
     return ((x << t.shift) >> t.shift) & tagmask;
 }
 __device__ __forceinline__ int ht16_insert_open(uint32_t* htw, const Ht16& t, uint32_t id, bool active) {
     const uint32_t tagmask = (1u << t.tb) - 1u;
     uint32_t x = id * kHt16A;
-    uint32_t slot = ht16_slot(t, x), val = ht16_tag(t, x, tagmask);
-    uint32_t* wp = htw + (slot >> 1);
-    uint32_t sh = (slot & 1u) << 4;
-    uint32_t w = *wp;  // (inactive lanes read some slot of the table too: no branch around the load)
-    uint32_t cur = (w >> sh) & 0xFFFFu;
-    const bool tryins = active && cur == 0xFFFFu;
-    uint32_t old = w;
-    if (tryins) old = atomicCAS(wp, w, w ^ ((0xFFFFu ^ val) << sh));
-    int res = (tryins && old == w) ? kHt16Inserted : kHt16Present;
-    bool pending = active && res != kHt16Inserted && cur != val;
-    if (ballot64(pending)) {
-        const uint32_t step = id * kHt16B2;
-        bool adv = !tryins;  // occupied by another id: next probe; lost the swap to the neighbour slot: the same slot again
-        uint32_t k = 0;
-        w = old;
-        while (pending) {
-            if (adv) {
-                ++k;
-                x += step;
-                if (k >= t.kmax) {
-                    res = kHt16Exhausted;
-                    break;
-                }
-                slot = ht16_slot(t, x);
-                val = ht16_tag(t, x, tagmask) | (k << t.tb);
-                wp = htw + (slot >> 1);
-                sh = (slot & 1u) << 4;
-                w = *wp;
-            }
-            cur = (w >> sh) & 0xFFFFu;
-            if (cur == val) {
+    const uint32_t step = id * kHt16B2;
+    uint32_t k = 0;
+    int res = kHt16Present;
+    bool pending = active;
+    uint32_t* wp = htw + ht16_bucket(t, x);
+    uint32_t val = ht16_tag(t, x, tagmask);
+    uint32_t w = *wp;  // (inactive lanes read some bucket of the table too: no branch around the load)
+    while (ballot64(pending)) {
+        if (pending) {
+            const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+            if (lo == val || hi == val) {
                 pending = false;  // present
-            } else if (cur == 0xFFFFu) {
-                old = atomicCAS(wp, w, w ^ ((0xFFFFu ^ val) << sh));
+            } else if (lo == 0xFFFFu || hi == 0xFFFFu) {
+                const uint32_t neww = lo == 0xFFFFu ? (w ^ (0xFFFFu ^ val)) : (w ^ ((0xFFFFu ^ val) << 16));
+                const uint32_t old = atomicCAS(wp, w, neww);
                 if (old == w) {
                     res = kHt16Inserted;
                     pending = false;
                 } else {
-                    w = old;
-                    adv = false;
+                    w = old;  // the other half changed meanwhile (another lane of this hop): the same bucket again
                 }
-            } else {
-                adv = true;
+            } else {  // both halves hold other ids: next probe
+                ++k;
+                x += step;
+                if (k >= t.kmax) {
+                    res = kHt16Exhausted;
+                    pending = false;
+                } else {
+                    wp = htw + ht16_bucket(t, x);
+                    val = ht16_tag(t, x, tagmask) | (k << t.tb);
+                    w = *wp;
+                }
             }
         }
     }
@@ -231,13 +226,13 @@ __device__ __forceinline__ int ht16_insert_open(uint32_t* htw, const Ht16& t, ui
 // lookup in the frozen table: true when `id` is present
 __device__ __forceinline__ bool ht16_contains(const uint32_t* htw, const Ht16& t, uint32_t id) {
     const uint32_t tagmask = (1u << t.tb) - 1u;
-    const uint16_t* h16 = reinterpret_cast<const uint16_t*>(htw);
     uint32_t x = id * kHt16A;
     const uint32_t step = id * kHt16B2;
     for (uint32_t k = 0; k < t.kmax; ++k, x += step) {
-        const uint32_t cur = h16[ht16_slot(t, x)];
-        if (cur == (ht16_tag(t, x, tagmask) | (k << t.tb))) return true;
-        if (cur == 0xFFFFu) return false;
+        const uint32_t w = htw[ht16_bucket(t, x)], val = ht16_tag(t, x, tagmask) | (k << t.tb);
+        const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+        if (lo == val || hi == val) return true;
+        if (lo == 0xFFFFu || hi == 0xFFFFu) return false;
     }
     return false;
 }
@@ -963,7 +958,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     const uint32_t ht_size = a.ht_entries;
     uint32_t status_early = 0;  // (HT16) an insert outside the hop found no slot: the query is re-run with a larger table
     const uint32_t ht_mod = a.ht_prime;  // probing modulus: largest prime <= ht_size (HT16: the number of 16-bit slots)
-    const Ht16 h16{a.ht_shift, a.ht_prime, a.ht_tb, a.ht_kmax};
+    const Ht16 h16 = ht16_of(a);
     // insert into the open table outside the hop (start points, the second phase of a range search)
     auto visit_open = [&](uint32_t id) {
         if constexpr (HT16) {

@@ -83,28 +83,27 @@ uint32_t snap_visited_entries(SearchArgs a, uint32_t cap_ids, uint32_t useful_wa
 uint32_t largest_prime_leq(uint32_t n);
 
 // ---- 16-bit table entries (SearchArgs::ht16; device side: ht16_insert_open) -----------------------------------------
-// Geometry of a table of `words` dwords = 2 * words slots (any even count) for ids below the index's slot count: m id
-// bits; the ids of one slot are at most ceil(2^m / slots) consecutive values, told apart by tb tag bits; 16 - tb bits
-// are left for the probe number.
+// Geometry of a table of `words` dwords = `words` buckets of two 16-bit entries (any count) for ids below the index's
+// slot count: m id bits; the ids of one bucket are at most ceil(2^m / words) consecutive values, told apart by tb tag
+// bits; 16 - tb bits are left for the probe number (at least two: three probes = six places per id).
 struct Ht16Geom {
     bool ok = false;
-    uint32_t shift = 0, tb = 0, kmax = 0, slots = 0;
+    uint32_t shift = 0, tb = 0, kmax = 0, slots = 0;  // slots = 2 * words: the entries the table holds
 };
 Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
     Ht16Geom g;
-    const uint32_t slots = words * 2u;
-    if (words < 32u || slots > 65536u * 2u) return g;
+    if (words < 32u || words > 65536u) return g;
     uint32_t m = 1;
     while (m < 32u && (1ull << m) < (uint64_t)nslots) ++m;
     if (m >= 32u) return g;
-    const uint64_t per_slot = ((1ull << m) + slots - 1) / slots;  // ids of one slot: at most this many consecutive values
+    const uint64_t per_bucket = ((1ull << m) + words - 1) / words;  // ids of one bucket: at most this many consecutive values
     uint32_t tb = 0;
-    while ((1ull << tb) < per_slot) ++tb;
-    if (tb > 13u) return g;  // fewer than 3 bits for the probe number: too few probes per id
+    while ((1ull << tb) < per_bucket) ++tb;
+    if (tb > 14u) return g;  // fewer than 2 bits for the probe number: too few probes per id
     g.tb = tb;
     g.shift = 32u - m;
     g.kmax = std::min<uint32_t>((1u << (16u - tb)) - 1u, 64u);
-    g.slots = slots;
+    g.slots = words * 2u;
     g.ok = true;
     return g;
 }

@@ -50,11 +50,10 @@ __host__ __device__ inline PairLds pair_lds_layout(uint32_t ht_words) {
 
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-// Insert into the open 16-bit table, written without a per-lane branch: the hop is bound by the scalar unit (every
-// `if` on a lane condition costs an exec-mask save / branch / restore there), so the probe is one straight body that
-// all lanes run until the last one is done -- a lane with nothing to insert swaps a dword of its own for itself.  Same probe
-// sequence, same table contents as ht16_insert_open.  Returns 1 = inserted (the id was new), 2 = no slot among its
-// probes (the caller freezes the table), 0 = already present / inactive.
+// Insert into the open 16-bit table, written without a per-lane branch: the hop is bound by instruction issue (every
+// `if` on a lane condition costs an exec-mask save / branch / restore), so the probe is one straight body that all lanes
+// run until the last one is done.  Same probe sequence, same table contents as ht16_insert_open.  Returns 1 = inserted
+// (the id was new), 2 = no room among its probes (the caller freezes the table), 0 = already present / inactive.
 // `own`: a dword of LDS that belongs to this lane alone -- a lane that has nothing (more) to insert swaps THAT word for
 // itself: compare-and-swaps of many lanes on one address (the lanes beyond a list's length all carry the same id) are
 // served one after the other, like a bank conflict.
@@ -65,18 +64,19 @@ __device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& 
     uint32_t k = 0, res = 0;
     bool pending = active;
     do {
-        const uint32_t slot = ht16_slot(t, x), val = ht16_tag(t, x, tagmask) | (k << t.tb);
-        uint32_t* const wp = pending ? htw + (slot >> 1) : own;
-        const uint32_t sh = (slot & 1u) << 4;
+        const uint32_t val = ht16_tag(t, x, tagmask) | (k << t.tb);
+        uint32_t* const wp = pending ? htw + ht16_bucket(t, x) : own;
         const uint32_t w = *wp;
-        const uint32_t cur = (w >> sh) & 0xFFFFu;
-        const bool present = cur == val, empty = cur == 0xFFFFu;
-        const bool tryins = pending & empty;
-        const uint32_t neww = tryins ? (w ^ ((0xFFFFu ^ val) << sh)) : w;
-        const uint32_t old = atomicCAS(wp, w, neww);  // (a lost swap -- the neighbour slot changed -- reads the dword again)
+        const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+        const bool present = (lo == val) | (hi == val);
+        const bool e0 = lo == 0xFFFFu, empty = e0 | (hi == 0xFFFFu);
+        const bool tryins = pending & !present & empty;
+        const uint32_t put = (0xFFFFu ^ val) << (e0 ? 0u : 16u);  // the first empty half: low, then high
+        const uint32_t neww = tryins ? (w ^ put) : w;
+        const uint32_t old = atomicCAS(wp, w, neww);  // (a lost swap -- the other half changed -- reads the bucket again)
         const bool inserted = tryins & (old == w);
         res = inserted ? 1u : res;
-        const bool next = pending & !present & !empty;  // the slot holds another id: next probe
+        const bool next = pending & !present & !empty;  // both halves hold other ids: next probe
         k += next ? 1u : 0u;
         x += next ? step : 0u;
         const bool exh = next & (k >= t.kmax);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint32_t* const sink = reinterpret_cast<uint32_t*>(hbase + L.sink_off) + li;  // this lane's own sink
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
-    const Ht16 h16{a.ht_shift, a.ht_prime, a.ht_tb, a.ht_kmax};
+    const Ht16 h16 = ht16_of(a);
     const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};

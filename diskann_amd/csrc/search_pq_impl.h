@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     float* const cbd = reinterpret_cast<float*>(smem + L.cbd_off);
     uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
-    const Ht16 h16{a.ht_shift, a.ht_prime, a.ht_tb, a.ht_kmax};
+    const Ht16 h16 = ht16_of(a);
     const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};

@@ -175,6 +175,34 @@ int32_t relaunch_if_exited(dann_index* idx, dann_server* s) {
     return launch_locked(idx, s);
 }
 
+}  // namespace
+
+// A mutation of the index is about to run (the caller holds the index exclusively and no ticket is outstanding): the
+// resident kernel is asked to leave and waited for.  Its waves read rows and adjacency with plain cached loads, and the
+// per-XCD L2s are not coherent within a launch: a wave that stays resident across the mutation could serve a stale line of
+// a row another kernel or a copy has rewritten.  The next submit finds the exit word and relaunches -- the kernel
+// boundary gives the acquire / invalidate.
+namespace dann {
+void server_quiesce(dann_index* idx) {
+    dann_server* s = idx->server.load(std::memory_order_seq_cst);
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    if (!s->launched || __atomic_load_n(&s->hv.h_ctl[1], __ATOMIC_ACQUIRE) != 0u) {
+        // never launched, or the dispatcher has already left: wait for the workers of that launch to drain
+        if (s->launched) {
+            DeviceGuard guard(idx->device);
+            (void)hipStreamSynchronize(s->ctx.stream);
+        }
+        return;
+    }
+    DeviceGuard guard(idx->device);
+    __atomic_store_n(&s->hv.h_ctl[0], 1u, __ATOMIC_RELEASE);  // the dispatcher polls this word, sets the exit word, leaves
+    (void)hipStreamSynchronize(s->ctx.stream);
+    __atomic_store_n(&s->hv.h_ctl[0], 0u, __ATOMIC_RELEASE);  // (not a stop: relaunch_if_exited may start it again)
+}
+}  // namespace dann
+
+namespace {
 // a wait that lasts this long is a fault (a lost ticket, a dead kernel), not load: report it instead of spinning on
 constexpr uint32_t kWaitLimitSeconds = 30;
 inline bool wait_expired(uint64_t spins, std::chrono::steady_clock::time_point& began) {
@@ -494,6 +522,10 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
             if (s->poisoned.load(std::memory_order_acquire) || ((spins & 1023u) == 0 && wait_expired(spins, began))) {
                 set_error("dann_search_wait: no answer for ticket %llu within %u s (or the server's ring is wedged): "
                           "dann_server_stop / dann_server_start", (unsigned long long)ticket, kWaitLimitSeconds);
+                // the ticket is given up: it no longer counts as outstanding (mutations of the index are not refused on
+                // its account).  Its result slot stays retired -- a late answer may still land in it.
+                s->slot_owner[slot].store(0, std::memory_order_release);
+                idx->srv_outstanding.add(-1);
                 return DANN_EHIP;
             }
         }

@@ -61,8 +61,8 @@ def test_search_parity_with_16_bit_entries(dtype, metric, dim, R, stride):
 
 
 def test_ids_that_run_out_of_probes_go_to_the_spill_table():
-    """2^20 slots over a table of 128 slots leave 13 tag bits and 7 probes per id: long before the table is 75 % full
-    some ids find all their probes taken.  They freeze the table and live in the spill table from then on; the used
+    """2^20 ids over a table of 64 buckets (128 entries) leave 14 tag bits and 3 probes per id: long before the table is
+    75 % full some ids find all their probes taken.  They freeze the table and live in the spill table from then on; the used
     ids are spread over the whole id range (the start point is the highest slot)."""
     rng = np.random.default_rng(5)
     cap, used, dim, R, nq = (1 << 20) - 1, 6000, 16, 32, 400
