@@ -935,14 +935,21 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
             "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()), "mean_hops": float(st[:, 1].mean()),
             "search_kernel_traffic": traffic,
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
-            "search_kernel": {"kernel": "beam_search_kernel<DT_PQ>", "kernel_family": family, "avg_kernel_ms": search_ms, "qps_search_only": args.nq / (search_ms * 1e-3),
+            "search_kernel": {"kernel": "pq_search_kernel" if family == "pq_lut" else "beam_search_kernel<DT_PQ>",
+                              "kernel_family": family, "avg_kernel_ms": search_ms,
+                              "qps_search_only": args.nq / (search_ms * 1e-3),
                               "algorithmic_bytes_per_launch": alg_search,
                               "algorithmic_GBps": alg_search / (search_ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": alg_search / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "bound": "LDS / latency, not HBM: 16-byte code rows (a 64-byte sector each), a 16 KB lookup "
-                                       "table per query in LDS, one dependent LDS lookup per chunk and candidate",
-                              "lds_lookups_per_launch": lds_lookups,
-                              "lds_lookups_per_s": lds_lookups / (search_ms * 1e-3),
+                              "bound": ("vector-instruction issue (profiles/r05_pq_*): the query's 16 x 256 f32 table lives in "
+                                        "64 VGPRs per lane and is looked up with ds_bpermute_b32 (4 permutes + a bit-field "
+                                        "select per chunk and candidate); ~10 KB of LDS and 128 VGPRs per query -> 16 queries "
+                                        "per CU; one contiguous read per hop with the packed layout") if family == "pq_lut" else
+                                       ("LDS / latency, not HBM: 16-byte code rows (a 64-byte sector each), a 16 KB lookup "
+                                        "table per query in LDS, one dependent LDS lookup per chunk and candidate"),
+                              "queries_per_cu": 16 if family == "pq_lut" else 6,
+                              "table_lookups_per_launch": lds_lookups,
+                              "table_lookups_per_s": lds_lookups / (search_ms * 1e-3),
                               "lut_build_flop_per_launch": lut_flop},
             "rerank_share_of_time": max(0.0, 1.0 - search_ms * 1e-3 / dt),
             "packed_neighbor_codes": None if t_pack is None else {

@@ -179,7 +179,7 @@ struct SearchArgs {
     uint32_t pqlut = 0;              // 1: PQ rows through pq_search_kernel (search_pq_impl.h: lookup table in registers, 16-bit
                                      //    visited table; plain Knn, <= 16 chunks, L + start points <= 256)
     uint32_t pair = 0;               // 1: two queries per wavefront (search_pair_impl.h; 128-byte integer rows, L + start
-                                     //    points <= 32, degree <= 32); ht_entries = table words of ONE query then
+                                     //    points <= 96, degree <= 64); ht_entries = table words of ONE query then
 };
 
 // Everything one in-flight search call needs besides the (read-only) index: its own stream and events, the retry
@@ -220,6 +220,7 @@ DANN_DECL_LAUNCH(sq8);
 DANN_DECL_LAUNCH(pq);
 #undef DANN_DECL_LAUNCH
 int32_t launch_search_pqlut(const SearchArgs& a, size_t lds, hipStream_t stream);  // search_pqlut.hip (SearchArgs::pqlut)
+int32_t launch_search_pair(const SearchArgs& a, size_t lds, hipStream_t stream);   // search_pair.hip (SearchArgs::pair)
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a);
 // enqueue the persistent server kernel (a.srv filled in) on ctx.stream; returns without waiting

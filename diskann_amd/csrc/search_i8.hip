@@ -1,11 +1,9 @@
 // beam_search_kernel instantiations for DT_I8 rows (see search_kernel_impl.h; split per row type so the
 // translation units compile in parallel)
 #include "search_kernel_impl.h"
-#include "search_pair_impl.h"
 
 namespace dann {
 int32_t launch_search_i8(const SearchArgs& a, uint32_t qcap, size_t lds, hipStream_t stream, int* regs_out) {
-    if (a.pair && !regs_out) return launch_pair_dt<DT_I8>(a, lds, stream);
     return launch_dt<DT_I8>(a, qcap, lds, stream, regs_out);
 }
 }  // namespace dann

@@ -52,7 +52,7 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    if (a.pair) return 2u * (size_t)pair_lds_layout(a.ht_entries).half_bytes;
+    if (a.pair) return 2u * (size_t)pair_lds_layout(pair_qe(a), pair_re(a), a.ht_entries).half_bytes;
     if (a.pqlut) return pq_lds_layout(pq_lut_qs(a), a.ht_entries).total;
     return search_lds_layout(a.ht_entries, cmax_of(a), lds_queue_entries(a), query_lds_bytes(a.ix), a.team != 0).total;
 }
@@ -227,6 +227,7 @@ int32_t launch_search(const SearchArgs& a, hipStream_t stream, int* regs_out) {
         return DANN_EOVERFLOW;
     }
     if (a.pqlut && !regs_out) return launch_search_pqlut(a, lds, stream);
+    if (a.pair && !regs_out) return launch_search_pair(a, lds, stream);
     switch (a.ix.dtype) {
         case DT_F32: return launch_search_f32(a, qcap, lds, stream, regs_out);
         case DT_F16: return launch_search_f16(a, qcap, lds, stream, regs_out);
@@ -346,7 +347,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             // tenth to spare: the step decides how many wavefronts share a CU, and the pair kernel lives on that
             // (profiles/r04m: 16 / 8 / 4 wavefronts per CU -> 2.09 / 2.94 / 5.27 ms)
             const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
-            const uint32_t fixed = pair_lds_layout(0).half_bytes;
+            const uint32_t fixed = pair_lds_layout(pair_qe(a), pair_re(a), 0).half_bytes;
             uint32_t words = 0;
             for (uint32_t g = 2; g <= kLdsGranules && !words; ++g) {
                 const uint32_t half = g * kLdsGranule / 2u;

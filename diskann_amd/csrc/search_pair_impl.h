@@ -17,9 +17,14 @@
 // half here: they live in pairs of scalars (x0 for lanes 0-31, x1 for lanes 32-63) and are turned into a vector
 // operand by one select where a lane needs "its" value.
 //
-// Eligibility (pair_eligible): plain Knn search (beam width 1, no filter, no tags, no record), integer rows of 128
-// bytes, L + start points <= 32, max_degree <= 32, a 16-bit table geometry for the index, a launch beyond the latency
-// regime.  Everything else takes beam_search_kernel.  A query that exhausts table and spill pool reports
+// Round 5: the same hop for L + start points <= 96 (up to three queue entries per lane: entry p of a half in lane
+// p & 31, register p >> 5) and max_degree <= 64 (two adjacency ids per lane; the hop's candidates are evaluated and merged in
+// two passes of 32 -- merging a hop's candidates in two batches is the same sequence of queue inserts) -- SURVEY 8(a)'s
+// C-int8 sizing (L = 64) and config 5's degree.
+//
+// Eligibility (pair_shape): plain Knn search (beam width 1, no filter, no tags, no record), integer rows of 128
+// bytes, L + start points <= 96, at most 32 start points, max_degree <= 64, a 16-bit table geometry for the index, a
+// launch beyond the latency regime.  Everything else takes beam_search_kernel.  A query that exhausts table and spill pool reports
 // DANN_EOVERFLOW and is re-run by search_with_retry through beam_search_kernel with a larger table.
 #pragma once
 #include "search_kernel_impl.h"
@@ -30,22 +35,43 @@ namespace {
 constexpr uint32_t kPairHalf = 32;
 // LDS of one half: candidates (ids, distances), the scatter buffer of the merge ((id, distance) pairs), the queue's
 // distances in order (what the lower-bound searches read), the survivors' distances of one merge, a sink for the
-// stores of lanes that have nothing to store, the visited table
+// stores of lanes that have nothing to store, the visited table.  QE = queue entries per lane (1: L + start points <=
+// 32, 2: <= 64), RE = adjacency ids per lane (1: degree <= 32, 2: <= 64).
 struct PairLds {
     uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, sd_off, sink_off, ht_off, half_bytes;
 };
-__host__ __device__ inline PairLds pair_lds_layout(uint32_t ht_words) {
+// keys of the queue image: a power of two beyond the queue's entries (the lower-bound search needs no bound check)
+__host__ __device__ inline uint32_t pair_qimg_keys(uint32_t qe) { return qe == 1u ? 64u : 128u; }
+__host__ __device__ inline PairLds pair_lds_layout(uint32_t qe, uint32_t re, uint32_t ht_words) {
     PairLds l;
     l.cand_id_off = 0;
-    l.cand_d_off = 128;
-    l.stage_off = 0;   // the scatter buffer of a merge takes the candidates' place: they are in registers by then
-    l.qimg_off = 256;  // 64 keys: the upper 32 stay "beyond the queue" (the lower-bound search needs no bound check)
-    l.sd_off = 512;
-    l.sink_off = 640;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
-                       // 8-byte stores of the merge's scatter sink into [sd, sink): the survivors' keys are dead by then
-    l.ht_off = 768;
+    l.cand_d_off = 128u * re;
+    uint32_t off = 256u * re;
+    if (re == 1u) {
+        // one pass per hop: the scatter buffer of the merge takes the candidates' place -- they are in registers by then
+        l.stage_off = 0;
+        off = 256u * qe > off ? 256u * qe : off;
+    } else {
+        // two passes per hop: the second pass's candidates are still in their buffer when the first pass is merged
+        l.stage_off = off;
+        off += 256u * qe;
+    }
+    l.qimg_off = off;  // the entries beyond the queue stay "empty" = larger than every distance
+    off += 4u * pair_qimg_keys(qe);
+    l.sd_off = off;
+    off += 128u;
+    l.sink_off = off;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
+    off += 128u;       // 8-byte stores of the merge's scatter sink into [sd, sink + 128): the survivors' keys are dead by then
+    l.ht_off = off;
     l.half_bytes = l.ht_off + ht_words * 4u;
     return l;
+}
+// the instantiation a launch takes: queue entries per lane = ceil((L + start points) / 32) (1 .. 3), two adjacency ids per
+// lane beyond degree 32 (which comes with at least two queue entries per lane: five instantiations per metric, not six)
+__host__ __device__ inline uint32_t pair_re(const SearchArgs& a) { return a.ix.max_degree > kPairHalf ? 2u : 1u; }
+__host__ __device__ inline uint32_t pair_qe(const SearchArgs& a) {
+    const uint32_t q = (a.l_value + a.ix.nstart + kPairHalf - 1u) / kPairHalf;
+    return (q < 2u && pair_re(a) == 2u) ? 2u : (q ? q : 1u);
 }
 
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -86,17 +112,19 @@ __device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& 
     return res;
 }
 
-template <int DT, int OP, bool NORM>
+template <int DT, int OP, bool NORM, int QE, int RE>
 __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     static_assert(DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8, "integer rows");
+    static_assert(QE >= 1 && QE <= 3 && (RE == 1 || (RE == 2 && QE >= 2)), "queue entries / adjacency ids per lane");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool SIGNED = DT == DT_I8;
+    constexpr uint32_t QP = QE == 1 ? 64u : 128u;  // keys of the queue image (pair_qimg_keys)
     const IndexView& ix = a.ix;
     const uint32_t lane = threadIdx.x, li = lane & 31u;
     const bool up = lane >= kPairHalf;     // this lane serves the second query
     const uint32_t g4 = (lane >> 3) & 3u;  // lane group within the half
     const int v = (int)(lane & 7u);
-    const uint32_t R = ix.max_degree, ns = ix.nstart, qcap = a.l_value + ns;  // qcap <= 32
+    const uint32_t R = ix.max_degree, ns = ix.nstart, qcap = a.l_value + ns;  // qcap <= 32 QE, R <= 32 RE, ns <= 32
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
     constexpr uint32_t kOverflow = (uint32_t)(-DANN_EOVERFLOW);
 
@@ -106,7 +134,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     const uint32_t slot_c = exists ? slot : a.nq - 1u;
     const uint32_t qi = a.qmap ? a.qmap[slot_c] : slot_c;
 
-    const PairLds L = pair_lds_layout(a.ht_entries);
+    const PairLds L = pair_lds_layout(QE, RE, a.ht_entries);
     uint8_t* const hbase = smem + (up ? L.half_bytes : 0u);
     uint32_t* const cand_id = reinterpret_cast<uint32_t*>(hbase + L.cand_id_off);
     float* const cand_d = reinterpret_cast<float*>(hbase + L.cand_d_off);
@@ -119,13 +147,14 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
     const Ht16 h16 = ht16_of(a);
-    const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
+    const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its entries)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
         for (uint32_t i = li * 4u; i < a.ht_entries; i += kPairHalf * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
-        cand_id[li] = 0u;
-        qimg[li] = kEmpty;
-        qimg[kPairHalf + li] = kEmpty;
+#pragma unroll
+        for (int e = 0; e < RE; ++e) cand_id[e * kPairHalf + li] = 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < QP / kPairHalf; ++e) qimg[e * kPairHalf + li] = kEmpty;
     }
     // the lane's 16 query bytes and the query's squared norm stay in registers (as in the fixed-length integer path)
     const uint8_t* const qsrc = reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
@@ -136,10 +165,15 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     }
     const int xx_pre = group_norm_int_pre<SIGNED>(xqi);
 
-    // ---- state.  Queue: entry p of a half in its lane p.  What is wave-uniform in beam_search_one is uniform per half
-    // here and kept in vector registers (every lane holds the value of its half): no scalar selects, no scalar pairs.
-    uint32_t qid = kEmpty;
-    float qd = 0.0f;
+    // ---- state.  Queue: entry p of a half in lane p & 31, register p >> 5.  What is wave-uniform in beam_search_one is
+    // uniform per half here and kept in vector registers (every lane holds the value of its half): no scalar selects.
+    uint32_t qid[QE];
+    float qd[QE];
+#pragma unroll
+    for (int e = 0; e < QE; ++e) {
+        qid[e] = kEmpty;
+        qd[e] = 0.0f;
+    }
     uint32_t sizev = 0, cmpsv = 0, hopsv = 0, htcv = ns, spcv = 0, stv = 0, ncv = 0;
     bool alivev = exists, openv = true;
     uint32_t* spv = nullptr;  // the half's spill table once its LDS table is frozen
@@ -186,98 +220,122 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
         const uint32_t id = ix.capacity + li;
         if (li < ns) cand_id[li] = id;
         __syncthreads();  // the tables are wiped
-        if (ballot64(ht16_insert_flat(ht, h16, id, on, sink) == 2u)) stv = kOverflow;  // (a table of >= 64 slots: never)
+        if (ballot64(ht16_insert_flat(ht, h16, id, on, sink) == 2u)) stv = kOverflow;  // (a table of >= 64 entries: never)
         ncv = alivev ? ns : 0u;
     }
     __syncthreads();
 
     uint32_t pfnv = kEmpty;  // the node whose adjacency row was requested ahead (pf_len / pf_val), per half
-    uint32_t pf_len = 0, pf_val = kEmpty;
+    uint32_t pf_len = 0, pf_val[RE];
+#pragma unroll
+    for (int e = 0; e < RE; ++e) pf_val[e] = kEmpty;
     for (;;) {
-        // ---- distances of cand_id[0 .. nc) of both halves: 4 lane groups per half, every row of the hop requested before
-        // the first one is evaluated (one memory round trip per hop: 4, 6 or 8 rows per lane group, by the larger of
-        // the halves' candidate counts).  The sums end up in lanes 0-3 of a group: lane u stores the result of row u.
-        {
-            const uint32_t nc0 = rl_u32(ncv, 0), nc1 = rl_u32(ncv, (int)kPairHalf);
-            const uint32_t ncmax = nc0 > nc1 ? nc0 : nc1;
-            auto gather = [&](auto tag) {
-                constexpr int U = decltype(tag)::value;
-                const uint8_t* rows[U];
-                float out[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t ci = (uint32_t)u * 4u + g4;
-                    const uint32_t raw = cand_id[ci];            // (read first, select after: no load under a branch)
-                    const uint32_t id = ci < ncv ? raw : 0u;     // unused slots evaluate row 0
-                    rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
-                }
-                group_distance_int_pre<OP, SIGNED, U>(xqi, xx_pre, rows, v, out);
-#pragma unroll
-                for (int h = 0; h < (U + 3) / 4; ++h) {
-                    float val = out[4 * h];
-                    const uint8_t* row = rows[4 * h];
-#pragma unroll
-                    for (int u = 1; u < 4 && 4 * h + u < U; ++u) {
-                        val = v == u ? out[4 * h + u] : val;
-                        if constexpr (DT == DT_SQ8 && OP != OP_L2) row = v == u ? rows[4 * h + u] : row;
-                    }
-                    const uint32_t ci = (uint32_t)(4 * h + v) * 4u + g4;
-                    const bool ok = (v < 4) & (4 * h + v < U) & (ci < ncv);
-                    float* dst = ok ? cand_d + (ci & 31u) : reinterpret_cast<float*>(sink);
-                    *dst = finish_distance<DT, OP, NORM>(val, qsrc, row, ix.dim, sqp);
-                }
-            };
-            if (ncmax > 24u) gather(std::integral_constant<int, 8>());
-            else if (ncmax > 16u) gather(std::integral_constant<int, 6>());
-            else if (ncmax) gather(std::integral_constant<int, 4>());
-            cmpsv += ncv;
-        }
-        __syncthreads();
-
-        // ---- merge the candidates into the queues (see merge_regs in beam_search_one for the rule and its proof):
-        // a surviving candidate j lands at #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)}, an old
-        // entry e moves up by #{surviving j: d_j <= d_e}.  The survivors' distances go to LDS in emission order; every
-        // lane walks them (broadcast reads), the lower bounds come from a binary search in the queue's distances.
-        {
-            const bool has = li < ncv;
-            const float nd = cand_d[li];
-            const uint32_t nid = cand_id[li];
-            asm volatile("" ::: "memory");  // (the scatter below is written over the candidates' buffers)
-            const uint32_t oknd = ordered_bits(nd), okq = ordered_bits(qd);
-            // a full queue rejects what is worse than its last entry (queue.rs:142-146)
-            const uint32_t okw = qimg[(sizev - 1u) & 63u];
-            const bool nvalid = has & (nd == nd) & !((sizev == qcap) & (okw < oknd));
-            const uint64_t km = ballot64(nvalid);
-            if (km) {
-                const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
-                const uint32_t nvv = (uint32_t)__popc(up ? k1 : k0);
-                const uint32_t nvmax = max((uint32_t)__popc(k0), (uint32_t)__popc(k1));
-                const uint32_t cj = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
-                sd[li] = kEmpty;  // (keys beyond a half's survivors: larger than every distance)
-                *(nvalid ? sd + cj : sink) = oknd;
-                __syncthreads();
-                uint32_t before = 0, shift = 0;
+        // ---- distances of the candidates and their merge into the queues, 32 candidates of each half per pass (one pass
+        // per hop up to degree 32, two beyond).  Merging a hop's candidates in two batches equals merging them at once:
+        // either way it is the sequence of NeighborPriorityQueue::insert calls in adjacency order (queue.rs:130-171).
+        const uint32_t nc0 = rl_u32(ncv, 0), nc1 = rl_u32(ncv, (int)kPairHalf);
+        const uint32_t ncboth = nc0 > nc1 ? nc0 : nc1;
+        cmpsv += ncv;
 #pragma nounroll
-                for (uint32_t t = 0; t < nvmax; ++t) {
-                    const uint32_t okj = sd[t];
-                    before += okj < oknd + (t > cj ? 1u : 0u) ? 1u : 0u;  // d_j < d, or equal and emitted later
-                    shift += okj <= okq ? 1u : 0u;                        // (entries at or beyond the size are never scattered)
-                }
-                uint32_t lb = 0;  // #{old e: d_e < d}
+        for (uint32_t c0 = 0; c0 < (RE == 1 ? 1u : ncboth); c0 += kPairHalf) {
+            // 4 lane groups per half, every row of the pass requested before the first one is evaluated (one memory round
+            // trip per pass: 4, 6 or 8 rows per lane group, by the larger of the halves' candidate counts).  The sums end
+            // up in lanes 0-3 of a group: lane u stores the result of row u.
+            {
+                const uint32_t ncmax = ncboth - c0;
+                auto gather = [&](auto tag) {
+                    constexpr int U = decltype(tag)::value;
+                    const uint8_t* rows[U];
+                    float out[U];
 #pragma unroll
-                for (uint32_t step = kPairHalf; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
-                const uint32_t pos_new = lb + before, np = li + shift;
-                *(((li < sizev) & (np < qcap)) ? stage + (np & 31u) : sink2) = make_uint2(qid, __builtin_bit_cast(uint32_t, qd));
-                *((nvalid & (pos_new < qcap)) ? stage + (pos_new & 31u) : sink2) = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
-                const uint32_t total = sizev + nvv;
-                sizev = total < qcap ? total : qcap;
-                __syncthreads();
-                const uint2 e = stage[li];
-                const bool in = li < sizev;
-                qid = in ? e.x : qid;
-                qd = in ? __builtin_bit_cast(float, e.y) : qd;
-                qimg[li] = in ? ordered_bits(qd) : kEmpty;
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t ci = c0 + (uint32_t)u * 4u + g4;
+                        const uint32_t raw = cand_id[ci];            // (read first, select after: no load under a branch)
+                        const uint32_t id = ci < ncv ? raw : 0u;     // unused slots evaluate row 0
+                        rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
+                    }
+                    group_distance_int_pre<OP, SIGNED, U>(xqi, xx_pre, rows, v, out);
+#pragma unroll
+                    for (int h = 0; h < (U + 3) / 4; ++h) {
+                        float val = out[4 * h];
+                        const uint8_t* row = rows[4 * h];
+#pragma unroll
+                        for (int u = 1; u < 4 && 4 * h + u < U; ++u) {
+                            val = v == u ? out[4 * h + u] : val;
+                            if constexpr (DT == DT_SQ8 && OP != OP_L2) row = v == u ? rows[4 * h + u] : row;
+                        }
+                        const uint32_t ci = c0 + (uint32_t)(4 * h + v) * 4u + g4;
+                        const bool ok = (v < 4) & (4 * h + v < U) & (ci < ncv);
+                        float* dst = ok ? cand_d + (ci & (kPairHalf * RE - 1u)) : reinterpret_cast<float*>(sink);
+                        *dst = finish_distance<DT, OP, NORM>(val, qsrc, row, ix.dim, sqp);
+                    }
+                };
+                if (ncmax > 24u) gather(std::integral_constant<int, 8>());
+                else if (ncmax > 16u) gather(std::integral_constant<int, 6>());
+                else if (ncmax) gather(std::integral_constant<int, 4>());
             }
+            __syncthreads();
+
+            // ---- merge (see merge_regs in beam_search_one for the rule and its proof): a surviving candidate j lands at
+            // #{old e: d_e < d_j} + #{surviving i: d_i < d_j or (d_i == d_j, i > j)}, an old entry e moves up by
+            // #{surviving j: d_j <= d_e}.  The survivors' distances go to LDS in emission order; every lane walks them
+            // (broadcast reads), the lower bounds come from a binary search in the queue's distances.
+            {
+                const bool has = c0 + li < ncv;
+                const float nd = cand_d[c0 + li];
+                const uint32_t nid = cand_id[c0 + li];
+                asm volatile("" ::: "memory");  // (one pass per hop: the scatter below is written over the candidates' buffers)
+                const uint32_t oknd = ordered_bits(nd);
+                uint32_t okq[QE];
+#pragma unroll
+                for (int e = 0; e < QE; ++e) okq[e] = ordered_bits(qd[e]);
+                // a full queue rejects what is worse than its last entry (queue.rs:142-146)
+                const uint32_t okw = qimg[(sizev - 1u) & (QP - 1u)];
+                const bool nvalid = has & (nd == nd) & !((sizev == qcap) & (okw < oknd));
+                const uint64_t km = ballot64(nvalid);
+                if (km) {
+                    const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
+                    const uint32_t nvv = (uint32_t)__popc(up ? k1 : k0);
+                    const uint32_t nvmax = max((uint32_t)__popc(k0), (uint32_t)__popc(k1));
+                    const uint32_t cj = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
+                    sd[li] = kEmpty;  // (keys beyond a half's survivors: larger than every distance)
+                    *(nvalid ? sd + cj : sink) = oknd;
+                    __syncthreads();
+                    uint32_t before = 0, shift[QE];
+#pragma unroll
+                    for (int e = 0; e < QE; ++e) shift[e] = 0;
+#pragma nounroll
+                    for (uint32_t t = 0; t < nvmax; ++t) {
+                        const uint32_t okj = sd[t];
+                        before += okj < oknd + (t > cj ? 1u : 0u) ? 1u : 0u;  // d_j < d, or equal and emitted later
+#pragma unroll
+                        for (int e = 0; e < QE; ++e) shift[e] += okj <= okq[e] ? 1u : 0u;  // (entries at or beyond the size are never scattered)
+                    }
+                    uint32_t lb = 0;  // #{old e: d_e < d}
+#pragma unroll
+                    for (uint32_t step = QP / 2u; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
+                    const uint32_t pos_new = lb + before;
+#pragma unroll
+                    for (int e = 0; e < QE; ++e) {
+                        const uint32_t p = (uint32_t)e * kPairHalf + li, np = p + shift[e];
+                        *(((p < sizev) & (np < qcap)) ? stage + np : sink2) = make_uint2(qid[e], __builtin_bit_cast(uint32_t, qd[e]));
+                    }
+                    *((nvalid & (pos_new < qcap)) ? stage + pos_new : sink2) = make_uint2(nid, __builtin_bit_cast(uint32_t, nd));
+                    const uint32_t total = sizev + nvv;
+                    sizev = total < qcap ? total : qcap;
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < QE; ++e) {
+                        const uint32_t p = (uint32_t)e * kPairHalf + li;
+                        const uint2 en = stage[p];
+                        const bool in = p < sizev;
+                        qid[e] = in ? en.x : qid[e];
+                        qd[e] = in ? __builtin_bit_cast(float, en.y) : qd[e];
+                        qimg[p] = in ? ordered_bits(qd[e]) : kEmpty;
+                    }
+                }
+            }
+            if constexpr (RE > 1) __syncthreads();  // (the next pass reads the queue image this one wrote)
         }
 
         // ---- pop: the closest unexpanded entry of each queue (queue.rs:297-313); a half without one has finished -------
@@ -285,59 +343,107 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                          // gets in front of it (kEmpty: none)
         uint32_t nodev;
         {
-            const uint64_t um = ballot64((li < sizev) & !(qid & kVisitedBit) & alivev & (stv == 0u));
-            if (!um) break;
-            const uint32_t mybits = up ? (uint32_t)(um >> 32) : (uint32_t)um;
-            alivev = mybits != 0u;
+            uint64_t um[QE];
+            uint64_t any = 0;
+#pragma unroll
+            for (int e = 0; e < QE; ++e) {
+                um[e] = ballot64(((uint32_t)e * kPairHalf + li < sizev) & !(qid[e] & kVisitedBit) & alivev & (stv == 0u));
+                any |= um[e];
+            }
+            if (!any) break;
             const uint32_t hb = up ? kPairHalf : 0u;
-            const uint32_t l1 = (uint32_t)__builtin_ctz(mybits | 0x80000000u);
-            const uint32_t rest = mybits & (mybits - 1u);
-            const uint32_t l2 = (uint32_t)__builtin_ctz(rest | 0x80000000u);
-            const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l1) << 2), (int)qid);
-            const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l2) << 2), (int)qid);
-            nodev = alivev ? n1 : 0u;
-            nextv = (alivev & (rest != 0u)) ? n2 : kEmpty;
-            qid |= (alivev & (li == l1)) ? kVisitedBit : 0u;
+            if constexpr (QE == 1) {
+                const uint32_t mybits = up ? (uint32_t)(um[0] >> 32) : (uint32_t)um[0];
+                alivev = mybits != 0u;
+                const uint32_t l1 = (uint32_t)__builtin_ctz(mybits | 0x80000000u);
+                const uint32_t rest = mybits & (mybits - 1u);
+                const uint32_t l2 = (uint32_t)__builtin_ctz(rest | 0x80000000u);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l1) << 2), (int)qid[0]);
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + l2) << 2), (int)qid[0]);
+                nodev = alivev ? n1 : 0u;
+                nextv = (alivev & (rest != 0u)) ? n2 : kEmpty;
+                qid[0] |= (alivev & (li == l1)) ? kVisitedBit : 0u;
+            } else {
+                // entry p of a half sits in lane p & 31 of register p >> 5: the first two set positions over the QE masks,
+                // from the last register down (what an earlier register holds precedes what has been found so far)
+                uint32_t p1 = kEmpty, p2 = kEmpty;
+#pragma unroll
+                for (int e = QE - 1; e >= 0; --e) {
+                    const uint32_t m = up ? (uint32_t)(um[e] >> 32) : (uint32_t)um[e];
+                    const uint32_t rest = m & (m - 1u);
+                    const uint32_t f1 = (uint32_t)e * kPairHalf + (uint32_t)__builtin_ctz(m | 0x80000000u);
+                    const uint32_t f2 = (uint32_t)e * kPairHalf + (uint32_t)__builtin_ctz(rest | 0x80000000u);
+                    p2 = m ? (rest ? f2 : p1) : p2;
+                    p1 = m ? f1 : p1;
+                }
+                alivev = p1 != kEmpty;
+                const int a1 = (int)((hb + (p1 & 31u)) << 2), a2 = (int)((hb + (p2 & 31u)) << 2);
+                uint32_t n1 = 0, n2 = 0;
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)qid[e]);
+                    const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)qid[e]);
+                    n1 = (p1 >> 5) == (uint32_t)e ? t1 : n1;
+                    n2 = (p2 >> 5) == (uint32_t)e ? t2 : n2;
+                }
+                nodev = alivev ? n1 : 0u;
+                nextv = (alivev & (p2 != kEmpty)) ? n2 : kEmpty;
+                const bool mine = alivev & (li == (p1 & 31u));
+#pragma unroll
+                for (int e = 0; e < QE; ++e) qid[e] |= (mine & ((p1 >> 5) == (uint32_t)e)) ? kVisitedBit : 0u;
+            }
             hopsv += alivev ? 1u : 0u;
         }
 
         // ---- expand: adjacency row (requested a hop ahead when the prediction held), visited filter, compaction ---------
         {
             const bool miss = alivev & (nodev != pfnv);
-            uint32_t lenl = pf_len, vall = pf_val;
+            uint32_t lenl = pf_len, vall[RE];
+#pragma unroll
+            for (int e = 0; e < RE; ++e) vall[e] = pf_val[e];
             if (ballot64(miss)) {  // some half has to read its row now (both do: a half that had it reads the same again)
                 const uint32_t* arow = ix.adj + (uint64_t)nodev * ix.adj_stride;
                 lenl = arow[0];
-                vall = arow[1u + (li < R ? li : R - 1u)];
+#pragma unroll
+                for (int e = 0; e < RE; ++e) {
+                    const uint32_t j = (uint32_t)e * kPairHalf + li;
+                    vall[e] = arow[1u + (j < R ? j : R - 1u)];
+                }
             }
             const uint32_t len = lenl < R ? lenl : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            // the open table takes ids up to 75 % of its slots; then it is frozen and new ids go to a spill table
+            // the open table takes ids up to 75 % of its entries; then it is frozen and new ids go to a spill table
             const bool live = alivev & (stv == 0u);
             if (ballot64(live & (openv ? (htcv + len > ht_limit) : (spcv + len > spill_limit)))) {
                 freeze(live & openv & (htcv + len > ht_limit));
                 if (alivev & !openv & (!spv | (spcv + len > spill_limit))) stv = kOverflow;
             }
-            const bool inb = alivev & (stv == 0u) & (li < len);
-            const uint32_t id = inb ? vall : kEmpty;
-            // (the 16-bit table holds ids below 2^m only; an id beyond the index is never a candidate anyway)
-            const bool act = inb & (id != kEmpty) & (id < ix.nslots);
-            const uint32_t r = ht16_insert_flat(ht, h16, id, act & openv, sink);
-            bool isnew = r == 1u;
-            const bool exh = r == 2u;
-            if (ballot64(exh | (act & !openv))) {  // (rare) no slot among an id's probes, or a frozen table
-                if (ballot64(exh)) {
-                    freeze(exh);  // that half's table is frozen; the id goes to its spill table
-                    if (exh && spv) isnew = spill_insert(spv, spill_mask, spill_shift, id);
+            uint32_t total_new = 0;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                if (e > 0 && !ballot64(alivev & (stv == 0u) & (len > kPairHalf))) break;  // (no list of this hop is that long)
+                const uint32_t j = (uint32_t)e * kPairHalf + li;
+                const bool inb = alivev & (stv == 0u) & (j < len);
+                const uint32_t id = inb ? vall[e] : kEmpty;
+                // (the 16-bit table holds ids below 2^m only; an id beyond the index is never a candidate anyway)
+                const bool act = inb & (id != kEmpty) & (id < ix.nslots);
+                const uint32_t r = ht16_insert_flat(ht, h16, id, act & openv, sink);
+                bool isnew = r == 1u;
+                const bool exh = r == 2u;
+                if (ballot64(exh | (act & !openv))) {  // (rare) no room among an id's probes, or a frozen table
+                    if (ballot64(exh)) {
+                        freeze(exh);  // that half's table is frozen; the id goes to its spill table
+                        if (exh && spv) isnew = spill_insert(spv, spill_mask, spill_shift, id);
+                    }
+                    if (act && !openv && !exh && spv && !stv && !isnew)
+                        isnew = !ht16_contains(ht, h16, id) && spill_insert(spv, spill_mask, spill_shift, id);
                 }
-                if (act && !openv && !exh && spv && !stv && !isnew)
-                    isnew = !ht16_contains(ht, h16, id) && spill_insert(spv, spill_mask, spill_shift, id);
+                const uint64_t km = ballot64(isnew);
+                const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
+                const uint32_t rank = total_new + __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
+                *(isnew ? cand_id + (rank & (kPairHalf * RE - 1u)) : sink) = id;
+                total_new += (uint32_t)__popc(up ? k1 : k0);
             }
-            const uint64_t km = ballot64(isnew);
-            const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(k1, up ? 0u : __builtin_amdgcn_mbcnt_lo(k0, 0u));
-            *(isnew ? cand_id + (rank & 31u) : sink) = id;
-            const uint32_t cnt = (uint32_t)__popc(up ? k1 : k0);
-            ncv = stv ? 0u : cnt;
+            ncv = stv ? 0u : total_new;
             htcv += openv ? ncv : 0u;
             spcv += openv ? 0u : ncv;
         }
@@ -346,7 +452,11 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
             pfnv = nextv;
             const uint32_t* prow = ix.adj + (uint64_t)(pfnv != kEmpty ? pfnv : 0u) * ix.adj_stride;
             pf_len = prow[0];
-            pf_val = prow[1u + (li < R ? li : R - 1u)];
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const uint32_t j = (uint32_t)e * kPairHalf + li;
+                pf_val[e] = prow[1u + (j < R ? j : R - 1u)];
+            }
         }
         __syncthreads();
     }
@@ -367,20 +477,24 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     }
     // ---- results: best entries in order, start points dropped (provider.rs:933-944) -----------------------------------
     {
-        const uint32_t id = qid & ~kVisitedBit;
-        const bool res = exists & (li < sizev) & (id < ix.capacity);
-        const uint64_t rm = ballot64(res);
-        const uint32_t r0 = (uint32_t)rm, r1 = (uint32_t)(rm >> 32);
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi(r1, up ? 0u : __builtin_amdgcn_mbcnt_lo(r0, 0u));
-        const uint32_t wv = (uint32_t)__popc(up ? r1 : r0);
+        uint32_t wv = 0;
+        uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
+        float* od = a.out_dists + (uint64_t)qi * a.k;
+#pragma unroll
+        for (int e = 0; e < QE; ++e) {
+            const uint32_t id = qid[e] & ~kVisitedBit;
+            const bool res = exists & ((uint32_t)e * kPairHalf + li < sizev) & (id < ix.capacity);
+            const uint64_t rm = ballot64(res);
+            const uint32_t r0 = (uint32_t)rm, r1 = (uint32_t)(rm >> 32);
+            const uint32_t r = wv + __builtin_amdgcn_mbcnt_hi(r1, up ? 0u : __builtin_amdgcn_mbcnt_lo(r0, 0u));
+            if (a.out_ids && res && r < a.k) {
+                oi[r] = id;
+                od[r] = qd[e];
+            }
+            wv += (uint32_t)__popc(up ? r1 : r0);
+        }
         const uint32_t written = wv < a.k ? wv : a.k;
         if (a.out_ids && exists) {
-            uint32_t* oi = a.out_ids + (uint64_t)qi * a.k;
-            float* od = a.out_dists + (uint64_t)qi * a.k;
-            if (res && r < a.k) {
-                oi[r] = id;
-                od[r] = qd;
-            }
             for (uint32_t t = written + li; t < a.k; t += kPairHalf) {
                 oi[t] = kEmpty;
                 od[t] = __builtin_inff();
@@ -407,8 +521,8 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
 inline bool pair_shape(const SearchArgs& a) {
     const int dt = a.ix.dtype;
     return plain_mode(a) && !a.team && !a.grid && !a.srv.ring && !a.rec_ids && !a.range_ids && !a.qslots && a.out_ids &&
-           (dt == DT_U8 || dt == DT_I8 || dt == DT_SQ8) && a.ix.dim == 128u && a.l_value + a.ix.nstart <= kPairHalf &&
-           a.ix.max_degree <= kPairHalf && a.ix.nstart >= 1u && a.ix.row_stride % 16u == 0u;
+           (dt == DT_U8 || dt == DT_I8 || dt == DT_SQ8) && a.ix.dim == 128u && a.l_value + a.ix.nstart <= 3u * kPairHalf &&
+           a.ix.max_degree <= 2u * kPairHalf && a.ix.nstart >= 1u && a.ix.nstart <= kPairHalf && a.ix.row_stride % 16u == 0u;
 }
 
 template <int DT>
@@ -431,14 +545,22 @@ int32_t launch_pair_dt(const SearchArgs& a, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return hip_fail(e, "pair_search_kernel launch");
         return DANN_OK;
     };
+    const uint32_t qe = pair_qe(a), re = pair_re(a);
+#define DANN_PAIR_GO(OPV, NORMV)                                                                   \
+    return re == 2u ? (qe == 3u ? go(pair_search_kernel<DT, OPV, NORMV, 3, 2>)                     \
+                                : go(pair_search_kernel<DT, OPV, NORMV, 2, 2>))                    \
+         : qe == 3u ? go(pair_search_kernel<DT, OPV, NORMV, 3, 1>)                                 \
+         : qe == 2u ? go(pair_search_kernel<DT, OPV, NORMV, 2, 1>)                                 \
+                    : go(pair_search_kernel<DT, OPV, NORMV, 1, 1>)
     if (op == OP_L2) {
         if constexpr (DT == DT_SQ8) {
-            if (norm) return go(pair_search_kernel<DT, OP_L2, true>);
+            if (norm) DANN_PAIR_GO(OP_L2, true);
         }
-        return go(pair_search_kernel<DT, OP_L2, false>);
+        DANN_PAIR_GO(OP_L2, false);
     }
-    if (op == OP_IP) return go(pair_search_kernel<DT, OP_IP, false>);
-    if constexpr (DT != DT_SQ8) return go(pair_search_kernel<DT, OP_COS, false>);
+    if (op == OP_IP) DANN_PAIR_GO(OP_IP, false);
+    if constexpr (DT != DT_SQ8) DANN_PAIR_GO(OP_COS, false);
+#undef DANN_PAIR_GO
     return DANN_EUNSUPPORTED;
 }
 

@@ -1,5 +1,5 @@
-"""Two queries per wavefront (search_pair_impl.h: the throughput path of 128-byte integer rows with L + start points <= 32
-and max_degree <= 32).  Everything it returns -- ids, distances, comparisons, hops, written, result_count -- must equal the
+"""Two queries per wavefront (search_pair_impl.h: the throughput path of 128-byte integer rows with L + start points <= 64
+and max_degree <= 64 -- one to three queue entries per lane (L + start points <= 96), one or two adjacency ids per lane).  Everything it returns -- ids, distances, comparisons, hops, written, result_count -- must equal the
 oracle's and beam_search_kernel's; odd batch sizes leave the upper half of the last wavefront idle; tiny explicit tables
 drive queries through the frozen-table / spill path and, beyond it, through the re-run with one wavefront per query."""
 import numpy as np
@@ -44,6 +44,10 @@ CASES = [
     (oracle.I8, oracle.L2, 32, 1),
     (oracle.I8, oracle.INNER_PRODUCT, 17, 3),
     (oracle.I8, oracle.COSINE, 8, 1),
+    # degree beyond 32: two adjacency ids per lane, the hop's candidates in two passes
+    (oracle.U8, oracle.L2, 64, 1),
+    (oracle.I8, oracle.INNER_PRODUCT, 33, 2),
+    (oracle.U8, oracle.COSINE, 47, 32),
 ]
 
 
@@ -52,47 +56,53 @@ def test_pair_kernel_equals_the_oracle(dtype, metric, R, nstart):
     rng = np.random.default_rng(500 + R + nstart)
     n, dim = 6000, 128
     data = rand_vectors(rng, dtype, n, dim)
-    adj = random_graph(rng, n, R, nstart=nstart, min_len=0 if R == 8 else None)
+    adj = random_graph(rng, n, R, nstart=nstart, min_len=0 if R in (8, 47) else None)
     oix, gix = make_pair(dtype, metric, data, adj, data[:nstart], R)
     for nq in (1, 2, 7, 64, 333):   # odd sizes: the last wavefront carries one query
         queries = rand_vectors(rng, dtype, nq, dim)
-        for L, k in ((1, 1), (5, 5), (10, 10), (26, 10), (32 - nstart, 10), (20, 40)):
-            _check(gix, oix, queries, L, k, (nq, L, k))
+        # one queue entry per lane up to L + start points = 32, two up to 64, three up to 96 (the kernel's limit)
+        for L, k in ((1, 1), (5, 5), (10, 10), (26, 10), (32 - nstart, 10), (20, 40), (33 - nstart, 10), (48, 48),
+                     (64 - nstart, 10), (64, 100), (65 - nstart, 10), (80, 20), (96 - nstart, 96)):
+            if L >= 1 and L + nstart <= 96:
+                _check(gix, oix, queries, L, k, (nq, L, k))
 
 
 def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits():
-    """L + start points = 33, degree 33, other row lengths: not the pair kernel's -- same results either way"""
+    """L + start points = 97, degree 65, other row lengths: not the pair kernel's -- same results either way"""
     rng = np.random.default_rng(9)
     n = 4000
-    for dtype, dim, R, L in ((oracle.U8, 128, 32, 32), (oracle.U8, 128, 33, 20), (oracle.U8, 100, 32, 20),
+    for dtype, dim, R, L in ((oracle.U8, 128, 32, 96), (oracle.U8, 128, 65, 20), (oracle.U8, 100, 32, 20),
                              (oracle.F32, 128, 32, 20)):
         data = rand_vectors(rng, dtype, n, dim)
         adj = random_graph(rng, n, R)
         oix, gix = make_pair(dtype, oracle.L2, data, adj, data[:1], R)
         # (50 queries: the latency regime -- a team per query where a team instantiation exists, i.e. 128-element rows)
-        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L), family="team" if dim == 128 else "one_wave")
+        # (a team needs an adjacency row that fits one 64-lane request: degree <= 63)
+        _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L),
+               family="team" if dim == 128 and R <= 63 else "one_wave")
         gix.debug_set(tune_off=4)
         _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L), family="one_wave")
 
 
-def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query():
+@pytest.mark.parametrize("R,L", [(32, 30), (64, 60), (40, 90)])
+def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query(R, L):
     """explicit tables of 64 .. 1024 words per query: frozen after a few hops, continued in the spill pool (20 000
     queries recycle its 512 tables many times), and a query that outgrows even that is re-run with one wave"""
     rng = np.random.default_rng(21)
-    n, dim, R, nq = 20000, 128, 32, 20000
+    n, dim, nq = 20000, 128, 20000
     data = rand_vectors(rng, oracle.U8, n, dim)
     adj = random_graph(rng, n, R)
     oix, gix = make_pair(oracle.U8, oracle.L2, data, adj, data[:1], R)
     queries = rand_vectors(rng, oracle.U8, nq, dim)
     gix.debug_set(tune_off=20)      # one wave per query, no teams
-    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(30), queries, 10))
+    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(L), queries, 10))
     assert fam == {"one_wave"}, fam
     gix.debug_set(tune_off=None)
     gix.set_visited_format(16)
     for words in (0, 64, 256, 1024):
         gix.set_visited_bits(words)
         for rep in range(2):
-            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(30), queries, 10))
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(L), queries, 10))
             # (tiny tables: queries that outgrow table + spill pool are re-run with one wavefront per query)
             assert "pair" in fam and fam <= {"pair", "one_wave"}, (fam, words)
             assert not gst["status"].any(), words
@@ -100,7 +110,7 @@ def test_pair_kernel_freezes_spills_and_gives_up_exactly_like_one_wave_per_query
             assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), words
     gix.set_visited_bits(0)
     gix.set_visited_format(0)
-    oi, od, oc, ost = oix.search_batch(queries[:300], 30, 1, 10)
+    oi, od, oc, ost = oix.search_batch(queries[:300], L, 1, 10)
     assert np.array_equal(ri[:300], oi) and np.array_equal(ost[:, 0], rst["cmps"][:300])
     assert rst["cmps"].mean() > 300
 
@@ -124,7 +134,7 @@ def test_pair_kernel_sq8_rows(metric, stride):
     gix.upload_graph(adj)
     for nq in (3, 40, 257):
         queries = da.sq8_compress(rng.normal(0.3, 0.5, (nq, dim)).astype(np.float32), shift, scale)
-        for L, k in ((8, 5), (26, 10), (31, 10)):
+        for L, k in ((8, 5), (26, 10), (31, 10), (40, 10), (63, 63), (64, 10), (95, 10)):
             _check(gix, oix, queries, L, k, (nq, L, k))
 
 
@@ -143,3 +153,5 @@ def test_default_threshold_pairs_exactly_from_twenty_queries_per_compute_unit():
     queries = rand_vectors(rng, oracle.I8, floor + 1, dim)
     for nq, family in ((floor - 1, "one_wave"), (floor, "pair"), (floor + 1, "pair")):
         _check(gix, oix, queries[:nq], 26, 10, nq, family=family)
+    _check(gix, oix, queries, 63, 10, "L = 63", family="pair")   # two queue entries per lane at the default threshold
+    _check(gix, oix, queries, 64, 10, "L = 64", family="pair")   # three (SURVEY 8(a)'s C-int8 sizing: L = 64 + the start point)
