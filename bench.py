@@ -1174,8 +1174,18 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
             "distinct_rows_per_launch": distinct_rows, "distinct_adjacency_rows_per_launch": distinct_adj,
             "first_touch_bytes_per_launch": compulsory, "share_of_algorithmic_bytes": compulsory / alg,
             "dram_rate_at_least_GBps": compulsory / (avg_ms * 1e-3) / 1e9,
+            # how likely is a RE-read to find its row still in the 256 MiB Infinity Cache?  The cache turns over in
+            # 256 MiB / (fabric rate); a row is read again reads_per_row times per launch at times spread over the launch
+            "mean_reads_per_distinct_row": int(st[:, 0].sum()) / max(distinct_rows, 1),
+            "infinity_cache_turnover_us": (256 << 20) / (achieved * 1e9) * 1e6,
+            "mean_interval_between_reads_of_a_row_us": avg_ms * 1e3 / max(int(st[:, 0].sum()) / max(distinct_rows, 1), 1e-9),
+            "model_share_of_rereads_within_one_turnover": 1.0 - float(np.exp(-((256 << 20) / (achieved * 1e9) * 1e6) /
+                                                                    (avg_ms * 1e3 / max(int(st[:, 0].sum()) / max(distinct_rows, 1), 1e-9)))),
             "note": "first-touch bytes must come from DRAM; the other reads of the launch (the same rows again, by other "
-                    "queries) are served by L2 / Infinity Cache / DRAM in a mix no counter of this rocprofv3 separates"}
+                    "queries) are served by L2 / Infinity Cache / DRAM in a mix no counter of this rocprofv3 separates "
+                    "(TCC_EA0_RDREQ_DRAM counts requests towards the memory controller, Infinity-Cache hits included). The "
+                    "model line: a re-read hits the Infinity Cache only if it falls within one cache turnover of the previous "
+                    "read of that row (Poisson arrivals)"}
     except Exception as e:  # noqa: BLE001
         res["hbm_side"] = {"error": str(e)[:200]}
     # ---- and the distance kernel where nothing CAN be cached: ExpandBeam::expand_beam batched (expand_beam_kernel) over
@@ -1457,6 +1467,7 @@ def int_rows_variant(args, torch, da, lib, _ffi, dev, local, base, queries, medo
         row_bytes = args.dim
     if args.visited_bits:  # experiment knob: explicit LDS visited-table size (never affects results)
         prov.set_visited_bits(args.visited_bits)
+        prov.set_visited_format(16)  # (explicit sizes reach the pair kernel with 16-bit entries only)
     prov.set_elements(0, rows)
     prov.build(da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE),
                0, args.n, args.growth, args.max_batch)

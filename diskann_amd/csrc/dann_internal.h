@@ -134,6 +134,8 @@ struct SearchArgs {
     uint32_t ht_shift = 0;       // 32 - m, m = bits of the index's slot count
     uint32_t ht_tb = 0;          // tag bits: 2^tb >= ceil(2^m / slots)
     uint32_t ht_kmax = 0;        // probes per id
+    uint32_t ht_open = 0;        // ids the open table takes before it is frozen (set with ht_prime: 75 % of the 32-bit
+                                 // table's prime, 75 % -- DANN_DBG_HT16_OPEN_EIGHTHS -- of the 16-bit table's entries)
     uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)
     float* out_dists = nullptr;
     dann_search_stats* stats = nullptr;
@@ -223,6 +225,8 @@ int32_t launch_search_pqlut(const SearchArgs& a, size_t lds, hipStream_t stream)
 int32_t launch_search_pair(const SearchArgs& a, size_t lds, hipStream_t stream);   // search_pair.hip (SearchArgs::pair)
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a);
+// load limit of the 16-bit visited tables of this index, in eighths of their entries (DANN_DBG_HT16_OPEN_EIGHTHS)
+uint32_t ht16_open_eighths(const dann_index* idx);
 // enqueue the persistent server kernel (a.srv filled in) on ctx.stream; returns without waiting
 int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a);  // also feeds clocks[0] with the main launch's HIP-event time
 size_t search_lds_bytes(const SearchArgs& a);

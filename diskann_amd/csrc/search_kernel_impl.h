@@ -466,7 +466,7 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     const uint32_t cstride = L.cand2_id_off - L.cand_id_off;
     const uint32_t ht_mod = a.ht_prime, R = ix.max_degree;
-    const uint32_t ht_limit = ht_mod - (ht_mod >> 2);
+    const uint32_t ht_limit = a.ht_open;
     const bool latency = (a.tune & kTuneRowPrefetch) != 0;
     uint32_t pf_dummy = 0;  // landing register of prefetch loads nothing reads
     auto buf_ids = [&](uint32_t b) { return reinterpret_cast<uint32_t*>(smem + L.cand_id_off + b * cstride); };
@@ -781,7 +781,7 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
             }
             if (len != kAdjPending) {
                 len = len < R ? len : R;
-                if (table_ids + len <= ht_mod - (ht_mod >> 2)) {  // (an expansion would not overflow the table)
+                if (table_ids + len <= a.ht_open) {  // (an expansion would not overflow the table)
                     const uint32_t id = lane < len ? val : kEmpty;
                     uint32_t slot = 0;
                     const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
@@ -1428,7 +1428,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
 #endif
             uint32_t len = hit ? adj_len(pf_lenv) : arow[0];
             len = len < R ? len : R;  // Neighbors::get clamps (neighbors.rs:146-148)
-            if (lds_open && ht_count + len > ht_mod - (ht_mod >> 2)) {
+            if (lds_open && ht_count + len > a.ht_open) {
                 // freeze the LDS table, claim a spill table (kept once claimed)
                 lds_open = false;
                 claim_spill();
@@ -1847,7 +1847,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             for (uint32_t i0 = 0; i0 < nf && !status; i0 += kWave) {
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nf - i0) < (uint32_t)kWave ? (nf - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                if (lds_open && ht_count + cnt > a.ht_open) status = (uint32_t)(-DANN_EOVERFLOW);
                 else if (i < nf) visit_open(u32_load(m_ids + i));
                 if (HT16 && ballot64(status_early != 0)) status = (uint32_t)(-DANN_EOVERFLOW);
                 ht_count += cnt;
@@ -1959,7 +1959,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             for (uint32_t i0 = 0; i0 < nr && !status; i0 += kWave) {
                 const uint32_t i = i0 + lane;
                 const uint32_t cnt = (nr - i0) < (uint32_t)kWave ? (nr - i0) : (uint32_t)kWave;
-                if (lds_open && ht_count + cnt > ht_mod - (ht_mod >> 2)) status = (uint32_t)(-DANN_EOVERFLOW);
+                if (lds_open && ht_count + cnt > a.ht_open) status = (uint32_t)(-DANN_EOVERFLOW);
                 else if (i < nr) visit_open(rids[i]);
                 if (HT16 && ballot64(status_early != 0)) status = (uint32_t)(-DANN_EOVERFLOW);
                 ht_count += cnt;

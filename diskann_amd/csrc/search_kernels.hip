@@ -110,8 +110,10 @@ Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
 // may this launch use 16-bit entries at all?  (plain-mode kernels, one wave per query)
 bool ht16_eligible(const SearchArgs& a) { return plain_mode(a) && !a.team; }
 
-// probing modulus / slot count and the 16-bit geometry of the table `a` has been given
-int32_t finish_visited_table(SearchArgs& a) {
+uint32_t ht16_open_eighths(const dann_index* idx) { return std::min(7u, std::max(4u, idx->dbg_u32(DANN_DBG_HT16_OPEN_EIGHTHS, 6u))); }
+
+// probing modulus / slot count, the 16-bit geometry and the open-table limit of the table `a` has been given
+int32_t finish_visited_table(SearchArgs& a, uint32_t open_eighths) {
     if (a.ht16) {
         const Ht16Geom g = ht16_geometry(a.ht_entries, a.ix.nslots);
         if (!g.ok || !ht16_eligible(a)) {
@@ -122,14 +124,16 @@ int32_t finish_visited_table(SearchArgs& a) {
         a.ht_shift = g.shift;
         a.ht_tb = g.tb;
         a.ht_kmax = g.kmax;
+        a.ht_open = (uint32_t)((uint64_t)g.slots * open_eighths / 8u);
     } else {
         a.ht_prime = largest_prime_leq(a.ht_entries);
+        a.ht_open = a.ht_prime - (a.ht_prime >> 2);
     }
     return DANN_OK;
 }
 // ids the open table takes before it is frozen
-uint64_t visited_open_capacity(const SearchArgs& a) {
-    return a.ht16 ? (uint64_t)a.ht_entries * 2u * 3u / 4u : (uint64_t)largest_prime_leq(a.ht_entries) * 3u / 4u;
+uint64_t visited_open_capacity(const SearchArgs& a, uint32_t open_eighths) {
+    return a.ht16 ? (uint64_t)a.ht_entries * 2u * open_eighths / 8u : (uint64_t)largest_prime_leq(a.ht_entries) * 3u / 4u;
 }
 
 // sizes the table of an automatically sized launch: the 32-bit table at the top of its occupancy step, or -- where the
@@ -283,7 +287,6 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     a.spill_slices = ctx.spill_slices;
     a.spill_bits = ctx.spill_bits;
     a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
-    DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     // latency regime with at most one query per SIMD: a team of four wavefronts per query -- queue, control, visited
     // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches only (the launch falls back to one wave
     // per query where no team instantiation exists).  Decided before the table is sized: teams carry more LDS.
@@ -296,6 +299,10 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                   team_shape(a)) ? 1u : 0u;
         if (idx->tune_off(8)) a.tune |= kTuneNoSpeculation;
     }
+    // the pool's allocation counter and busy flags start every launch at zero -- except a team launch, which never
+    // touches the pool (a team gives a query that outgrows its table back to the host): one device operation less on
+    // the single-query path
+    if (!a.team) DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  A pair-hop is longer
     // than a hop of one query, so the pairing pays once the chip is full: measured on 1 M u8 rows at L = 26
     // (scratch/pair_latency.py, kernel us, pair / one wave per query): 4 096 queries 292 / 260, 6 144: 301 / 346,
@@ -353,7 +360,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                 const uint32_t half = g * kLdsGranule / 2u;
                 if (half <= fixed) continue;
                 const uint32_t w = std::min<uint32_t>((half - fixed) / 4u / 4u * 4u, 16384u);
-                if ((uint64_t)w * 2u * 3u / 4u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
             }
             if (words) {
                 a.ht16 = 1;
@@ -372,7 +379,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             for (uint32_t g = kLdsGranules / 16u; g <= kLdsGranules && !words; ++g) {
                 if (g * kLdsGranule <= fixed) continue;
                 const uint32_t w = std::min<uint32_t>((g * kLdsGranule - fixed) / 4u / 64u * 64u, 32768u);
-                if ((uint64_t)w * 2u * 3u / 4u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
             }
             if (words) {
                 a.ht16 = 1;
@@ -410,8 +417,8 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // full table forever (explicit dann_set_visited_bits sizes and small calibrated sizes are grown, never results)
     {
         const uint64_t floor_ids = (uint64_t)a.ix.nstart + (uint64_t)a.beam_width * a.ix.max_degree + 1;
-        while (a.ht_entries < 32768 && visited_open_capacity(a) <= floor_ids) a.ht_entries *= 2;
-        if (visited_open_capacity(a) <= floor_ids) {
+        while (a.ht_entries < 32768 && visited_open_capacity(a, ht16_open_eighths(idx)) <= floor_ids) a.ht_entries *= 2;
+        if (visited_open_capacity(a, ht16_open_eighths(idx)) <= floor_ids) {
             set_error("visited table: %u start points + beam %u x degree %u do not fit the largest LDS table", a.ix.nstart,
                       a.beam_width, a.ix.max_degree);
             return DANN_EINVAL;
@@ -438,7 +445,7 @@ int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     int32_t rc = prepare_launch(idx, ctx, a, a.srv.workers);
     if (rc != DANN_OK) return rc;
     a.fail_flag = nullptr;
-    if (int32_t frc = finish_visited_table(a)) return frc;
+    if (int32_t frc = finish_visited_table(a, ht16_open_eighths(idx))) return frc;
     rc = launch_search(a, ctx.stream);
     if (rc == DANN_OK) {
         std::lock_guard<std::mutex> lk(idx->stat_mu);
@@ -478,7 +485,7 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     // HIP events bracket exactly the beam-search launches, on the stream they run on
     float last_ms = 0.f;
     auto timed_launch = [&](SearchArgs& args) -> int32_t {
-        if (int32_t frc = finish_visited_table(args)) return frc;
+        if (int32_t frc = finish_visited_table(args, ht16_open_eighths(idx))) return frc;
 #ifdef DANN_PHASE_CYCLES
         args.phase_cycles = dann_phase_buffer();
 #endif

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
     const Ht16 h16 = ht16_of(a);
-    const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its entries)
+    const uint32_t ht_limit = a.ht_open;  // ids the open table takes (75 % of its entries by default)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
         for (uint32_t i = li * 4u; i < a.ht_entries; i += kPairHalf * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     uint32_t* const ht = reinterpret_cast<uint32_t*>(smem + L.ht_off);
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     const Ht16 h16 = ht16_of(a);
-    const uint32_t ht_limit = a.ht_prime - (a.ht_prime >> 2);  // ids the open table takes (75 % of its slots)
+    const uint32_t ht_limit = a.ht_open;  // ids the open table takes (75 % of its entries by default)
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
         for (uint32_t i = lane * 4u; i < a.ht_entries; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;

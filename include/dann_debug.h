@@ -48,7 +48,9 @@ enum {
     DANN_DBG_BACKEDGE_GRAM_ROWS = 9,     /* Gram rows per back-edge list (default degree + 8 rounded up to 32) */
     DANN_DBG_SERVER_MAX_RESIDENT_US = 10,/* residency bound of the server kernel, read by dann_server_start (default 200000) */
     DANN_DBG_VERBOSE = 11,               /* 1: launch sizing decisions on stderr (default 0) */
-    DANN_DBG_COUNT = 12
+    DANN_DBG_HT16_OPEN_EIGHTHS = 12,     /* load (in eighths of its entries, 4 .. 7) up to which a 16-bit visited table takes
+                                            new ids before it is frozen (default 6 = 75 %) */
+    DANN_DBG_COUNT = 13
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
 int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);

@@ -65,5 +65,20 @@ if wl in ("large",):
     json.dump({"source": f"profiles/{name}_{wl}_summary.json", "workload": spec, "L": plain["L"],
                "nq": int(plain["workload"].split(" queries/launch")[0].split()[-1]),
                "hbm_bytes_per_launch_corrected": hbm}, open(f"{P}/pmc_large_latest.json", "w"), indent=1)
+if wl == "pq":  # bench.py reads this for pq.search_kernel_traffic (rocprofv3 cannot run inside bench.py)
+    sk = plain["search_kernel"]
+    json.dump({"source": f"profiles/{name}_{wl}_summary.json (profiles/run_only.sh {tag} pq: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum "
+                         "TCC_MISS_sum in separate --pmc passes over `python bench.py --only pq --L <L>`; rows of the timed launch)",
+               "workload": {"nq": 100000, "L": plain["L"], "n": 1000000, "dim": 128, "chunks": plain["chunks"]},
+               "kernel": sk.get("kernel"), "kernel_family": sk.get("kernel_family"),
+               "packed_neighbor_codes": plain.get("packed_neighbor_codes") is not None,
+               "FETCH_SIZE_kb_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": vals["WRITE_SIZE"],
+               "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section), as for the headline kernel",
+               "fabric_bytes_per_launch_corrected": hbm, "algorithmic_bytes_per_launch": alg,
+               "TCC_HIT_sum": vals.get("TCC_HIT_sum"), "TCC_MISS_sum": vals.get("TCC_MISS_sum"),
+               "l2_hit_rate": summary["l2_hit_rate"], "avg_duration_us_under_pmc": summary["avg_duration_us_under_pmc"],
+               "kernel_trace_avg_ms": float(trace["avg_ms"]) if trace else None,
+               "queries_per_cu": sk.get("queries_per_cu"), "traffic_over_algorithmic": hbm / alg},
+              open(f"{P}/pmc_pq_latest.json", "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("hbm_bytes_per_launch_corrected", "traffic_over_algorithmic", "l2_hit_rate",
                                           "avg_duration_us_under_pmc")}, indent=1), trace)
