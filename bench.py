@@ -459,9 +459,10 @@ def main():
         # the other BASELINE.json configurations, measured on the same index (not the headline):
         # configs[1] single-query beam search at L=64, configs[2] 1024 concurrent queries
         def timed_small(nq_small, L_small, reps):
-            lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), nq_small, L_small, W, k,
-                                         C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dists.data_ptr()),
-                                         C.c_void_p(d_stats.data_ptr()))
+            d_ids.zero_()  # (a launch that skipped queries must not pass the oracle check on a previous call's rows)
+            _ffi.check(lib.dann_search_batch_device(prov._h, C.c_void_p(queries.data_ptr()), nq_small, L_small, W, k,
+                                                    C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dists.data_ptr()),
+                                                    C.c_void_p(d_stats.data_ptr())), "dann_search_batch_device")
             torch.cuda.synchronize()
             t_0 = time.perf_counter()
             for r in range(reps):

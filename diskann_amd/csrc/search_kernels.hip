@@ -294,15 +294,14 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // (dann_debug_set; read on every call).
     {
         const uint32_t limit = idx->dbg_u32(DANN_DBG_TEAM_MAX_QUERIES, 4u * idx->num_cus);
-        a.team = (inflight <= limit && !a.grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && plain_mode(a) &&
+        // (dann_set_max_concurrency: the launch will be `max_concurrency` persistent waves over the batch -- search_with_retry
+        // sets a.grid after this function -- never teams; they draw their queries from a counter in the spill pool's pad)
+        const bool will_grid = idx->max_concurrency && a.nq > idx->max_concurrency && plain_mode(a);
+        a.team = (inflight <= limit && !a.grid && !will_grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && plain_mode(a) &&
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !idx->tune_off(4) &&
                   team_shape(a)) ? 1u : 0u;
         if (idx->tune_off(8)) a.tune |= kTuneNoSpeculation;
     }
-    // the pool's allocation counter and busy flags start every launch at zero -- except a team launch, which never
-    // touches the pool (a team gives a query that outgrows its table back to the host): one device operation less on
-    // the single-query path
-    if (!a.team) DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  A pair-hop is longer
     // than a hop of one query, so the pairing pays once the chip is full: measured on 1 M u8 rows at L = 26
     // (scratch/pair_latency.py, kernel us, pair / one wave per query): 4 096 queries 292 / 260, 6 144: 301 / 346,
@@ -318,6 +317,10 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             a.team = 0;
         }
     }
+    // the pool's allocation counter and busy flags start every launch at zero -- except a team launch, which never
+    // touches the pool (a team gives a query that outgrows its table back to the host): one device operation less on
+    // the single-query path
+    if (!a.team) DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     // PQ rows of at most 16 chunks, plain Knn search: the lookup table in registers (search_pq_impl.h).
     // DANN_DBG_TUNE_OFF bit 32: development switch.
     a.pqlut = (pq_lut_shape(a) && idx->visited_format != 32u && !idx->tune_off(32)) ? 1u : 0u;
