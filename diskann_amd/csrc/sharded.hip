@@ -169,15 +169,18 @@ struct dann_comm {
 
 namespace {
 // A rank that leaves a collective sequence with an error releases the ranks waiting for it (in-process communicators;
-// the group stays failed: its ranks are out of step for good).  An argument error reported before the first collective
-// of the call is the same on every rank (the arguments are) and nobody waits for anybody: the communicator stays usable.
+// the group stays failed: its ranks are out of step for good).  The one exception: an error found by the checks of the
+// call's own arguments that every rank passes alike by contract (null output pointers, k = 0, a bad growth factor ...),
+// before anything rank-specific is looked at -- `past_args` still false -- is the same on every rank and nobody waits
+// for anybody: the communicator stays usable.  Everything later (a null or foreign index on ONE rank, a per-rank
+// capacity or dtype mismatch, an unsupported configuration of one device, an exception) releases the peers.
 struct AbortOnError {
     dann_comm* c;
     int32_t rc = DANN_OK;
+    bool past_args = false;
     explicit AbortOnError(dann_comm* comm) : c(comm) { c->in_sequence = false; }
     ~AbortOnError() {
-        const bool argument = rc == DANN_EINVAL || rc == DANN_EBOUNDS || rc == DANN_ELENGTH || rc == DANN_EUNSUPPORTED;
-        if (rc < 0 && (c->in_sequence || !argument)) c->abort();
+        if (rc < 0 && (c->in_sequence || past_args)) c->abort();
     }
 };
 }  // namespace
@@ -334,9 +337,11 @@ int32_t dann_memcpy_device(int32_t device, void* dst, const void* src, uint64_t 
 
 // ---- sharded build ----------------------------------------------------------------------------------------------------
 static int32_t build_sharded_impl(dann_index* idx, dann_comm* comm, const dann_build_config* cfg, uint32_t first, uint32_t n,
-                                  float growth, uint32_t max_batch, uint64_t* stats) {
-    if (!idx || !comm || !cfg) return DANN_EINVAL;
+                                  float growth, uint32_t max_batch, uint64_t* stats, bool* past_args) {
+    if (!comm || !cfg) return DANN_EINVAL;
     if (!(growth > 0.0f) || max_batch == 0) return DANN_EINVAL;
+    *past_args = true;  // (from here on an error may be this rank's alone: AbortOnError releases the peers)
+    if (!idx) return DANN_EINVAL;
     if ((uint64_t)first + n > idx->cfg.capacity) return DANN_EBOUNDS;
     const uint32_t world = comm->world, rank = comm->rank;
     DeviceGuard guard(idx->device);
@@ -459,9 +464,10 @@ int32_t dann_build_sharded(dann_index* idx, dann_comm* comm, const dann_build_co
     if (!comm) return DANN_EINVAL;
     AbortOnError guard(comm);
     try {
-        guard.rc = build_sharded_impl(idx, comm, cfg, first, n, growth, max_batch, stats);
+        guard.rc = build_sharded_impl(idx, comm, cfg, first, n, growth, max_batch, stats, &guard.past_args);
     } catch (...) {
         guard.rc = DANN_EINVAL;
+        guard.past_args = true;
         throw;
     }
     return guard.rc;
@@ -469,10 +475,12 @@ int32_t dann_build_sharded(dann_index* idx, dann_comm* comm, const dann_build_co
 
 // ---- sharded search: every rank searches its partition of the block, the results are all-gathered -------------------
 static int32_t search_sharded_impl(dann_index* idx, dann_comm* comm, const void* queries, uint32_t nq, uint32_t l_value,
-                                   uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists) {
-    if (!idx || !comm) return DANN_EINVAL;
+                                   uint32_t beam_width, uint32_t k, uint32_t* out_ids, float* out_dists, bool* past_args) {
+    if (!comm) return DANN_EINVAL;
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
+    *past_args = true;  // (from here on an error may be this rank's alone: AbortOnError releases the peers)
+    if (!idx) return DANN_EINVAL;
     const uint32_t world = comm->world, rank = comm->rank;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;
     uint32_t lo, hi, l0, h0;
@@ -534,9 +542,10 @@ int32_t dann_search_sharded(dann_index* idx, dann_comm* comm, const void* querie
     if (!comm) return DANN_EINVAL;
     AbortOnError guard(comm);
     try {
-        guard.rc = search_sharded_impl(idx, comm, queries, nq, l_value, beam_width, k, out_ids, out_dists);
+        guard.rc = search_sharded_impl(idx, comm, queries, nq, l_value, beam_width, k, out_ids, out_dists, &guard.past_args);
     } catch (...) {
         guard.rc = DANN_EINVAL;
+        guard.past_args = true;
         throw;
     }
     return guard.rc;
