@@ -689,14 +689,20 @@ __device__ __forceinline__ void group_distance_int_pre(const uint4& x, int xx, c
             xy = dot4<SIGNED>(xs[i], yw[i], xy);
             if (OP != OP_IP) yy = dot4<SIGNED>(yw[i], yw[i], yy);
         }
+        if (OP == OP_L2) {
+            // |x - y|^2 = xx + sum(yy - 2 xy): one cross-lane sum of the lane's yy - 2 xy instead of two (integer sums modulo
+            // 2^32: any order and grouping is bit-identical)
+            const int st = group8_sum((int)((uint32_t)yy - 2u * (uint32_t)xy));
+            out[u] = (float)(int)((uint32_t)xx + (uint32_t)st);
+            continue;
+        }
         const int sxy = group8_sum(xy);
         if (OP == OP_IP) {
             out[u] = (float)sxy;
             continue;
         }
         const int syy = group8_sum(yy);
-        if (OP == OP_L2) out[u] = (float)(int)((uint32_t)xx + (uint32_t)syy - 2u * (uint32_t)sxy);
-        else out[u] = cosine_finish((float)xx, (float)syy, (float)sxy);
+        out[u] = cosine_finish((float)xx, (float)syy, (float)sxy);
     }
 }
 template <bool SIGNED>

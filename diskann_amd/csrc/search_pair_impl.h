@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     const int v = (int)(lane & 7u);
     const uint32_t R = ix.max_degree, ns = ix.nstart, qcap = a.l_value + ns;  // qcap <= 32 QE, R <= 32 RE, ns <= 32
     const SqParams sqp{ix.sq_k, ix.sq_shift_norm_sq};
+    const uint32_t row_stride32 = (uint32_t)ix.row_stride;  // (dann_config::row_stride is 32 bits wide)
     constexpr uint32_t kOverflow = (uint32_t)(-DANN_EOVERFLOW);
 
     // ---- the two queries of this wavefront (the upper half of the last wavefront of an odd batch idles) --------------
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                         const uint32_t ci = c0 + (uint32_t)u * 4u + g4;
                         const uint32_t raw = cand_id[ci];            // (read first, select after: no load under a branch)
                         const uint32_t id = ci < ncv ? raw : 0u;     // unused slots evaluate row 0
-                        rows[u] = ix.rows + (uint64_t)id * ix.row_stride;
+                        rows[u] = ix.rows + (uint64_t)id * row_stride32;  // (one 32 x 32 -> 64-bit multiply-add per row)
                     }
                     group_distance_int_pre<OP, SIGNED, U>(xqi, xx_pre, rows, v, out);
 #pragma unroll
