@@ -40,5 +40,12 @@ def make_pair(dtype, metric, data, adj, start_rows, max_degree, row_stride=0):
     return oix, gix
 
 
+def teams_on():
+    """False when the suite runs with DANN_TUNE_OFF bit 4 (the whole-suite 16-bit-table mode of tests/conftest.py switches
+    the teams off through the Python Provider): tests that assert the kernel family of a small launch ask this"""
+    import os
+    return not (int(os.environ.get("DANN_TUNE_OFF", "0") or 0, 0) & 4)
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import bits, make_pair, rand_vectors, random_graph
+from helpers import bits, make_pair, rand_vectors, random_graph, teams_on
 
 pytestmark = pytest.mark.gpu
 da = pytest.importorskip("diskann_amd")
@@ -79,7 +79,7 @@ def test_pair_kernel_and_one_wave_per_query_agree_beyond_the_pair_limits():
         # (50 queries: the latency regime -- a team per query where a team instantiation exists, i.e. 128-element rows)
         # (a team needs an adjacency row that fits one 64-lane request: degree <= 63)
         _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L),
-               family="team" if dim == 128 and R <= 63 else "one_wave")
+               family="team" if dim == 128 and R <= 63 and teams_on() else "one_wave")
         gix.debug_set(tune_off=4)
         _check(gix, oix, rand_vectors(rng, dtype, 50, dim), L, 10, (dtype, dim, R, L), family="one_wave")
 
