@@ -2333,11 +2333,18 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         }
         const uint32_t short_pcap = next_pow2(std::max<uint32_t>(pg, ix.max_degree + 1u));
         const uint32_t short_cap = want_gram ? pg : short_pcap;
-        // small rows without the MFMA path: the single-kernel form (list build + prune per target, pool sized by the
-        // longest list of the batch) is faster than scan + worklists (measured: 1 M x 128 build 0.68 s vs 0.78 s);
-        // rows of 1 KiB and more take the split form (1 M x 768: 5.2 s -> 3.5 s, 3.25 s with the MFMA path)
+        // small rows without the MFMA path: the single-kernel form (list build + prune per target, its LDS pool sized by
+        // the longest list of the batch) only while that pool is small.  One hub with a thousand back-edges in a batch
+        // (the 65 536-point batches of a 10 M-point build) sizes EVERY workgroup's LDS for its list -- 2 - 5 lists per CU
+        // instead of 20: the phase was 60 % of the 10 M x 128 build (6.2 of 10.3 s).  Beyond kSinglePool entries the split
+        // form runs the short lists at full occupancy and the hubs in a launch of their own.  Measured, round 5
+        // (scratch/r05_backedge_ab.sh; pool limit 8192 / 512 / 256 / 128 / 64): 10 M x 128 build 10.2 / 6.6 / 6.0 / 6.0 /
+        // 6.0 s, 1 M x 128 build 0.64 / 0.64 / 0.62 / 0.61 / 0.61 s (round 2 had measured the split form slower at 1 M:
+        // 0.78 against 0.68 s, before the scan kernel served four targets per wavefront).  Rows of 1 KiB and more always
+        // take the split form (1 M x 768: 5.2 s -> 3.5 s, 3.25 s with the MFMA path).
         const uint32_t pcap_all = next_pow2(ix.max_degree + h_meta[2]);
-        if (!want_gram && ix.layer_bytes < 1024u && world <= 1u) {
+        const uint32_t single_pool = idx->dbg_u32(DANN_DBG_BACKEDGE_SINGLE_POOL, 128u);
+        if (!want_gram && ix.layer_bytes < 1024u && world <= 1u && pcap_all <= single_pool) {
             if (pcap_all > kMaxPool) {
                 set_error("a node received %u back-edges in one batch (cap %u): lower max_batch", h_meta[2], kMaxPool);
                 return DANN_EOVERFLOW;

@@ -50,7 +50,10 @@ enum {
     DANN_DBG_VERBOSE = 11,               /* 1: launch sizing decisions on stderr (default 0) */
     DANN_DBG_HT16_OPEN_EIGHTHS = 12,     /* load (in eighths of its entries, 4 .. 7) up to which a 16-bit visited table takes
                                             new ids before it is frozen (default 6 = 75 %) */
-    DANN_DBG_COUNT = 13
+    DANN_DBG_BACKEDGE_SINGLE_POOL = 13,  /* small rows: the back-edge phase runs as ONE kernel (list build + prune per target, LDS
+                                            pool sized by the batch's longest list) while that pool has at most this many
+                                            entries; beyond it, scan + short / long worklists (default 128) */
+    DANN_DBG_COUNT = 14
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
 int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);
