@@ -16,12 +16,15 @@
 // equal pool distances keep their original pool order).
 //
 // One wavefront owns one point.  The candidate pool is sorted in LDS (bitonic, 64-bit
-// keys = order-preserving distance bits : pool position); the alpha sweep runs with
-// wave-uniform control flow and evaluates the "candidate vs already selected" distances it
-// needs 64/G pairs at a time with the same G-lane bit-exact distance groups as the search
-// path, consuming them in the reference's sequential order (so `last_checked`, and with it
-// the inner-product "Occluding" rule that depends on *when* a pair is evaluated, are
-// reproduced exactly; surplus speculative distances are discarded).
+// keys = order-preserving distance bits : pool position).  The alpha sweep keeps 64/G
+// candidates in flight, one per G-lane distance group (the same bit-exact groups as the
+// search path): each walks the selected list in the reference's order, is rejected at the
+// first entry that pushes its factor past alpha, and is selected only once it is the oldest
+// candidate in flight and has seen the whole list -- so `last_checked`, and with it the
+// inner-product "Occluding" rule that depends on *when* a pair is evaluated, are reproduced
+// exactly, and no distance is evaluated that the sequential sweep would not evaluate
+// (prune_sorted_pool; rounds 1-4 visited one candidate at a time with 64/G speculative
+// distances per round and were bound by the scalar unit: profiles/r05_prune_counters.txt).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -123,7 +126,6 @@ template <int DT, int OP, bool NORM>
 __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t P,
                                   uint32_t pcap, uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out) {
     using S = Scheme<DT, OP, true>;
-    using RT = typename RowType<DT>::type;
     constexpr int G = S::G, GROUPS = kWave / G;
     const uint32_t lane = threadIdx.x;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem + L.keys_off);
@@ -156,9 +158,10 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
     for (uint32_t i = lane; i < N; i += kWave) {
         const uint32_t pos = (uint32_t)keys[i];
-        sid[i] = pid[pos];
+        const uint32_t id = pid[pos];
+        sid[i] = id;
         sd[i] = pd[pos];
-        occ[i] = 0.0f;
+        occ[i] = (id == location || id >= ix.nslots) ? 3.402823466e+38f : 0.0f;  // excluded / not retrievable: never visited
         last[i] = 0;
     }
     __syncthreads();
@@ -171,66 +174,93 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     float cur_alpha = 1.0f;
     uint32_t found = 0, npairs = 0;
     const int g = lane / G, v = lane % G;
+    // The reference visits the sorted candidates one after another, each against the entries selected so far
+    // (prune.rs:196-232).  Here GROUPS of them are in flight at once, one per lane group, each walking sel[] on its
+    // own, one entry per step of the wave:
+    //   * candidates are handed out in list order (the pass's worklist: those whose factor does not exceed cur_alpha);
+    //   * a candidate is REJECTED as soon as its running factor exceeds cur_alpha -- against a prefix of sel[], which is
+    //     append-only, so it is the prefix the sequential visit would have walked;
+    //   * a candidate that has seen all of sel[] is SELECTED only when it is the oldest one in flight: every earlier
+    //     candidate is resolved by then, so sel[] is what the sequential visit would have found, and later candidates
+    //     in flight meet the new entry at its place in the order (they are at or before the old end of sel[]).
+    // Same factors (each group applies update_occlude in sel[] order), same last_checked, same sel[]; no distance is
+    // evaluated speculatively, and the per-candidate scalar control flow of the one-at-a-time form (45 k scalar
+    // instructions per prune, one per CU-cycle: profiles/r05_prune_counters.txt) is paid once per GROUPS candidates.
+    uint16_t* work = reinterpret_cast<uint16_t*>(smem + L.keys_off);  // the sort keys are dead by now
+    const uint32_t gbit = (uint32_t)(g * G);
     if (N > 0) {
         while (found < degree) {
-            for (uint32_t i = 0; i < N && found < degree; ++i) {
-                float o = occ[i];
-                uint32_t l = last[i];
-                if (o > cur_alpha) continue;
-                const uint32_t idi = sid[i];
-                if (idi == location || idi >= ix.nslots) {  // excluded / not retrievable
-                    if (lane == 0) occ[i] = 3.402823466e+38f;
-                    continue;
-                }
-                const RT* xi = reinterpret_cast<const RT*>(ix.rows + (uint64_t)idi * ix.row_stride);
-                const float di = sd[i];
-                bool rejected = false;
-                while (l != found && !rejected) {
-                    const uint32_t cnt = (found - l) < (uint32_t)GROUPS ? (found - l) : (uint32_t)GROUPS;
-                    npairs += cnt;
-                    // speculative distances for selected entries l .. l+cnt (one group each)
-                    float d = 0.0f;
-                    {
-                        const bool have = (uint32_t)g < cnt;
-                        const uint32_t rp = have ? sel[l + g] : 0u;
-                        if (have && rp < i) {
-                            const uint8_t* y = ix.rows + (uint64_t)sid[rp] * ix.row_stride;
-                            d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(reinterpret_cast<const uint8_t*>(xi), y, (int)ix.dim, v),
-                                                              reinterpret_cast<const uint8_t*>(xi), y, ix.dim,
-                                                              SqParams{ix.sq_k, ix.sq_shift_norm_sq});
-                        }
-                    }
-                    // consume in order (prune.rs:196-232)
-                    for (uint32_t gg = 0; gg < cnt; ++gg) {
-                        const uint32_t rp = sel[l + gg];
-                        if (rp >= i) continue;
-                        const float dg =
-                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), gg * G));
-                        o = update_occlude<OP>(di, dg, o, cur_alpha, occluding);
-                        if (o > cur_alpha) {
-                            l = l + gg + 1;
-                            rejected = true;
-                            break;
-                        }
-                    }
-                    if (!rejected) l += cnt;
-                }
-                __syncthreads();
-                if (lane == 0) {
-                    last[i] = (uint16_t)l;
-                    if (o > cur_alpha) {
-                        occ[i] = o;
-                    } else {
-                        occ[i] = 3.402823466e+38f;
-                        sel[found] = i;
-                    }
-                }
-                if (!(o > cur_alpha)) ++found;
-                __syncthreads();
+            uint32_t M = 0;
+            for (uint32_t base = 0; base < N; base += kWave) {
+                const uint32_t i = base + lane;
+                const bool act = i < N && !(occ[i] > cur_alpha);
+                const uint64_t m = ballot64(act);
+                if (act) work[M + mbcnt(m)] = (uint16_t)i;
+                M += (uint32_t)__builtin_popcountll(m);
             }
+            __syncthreads();
+            uint32_t next = 0;
+            bool busy = false;
+            uint32_t c = 0, w = 0, l = 0;
+            float o = 0.0f, di = 0.0f;
+            const uint8_t* xi = ix.rows;
+            for (;;) {
+                // idle groups take the next candidates of the worklist, in group order
+                const uint64_t im = ballot64(!busy && v == 0);
+                if (im != 0 && next < M) {
+                    const uint32_t wi = next + (uint32_t)__builtin_popcountll(im & ((1ull << gbit) - 1ull));
+                    if (!busy && wi < M) {
+                        w = wi;
+                        c = work[wi];
+                        l = last[c];
+                        o = occ[c];
+                        di = sd[c];
+                        xi = ix.rows + (uint64_t)sid[c] * ix.row_stride;
+                        busy = true;
+                    }
+                    const uint32_t nidle = (uint32_t)__builtin_popcountll(im);
+                    next = next + nidle < M ? next + nidle : M;
+                }
+                if (ballot64(busy) == 0) break;  // worklist done, nothing in flight
+                uint32_t wmin = busy ? w : 0xFFFFFFFFu;  // the oldest candidate in flight
+#pragma unroll
+                for (int off = 32; off >= G; off >>= 1) {
+                    const uint32_t t = (uint32_t)__shfl_xor((int)wmin, off);
+                    wmin = t < wmin ? t : wmin;
+                }
+                bool rej = false, evaluated = false;
+                if (busy && l < found) {
+                    const uint32_t rp = sel[l];
+                    ++l;
+                    if (rp < c) {
+                        const uint8_t* y = ix.rows + (uint64_t)sid[rp] * ix.row_stride;
+                        const float d = finish_distance<DT, OP, NORM>(group_distance_rows<DT, OP>(xi, y, (int)ix.dim, v), xi, y,
+                                                                      ix.dim, SqParams{ix.sq_k, ix.sq_shift_norm_sq});
+                        o = update_occlude<OP>(di, d, o, cur_alpha, occluding);  // (meaningful in the group's lane 0)
+                        rej = o > cur_alpha;
+                        evaluated = v == 0;
+                    }
+                }
+                npairs += (uint32_t)__builtin_popcountll(ballot64(evaluated));
+                const bool grej = (ballot64(rej && v == 0) >> gbit) & 1ull;
+                const bool ready = busy && !grej && l == found && w == wmin;  // at most one group
+                const bool commit = ballot64(ready) != 0;
+                if (grej || ready) {
+                    if (v == 0) {
+                        last[c] = (uint16_t)l;
+                        occ[c] = grej ? o : 3.402823466e+38f;
+                        if (ready) sel[found] = c;
+                    }
+                    busy = false;
+                }
+                if (commit) ++found;
+                __syncthreads();
+                if (found >= degree) break;
+            }
+            if (found >= degree) break;
             if (cur_alpha == alpha) break;
-            const float next = cur_alpha * inc;
-            cur_alpha = next < alpha ? next : alpha;
+            const float next_alpha = cur_alpha * inc;
+            cur_alpha = next_alpha < alpha ? next_alpha : alpha;
         }
     }
     // ---- neighbours + optional saturation (index.rs:2626-2649) ---------------------------
