@@ -46,9 +46,18 @@ struct PruneCfg {
     uint32_t saturate_after_prune;
     // optional device counters (u64): [0] pair distances of the sweeps (row kernel), [1] list / extra distances
     // d(location, c), [2] rows that went through an MFMA Gram, [3] Gram entries computed (x dim x 2 = MFMA flop),
-    // [4] pair distances the lazy scans of the Gram sweeps asked for, [5] those answered by an exact re-evaluation
+    // [4] pair distances the lazy scans of the Gram sweeps asked for, [5] those answered by an exact re-evaluation,
+    // [6] back-edge prunes through the MFMA path, [7] back-edge prunes of lists too long for it.
+    // kStatStripes copies of the eight, one 64-byte line each, a workgroup adds to the copy of its index (stat_stripe):
+    // every workgroup of a prune launch ends with a few of these adds, and atomics on ONE address are served one after
+    // another -- 354 k of them per launch were 3 ms of backedge_scan_kernel's 4.4 ms at 10 M points
+    // (profiles/r05_scan_atomics.txt).  dann_build_counters sums the copies.
     unsigned long long* counters;
 };
+constexpr uint32_t kStatStripes = 256;
+__device__ __forceinline__ unsigned long long* stat_stripe(unsigned long long* counters) {
+    return counters + (size_t)(blockIdx.x & (kStatStripes - 1u)) * 8u;
+}
 
 struct PoolLds {
     uint32_t keys_off, pid_off, pd_off, sid_off, sd_off, occ_off, last_off, sel_off, total;
@@ -126,7 +135,7 @@ template <int DT, int OP, bool NORM>
 __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint32_t location, uint32_t P,
                                   uint32_t pcap, uint8_t* smem, const PoolLds& L, bool force_saturate, uint32_t* out) {
     using S = Scheme<DT, OP, true>;
-    constexpr int G = S::G, GROUPS = kWave / G;
+    constexpr int G = S::G;
     const uint32_t lane = threadIdx.x;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem + L.keys_off);
     const uint32_t* pid = reinterpret_cast<const uint32_t*>(smem + L.pid_off);
@@ -283,7 +292,7 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     for (uint32_t n = lane; n < nout; n += kWave) out[1 + n] = sid[sel[n]];
     if (lane == 0) {
         out[0] = nout;
-        if (cfg.counters) atomicAdd(&cfg.counters[0], (unsigned long long)npairs);
+        if (cfg.counters) atomicAdd(&stat_stripe(cfg.counters)[0], (unsigned long long)npairs);
     }
 }
 
@@ -461,7 +470,7 @@ struct BackArgs {
     uint32_t nkeys;
     uint32_t pcap;
     uint32_t* err;
-    uint32_t* counters;        // [0] appends, [1] prunes
+    uint32_t count_long = 0;   // this launch prunes the lists too long for the MFMA path: counted in counters[7]
     const uint32_t* work;      // optional: segment indices to process (targets whose list needs a prune)
 };
 
@@ -479,7 +488,6 @@ struct ScanArgs {
     uint32_t* work_short;
     uint32_t* work_long;
     uint32_t* counts;          // [0] #short [1] #long [2] longest list among the long ones
-    uint32_t* counters;        // [0] appends
     uint32_t rank = 0, world = 1;  // owner-partitioned commit: only targets with id % world == rank are queued here
 };
 
@@ -580,7 +588,6 @@ __global__ __launch_bounds__(kWave) void backedge_scan_kernel(ScanArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (sl == 0) {
             arow[0] = len + take;
-            if (a.counters) atomicAdd(&a.counters[0], 1u);
         }
         return;
     }
@@ -644,17 +651,16 @@ __global__ __launch_bounds__(kWave) void backedge_kernel(BackArgs a) {
         __syncthreads();
         if (lane == 0) {
             arow[0] = len + take;
-            if (a.counters) atomicAdd(&a.counters[0], 1u);
         }
         return;
     }
     fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
-    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
+    if (lane == 0 && a.cfg.counters) atomicAdd(&stat_stripe(a.cfg.counters)[1], (unsigned long long)cnt);
     __syncthreads();
     // the list lives in LDS, so the result can go straight into the adjacency row (nobody
     // else reads this row during the back-edge phase)
     prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, src, cnt, a.pcap, smem, L, false, arow);
-    if (lane == 0 && a.counters) atomicAdd(&a.counters[1], 1u);
+    if (lane == 0 && a.count_long && a.cfg.counters) atomicAdd(&stat_stripe(a.cfg.counters)[7], 1ull);
 }
 
 
@@ -918,13 +924,13 @@ __device__ void sweep_sorted_pool_gram(const IndexView& ix, const PruneCfg& cfg,
     if (lane == 0) {
         out[0] = nout;
         if (cfg.counters) {
-            atomicAdd(&cfg.counters[0], (unsigned long long)nexact);
+            atomicAdd(&stat_stripe(cfg.counters)[0], (unsigned long long)nexact);
             if (gc.count_rows) {
-                atomicAdd(&cfg.counters[2], (unsigned long long)P);
-                atomicAdd(&cfg.counters[3], (unsigned long long)P * P);
+                atomicAdd(&stat_stripe(cfg.counters)[2], (unsigned long long)P);
+                atomicAdd(&stat_stripe(cfg.counters)[3], (unsigned long long)P * P);
             }
-            atomicAdd(&cfg.counters[4], (unsigned long long)nasked);
-            atomicAdd(&cfg.counters[5], (unsigned long long)nexact);
+            atomicAdd(&stat_stripe(cfg.counters)[4], (unsigned long long)nasked);
+            atomicAdd(&stat_stripe(cfg.counters)[5], (unsigned long long)nexact);
         }
     }
 }
@@ -1177,9 +1183,9 @@ __device__ void sweep_gram_batched(const IndexView& ix, const PruneCfg& cfg, uin
     if (lane == 0) {
         out[0] = nout;
         if (cfg.counters) {
-            atomicAdd(&cfg.counters[0], (unsigned long long)nexact);
-            atomicAdd(&cfg.counters[4], (unsigned long long)nasked);
-            atomicAdd(&cfg.counters[5], (unsigned long long)nexact);
+            atomicAdd(&stat_stripe(cfg.counters)[0], (unsigned long long)nexact);
+            atomicAdd(&stat_stripe(cfg.counters)[4], (unsigned long long)nasked);
+            atomicAdd(&stat_stripe(cfg.counters)[5], (unsigned long long)nexact);
         }
     }
 }
@@ -1268,7 +1274,7 @@ __global__ __launch_bounds__(kWave) void pool_sort_kernel(SortArgs sa) {
                 }
             }
         }
-        if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)nex);
+        if (lane == 0 && a.cfg.counters) atomicAdd(&stat_stripe(a.cfg.counters)[1], (unsigned long long)nex);
     }
     wave_sync();
     const uint32_t N = sort_pool_wave(a.cfg, cnt + nex, a.pcap, smem, L);
@@ -1546,8 +1552,8 @@ __global__ __launch_bounds__(512, MAXNT == 1 ? 6 : 4) void gram_tiles_kernel(Til
         if ((tid & 7u) == 0 && r < nrows) nr[r] = (float)v;
     }
     if (tid == 0 && a.counters) {
-        atomicAdd(&a.counters[2], (unsigned long long)nrows);
-        atomicAdd(&a.counters[3], (unsigned long long)T * 1024ull);
+        atomicAdd(&stat_stripe(a.counters)[2], (unsigned long long)nrows);
+        atomicAdd(&stat_stripe(a.counters)[3], (unsigned long long)T * 1024ull);
     }
 }
 
@@ -1593,8 +1599,6 @@ struct SweepArgs {
     // back-edge prunes (add_edge_and_prune): the location of item i is out_loc[i] and the result goes straight into its
     // adjacency row (nobody else reads that row during the back-edge phase); null = pool prune (p.locs, p.out)
     const uint32_t* out_loc = nullptr;
-    uint32_t* prunes = nullptr;      // [0] += 1 per pruned list (BackArgs::counters + 1)
-    uint32_t* mfma_prunes = nullptr; // optional statistic
     uint32_t one_by_one = 0;         // development switch (DANN_DBG_SWEEP_ONE_BY_ONE): the candidate-at-a-time sweep
     const uint32_t* order = nullptr; // optional: workgroup b works on item order[b] (longest lists first)
     uint32_t compact_lds = 0;        // sweep_lds_layout instead of pool_lds_layout (the batched sweep only)
@@ -1644,10 +1648,7 @@ __global__ __launch_bounds__(kWave) void pool_sweep_kernel(SweepArgs sa) {
                                          reinterpret_cast<float*>(smem + ((L.total + 15u) & ~15u)));
     else
         sweep_sorted_pool_gram<DT, OP, NORM>(a.ix, a.cfg, location, N, smem, L, a.force_saturate != 0, out, gc);
-    if (lane == 0 && sa.out_loc) {
-        if (sa.prunes) atomicAdd(sa.prunes, 1u);
-        if (sa.mfma_prunes) atomicAdd(sa.mfma_prunes, 1u);
-    }
+    if (lane == 0 && sa.out_loc && a.cfg.counters) atomicAdd(&stat_stripe(a.cfg.counters)[6], 1ull);
 }
 
 // back-edges on the matrix cores, first of three kernels (the other two are gram_tiles_kernel and pool_sweep_kernel):
@@ -1712,12 +1713,11 @@ __global__ __launch_bounds__(kWave) void backedge_list_kernel(BackListArgs la) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             arow[0] = len + take;
-            if (a.counters) atomicAdd(&a.counters[0], 1u);
         }
         return;
     }
     fill_list_distances<DT, OP, NORM>(a.ix, src, pid, pd, cnt);
-    if (lane == 0 && a.cfg.counters) atomicAdd(&a.cfg.counters[1], (unsigned long long)cnt);
+    if (lane == 0 && a.cfg.counters) atomicAdd(&stat_stripe(a.cfg.counters)[1], (unsigned long long)cnt);
     wave_sync();
     const uint32_t N = sort_pool_wave(a.cfg, cnt, a.pcap, smem, L);
     uint32_t* gs = la.sid + (uint64_t)wi * a.pcap;
@@ -1950,7 +1950,7 @@ struct BuildScratch {
     uint32_t batch_cap = 0, rec_stride = 0, pend_stride = 0, degree = 0;
     bool bootstrap_too_big = false;  // set when a batch needed the bootstrap with more members than its pool holds
     DevBuf slots, rec_ids, rec_d, rec_n, stats, pending, pending2, keys_in, keys_out, seg_start, seg_len, meta, sort_tmp;
-    DevBuf counters;  // 8 x u64, see PruneCfg::counters (accumulate until dann_build_counters_reset)
+    DevBuf counters;  // kStatStripes x 8 x u64, see PruneCfg::counters (accumulate over the index's lifetime)
     size_t sort_tmp_bytes = 0;
     // MFMA pool prune: sorted pools, Gram blocks and norms of one batch slice (grow-only)
     DevBuf g_sid, g_sd, g_sn, g_loc, g_gram, g_nrm, g_order;
@@ -2024,8 +2024,8 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
     DANN_HIP(s.meta.alloc(128));  // 16 words of flags and counts + the insert searches' totals (stats_reduce_kernel)
     DANN_HIP(hipMemset(s.meta.p, 0, 64));  // the commit phase may run first on this handle (sharded build: empty slice)
     if (!s.counters.p) {
-        DANN_HIP(s.counters.alloc(64));
-        DANN_HIP(hipMemset(s.counters.p, 0, 64));
+        DANN_HIP(s.counters.alloc((size_t)kStatStripes * 64));
+        DANN_HIP(hipMemset(s.counters.p, 0, (size_t)kStatStripes * 64));
     }
     size_t tmp = 0;
     DANN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, s.keys_in.as<uint64_t>(), s.keys_out.as<uint64_t>(),
@@ -2340,9 +2340,8 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         ba.nkeys = h_meta[1];
         ba.pcap = 0;  // set per launch below
         ba.err = meta + 3;
-        ba.counters = meta + 4;
         ba.work = nullptr;
-        DANN_HIP(hipMemsetAsync(meta + 8, 0, 20, st));  // MFMA / lazy prune counters, worklist counts
+        DANN_HIP(hipMemsetAsync(meta + 10, 0, 12, st));  // worklist counts
         // (1) every target: append if the list still fits, else queue it.  Lists of up to `short_cap` entries go
         //     to the short worklist (pool of 128 slots: full occupancy, and the MFMA path when it applies), the
         //     rare long ones (hubs hit by many back-edges in one batch) to a launch of their own whose LDS pool
@@ -2395,7 +2394,6 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         sa.work_short = work;
         sa.work_long = work + ba.nseg;
         sa.counts = meta + 10;
-        sa.counters = meta + 4;
         sa.rank = rank;
         sa.world = world;
         hipLaunchKernelGGL(backedge_scan_kernel, dim3((ba.nseg + 3u) / 4u), dim3(kWave), 0, st, sa);
@@ -2420,6 +2418,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
             bl.work = work + ba.nseg;
             bl.nseg = h_counts[1];
             bl.pcap = next_pow2(h_counts[2]);
+            bl.count_long = want_gram ? 1u : 0u;
             if (bl.pcap > kMaxPool) {
                 set_error("a node received back-edges for a list of %u entries in one batch (cap %u): lower max_batch",
                           h_counts[2], kMaxPool);
@@ -2489,8 +2488,6 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 sw.one_by_one = sweep_one_by_one(idx);
                 sw.order = ta.order;
                 sw.out_loc = la.loc;
-                sw.prunes = meta + 5;       // BackArgs::counters[1]
-                sw.mfma_prunes = meta + 8;
                 sw.compact_lds = sweep_is_batched(pc, mg, sw.one_by_one) ? 1u : 0u;
                 rc = dispatch_float<SweepLauncher>(ix, sw, nshort, sweep_lds_bytes(sw), st);
                 if (rc != DANN_OK) return rc;
@@ -2518,11 +2515,9 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         }
         }
     }
-    uint32_t h_tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // meta[3..10]: err, appends, prunes, max record, -, MFMA prunes, lazy prunes
+    uint32_t h_tail[1] = {0};  // meta[3]: err
     DANN_HIP(hipMemcpyAsync(h_tail, meta + 3, sizeof(h_tail), hipMemcpyDeviceToHost, st));
     DANN_HIP(hipStreamSynchronize(st));
-    idx->build_counters[0] += h_tail[5];
-    idx->build_counters[1] += h_tail[6];
     if (h_tail[0]) {
         set_error("back-edge list overflow");
         return DANN_EOVERFLOW;
@@ -2748,10 +2743,13 @@ int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n) tr
         if (s.counters.p) {
             DeviceGuard guard(idx->device);
             DANN_HIP(hipStreamSynchronize(idx->main.stream));
-            DANN_HIP(hipMemcpy(dev, s.counters.p, 64, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> stripes((size_t)kStatStripes * 8);
+            DANN_HIP(hipMemcpy(stripes.data(), s.counters.p, stripes.size() * 8, hipMemcpyDeviceToHost));
+            for (uint32_t t = 0; t < kStatStripes; ++t)
+                for (uint32_t c = 0; c < 8; ++c) dev[c] += stripes[(size_t)t * 8 + c];
         }
     }
-    const uint64_t all[10] = {idx->build_counters[0], idx->build_counters[1], idx->build_counters[2], idx->build_counters[3],
+    const uint64_t all[10] = {dev[6], dev[7], idx->build_counters[2], idx->build_counters[3],
                               dev[0], dev[1], dev[2], dev[3], dev[4], dev[5]};
     for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? all[i] : 0u;
     return DANN_OK;

@@ -303,7 +303,7 @@ struct dann_index {
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
     // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of
     // the insert-time searches (host side; the device-side counters live in the build scratch)
-    uint64_t build_counters[4] = {0, 0, 0, 0};
+    uint64_t build_counters[4] = {0, 0, 0, 0};  // [2] comparisons, [3] hops of the insert searches ([0], [1]: unused)
     float* d_pq_pivots = nullptr;
     uint32_t* d_pq_offsets = nullptr;
     // dann_pq_pack_neighbors: adjacency + neighbours' code rows per node; dropped (valid = false) by every mutation
