@@ -1758,7 +1758,8 @@ __global__ void seglen_kernel(const uint64_t* keys, const uint32_t* seg_start, u
     uint32_t e = st + 1;
     while (e < meta[1] && (uint32_t)(keys[e] >> 32) == tgt) ++e;
     seg_len[st] = e - st;
-    atomicMax(&meta[2], e - st);
+    // (a maximum only grows: skip the atomic when a plain read already shows it -- one address, a million segments)
+    if (e - st > __hip_atomic_load(&meta[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&meta[2], e - st);
 }
 
 __global__ void set_bulk_kernel(IndexView ix, const uint32_t* locs, const uint32_t* pending, uint32_t pend_stride,

@@ -2115,7 +2115,10 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
         }
         if (status && a.fail_flag) __hip_atomic_store(a.fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.rec_n) a.rec_n[qi] = nrec;
-        if (a.rec_max) atomicMax(a.rec_max, nrec);
+        // (the maximum only grows: a plain read that already shows a value >= nrec makes the atomic unnecessary, and a
+        // stale smaller one only costs the atomic it would have cost anyway -- atomics on one address are served one
+        // after another, and every insert search of a batch ends here: profiles/r05_scan_atomics.txt)
+        if (a.rec_max && nrec > __hip_atomic_load(a.rec_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.rec_max, nrec);
         if (a.range_second) a.range_second[qi] = range_second;
     }
 }
