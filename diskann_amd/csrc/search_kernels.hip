@@ -138,7 +138,7 @@ uint64_t visited_open_capacity(const SearchArgs& a, uint32_t open_eighths) {
 
 // sizes the table of an automatically sized launch: the 32-bit table at the top of its occupancy step, or -- where the
 // kernel has them and they buy a higher step -- 16-bit entries, also at the top of their step
-void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves, uint32_t format) {
+void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves, uint32_t format, uint32_t open_eighths) {
     a.ht16 = 0;
     a.ht_entries = snap_visited_entries(a, cap_ids, useful_waves);
     if (format == 32u || !ht16_eligible(a)) return;
@@ -148,7 +148,8 @@ void choose_visited_table(SearchArgs& a, uint32_t cap_ids, uint32_t useful_waves
         const uint64_t granules = (search_lds_bytes(t) + kLdsGranule - 1) / kLdsGranule;
         return granules > kLdsGranules ? 0u : std::min<uint32_t>(kLdsGranules / (uint32_t)granules, useful_waves);
     };
-    const uint64_t need = std::max<uint64_t>((uint64_t)((double)cap_ids / 0.75), 512);
+    // 16-bit entries the table needs so that cap_ids of them are below its open limit (open_eighths / 8 of the slots)
+    const uint64_t need = std::max<uint64_t>(((uint64_t)cap_ids * 8u + open_eighths - 1u) / open_eighths, 512);
     uint32_t words = (uint32_t)std::min<uint64_t>(((need + 1) / 2 + 63) / 64 * 64, 32768);  // multiples of 64 words
     while (words < 32768u && !ht16_geometry(words, a.ix.nslots).ok) words = std::min<uint32_t>(words * 2u, 32768u);
     if (!ht16_geometry(words, a.ix.nslots).ok) return;
@@ -391,7 +392,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                 a.pqlut = 0;
             }
         }
-        if (!a.pair && !a.pqlut) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format);
+        if (!a.pair && !a.pqlut) choose_visited_table(a, cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), waves, idx->visited_format, ht16_open_eighths(idx));
         if (idx->verbose() && (cal.calls & (cal.calls - 1)) == 0)
             fprintf(stderr, "[dann] L=%u W=%u: visited cap %u (%s) -> %u %s, %zu B LDS\n", a.l_value, a.beam_width,
                     cal.cap_ids ? cal.cap_ids : prior_visited_cap(a), cal.cap_ids ? "p90" : "prior",

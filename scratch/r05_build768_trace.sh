@@ -7,5 +7,5 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt768 -o k -- python $R/ben
 python $R/profiles/summarize_rocprof.py trace /tmp/kt768/k_results.db $O/build768_kernel_trace.csv 20 > /dev/null 2>&1
 cut -c1-170 $O/build768_kernel_trace.csv
 grep -E "build [0-9.]+s" $O/build768.err | tail -2
-timeout 300 python $R/bench.py --only build768 --build-spec $SPEC > $O/build768_plain.json 2> $O/build768_plain.err
+[ -n "$NOPLAIN" ] || timeout 300 python $R/bench.py --only build768 --build-spec $SPEC > $O/build768_plain.json 2> $O/build768_plain.err
 grep -E "build [0-9.]+s" $O/build768_plain.err | tail -2
