@@ -289,8 +289,9 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     a.spill_bits = ctx.spill_bits;
     a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
     // latency regime with at most one query per SIMD: a team of four wavefronts per query -- queue, control, visited
-    // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches only (the launch falls back to one wave
-    // per query where no team instantiation exists).  Decided before the table is sized: teams carry more LDS.
+    // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches and the build's insert-time searches (the
+    // queue wave's pop records the visited node) only (the launch falls back to one wave per query where no team
+    // instantiation exists).  Decided before the table is sized: teams carry more LDS.
     // DANN_DBG_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_DBG_TEAM_MAX_QUERIES: development switches
     // (dann_debug_set; read on every call).
     {
@@ -298,7 +299,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         // (dann_set_max_concurrency: the launch will be `max_concurrency` persistent waves over the batch -- search_with_retry
         // sets a.grid after this function -- never teams; they draw their queries from a counter in the spill pool's pad)
         const bool will_grid = idx->max_concurrency && a.nq > idx->max_concurrency && plain_mode(a);
-        a.team = (inflight <= limit && !a.grid && !will_grid && !a.srv.ring && !a.range_ids && !a.rec_ids && !a.qmap && plain_mode(a) &&
+        a.team = (inflight <= limit && !a.grid && !will_grid && !a.srv.ring && !a.range_ids && !a.qmap && plain_mode(a) &&
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !idx->tune_off(4) &&
                   team_shape(a)) ? 1u : 0u;
         if (idx->tune_off(8)) a.tune |= kTuneNoSpeculation;

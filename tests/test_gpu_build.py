@@ -83,6 +83,33 @@ def test_insert_batch_matches_oracle_multi_insert(dtype, metric, dim, ibc):
     assert s == n
 
 
+@pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.U8, oracle.L2)])
+def test_small_batches_of_128d_rows_are_searched_by_teams(dtype, metric):
+    """the batches of a build's geometric phase are smaller than the chip: their insert-time searches (VisitedSearchRecord:
+    every popped node recorded, search/record.rs:86-93) go to the team-of-four kernel where one exists (128-element rows).
+    Same records, hence the same adjacency as the oracle's multi_insert after every batch."""
+    rng = np.random.default_rng(128)
+    n, dim, R, maxdeg, lb = 2200, 128, 12, 16, 60
+    data = rand_vectors(rng, dtype, n, dim)
+    start = data[:1].copy()
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(dtype, metric, data, adj, start, maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, intra_batch_candidates=oracle.IBC_NONE)
+    s = 0
+    for b in (1, 2, 5, 40, 150, 600, 1024, 378):
+        slots = np.arange(s, s + b, dtype=np.uint32)
+        oix.multi_insert(ocfg, slots)
+        _, fam = gix.last_family(lambda: gix.insert_batch(gcfg, slots))
+        assert "team" in fam and fam <= {"team", "one_wave"}, (b, fam)   # (one_wave: re-runs of a search that outgrew its table)
+        got = gix.download_graph()
+        lens = oix.adj[:, 0]
+        assert np.array_equal(got[:, 0], lens), (b, np.nonzero(got[:, 0] != lens)[0][:5])
+        mask = np.arange(maxdeg)[None, :] < lens[:, None]
+        assert np.array_equal(got[:, 1:][mask], oix.adj[:, 1:][mask]), b
+        s += b
+    assert s == n
+
+
 def test_dann_build_schedule_and_recall():
     rng = np.random.default_rng(8)
     n, dim, R, maxdeg, lb = 3000, 32, 16, 20, 40
