@@ -46,6 +46,46 @@ def test_prune_batch_matches_oracle(dtype, metric):
             assert np.array_equal(got[i, 1:1 + want.size], want), (i, sat)
 
 
+@pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.F16, oracle.L2), (oracle.F32, oracle.INNER_PRODUCT),
+                                          (oracle.I8, oracle.L2), (oracle.F32, oracle.COSINE)])
+def test_prune_with_duplicate_rows_ties_and_long_pools(dtype, metric):
+    """pools in which many rows are copies of each other: pair distances of exactly zero (update_occlude_factor's f32::MAX
+    branch, config/mod.rs:86-88), equal pool distances (the sort's tie rule) and runs of candidates that are rejected or
+    selected together -- what the in-flight sweep of prune_sorted_pool has to order exactly like the sequential visit.
+    Pools of up to 900 entries (several worklist passes, max_occlusion cuts the list), both saturation settings."""
+    rng = np.random.default_rng(77)
+    n, dim, R, maxdeg = 2400, 24, 20, 24
+    data = rand_vectors(rng, dtype, n, dim)
+    data[1::3] = data[0:-1:3][: data[1::3].shape[0]]        # every third row repeats its predecessor
+    data[300:340] = data[300]                               # a block of forty identical rows
+    adj = random_graph(rng, n, maxdeg)
+    oix, gix = make_pair(dtype, metric, data, adj, data[:1], maxdeg)
+    for alpha in (1.0, 1.2):
+        ocfg, gcfg = _cfgs(R, maxdeg, 50, alpha=alpha)
+        locs = rng.choice(n, 40, replace=False).astype(np.uint32)
+        locs[0] = 301
+        pools, dists, off = [], [], [0]
+        for i, loc in enumerate(locs):
+            m = [3, 40, 64, 65, 129, 257, 600, 900][i % 8]
+            ids = rng.choice(n, m, replace=False).astype(np.uint32)
+            if i % 4 == 0 and m >= 40:
+                ids[:30] = np.arange(300, 330, dtype=np.uint32)   # thirty copies of one row at the front of the list
+                ids = np.unique(ids)[: m]
+                rng.shuffle(ids)
+                m = ids.size
+            d = np.array([oracle.distance(dtype, metric, data[loc], data[j]) for j in ids], np.float32)
+            pools.append(ids)
+            dists.append(d)
+            off.append(off[-1] + m)
+        pid, pdd = np.concatenate(pools), np.concatenate(dists)
+        for sat in (False, True):
+            got = gix.prune_batch(gcfg, locs, pid, pdd, np.array(off, np.uint64), force_saturate=sat)
+            for i, loc in enumerate(locs):
+                want, _ = oix.prune_pool(ocfg, int(loc), pools[i], dists[i], force_saturate=sat)
+                assert got[i, 0] == want.size, (i, sat, alpha)
+                assert np.array_equal(got[i, 1:1 + want.size], want), (i, sat, alpha)
+
+
 BUILD_CASES = [
     (oracle.F32, oracle.L2, 32, oracle.IBC_NONE),
     (oracle.F32, oracle.L2, 32, 4),
