@@ -21,9 +21,9 @@ NP_DTYPE = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8, SQ8: np
 
 def build(force=False):
     src = os.path.join(_HERE, "dann_oracle.cpp")
-    hdr = os.path.join(_HERE, "dann_oracle.h")
+    hdrs = [os.path.join(_HERE, h) for h in ("dann_oracle.h", "rust_unstable_sort.h")]
     stale = (not os.path.exists(_LIB)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB) for p in (src, hdr) if os.path.exists(p)
+        os.path.getmtime(p) > os.path.getmtime(_LIB) for p in [src] + hdrs if os.path.exists(p)
     )
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "all"])
@@ -121,6 +121,10 @@ def lib():
     L.orc_bench_distance.argtypes = [i32, i32, u32, u64, u32, i32, u32, u64, vp]
     L.orc_set_tie_rule.restype = None
     L.orc_set_tie_rule.argtypes = [i32, u64]
+    L.orc_rust_sort.restype = C.c_int64
+    L.orc_rust_sort.argtypes = [i32, vp, vp, u64, u64]
+    L.orc_rust_sort_fallbacks.restype = u64
+    L.orc_rust_sort_fallbacks.argtypes = []
     L.orc_insert.restype = i32
     L.orc_insert.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp]
     L.orc_multi_insert.restype = i32
@@ -383,6 +387,8 @@ class Index:
         return out[:n].copy(), int(evals[0])
 
     def insert(self, cfg, slot, counters=None):
+        """counters: None or five uint64 words (query distances, pair distances, set_neighbors, appends, get_neighbors)"""
+        _check_counters(counters)
         rc = lib().orc_insert(C.byref(self._c), C.byref(cfg), slot, _p(counters))
         if rc < 0:
             raise RuntimeError(f"orc_insert failed: {rc}")
@@ -390,6 +396,7 @@ class Index:
 
     def multi_insert(self, cfg, slots, counters=None):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
+        _check_counters(counters)
         rc = lib().orc_multi_insert(C.byref(self._c), C.byref(cfg), _p(s), s.size, _p(counters))
         if rc < 0:
             raise RuntimeError(f"orc_multi_insert failed: {rc}")
@@ -413,10 +420,34 @@ def bench_distance(dtype, metric, dim, nrows, loops, random_order=False, threads
     return float(r)
 
 
+def _check_counters(counters):
+    if counters is not None and (counters.dtype != np.uint64 or counters.size < 5 or not counters.flags.c_contiguous):
+        raise ValueError("counters: five contiguous uint64 words")
+
+
 def set_tie_rule(rule=0, seed=0):
-    """order of equal-distance candidates in RobustPrune's sort: 0 = the oracle's rule (pool position); 1..5 see
-    dann_oracle.cpp sort_pool -- only the tie-envelope measurement of tests/test_oracle_build.py uses them"""
+    """order of equal-distance candidates in RobustPrune's sort: 0 = the oracle's rule (pool position), the one the
+    product implements; 1..5 see dann_oracle.cpp sort_pool (tie-envelope measurement); 6 = Rust's own order
+    (oracle/rust_unstable_sort.h), which reproduces the reference's tie-heavy grid_insert goldens exactly"""
     lib().orc_set_tie_rule(rule, seed)
+
+
+RUST_SORTED_NEIGHBORS, RUST_SORT_UNSTABLE, RUST_SMALL_SORT, RUST_SELECT_NTH = 0, 1, 2, 3
+
+
+def rust_sort(mode, ids, dists, max_or_index=0):
+    """the restated Rust unstable sort / selection (oracle/rust_unstable_sort.h) over (ids, dists) pairs compared by
+    distance alone; returns the reordered (ids, dists) -- truncated to `max_or_index` entries for RUST_SORTED_NEIGHBORS"""
+    i = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+    d = np.ascontiguousarray(dists, dtype=np.float32).copy()
+    n = lib().orc_rust_sort(mode, _p(i), _p(d), i.size, int(max_or_index))
+    if n < 0:
+        raise ValueError("orc_rust_sort: bad arguments")
+    return i[:n], d[:n]
+
+
+def rust_sort_fallbacks():
+    return int(lib().orc_rust_sort_fallbacks())
 
 
 def gram_chain(rows):

@@ -9,9 +9,12 @@
  *
  * Where the reference leaves behaviour unspecified (tie order of the unstable sort in
  * internal/sorted_neighbors.rs:36-40) the oracle fixes a rule and says so:
- * ORACLE TIE RULE = ascending distance, ties by original position in the pool.
+ * ORACLE TIE RULE = ascending distance, ties by original position in the pool (the rule the product implements).
+ * Rust's own order is available as tie rule 6 (rust_unstable_sort.h): under it every reference grid_insert golden is
+ * reproduced exactly, which is what pins the build half of this file.
  */
 #include "dann_oracle.h"
+#include "rust_unstable_sort.h"
 
 #include <algorithm>
 #include <chrono>
@@ -709,8 +712,12 @@ struct PNeighbor {
  *   5 a hypothesis about small pools: when the whole pool is kept (max >= len) select_nth_unstable_by(len - 1) swaps
  *     the FIRST maximum with the last element, and a prefix of <= 20 entries is sorted by insertion (stable on the
  *     order after that swap); longer prefixes fall back to rule 0.  Public descriptions of Rust >= 1.81's sort, not
- *     checked against its source. */
+ *     checked against its source.
+ *   6 Rust's own order: select_nth_unstable_by + sort_unstable_by as restated in rust_unstable_sort.h (ipnsort and
+ *     its selection, for 8-byte Copy elements).  With it the oracle reproduces every counter of the reference's
+ *     twelve tie-heavy grid_insert goldens exactly (tests/test_oracle_build.py). */
 static int g_tie_rule = 0;
+static uint64_t g_rust_fallbacks = 0;
 static uint64_t g_tie_state = 0x9E3779B97F4A7C15ull;
 void tie_rule_set(int32_t rule, uint64_t seed) {
     g_tie_rule = rule;
@@ -743,6 +750,9 @@ void sort_pool(std::vector<PNeighbor>& pool, size_t max) {
                 return;
             }
             break;
+        case 6:
+            g_rust_fallbacks += rust_sort::sorted_neighbors(pool, max, by_d) ? 1 : 0;
+            return;
         default: break;
     }
     std::stable_sort(pool.begin(), pool.end(), by_d);
@@ -855,6 +865,7 @@ void add_edge_and_prune(const View& v, const orc_build_config* cfg, const uint32
                         uint32_t source, uint64_t* counters) {
     const uint32_t* adj;
     uint32_t n = v.get_neighbors(source, &adj);
+    if (counters) ++counters[4];
     std::vector<uint32_t> list(adj, adj + n);
     uint32_t added = 0;
     for (uint32_t t = 0; t < nt; ++t) { /* AdjacencyList::extend_from_slice keeps ids unique */
@@ -1509,6 +1520,32 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
 
 void orc_set_tie_rule(int32_t rule, uint64_t seed) { tie_rule_set(rule, seed); }
 
+/* the restated Rust sort on its own (tests/test_oracle_rust_sort.py): mode 0 = SortedNeighbors::new(v, max) -- returns
+ * the new length; mode 1 = sort_unstable_by over the whole slice; mode 2 = the <= 32-element small sort alone;
+ * mode 3 = select_nth_unstable_by(max) alone.  -1 on bad arguments. */
+int64_t orc_rust_sort(int32_t mode, uint32_t* ids, float* dists, uint64_t n, uint64_t max) {
+    if ((n && (!ids || !dists)) || (mode == 2 && n > 32) || (mode == 3 && max >= n)) return -1;
+    std::vector<PNeighbor> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = {ids[i], dists[i], (uint32_t)i};
+    auto by_d = [](const PNeighbor& a, const PNeighbor& b) { return a.d < b.d; };
+    rust_sort::Impl<PNeighbor, decltype(by_d)> s(by_d);
+    switch (mode) {
+        case 0: g_rust_fallbacks += rust_sort::sorted_neighbors(v, (size_t)max, by_d) ? 1 : 0; break;
+        case 1: s.sort_unstable(v.data(), v.size()); break;
+        case 2: s.small_sort_network(v.data(), v.size()); break;
+        case 3: s.select_nth_unstable(v.data(), v.size(), (size_t)max); g_rust_fallbacks += s.fallback_used ? 1 : 0; break;
+        default: return -1;
+    }
+    for (size_t i = 0; i < v.size(); ++i) {
+        ids[i] = v[i].id;
+        dists[i] = v[i].d;
+    }
+    return (int64_t)v.size();
+}
+/* how often the selection's median-of-medians fallback (restated as a plain sort, rust_unstable_sort.h) was reached
+ * since the library was loaded: a pin that relies on rule 6 asserts this stays 0 */
+uint64_t orc_rust_sort_fallbacks(void) { return g_rust_fallbacks; }
+
 /* ---- CPU distance micro-benchmark (bench.py cpu_distance_kernels; never used by a test as a checker) -----------------
  * The shape of diskann-benchmark-simd (src/lib.rs:716-771, examples/simd.json): ONE query against `nrows` contiguous
  * rows, `loops` times over -- everything stays in L1/L2, the number is the kernel's arithmetic rate.  random_order != 0
@@ -1607,7 +1644,10 @@ double orc_bench_distance(int32_t dtype, int32_t metric, uint32_t dim, uint64_t 
     return total;
 }
 
-/* counters: [0] query distances, [1] pair (prune) distances, [2] set_neighbors, [3] appends */
+/* counters (five words): [0] query distances, [1] pair (prune) distances, [2] set_neighbors, [3] appends,
+ * [4] get_neighbors calls -- one per expanded node of an insert search (the test provider's expand_beam,
+ * graph/test/provider.rs:1207-1232) and one per add_edge_and_prune (index.rs:2276-2280); [2]-[4] are what the
+ * reference's grid_insert goldens hold as insert_metrics.{set_neighbors, append_neighbors, get_neighbors} */
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters) {
     if (!ix || !cfg || slot >= ix->capacity) return -1;
     View v(ix);
@@ -1619,7 +1659,7 @@ int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, ui
     SearchOut so;
     so.record = &rec;
     search_internal(qc, best, visited, 1, so);
-    if (counters) counters[0] += so.cmps;
+    if (counters) counters[0] += so.cmps, counters[4] += so.hops;
     std::vector<PNeighbor> pool;
     record_to_pool(rec, pool);
     sort_pool(pool, cfg->max_occlusion_size);
@@ -1656,7 +1696,7 @@ int32_t orc_multi_insert(orc_index* ix, const orc_build_config* cfg, const uint3
         SearchOut so;
         so.record = &rec;
         search_internal(qc, best, visited, 1, so);
-        if (counters) counters[0] += so.cmps;
+        if (counters) counters[0] += so.cmps, counters[4] += so.hops;
         /* robust_prune_with (index.rs:2476-2532): extras = around(ids, pos, cand)
          * (utils/async_tools.rs:51-131).  inmem2's PruneAccessor::fill is zero-copy
          * (provider.rs:757-765), so every id is retrievable. */
@@ -1701,6 +1741,11 @@ int32_t orc_multi_insert(orc_index* ix, const orc_build_config* cfg, const uint3
             for (uint32_t e : edges[pos].edges) push_unique(e);
             for (uint32_t o = 0; o < n; ++o)
                 if (edges[o].source != edges[pos].source) push_unique(edges[o].source);
+            /* from_iter_untrusted is sort_unstable + dedup (adjacencylist.rs:181-190): the list robust_prune_list walks
+             * is in ascending id order.  Under the oracle's own tie rules the order of first occurrence is kept (it is
+             * what the product's bootstrap kernel does, and only ties can tell the two apart); the restated Rust sort
+             * (rule 6) gets the reference's order. */
+            if (g_tie_rule == 6) std::sort(cands.begin(), cands.end());
             next[pos].source = edges[pos].source;
             robust_prune_list(v, cfg, edges[pos].source, cands, true, next[pos].edges, counters);
         }

@@ -10,7 +10,8 @@
  * Parity pins (tests/golden/, tests/test_oracle_*.py): the reference's own golden JSONs --
  * grid_search (18 cases: ids, distances, comparisons, hops), range_search (5), inline (12,
  * incl. AdaptiveL), multihop (2), filtered_range_search (7), paged_search (3, page by page),
- * grid_insert (1-D cases exact, tie-heavy 3-D / 4-D lattices soft) -- the exhaustive f16
+ * grid_insert (all 15 cases exact -- the 12 tie-heavy lattices under tie rule 6, Rust's own sort order
+ * restated in rust_unstable_sort.h) -- the exhaustive f16
  * conversion table, the in-source provider `smoke` expectations, compute_adaptive_l's unit
  * tests, the PQ lookup KAT and the Chunk::find_closest test pattern, the SQ training
  * contract.  The reference itself (Rust) cannot be compiled in this image (no cargo/rustc),
@@ -165,12 +166,20 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
                        uint32_t* pool_ids, float* pool_dists, uint32_t pool_n, int32_t force_saturate,
                        uint32_t* out_neighbors, uint64_t* pair_evals);
 /* DiskANNIndex::insert for a row already stored at `slot` (index.rs:226-341). */
-/* tie order of RobustPrune's candidate sort (see sort_pool): 0 = the oracle's rule (pool position); 1..5 = alternative
- * orders used only to measure the tie envelope of the reference's grid_insert goldens.  Process-global, not thread-safe. */
+/* tie order of RobustPrune's candidate sort (see sort_pool): 0 = the oracle's rule (pool position), the rule the product
+ * implements; 1..5 = alternative orders used only to measure the tie envelope of the reference's grid_insert goldens;
+ * 6 = Rust's own select_nth_unstable_by + sort_unstable_by order (rust_unstable_sort.h), under which every counter and
+ * every search result of all fifteen grid_insert goldens is reproduced exactly.  Process-global, not thread-safe. */
 void orc_set_tie_rule(int32_t rule, uint64_t seed);
+/* the restated Rust sort on its own, in place over (ids, dists): mode 0 SortedNeighbors::new(v, max) (returns the new
+ * length), 1 sort_unstable_by, 2 the small sort (n <= 32), 3 select_nth_unstable_by(max) */
+int64_t orc_rust_sort(int32_t mode, uint32_t* ids, float* dists, uint64_t n, uint64_t max);
+uint64_t orc_rust_sort_fallbacks(void);
 /* CPU distance micro-benchmark in the shape of diskann-benchmark-simd (see dann_oracle.cpp); distances per second */
 double orc_bench_distance(int32_t dtype, int32_t metric, uint32_t dim, uint64_t nrows, uint32_t loops, int32_t random_order,
                           uint32_t threads, uint64_t seed, double* checksum);
+/* counters: NULL or five words, added to: query distances, pair (prune) distances, set_neighbors, append_neighbors,
+ * get_neighbors (the last three as the reference's test provider counts them, graph/test/provider.rs:196-220) */
 int32_t orc_insert(orc_index* ix, const orc_build_config* cfg, uint32_t slot, uint64_t* counters);
 /* DiskANNIndex::multi_insert for rows already stored at slots[0..n)
  * (index.rs:815-1030, max_minibatch_par = 1). */
