@@ -86,6 +86,9 @@ def parse():
                     help="file: load the built graph from it when present, else build and save it (profiling passes "
                          "under rocprofv3 --pmc skip the thousands of build dispatches this way)")
     ap.add_argument("--visited-bits", type=int, default=0)
+    ap.add_argument("--prune-tie-order", default="default", choices=["default", "position", "rust"],
+                    help="dann_set_prune_tie_order on every index the run builds (A/B of the build legs; searches and "
+                         "recall do not depend on it on this continuous data)")
     ap.add_argument("--visited-format", type=int, default=0, choices=[0, 16, 32],
                     help="experiment knob: width of a visited-table entry on every index of the run (0 = automatic)")
     ap.add_argument("--sq8-stride", type=int, default=256,
@@ -166,6 +169,14 @@ def main():
             _init(self, *a, **kw)
             self.set_visited_format(args.visited_format)
         da.Provider.__init__ = _init_fmt
+
+    if args.prune_tie_order != "default":
+        _init_t = da.Provider.__init__
+
+        def _init_tie(self, *a, **kw):
+            _init_t(self, *a, **kw)
+            self.set_prune_tie_order(da.TIE_RUST if args.prune_tie_order == "rust" else da.TIE_POSITION)
+        da.Provider.__init__ = _init_tie
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

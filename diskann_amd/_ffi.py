@@ -15,6 +15,7 @@ COSINE, INNER_PRODUCT, L2, COSINE_NORMALIZED = 0, 1, 2, 3
 OK, EINVAL, ELENGTH, EBOUNDS, ETOOLONG, EHIP, ENOMEM, EOVERFLOW, EUNSUPPORTED, EINTERNAL, EBUSY = (
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)
 IBC_NONE, IBC_ALL = 0, 0xFFFFFFFF
+TIE_POSITION, TIE_RUST = 0, 1  # dann_set_prune_tie_order
 BUILD_MFMA_BACKEDGE, BUILD_MFMA_POOL, BUILD_ROW_KERNEL_ONLY = 1, 2, 4
 
 
@@ -146,6 +147,7 @@ SYMBOLS = {
     "dann_set_visited_bits": (_i32, [_vp, _u32]),
     "dann_set_visited_format": (_i32, [_vp, _u32]),
     "dann_set_max_concurrency": (_i32, [_vp, _u32]),
+    "dann_set_prune_tie_order": (_i32, [_vp, _u32]),
     "dann_comm_create_callbacks": (_i32, [_vp, _P(_vp)]),
     "dann_comm_rccl_unique_id": (_i32, [_vp]),
     "dann_comm_create_rccl": (_i32, [_vp, _u32, _u32, _i32, _P(_vp)]),

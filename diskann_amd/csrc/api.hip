@@ -1742,4 +1742,11 @@ int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight
     return DANN_OK;
 } DANN_CATCH_ALL
 
+int32_t dann_set_prune_tie_order(dann_index* idx, uint32_t order) try {
+    if (!idx || (order != DANN_TIE_POSITION && order != DANN_TIE_RUST)) return DANN_EINVAL;
+    dann::ExclusiveGuard g(idx);  // not while a build is running on another thread
+    idx->prune_tie_order = order;
+    return DANN_OK;
+} DANN_CATCH_ALL
+
 }  // extern "C"

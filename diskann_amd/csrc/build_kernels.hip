@@ -33,6 +33,7 @@
 
 #include "dann_device.h"
 #include "dann_internal.h"
+#include "rust_order.h"
 
 namespace dann {
 namespace {
@@ -44,6 +45,8 @@ struct PruneCfg {
     uint32_t pruned_degree, max_degree, max_occlusion;
     float alpha;
     uint32_t saturate_after_prune;
+    uint32_t tie_order;  // dann_set_prune_tie_order: DANN_TIE_POSITION (bitonic sort on (distance, pool position)) or
+                         // DANN_TIE_RUST (rust_order.h, one lane; the bootstrap's candidates in ascending id order)
     // optional device counters (u64): [0] pair distances of the sweeps (row kernel), [1] list / extra distances
     // d(location, c), [2] rows that went through an MFMA Gram, [3] Gram entries computed (x dim x 2 = MFMA flop),
     // [4] pair distances the lazy scans of the Gram sweeps asked for, [5] those answered by an exact re-evaluation,
@@ -129,6 +132,20 @@ __device__ __forceinline__ float update_occlude(float d_ik, float d_jk, float cu
     return cur;
 }
 
+// DANN_TIE_RUST: the pool order of SortedNeighbors::new as the reference's own sort leaves it (rust_order.h).  Lane 0 walks
+// the algorithm over the pool positions, kept in the `last` array (16 bits per slot, zeroed by the caller's final loop
+// after it has read them); stacks and merge buffer in the region of the sort keys, which this path does not use.  Pools
+// of fewer than 64 slots have less than kWorkBytes there -- and need none of it beyond the 64-byte merge buffer
+// (quicksort starts at 33 entries).  The caller synchronises the wave afterwards.
+__device__ __forceinline__ void rust_order_by_lane0(const PruneCfg& cfg, uint32_t P, uint8_t* smem, const PoolLds& L) {
+    uint16_t* ord = reinterpret_cast<uint16_t*>(smem + L.last_off);
+    const float* pd = reinterpret_cast<const float*>(smem + L.pd_off);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < P; i += kWave) ord[i] = (uint16_t)i;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) rust_order::sorted_neighbors(ord, pd, P, cfg.max_occlusion, smem + L.keys_off);
+}
+
 // Sort pid/pd[0..P) (already in LDS) by (distance, position), truncate to max_occlusion,
 // run occlude_list for `location` and write [len, ids...] to `out`.
 template <int DT, int OP, bool NORM>
@@ -147,9 +164,14 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
 
     // ---- SortedNeighbors::new -------------------------------------------------------
-    for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    const bool rust = cfg.tie_order != 0;
+    if (rust) {
+        rust_order_by_lane0(cfg, P, smem, L);
+    } else {
+        for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    }
     __syncthreads();
-    for (uint32_t k = 2; k <= pcap; k <<= 1) {
+    for (uint32_t k = 2; !rust && k <= pcap; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
                 const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
@@ -166,7 +188,7 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     }
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
     for (uint32_t i = lane; i < N; i += kWave) {
-        const uint32_t pos = (uint32_t)keys[i];
+        const uint32_t pos = rust ? (uint32_t)last[i] : (uint32_t)keys[i];
         const uint32_t id = pid[pos];
         sid[i] = id;
         sd[i] = pd[pos];
@@ -454,6 +476,21 @@ __global__ __launch_bounds__(kWave) void bootstrap_kernel(ListArgs a) {
         cnt += (uint32_t)__popcll(m);
     }
     __syncthreads();
+    if (a.cfg.tie_order != 0) {
+        // from_iter_untrusted is sort_unstable + dedup (adjacencylist.rs:181-190): robust_prune_list walks the candidates
+        // in ascending id order, and the reference's sort sees them arrive in that order.  The ids are distinct: an id's
+        // rank is the number of smaller ones.
+        uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + L.keys_off);
+        for (uint32_t i = lane; i < cnt; i += kWave) {
+            const uint32_t id = pid[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < cnt; ++j) r += pid[j] < id ? 1u : 0u;
+            tmp[r] = id;
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < cnt; i += kWave) pid[i] = tmp[i];
+        __syncthreads();
+    }
     fill_list_distances<DT, OP, NORM>(a.ix, loc, pid, pd, cnt);
     __syncthreads();
     prune_sorted_pool<DT, OP, NORM>(a.ix, a.cfg, loc, cnt, a.pcap, smem, L, true, out);
@@ -723,9 +760,14 @@ __device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pca
     float* sd = reinterpret_cast<float*>(smem + L.sd_off);
     float* occ = reinterpret_cast<float*>(smem + L.occ_off);
     uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
-    for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    const bool rust = cfg.tie_order != 0;
+    if (rust) {
+        rust_order_by_lane0(cfg, P, smem, L);
+    } else {
+        for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    }
     wave_sync();
-    for (uint32_t k = 2; k <= pcap; k <<= 1) {
+    for (uint32_t k = 2; !rust && k <= pcap; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
                 const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
@@ -741,6 +783,10 @@ __device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pca
         }
     }
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
+    if (rust) {  // the work area of the walk is dead: keys[i] = pool position of sorted entry i, as the sort leaves it
+        wave_sync();
+        for (uint32_t i = lane; i < N; i += kWave) keys[i] = last[i];
+    }
     for (uint32_t i = lane; i < N; i += kWave) {
         const uint32_t pos = (uint32_t)keys[i];
         sid[i] = pid[pos];
@@ -1886,8 +1932,9 @@ uint32_t next_pow2(uint32_t x) {
 uint32_t sweep_one_by_one(const dann_index* idx) { return idx->dbg_u32(DANN_DBG_SWEEP_ONE_BY_ONE, 0u) ? 1u : 0u; }
 bool pool_gram_default(const dann_index* idx) { return idx->dbg_u32(DANN_DBG_POOL_GRAM, 1u) != 0u; }
 
-PruneCfg to_prune_cfg(const dann_build_config& c) {
+PruneCfg to_prune_cfg(const dann_index* idx, const dann_build_config& c) {
     PruneCfg p;
+    p.tie_order = idx->prune_tie_order;
     p.pruned_degree = c.pruned_degree;
     p.max_degree = c.max_degree;
     p.max_occlusion = c.max_occlusion_size ? c.max_occlusion_size : 750;
@@ -2109,7 +2156,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
                                 const uint32_t* d_slots, uint32_t n, uint32_t lo, uint32_t hi,
                                 uint32_t* d_pending_out) {
     const IndexView ix = idx->view();
-    PruneCfg pc = to_prune_cfg(cfg);
+    PruneCfg pc = to_prune_cfg(idx, cfg);
     pc.counters = s.counters.as<unsigned long long>();
     hipStream_t st = idx->main.stream;
     const uint32_t m = hi - lo;
@@ -2265,7 +2312,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
     if (count_out) *count_out = 0;
     s.bootstrap_too_big = false;
     const IndexView ix = idx->view();
-    PruneCfg pc = to_prune_cfg(cfg);
+    PruneCfg pc = to_prune_cfg(idx, cfg);
     pc.counters = s.counters.as<unsigned long long>();
     hipStream_t st = idx->main.stream;
     const uint32_t cand = cfg.intra_batch_candidates == 0xFFFFFFFFu ? n : std::min(cfg.intra_batch_candidates, n);
@@ -2837,7 +2884,7 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
     DANN_HIP(hipMemsetAsync(derr.p, 0, 4, st));
     PoolArgs pa;
     pa.ix = idx->view();
-    pa.cfg = to_prune_cfg(*cfg);
+    pa.cfg = to_prune_cfg(idx, *cfg);
     pa.locs = dl.as<uint32_t>();
     pa.pool_ids = di.as<uint32_t>();
     pa.pool_d = dd.as<float>();

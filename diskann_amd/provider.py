@@ -492,6 +492,11 @@ class Provider:
         """Queries in flight per search call (0 = all): n persistent wavefronts share the call's queries."""
         check(_ffi.lib().dann_set_max_concurrency(self._h, n), "dann_set_max_concurrency")
 
+    def set_prune_tie_order(self, order):
+        """TIE_POSITION (default): equal-distance prune candidates keep their pool order; TIE_RUST: the order the
+        reference's own sort leaves them in (conformance mode for tie-heavy data, slower prunes)."""
+        check(_ffi.lib().dann_set_prune_tie_order(self._h, int(order)), "dann_set_prune_tie_order")
+
     # -- search server: N callers on one shared index, one query per call, no kernel launch per call ----------
     def server_start(self, l_value, k=10, workers=1024, ring=0, idle_timeout_us=0):
         cfg = _ffi.ServerConfig(int(l_value), int(k), int(workers), int(ring), int(idle_timeout_us))

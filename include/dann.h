@@ -460,6 +460,19 @@ int32_t dann_set_visited_format(dann_index* idx, uint32_t entry_bits);
  * of its batch.  Applies to the plain searches (beam width 1, no filter, no inline tags, degree <= 64: Knn, Range,
  * the insert search); the other modes keep one wavefront per query.  Never affects results. */
 int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight);
+/* Order of EQUAL-distance candidates in RobustPrune's candidate pool (every prune of dann_prune_batch,
+ * dann_insert_batch*, dann_build*).  SortedNeighbors::new (diskann/src/graph/internal/sorted_neighbors.rs:26-44) sorts
+ * with select_nth_unstable_by + sort_unstable_by, whose order of equal keys is unspecified in the API and a
+ * deterministic function of the pool's arrival order in the implementation.
+ *   DANN_TIE_POSITION (default): equal distances keep their pool order (a stable sort; one wavefront-wide sorting
+ *     network per pool) -- the fast path; identical to the reference wherever the distances of a pool are distinct.
+ *   DANN_TIE_RUST: the order the reference's own toolchain leaves (rust-toolchain.toml: 1.97.1; core's "ipnsort" and
+ *     its selection, Rust >= 1.81), walked sequentially by one lane per pool (csrc/rust_order.h), and the bootstrap's
+ *     candidate list in AdjacencyList::from_iter_untrusted's ascending id order (adjacencylist.rs:181-190): the
+ *     conformance mode for tie-heavy inputs (integer lattices, duplicated rows).  With it the GPU build reproduces the
+ *     reference's tie-heavy grid_insert goldens (tests/test_gpu_tie_order.py); prunes are several times slower. */
+enum { DANN_TIE_POSITION = 0, DANN_TIE_RUST = 1 };
+int32_t dann_set_prune_tie_order(dann_index* idx, uint32_t order);
 
 /* ---- multi-GPU (replicated index per device).  Search shards with no data-path collective; the build splits every
  * multi_insert batch at its only exchange point (diskann/src/graph/index.rs:815-1030, :911-1024): candidates per rank,
