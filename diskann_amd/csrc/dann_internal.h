@@ -299,7 +299,7 @@ struct dann_index {
     uint32_t visited_bits = 0;
     uint32_t visited_format = 0;   // dann_set_visited_format: 0 = automatic, 32 / 16 = entry width of the LDS visited table
     uint32_t max_concurrency = 0;  // dann_set_max_concurrency: queries in flight per search call (0 = all of them)
-    uint32_t prune_tie_order = 0;  // dann_set_prune_tie_order: DANN_TIE_POSITION / DANN_TIE_RUST
+    uint32_t prune_tie_order = DANN_TIE_RUST;  // dann_set_prune_tie_order: DANN_TIE_RUST (default) / DANN_TIE_POSITION
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
     // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of

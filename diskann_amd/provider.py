@@ -493,8 +493,8 @@ class Provider:
         check(_ffi.lib().dann_set_max_concurrency(self._h, n), "dann_set_max_concurrency")
 
     def set_prune_tie_order(self, order):
-        """TIE_POSITION (default): equal-distance prune candidates keep their pool order; TIE_RUST: the order the
-        reference's own sort leaves them in (conformance mode for tie-heavy data, slower prunes)."""
+        """TIE_RUST (default): equal-distance prune candidates in the order the reference's own sort leaves them in;
+        TIE_POSITION: they keep their pool order (same graph on tie-free data, builds 7-19 % faster)."""
         check(_ffi.lib().dann_set_prune_tie_order(self._h, int(order)), "dann_set_prune_tie_order")
 
     # -- search server: N callers on one shared index, one query per call, no kernel launch per call ----------

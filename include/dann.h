@@ -464,13 +464,15 @@ int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight
  * dann_insert_batch*, dann_build*).  SortedNeighbors::new (diskann/src/graph/internal/sorted_neighbors.rs:26-44) sorts
  * with select_nth_unstable_by + sort_unstable_by, whose order of equal keys is unspecified in the API and a
  * deterministic function of the pool's arrival order in the implementation.
- *   DANN_TIE_POSITION (default): equal distances keep their pool order (a stable sort; one wavefront-wide sorting
- *     network per pool) -- the fast path; identical to the reference wherever the distances of a pool are distinct.
- *   DANN_TIE_RUST: the order the reference's own toolchain leaves (rust-toolchain.toml: 1.97.1; core's "ipnsort" and
- *     its selection, Rust >= 1.81), walked sequentially by one lane per pool (csrc/rust_order.h), and the bootstrap's
- *     candidate list in AdjacencyList::from_iter_untrusted's ascending id order (adjacencylist.rs:181-190): the
- *     conformance mode for tie-heavy inputs (integer lattices, duplicated rows).  With it the GPU build reproduces the
- *     reference's tie-heavy grid_insert goldens (tests/test_gpu_tie_order.py); prunes are several times slower. */
+ *   DANN_TIE_RUST (default): the order the reference's own toolchain leaves (rust-toolchain.toml: 1.97.1; core's
+ *     "ipnsort" and its selection, Rust >= 1.81), walked sequentially by one lane per pool (csrc/rust_order.h), and the
+ *     bootstrap's candidate list in AdjacencyList::from_iter_untrusted's ascending id order (adjacencylist.rs:181-190).
+ *     With it the GPU build reproduces the reference's tie-heavy grid_insert goldens (tests/test_gpu_tie_order.py):
+ *     the graph is the reference's graph on integer lattices, byte data and duplicated rows as well.
+ *   DANN_TIE_POSITION: equal distances keep their pool order (a stable sort; one wavefront-wide sorting network per
+ *     pool).  Identical to DANN_TIE_RUST wherever the distances of a pool are distinct; on tied pools one of the orders
+ *     the reference's API permits, not the one its implementation produces.  Builds are 7-19 % faster (1 M x 768 f32:
+ *     2.04 against 2.18 s; 10 M x 128: 3.7 against 4.4 s, profiles/r05_reentry_bench*.json). */
 enum { DANN_TIE_POSITION = 0, DANN_TIE_RUST = 1 };
 int32_t dann_set_prune_tie_order(dann_index* idx, uint32_t order);
 

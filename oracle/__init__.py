@@ -425,10 +425,14 @@ def _check_counters(counters):
         raise ValueError("counters: five contiguous uint64 words")
 
 
-def set_tie_rule(rule=0, seed=0):
-    """order of equal-distance candidates in RobustPrune's sort: 0 = the oracle's rule (pool position), the one the
-    product implements; 1..5 see dann_oracle.cpp sort_pool (tie-envelope measurement); 6 = Rust's own order
-    (oracle/rust_unstable_sort.h), which reproduces the reference's tie-heavy grid_insert goldens exactly"""
+DEFAULT_TIE_RULE, POSITION_TIE_RULE = 6, 0
+
+
+def set_tie_rule(rule=DEFAULT_TIE_RULE, seed=0):
+    """order of equal-distance candidates in RobustPrune's sort: 6 (default) = Rust's own order
+    (oracle/rust_unstable_sort.h), which reproduces the reference's tie-heavy grid_insert goldens exactly -- the
+    product's DANN_TIE_RUST; 0 = pool position, the product's DANN_TIE_POSITION; 1..5 see dann_oracle.cpp sort_pool
+    (tie-envelope measurement).  set_tie_rule() restores the default."""
     lib().orc_set_tie_rule(rule, seed)
 
 

@@ -9,9 +9,10 @@
  *
  * Where the reference leaves behaviour unspecified (tie order of the unstable sort in
  * internal/sorted_neighbors.rs:36-40) the oracle fixes a rule and says so:
- * ORACLE TIE RULE = ascending distance, ties by original position in the pool (the rule the product implements).
- * Rust's own order is available as tie rule 6 (rust_unstable_sort.h): under it every reference grid_insert golden is
- * reproduced exactly, which is what pins the build half of this file.
+ * the candidate sort of RobustPrune follows Rust's own order (tie rule 6, rust_unstable_sort.h: under it every
+ * reference grid_insert golden is reproduced exactly, which is what pins the build half of this file; the product's
+ * default, DANN_TIE_RUST); tie rule 0 = ascending distance, ties by original position in the pool (the product's
+ * DANN_TIE_POSITION).  The post-processing sorts of the filtered searches are restated as stable sorts.
  */
 #include "dann_oracle.h"
 #include "rust_unstable_sort.h"
@@ -706,7 +707,7 @@ struct PNeighbor {
  * sort_unstable_by: the order of candidates at EQUAL distance is whatever Rust's unstable sort leaves (its source is
  * not in this image).  The oracle's rule is "ties by pool position" (rule 0); the other rules exist to measure how far
  * a tie order can move the reference's grid_insert counters (tests/test_oracle_build.py, tie envelope) -- the
- * product and every parity test use rule 0:
+ * default is rule 6 (the product's DANN_TIE_RUST); rule 0 is the product's DANN_TIE_POSITION:
  *   0 pool position ascending (stable)   1 pool position descending   2 id ascending   3 id descending
  *   4 a seeded shuffle of the tied entries (a fresh permutation per sort)
  *   5 a hypothesis about small pools: when the whole pool is kept (max >= len) select_nth_unstable_by(len - 1) swaps
@@ -716,7 +717,7 @@ struct PNeighbor {
  *   6 Rust's own order: select_nth_unstable_by + sort_unstable_by as restated in rust_unstable_sort.h (ipnsort and
  *     its selection, for 8-byte Copy elements).  With it the oracle reproduces every counter of the reference's
  *     twelve tie-heavy grid_insert goldens exactly (tests/test_oracle_build.py). */
-static int g_tie_rule = 0;
+static int g_tie_rule = 6; /* the reference's own order; 0 = the product's DANN_TIE_POSITION */
 static uint64_t g_rust_fallbacks = 0;
 static uint64_t g_tie_state = 0x9E3779B97F4A7C15ull;
 void tie_rule_set(int32_t rule, uint64_t seed) {
@@ -1742,9 +1743,9 @@ int32_t orc_multi_insert(orc_index* ix, const orc_build_config* cfg, const uint3
             for (uint32_t o = 0; o < n; ++o)
                 if (edges[o].source != edges[pos].source) push_unique(edges[o].source);
             /* from_iter_untrusted is sort_unstable + dedup (adjacencylist.rs:181-190): the list robust_prune_list walks
-             * is in ascending id order.  Under the oracle's own tie rules the order of first occurrence is kept (it is
-             * what the product's bootstrap kernel does, and only ties can tell the two apart); the restated Rust sort
-             * (rule 6) gets the reference's order. */
+             * is in ascending id order (rule 6, and the product under DANN_TIE_RUST).  Under the position rules the order of
+             * first occurrence is kept (the product's bootstrap kernel under DANN_TIE_POSITION; only ties can tell the
+             * two apart). */
             if (g_tie_rule == 6) std::sort(cands.begin(), cands.end());
             next[pos].source = edges[pos].source;
             robust_prune_list(v, cfg, edges[pos].source, cands, true, next[pos].edges, counters);

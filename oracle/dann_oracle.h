@@ -166,10 +166,11 @@ int32_t orc_prune_pool(const orc_index* ix, const orc_build_config* cfg, uint32_
                        uint32_t* pool_ids, float* pool_dists, uint32_t pool_n, int32_t force_saturate,
                        uint32_t* out_neighbors, uint64_t* pair_evals);
 /* DiskANNIndex::insert for a row already stored at `slot` (index.rs:226-341). */
-/* tie order of RobustPrune's candidate sort (see sort_pool): 0 = the oracle's rule (pool position), the rule the product
- * implements; 1..5 = alternative orders used only to measure the tie envelope of the reference's grid_insert goldens;
- * 6 = Rust's own select_nth_unstable_by + sort_unstable_by order (rust_unstable_sort.h), under which every counter and
- * every search result of all fifteen grid_insert goldens is reproduced exactly.  Process-global, not thread-safe. */
+/* tie order of RobustPrune's candidate sort (see sort_pool): 6 (default) = Rust's own select_nth_unstable_by +
+ * sort_unstable_by order (rust_unstable_sort.h), under which every counter and every search result of all fifteen
+ * grid_insert goldens is reproduced exactly -- the product's DANN_TIE_RUST; 0 = pool position, the product's
+ * DANN_TIE_POSITION; 1..5 = alternative orders used only to measure the tie envelope of the reference's grid_insert
+ * goldens.  Process-global, not thread-safe. */
 void orc_set_tie_rule(int32_t rule, uint64_t seed);
 /* the restated Rust sort on its own, in place over (ids, dists): mode 0 SortedNeighbors::new(v, max) (returns the new
  * length), 1 sort_unstable_by, 2 the small sort (n <= 32), 3 select_nth_unstable_by(max) */

@@ -37,7 +37,7 @@ for f in _files(os.path.join(ROOT, 'tests', 'golden')):
         hi = t if hi is None else [max(a, b) for a, b in zip(hi, t)]
         best_exact = max(best_exact, ex)
         hits += int(t[:2] == ref[:2])
-    oracle.set_tie_rule(0, 0)
+    oracle.set_tie_rule()
     inside = [l <= r <= h for l, r, h in zip(lo, ref, hi)]
     out[name] = dict(reference=ref, rules={k: dict(tuple=v[0], searches_exact=v[1]) for k, v in rows.items()},
                      shuffle_min=lo, shuffle_max=hi, reference_inside=inside, shuffles_matching_both_counters=hits,

@@ -1,9 +1,9 @@
-"""dann_set_prune_tie_order(idx, DANN_TIE_RUST): the GPU prune orders equal-distance candidates the way the reference's own
-sort does (csrc/rust_order.h).  The headline: the reference's fifteen grid_insert goldens -- twelve of them integer
+"""dann_set_prune_tie_order: by default (DANN_TIE_RUST) the GPU prune orders equal-distance candidates the way the reference's
+own sort does (csrc/rust_order.h).  The headline: the reference's fifteen grid_insert goldens -- twelve of them integer
 lattices on which nearly every pool has ties -- built on the GPU and searched on the GPU reproduce the golden files:
 ids, distances, comparisons and hops of both post-build searches, and an adjacency identical to the oracle's, whose
-set_neighbors / append_neighbors / get_neighbors counters are the goldens' (tests/test_oracle_build.py).  Under the
-default order (pool position) the same builds equal the oracle under its own rule."""
+set_neighbors / append_neighbors / get_neighbors counters are the goldens' (tests/test_oracle_build.py).  Under
+DANN_TIE_POSITION (the faster sort) the same builds equal the oracle under the position rule."""
 import json
 import os
 import re
@@ -83,15 +83,36 @@ def test_grid_insert_goldens_on_the_gpu_in_the_references_tie_order(golden_dir):
                 assert [float(d) for d in dists[0][:k]] == [w[1] for w in sc["results"]], f["test"]
                 assert int(st["cmps"][0]) == sc["comparisons"] and int(st["hops"][0]) == sc["hops"], f["test"]
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
 def test_grid_insert_goldens_on_the_gpu_in_pool_order(golden_dir):
-    """the default order on the same tie-heavy builds: the GPU equals the oracle under its own rule (pool position)"""
+    """DANN_TIE_POSITION (the faster sort) on the same tie-heavy builds: the GPU equals the oracle under the position rule"""
     files = json.load(open(os.path.join(golden_dir, "grid_insert.json")))
-    for f in files:
-        _, oix, gix, _ = _build_both(f, da.TIE_POSITION, 0)
-        assert _same_graph(gix, oix), f["test"]
+    try:
+        for f in files:
+            _, oix, gix, _ = _build_both(f, da.TIE_POSITION, oracle.POSITION_TIE_RULE)
+            assert _same_graph(gix, oix), f["test"]
+    finally:
+        oracle.set_tie_rule()
+
+
+def test_the_default_order_is_the_references():
+    """nothing set on either side: oracle and product both follow Rust's order (a lattice batch with ties in every pool)"""
+    data = grid_data(3, 5)
+    n, deg = data.shape[0], 6
+    start = grid_start_point(3, 5)
+    oix = oracle.Index(oracle.F32, oracle.L2, 3, n, deg, start)
+    oix.set_rows(0, data)
+    gix = da.Provider(da.F32, da.L2, 3, n, deg, start)
+    gix.set_elements(0, data)
+    cnt = np.zeros(5, np.uint64)
+    for s in range(0, n, 25):
+        slots = np.arange(s, min(s + 25, n), dtype=np.uint32)
+        oix.multi_insert(oracle.build_config(4, deg, 100, intra_batch_candidates=oracle.IBC_NONE), slots, cnt)
+        gix.insert_batch(da.build_config(4, deg, 100, intra_batch_candidates=da.IBC_NONE), slots)
+    assert [int(cnt[2]), int(cnt[3])] == [133, 131]   # insert_3_5_batch_25/ibc_none of the reference's goldens
+    assert _same_graph(gix, oix)
 
 
 @pytest.mark.parametrize("dtype,metric,dim", [(oracle.F32, oracle.L2, 24), (oracle.U8, oracle.L2, 16),
@@ -132,7 +153,7 @@ def test_prune_batch_in_the_references_tie_order(dtype, metric, dim):
                     assert got[i, 0] == want.size, (i, sat, occl)
                     assert np.array_equal(got[i, 1:1 + want.size], want), (i, sat, occl)
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
 @pytest.mark.parametrize("dtype,dim,ibc", [(oracle.U8, 16, 4), (oracle.F32, 256, oracle.IBC_NONE), (oracle.F32, 32, oracle.IBC_ALL)])
@@ -159,7 +180,7 @@ def test_batched_build_on_integer_data_in_the_references_tie_order(dtype, dim, i
             s0 += b
         assert s0 == n
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
 def test_the_two_orders_differ_only_where_distances_tie():

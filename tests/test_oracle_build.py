@@ -5,9 +5,10 @@ own result depends on the order Rust's unstable sort leaves equal distances in
 (internal/sorted_neighbors.rs:36-40).  With that sort restated (oracle/rust_unstable_sort.h,
 tie rule 6) the oracle reproduces ALL fifteen goldens exactly: set_neighbors, append_neighbors
 and get_neighbors of the build, and ids, distances, comparisons and hops of every post-build
-search (test_grid_insert_all_goldens_exact_with_rust_sort).  Under its own rule (pool position,
-the rule the product implements) the oracle's counters are recorded next to the reference's, and
-every counter of every golden lies inside the range alternative tie orders span."""
+search (test_grid_insert_all_goldens_exact_with_rust_sort); rule 6 is the oracle's default and
+the product's (DANN_TIE_RUST).  Under the position rule (the product's DANN_TIE_POSITION) the
+oracle's counters are recorded next to the reference's, and every counter of every golden lies
+inside the range alternative tie orders span."""
 import json
 import os
 import re
@@ -90,12 +91,13 @@ def test_grid_insert_all_goldens_exact_with_rust_sort(golden_dir):
         assert seen == 15
         assert oracle.rust_sort_fallbacks() == before  # the selection's median-of-medians fallback is never reached
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
-# (set_neighbors, append_neighbors) of the oracle under its own tie rule (pool position) next to the reference's, per
-# lattice golden -- measured, not a tolerance: append_neighbors is off by up to 12 % on the 3-D lattices.  The next test
-# shows that this is the freedom the reference's unstable sort has, not a different rule.
+# (set_neighbors, append_neighbors) of the oracle under the position rule (equal distances keep their pool order: the
+# product's DANN_TIE_POSITION) next to the reference's, per lattice golden -- measured, not a tolerance: append_neighbors
+# is off by up to 12 % on the 3-D lattices.  The next test shows that this is the freedom the reference's unstable sort
+# has, not a different rule; under the default rule (Rust's own order) the goldens are reproduced exactly, see above.
 ORACLE_VS_REFERENCE = {
     "insert_3_5_batch_125/ibc_all": ([125, 83], [125, 81]),
     "insert_3_5_batch_125/ibc_max_4": ([125, 83], [125, 74]),
@@ -141,18 +143,22 @@ def _reference_tuple(p):
 
 
 def test_grid_insert_lattice_counters_as_measured(golden_dir):
-    """the oracle's counters on the 12 tie-heavy lattice goldens are exactly the recorded ones (a regression pin of the
-    oracle) and the reference's are the recorded ones too (a pin of the table above)"""
-    oracle.set_tie_rule(0, 0)
-    seen = 0
-    for f in _lattice_files(golden_dir):
-        name = f["test"].split("grid_insert/")[1]
-        mine, ref = ORACLE_VS_REFERENCE[name]
-        tup, _ = _tuple(f)
-        assert tup[:2] == mine, name
-        assert _reference_tuple(f["payload"])[:2] == ref, name
-        seen += 1
-    assert seen == 12
+    """under the position rule (the product's DANN_TIE_POSITION) the oracle's counters on the 12 tie-heavy lattice goldens
+    are exactly the recorded ones (a regression pin of that rule) and the reference's are the recorded ones too (a pin of
+    the table above)"""
+    try:
+        oracle.set_tie_rule(oracle.POSITION_TIE_RULE)
+        seen = 0
+        for f in _lattice_files(golden_dir):
+            name = f["test"].split("grid_insert/")[1]
+            mine, ref = ORACLE_VS_REFERENCE[name]
+            tup, _ = _tuple(f)
+            assert tup[:2] == mine, name
+            assert _reference_tuple(f["payload"])[:2] == ref, name
+            seen += 1
+        assert seen == 12
+    finally:
+        oracle.set_tie_rule()
 
 
 def test_grid_insert_lattice_tie_envelope(golden_dir):
@@ -176,7 +182,7 @@ def test_grid_insert_lattice_tie_envelope(golden_dir):
                 hi = t if hi is None else [max(a, b) for a, b in zip(hi, t)]
             assert all(l <= r <= h for l, r, h in zip(lo, ref, hi)), (f["test"], ref, lo, hi)
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
 def test_small_pool_hypothesis_reproduces_the_single_insert_3d_counters(golden_dir):
@@ -190,7 +196,7 @@ def test_small_pool_hypothesis_reproduces_the_single_insert_3d_counters(golden_d
         tup, _ = _tuple(f)
         assert tup[:2] == _reference_tuple(f["payload"])[:2] == [206, 388]
     finally:
-        oracle.set_tie_rule(0, 0)
+        oracle.set_tie_rule()
 
 
 def test_prune_matches_bruteforce_rule():
