@@ -134,9 +134,20 @@ __device__ __forceinline__ float update_occlude(float d_ik, float d_jk, float cu
 
 // DANN_TIE_RUST: the pool order of SortedNeighbors::new as the reference's own sort leaves it (rust_order.h).  Lane 0 walks
 // the algorithm over the pool positions, kept in the `last` array (16 bits per slot, zeroed by the caller's final loop
-// after it has read them); stacks and merge buffer in the region of the sort keys, which this path does not use.  Pools
-// of fewer than 64 slots have less than kWorkBytes there -- and need none of it beyond the 64-byte merge buffer
-// (quicksort starts at 33 entries).  The caller synchronises the wave afterwards.
+// after it has read them); stacks and merge buffer in the region of the sort keys, whose contents (the network's output)
+// are dead once the walk is decided.  Pools of fewer than 64 slots have less than kWorkBytes there -- and need none of it
+// beyond the 64-byte merge buffer (quicksort starts at 33 entries).  The caller synchronises the wave afterwards.
+//
+// The walk is only needed where it can matter: a pool whose distances are all distinct (and ordered: no NaN) has one
+// sorted order, and select_nth_unstable_by + sort_unstable_by + truncate leave exactly its head -- what the sorting
+// network has already produced.  pool_has_ties looks at neighbouring keys of the network's output (wave-uniform result);
+// on continuous data nearly every pool takes the network alone, on byte data and lattices the tied pools are walked.
+__device__ __forceinline__ bool pool_has_ties(const uint64_t* keys, uint32_t P, bool lane_saw_nan) {
+    const uint32_t lane = threadIdx.x & 63u;
+    bool tie = lane_saw_nan;
+    for (uint32_t i = lane; i + 1 < P; i += kWave) tie |= (uint32_t)(keys[i] >> 32) == (uint32_t)(keys[i + 1] >> 32);
+    return ballot64(tie) != 0;
+}
 __device__ __forceinline__ void rust_order_by_lane0(const PruneCfg& cfg, uint32_t P, uint8_t* smem, const PoolLds& L) {
     uint16_t* ord = reinterpret_cast<uint16_t*>(smem + L.last_off);
     const float* pd = reinterpret_cast<const float*>(smem + L.pd_off);
@@ -164,14 +175,14 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
     uint32_t* sel = reinterpret_cast<uint32_t*>(smem + L.sel_off);
 
     // ---- SortedNeighbors::new -------------------------------------------------------
-    const bool rust = cfg.tie_order != 0;
-    if (rust) {
-        rust_order_by_lane0(cfg, P, smem, L);
-    } else {
-        for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    bool saw_nan = false;
+    for (uint32_t i = lane; i < pcap; i += kWave) {
+        const float d = i < P ? pd[i] : 0.0f;
+        saw_nan |= d != d;
+        keys[i] = i < P ? sort_key(d, i) : ~0ull;
     }
     __syncthreads();
-    for (uint32_t k = 2; !rust && k <= pcap; k <<= 1) {
+    for (uint32_t k = 2; k <= pcap; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
                 const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
@@ -185,6 +196,13 @@ __device__ void prune_sorted_pool(const IndexView& ix, const PruneCfg& cfg, uint
             }
             __syncthreads();
         }
+    }
+    // DANN_TIE_RUST: a pool with equal (or unordered) distances is ordered by the reference's own sort instead
+    const bool rust = cfg.tie_order != 0 && pool_has_ties(keys, P, saw_nan);
+    if (rust) {
+        __syncthreads();
+        rust_order_by_lane0(cfg, P, smem, L);
+        __syncthreads();
     }
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
     for (uint32_t i = lane; i < N; i += kWave) {
@@ -760,14 +778,14 @@ __device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pca
     float* sd = reinterpret_cast<float*>(smem + L.sd_off);
     float* occ = reinterpret_cast<float*>(smem + L.occ_off);
     uint16_t* last = reinterpret_cast<uint16_t*>(smem + L.last_off);
-    const bool rust = cfg.tie_order != 0;
-    if (rust) {
-        rust_order_by_lane0(cfg, P, smem, L);
-    } else {
-        for (uint32_t i = lane; i < pcap; i += kWave) keys[i] = i < P ? sort_key(pd[i], i) : ~0ull;
+    bool saw_nan = false;
+    for (uint32_t i = lane; i < pcap; i += kWave) {
+        const float d = i < P ? pd[i] : 0.0f;
+        saw_nan |= d != d;
+        keys[i] = i < P ? sort_key(d, i) : ~0ull;
     }
     wave_sync();
-    for (uint32_t k = 2; !rust && k <= pcap; k <<= 1) {
+    for (uint32_t k = 2; k <= pcap; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (pcap >> 1); t += kWave) {
                 const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
@@ -783,8 +801,10 @@ __device__ uint32_t sort_pool_wave(const PruneCfg& cfg, uint32_t P, uint32_t pca
         }
     }
     const uint32_t N = P < cfg.max_occlusion ? P : cfg.max_occlusion;
-    if (rust) {  // the work area of the walk is dead: keys[i] = pool position of sorted entry i, as the sort leaves it
+    if (cfg.tie_order != 0 && pool_has_ties(keys, P, saw_nan)) {  // (see prune_sorted_pool)
         wave_sync();
+        rust_order_by_lane0(cfg, P, smem, L);
+        wave_sync();  // the work area of the walk is dead: keys[i] = pool position of sorted entry i, as the sort leaves it
         for (uint32_t i = lane; i < N; i += kWave) keys[i] = last[i];
     }
     for (uint32_t i = lane; i < N; i += kWave) {

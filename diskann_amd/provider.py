@@ -494,7 +494,7 @@ class Provider:
 
     def set_prune_tie_order(self, order):
         """TIE_RUST (default): equal-distance prune candidates in the order the reference's own sort leaves them in;
-        TIE_POSITION: they keep their pool order (same graph on tie-free data, builds 7-19 % faster)."""
+        TIE_POSITION: they keep their pool order (same graph on tie-free data; tied pools skip the serial walk)."""
         check(_ffi.lib().dann_set_prune_tie_order(self._h, int(order)), "dann_set_prune_tie_order")
 
     # -- search server: N callers on one shared index, one query per call, no kernel launch per call ----------

@@ -469,10 +469,12 @@ int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight
  *     bootstrap's candidate list in AdjacencyList::from_iter_untrusted's ascending id order (adjacencylist.rs:181-190).
  *     With it the GPU build reproduces the reference's tie-heavy grid_insert goldens (tests/test_gpu_tie_order.py):
  *     the graph is the reference's graph on integer lattices, byte data and duplicated rows as well.
+ *     Only pools that hold equal distances are walked (the sorting network's output is inspected first): builds of
+ *     float rows cost what they cost under DANN_TIE_POSITION, a 200 k x 128 u8 build 12 % more.
  *   DANN_TIE_POSITION: equal distances keep their pool order (a stable sort; one wavefront-wide sorting network per
- *     pool).  Identical to DANN_TIE_RUST wherever the distances of a pool are distinct; on tied pools one of the orders
- *     the reference's API permits, not the one its implementation produces.  Builds are 7-19 % faster (1 M x 768 f32:
- *     2.04 against 2.18 s; 10 M x 128: 3.7 against 4.4 s, profiles/r05_reentry_bench*.json). */
+ *     pool, no walk).  Identical to DANN_TIE_RUST wherever the distances of a pool are distinct; on tied pools one of the
+ *     orders the reference's API permits, not the one its implementation produces.
+ * Replicas of one sharded build (dann_build_sharded; dann_multi_build: dann_multi_replica) must use the same order. */
 enum { DANN_TIE_POSITION = 0, DANN_TIE_RUST = 1 };
 int32_t dann_set_prune_tie_order(dann_index* idx, uint32_t order);
 
