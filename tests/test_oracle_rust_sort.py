@@ -98,3 +98,21 @@ def test_rule_six_is_not_stable_on_tied_pools():
         si, _ = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, ids, d, 60)
         differs += int(si.tolist() != np.argsort(d, kind="stable").tolist())
     assert differs > 40
+
+
+def test_reference_sorted_neighbors_unit_test():
+    """sorted_neighbors.rs:77-109 (`test_sorted_neighbors`): ten neighbours (id i, distance i / 10) shuffled, max = 0 .. 11:
+    SortedNeighbors::new leaves the first min(10, max) of the sorted list and truncates the vector (any shuffle will do:
+    the distances are distinct); :68-75 (`test_empty_neighbors`): an empty vector stays empty for every max."""
+    ids = np.arange(1, 11, dtype=np.uint32)
+    d = (ids / 10.0).astype(np.float32)
+    rng = np.random.default_rng(0xD6152FB9)
+    for mx in range(0, 12):
+        for _ in range(10):
+            p = rng.permutation(10)
+            si, sd = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, ids[p], d[p], mx)
+            n = min(10, mx)
+            assert si.tolist() == ids[:n].tolist() and sd.tolist() == d[:n].tolist()
+    for mx in range(10):
+        si, _ = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, np.zeros(0, np.uint32), np.zeros(0, np.float32), mx)
+        assert si.size == 0
