@@ -117,6 +117,7 @@ SYMBOLS = {
     "dann_search_record_batch": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp]),
     "dann_prune_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "dann_insert_batch": (_i32, [_vp, _P(BuildConfig), _vp, _u32]),
+    "dann_insert": (_i32, [_vp, _P(BuildConfig), _u32]),
     "dann_insert_batch_candidates": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _u32, _u32, _vp]),
     "dann_insert_batch_commit": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp]),
     "dann_insert_batch_commit_part": (_i32, [_vp, _P(BuildConfig), _vp, _u32, _vp, _u32, _u32, _vp, _u32, _P(_u32)]),

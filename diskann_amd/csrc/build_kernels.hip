@@ -1796,13 +1796,15 @@ __global__ __launch_bounds__(kWave) void backedge_list_kernel(BackListArgs la) {
 }
 
 // ---- small utility kernels -------------------------------------------------------------------
+// `limit`: back-edges go to the first `limit` neighbours of a new point only (DiskANNIndex::insert takes
+// max_backedges of them, index.rs:324-327; multi_insert all, index.rs:123-143)
 __global__ void make_keys_kernel(const uint32_t* locs, const uint32_t* pending, uint32_t pend_stride, uint32_t n,
-                                 uint32_t degree, uint64_t* keys) {
+                                 uint32_t degree, uint64_t* keys, uint32_t limit) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * degree) return;
     const uint32_t item = t / degree, e = t % degree;
     const uint32_t* row = pending + (uint64_t)item * pend_stride;
-    keys[t] = e < row[0] ? (((uint64_t)row[1 + e] << 32) | locs[item]) : ~0ull;
+    keys[t] = (e < row[0] && e < limit) ? (((uint64_t)row[1 + e] << 32) | locs[item]) : ~0ull;
 }
 
 __global__ void segment_kernel(const uint64_t* keys, uint32_t total, uint32_t* seg_start, uint32_t* meta) {
@@ -2328,7 +2330,8 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
 // pending rows of the *whole* batch, so identical replicas stay identical.
 static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, BuildScratch& s, const uint32_t* d_slots,
                             uint32_t n, const uint32_t* d_pending, uint32_t rank = 0, uint32_t world = 1,
-                            uint32_t* d_rows_out = nullptr, uint32_t rows_cap = 0, uint32_t* count_out = nullptr) {
+                            uint32_t* d_rows_out = nullptr, uint32_t rows_cap = 0, uint32_t* count_out = nullptr,
+                            uint32_t backedge_limit = 0xFFFFFFFFu) {
     if (count_out) *count_out = 0;
     s.bootstrap_too_big = false;
     const IndexView ix = idx->view();
@@ -2343,7 +2346,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
         const uint32_t total = n * s.degree;
         DANN_HIP(hipMemsetAsync(meta, 0, 12, st));  // nseg, nkeys, maxseg -- the error word meta[3] is sticky
         hipLaunchKernelGGL(make_keys_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slots, pending,
-                           s.pend_stride, n, s.degree, s.keys_in.as<uint64_t>());
+                           s.pend_stride, n, s.degree, s.keys_in.as<uint64_t>(), backedge_limit);
         size_t tmp = s.sort_tmp_bytes;
         DANN_HIP(hipcub::DeviceRadixSort::SortKeys(s.sort_tmp.p, tmp, s.keys_in.as<uint64_t>(),
                                                    s.keys_out.as<uint64_t>(), (int)total, 0, 64, st));
@@ -2594,10 +2597,10 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
 }
 
 static int32_t insert_batch_device(dann_index* idx, const dann_build_config& cfg, BuildScratch& s,
-                                   const uint32_t* d_slots, uint32_t n) {
+                                   const uint32_t* d_slots, uint32_t n, uint32_t backedge_limit = 0xFFFFFFFFu) {
     int32_t rc = batch_candidates(idx, cfg, s, d_slots, n, 0, n, s.pending.as<uint32_t>());
     if (rc != DANN_OK) return rc;
-    return batch_commit(idx, cfg, s, d_slots, n, s.pending.as<uint32_t>());
+    return batch_commit(idx, cfg, s, d_slots, n, s.pending.as<uint32_t>(), 0, 1, nullptr, 0, nullptr, backedge_limit);
 }
 
 }  // namespace dann
@@ -2642,6 +2645,33 @@ int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const u
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipMemcpyAsync(s.slots.p, slots, (size_t)n * 4, hipMemcpyHostToDevice, idx->main.stream));
     return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), n);
+} DANN_CATCH_ALL
+
+// DiskANNIndex::insert (index.rs:226-341): the insert search, the prune, set_neighbors, then add_edge_and_prune for the
+// first max_backedges of the new neighbours (:324-327) -- a multi_insert of one point whose back-edges stop there.
+int32_t dann_insert(dann_index* idx, const dann_build_config* cfg, uint32_t slot) try {
+    if (!idx) return DANN_EINVAL;
+    ::dann::ExclusiveGuard lock(idx);
+    DANN_MUTATION(idx);
+    DeviceGuard guard(idx->device);
+    int32_t rc = validate_cfg(idx, cfg);
+    if (rc != DANN_OK) return rc;
+    if (cfg->max_backedges > cfg->pruned_degree) {  // config/mod.rs:308-311
+        set_error("parameter \"max_backedges\" (%u) must not be greater than \"pruned_degree\" (%u)", cfg->max_backedges,
+                  cfg->pruned_degree);
+        return DANN_EINVAL;
+    }
+    if (slot >= idx->cfg.capacity) {
+        set_error("slot %u out of bounds (capacity %u)", slot, idx->cfg.capacity);
+        return DANN_EBOUNDS;
+    }
+    BuildScratch& s = scratch_of(idx);
+    const uint32_t rec_stride = 4 * (cfg->l_build + idx->cfg.num_start_points) + 64;
+    rc = ensure_scratch(s, 1, rec_stride, cfg->pruned_degree);
+    if (rc != DANN_OK) return rc;
+    DANN_HIP(hipMemcpyAsync(s.slots.p, &slot, 4, hipMemcpyHostToDevice, idx->main.stream));
+    DANN_HIP(hipStreamSynchronize(idx->main.stream));  // (`slot` lives on this frame)
+    return insert_batch_device(idx, *cfg, s, s.slots.as<uint32_t>(), 1, cfg->max_backedges ? cfg->max_backedges : cfg->pruned_degree);
 } DANN_CATCH_ALL
 
 // multi-GPU build: phase 1 on a slice of the batch, phase 2 with the all-gathered pending rows.

@@ -349,6 +349,10 @@ class Provider:
         return rid, rd, rn, stats
 
     # -- build -------------------------------------------------------------------
+    def insert(self, cfg, slot):
+        """DiskANNIndex::insert of the row stored at `slot` (back-edges to the first cfg.max_backedges new neighbours)."""
+        check(_ffi.lib().dann_insert(self._h, C.byref(cfg), int(slot)), "dann_insert")
+
     def insert_batch(self, cfg, slots):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         check(_ffi.lib().dann_insert_batch(self._h, C.byref(cfg), _p(s), s.size), "dann_insert_batch")

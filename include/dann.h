@@ -292,6 +292,12 @@ int32_t dann_prune_batch(dann_index* idx, const dann_build_config* cfg, const ui
                          int32_t force_saturate, uint32_t* out_adj);
 /* DiskANNIndex::multi_insert (index.rs:815-1030) for rows already stored at `slots` */
 int32_t dann_insert_batch(dann_index* idx, const dann_build_config* cfg, const uint32_t* slots, uint32_t n);
+/* DiskANNIndex::insert (diskann/src/graph/index.rs:226-341) for a row already stored at `slot`: insert search (beam 1,
+ * L = l_build), RobustPrune of the visited record, set_neighbors, then add_edge_and_prune towards the first
+ * cfg->max_backedges of the new neighbours (:324-327; 0 = pruned_degree, the reference's default; more than
+ * pruned_degree is DANN_EINVAL as in config/mod.rs:308-311).  With the default it equals dann_insert_batch of one
+ * point; multi_insert itself sends back-edges to every new neighbour (index.rs:123-143). */
+int32_t dann_insert(dann_index* idx, const dann_build_config* cfg, uint32_t slot);
 /* multi-GPU build (replicated index, batch partitioned across ranks): multi_insert split at its
  * only exchange point.  Phase 1 = candidate generation (search + RobustPrune, index.rs:349-434) for the
  * batch positions [lo, hi), reading the graph only; phase 2 = graph update (index.rs:911-1024) from the

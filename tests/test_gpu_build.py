@@ -476,3 +476,30 @@ def test_large_rows_take_the_split_back_edge_path(flags):
     assert np.array_equal(gix.download_graph(), oix.adj)
     cnt = gix.build_counters()
     assert (cnt[0] == 0) == bool(flags)
+
+
+@pytest.mark.parametrize("max_backedges", [1, 2, None])
+def test_dann_insert_is_the_references_single_insert(max_backedges):
+    """DiskANNIndex::insert (index.rs:226-341): back-edges go to the first max_backedges of the new neighbours only
+    (:324-327).  dann_insert == the oracle's insert for a small max_backedges and for the default (pruned_degree), where it
+    also equals dann_insert_batch of one point; more than pruned_degree is refused (config/mod.rs:308-311)."""
+    rng = np.random.default_rng(92)
+    n, dim, R, maxdeg, lb = 300, 12, 6, 8, 20
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    adj = np.zeros((n + 1, maxdeg + 1), np.uint32)
+    oix, gix = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], maxdeg)
+    ocfg, gcfg = _cfgs(R, maxdeg, lb, max_backedges=max_backedges)
+    for i in range(n):
+        oix.insert(ocfg, i)
+        gix.insert(gcfg, i)
+    g = gix.download_graph()
+    assert np.array_equal(g[:, 0], oix.adj[:, 0])
+    mask = np.arange(maxdeg)[None, :] < oix.adj[:, :1]
+    assert np.array_equal(g[:, 1:][mask], oix.adj[:, 1:][mask])
+    if max_backedges == 1:   # fewer back-edges than multi_insert sends: the graphs differ
+        _, gb = make_pair(oracle.F32, oracle.L2, data, adj, data[:1], maxdeg)
+        for i in range(n):
+            gb.insert_batch(gcfg, [i])
+        assert not np.array_equal(gb.download_graph()[:, 0], g[:, 0])
+    with pytest.raises(da.DannError):
+        gix.insert(da.build_config(R, maxdeg, lb, max_backedges=R + 1), 0)
