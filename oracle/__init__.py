@@ -125,6 +125,8 @@ def lib():
     L.orc_rust_sort.argtypes = [i32, vp, vp, u64, u64]
     L.orc_rust_sort_fallbacks.restype = u64
     L.orc_rust_sort_fallbacks.argtypes = []
+    L.orc_rust_sort_paths.restype = u32
+    L.orc_rust_sort_paths.argtypes = [vp, u32]
     L.orc_insert.restype = i32
     L.orc_insert.argtypes = [P(OrcIndex), P(OrcBuildConfig), u32, vp]
     L.orc_multi_insert.restype = i32
@@ -448,6 +450,19 @@ def rust_sort(mode, ids, dists, max_or_index=0):
     if n < 0:
         raise ValueError("orc_rust_sort: bad arguments")
     return i[:n], d[:n]
+
+
+RUST_SORT_PATHS = ("insertion_20", "run_kept", "run_reversed", "quicksort", "small_network", "sort9", "sort13", "merge",
+                   "partition_lt", "partition_le", "median3", "median3_rec", "heapsort", "select_max", "select_min",
+                   "select_loop", "select_insertion_16", "select_partition_lt", "select_partition_le", "select_fallback")
+
+
+def rust_sort_paths():
+    """how often each part of the restated Rust sort ran since the library was loaded (name -> count)"""
+    out = np.zeros(len(RUST_SORT_PATHS), np.uint64)
+    n = lib().orc_rust_sort_paths(_p(out), out.size)
+    assert n == len(RUST_SORT_PATHS)
+    return dict(zip(RUST_SORT_PATHS, (int(x) for x in out)))
 
 
 def rust_sort_fallbacks():

@@ -1546,6 +1546,11 @@ int64_t orc_rust_sort(int32_t mode, uint32_t* ids, float* dists, uint64_t n, uin
 /* how often the selection's median-of-medians fallback (restated as a plain sort, rust_unstable_sort.h) was reached
  * since the library was loaded: a pin that relies on rule 6 asserts this stays 0 */
 uint64_t orc_rust_sort_fallbacks(void) { return g_rust_fallbacks; }
+/* path counters of the restated sort (rust_sort::Path order), `n` words copied; returns the number of paths */
+uint32_t orc_rust_sort_paths(uint64_t* out, uint32_t n) {
+    for (uint32_t i = 0; i < n && i < (uint32_t)rust_sort::P_COUNT; ++i) out[i] = rust_sort::path_counters()[i];
+    return (uint32_t)rust_sort::P_COUNT;
+}
 
 /* ---- CPU distance micro-benchmark (bench.py cpu_distance_kernels; never used by a test as a checker) -----------------
  * The shape of diskann-benchmark-simd (src/lib.rs:716-771, examples/simd.json): ONE query against `nrows` contiguous

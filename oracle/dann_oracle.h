@@ -176,6 +176,8 @@ void orc_set_tie_rule(int32_t rule, uint64_t seed);
  * length), 1 sort_unstable_by, 2 the small sort (n <= 32), 3 select_nth_unstable_by(max) */
 int64_t orc_rust_sort(int32_t mode, uint32_t* ids, float* dists, uint64_t n, uint64_t max);
 uint64_t orc_rust_sort_fallbacks(void);
+/* how often each part of the restated sort ran since the library was loaded (rust_sort::Path order) */
+uint32_t orc_rust_sort_paths(uint64_t* out, uint32_t n);
 /* CPU distance micro-benchmark in the shape of diskann-benchmark-simd (see dann_oracle.cpp); distances per second */
 double orc_bench_distance(int32_t dtype, int32_t metric, uint32_t dim, uint64_t nrows, uint32_t loops, int32_t random_order,
                           uint32_t threads, uint64_t seed, double* checksum);

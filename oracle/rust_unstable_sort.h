@@ -25,9 +25,16 @@
  *   - select_nth_unstable: index == len - 1 / 0 swap in the (last) maximum / (first) minimum; else the same pivot and
  *     partition with an insertion sort at <= 16 elements and a median-of-medians fallback after 16 rounds.
  * The source itself is not in this image, so the restatement is PINNED BY THE REFERENCE'S OWN GOLDEN VECTORS instead:
- * with it, the oracle reproduces every counter of all twelve tie-heavy grid_insert goldens
- * (tests/test_oracle_build.py::test_grid_insert_lattices_exact_with_rust_sort) -- the networks are also checked to be
+ * with it, the oracle reproduces every counter and every search result of all fifteen grid_insert goldens
+ * (tests/test_oracle_build.py::test_grid_insert_all_goldens_exact_with_rust_sort) -- the networks are also checked to be
  * sorting networks (0-1 principle) in tests/test_oracle_rust_sort.py.
+ * What the goldens reach (path counters below, asserted by the same test): the 20-entry insertion sort, kept runs, the
+ * quicksort with both partitions (`<` 13 388 times, `<=` against an equal ancestor 1 671 times), median-of-three and the
+ * recursive pseudo-median (6 235 times), the network small sort with both networks and the merge (15 860 times), and the
+ * selection's first-maximum swap (4 504 times: a pool never exceeds max_occlusion_size = 750 there).  What they do NOT
+ * reach, and what therefore rests on the published algorithm alone: the selection's partition loop (pools longer than
+ * max_occlusion_size), its first-minimum case (max_occlusion_size = 1), strictly descending runs, the heapsort after
+ * 2 log2(n) bad partitions and the median-of-medians fallback.
  *
  * All comparisons go through `less(a, b)`; an element that compares neither way (equal distance, or NaN:
  * fast_distance maps an undefined partial_cmp to Equal, neighbor/mod.rs:150-154) is "not less", exactly as
@@ -40,6 +47,19 @@
 #include <vector>
 
 namespace rust_sort {
+
+/* which parts of the algorithm ran (process-wide, not thread-safe; tests only): the grid_insert goldens pin the parts they
+ * reach, orc_rust_sort_paths reports which those are */
+enum Path {
+    P_INSERTION_20, P_RUN_KEPT, P_RUN_REVERSED, P_QUICKSORT, P_SMALL_NETWORK, P_SORT9, P_SORT13, P_MERGE, P_PARTITION_LT,
+    P_PARTITION_LE, P_MEDIAN3, P_MEDIAN3_REC, P_HEAPSORT, P_SELECT_MAX, P_SELECT_MIN, P_SELECT_LOOP, P_SELECT_INSERTION_16,
+    P_SELECT_PARTITION_LT, P_SELECT_PARTITION_LE, P_SELECT_FALLBACK, P_COUNT
+};
+inline unsigned long long* path_counters() {
+    static unsigned long long c[P_COUNT] = {0};
+    return c;
+}
+inline void hit(Path p) { ++path_counters()[p]; }
 
 template <class T, class Less>
 struct Impl {
@@ -66,12 +86,14 @@ struct Impl {
         if (less(v[b], v[a])) std::swap(v[a], v[b]);
     }
     void sort9_optimal(T* v) {
+        hit(P_SORT9);
         static const uint8_t net[25][2] = {{0, 3}, {1, 7}, {2, 5}, {4, 8}, {0, 7}, {2, 4}, {3, 8}, {5, 6}, {0, 2},
                                            {1, 3}, {4, 5}, {7, 8}, {1, 4}, {3, 6}, {5, 7}, {0, 1}, {2, 4}, {3, 5},
                                            {6, 8}, {2, 3}, {4, 5}, {6, 7}, {1, 2}, {3, 4}, {5, 6}};
         for (auto& p : net) cswap(v, p[0], p[1]);
     }
     void sort13_optimal(T* v) {
+        hit(P_SORT13);
         static const uint8_t net[45][2] = {
             {0, 12}, {1, 10}, {2, 9},  {3, 7},  {5, 11}, {6, 8},  {1, 6},  {2, 3},   {4, 11}, {7, 9},  {8, 10}, {0, 4},
             {1, 2},  {3, 6},  {7, 8},  {9, 10}, {11, 12}, {4, 6}, {5, 9},  {8, 11},  {10, 12}, {0, 5}, {3, 8},  {4, 7},
@@ -83,6 +105,7 @@ struct Impl {
      * element is taken unless the right one is less; backward: the right element is taken unless it is less than the
      * left one -- a stable merge whichever end writes a slot. */
     void bidirectional_merge(const T* v, size_t len, T* dst) {
+        hit(P_MERGE);
         const size_t half = len / 2;
         const T *left = v, *right = v + half;
         const T *left_rev = v + half - 1, *right_rev = v + len - 1;
@@ -105,6 +128,7 @@ struct Impl {
     /* small_sort_network, len <= 32 */
     void small_sort_network(T* v, size_t len) {
         if (len < 2) return;
+        hit(P_SMALL_NETWORK);
         const size_t half = len / 2;
         const bool no_merge = len < 18;
         T* region = v;
@@ -151,6 +175,7 @@ struct Impl {
     size_t choose_pivot(const T* v, size_t len) { /* len >= 8 */
         const size_t n8 = len / 8;
         const T *a = v, *b = v + n8 * 4, *c = v + n8 * 7;
+        hit(len < 64 ? P_MEDIAN3 : P_MEDIAN3_REC);
         return (size_t)((len < 64 ? median3(a, b, c) : median3_rec(a, b, c, n8)) - v);
     }
 
@@ -194,6 +219,7 @@ struct Impl {
         }
     }
     void heapsort(T* v, size_t len) {
+        hit(P_HEAPSORT);
         for (size_t i = len + len / 2; i-- > 0;) {
             size_t sift_idx;
             if (i >= len) sift_idx = i - len;
@@ -218,12 +244,14 @@ struct Impl {
             --limit;
             const size_t pivot_pos = choose_pivot(v, len);
             if (ancestor && !less(*ancestor, v[pivot_pos])) {
+                hit(P_PARTITION_LE);
                 const size_t num_le = partition(v, len, pivot_pos, true);
                 v += num_le + 1;
                 len -= num_le + 1;
                 ancestor = nullptr;
                 continue;
             }
+            hit(P_PARTITION_LT);
             const size_t num_lt = partition(v, len, pivot_pos, false);
             quicksort(v, num_lt, ancestor, limit);
             anc_copy = v[num_lt]; /* the pivot stays in place; a copy is the same value */
@@ -236,6 +264,7 @@ struct Impl {
     void sort_unstable(T* v, size_t len) {
         if (len < 2) return;
         if (len <= 20) {
+            hit(P_INSERTION_20);
             insertion_sort_shift_left(v, len, 1);
             return;
         }
@@ -246,10 +275,12 @@ struct Impl {
         else
             while (run < len && !less(v[run], v[run - 1])) ++run;
         if (run == len) {
+            hit(desc ? P_RUN_REVERSED : P_RUN_KEPT);
             if (desc)
                 for (size_t i = 0, j = len - 1; i < j; ++i, --j) std::swap(v[i], v[j]);
             return;
         }
+        hit(P_QUICKSORT);
         uint32_t lg = 0;
         for (size_t x = len | 1; x > 1; x >>= 1) ++lg;
         quicksort(v, len, nullptr, 2 * lg);
@@ -265,10 +296,12 @@ struct Impl {
         uint32_t limit = 16;
         for (;;) {
             if (len <= 16) {
+                hit(P_SELECT_INSERTION_16);
                 if (len >= 2) insertion_sort_shift_left(v, len, 1);
                 return;
             }
             if (limit == 0) {
+                hit(P_SELECT_FALLBACK);
                 fallback_used = true;
                 sort_unstable(v, len);
                 return;
@@ -276,6 +309,7 @@ struct Impl {
             --limit;
             const size_t pivot_pos = choose_pivot(v, len);
             if (ancestor && !less(*ancestor, v[pivot_pos])) {
+                hit(P_SELECT_PARTITION_LE);
                 const size_t mid = partition(v, len, pivot_pos, true) + 1;
                 if (mid > index) return;
                 v += mid;
@@ -284,6 +318,7 @@ struct Impl {
                 ancestor = nullptr;
                 continue;
             }
+            hit(P_SELECT_PARTITION_LT);
             const size_t mid = partition(v, len, pivot_pos, false);
             if (mid < index) {
                 anc_copy = v[mid];
@@ -300,16 +335,19 @@ struct Impl {
     }
     void select_nth_unstable(T* v, size_t len, size_t index) { /* index < len */
         if (index == len - 1) {
+            hit(P_SELECT_MAX);
             size_t mx = 0; /* max_index: reduce keeps acc unless acc < t -> the FIRST maximum */
             for (size_t i = 1; i < len; ++i)
                 if (less(v[mx], v[i])) mx = i;
             std::swap(v[mx], v[index]);
         } else if (index == 0) {
+            hit(P_SELECT_MIN);
             size_t mn = 0; /* min_index: reduce takes t when t < acc -> the FIRST minimum */
             for (size_t i = 1; i < len; ++i)
                 if (less(v[i], v[mn])) mn = i;
             std::swap(v[mn], v[index]);
         } else {
+            hit(P_SELECT_LOOP);
             select_loop(v, len, index, nullptr);
         }
     }

@@ -75,6 +75,7 @@ def test_grid_insert_all_goldens_exact_with_rust_sort(golden_dir):
     try:
         oracle.set_tie_rule(6, 0)
         before = oracle.rust_sort_fallbacks()
+        paths0 = oracle.rust_sort_paths()
         seen = 0
         for f in _files(golden_dir):
             p = f["payload"]
@@ -90,6 +91,14 @@ def test_grid_insert_all_goldens_exact_with_rust_sort(golden_dir):
             seen += 1
         assert seen == 15
         assert oracle.rust_sort_fallbacks() == before  # the selection's median-of-medians fallback is never reached
+        # which parts of the restated sort these vectors pin, and which they do not (oracle/rust_unstable_sort.h)
+        ran = {k: v - paths0[k] for k, v in oracle.rust_sort_paths().items()}
+        for part in ("insertion_20", "run_kept", "quicksort", "small_network", "sort9", "sort13", "merge", "partition_lt",
+                     "partition_le", "median3", "median3_rec", "select_max"):
+            assert ran[part] > 0, part
+        assert ran["partition_le"] > 1000 and ran["median3_rec"] > 5000 and ran["small_network"] > 10000
+        for part in ("run_reversed", "heapsort", "select_min", "select_loop", "select_fallback"):
+            assert ran[part] == 0, part   # not reached by any reference-held vector: restated from the published algorithm
     finally:
         oracle.set_tie_rule()
 
