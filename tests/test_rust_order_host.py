@@ -17,6 +17,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = r"""
 #include "rust_order.h"
 #include <cstring>
+// the kernels hand the walk the LDS region of the sort keys: 8 bytes per pool slot, pool slots = the next power of two
+// at or above the pool's length -- less than kWorkBytes for pools of fewer than 64 slots
+extern "C" int ro_sorted_neighbors_lds(const float* d, unsigned P, unsigned max, unsigned short* out) {
+    unsigned pcap = 1;
+    while (pcap < P) pcap <<= 1;
+    const unsigned region = pcap * 8u;
+    static unsigned char work[4096 * 8 + 64];
+    std::memset(work, 0xA5, sizeof work);
+    for (unsigned i = 0; i < P; ++i) out[i] = (unsigned short)i;
+    const bool fb = dann::rust_order::sorted_neighbors(out, d, P, max, work);
+    for (unsigned i = region; i < sizeof work; ++i)
+        if (work[i] != 0xA5) return -1;  // wrote past the region of the sort keys
+    return fb ? 1 : 0;
+}
 extern "C" int ro_sorted_neighbors(const float* d, unsigned P, unsigned max, unsigned short* out) {
     alignas(8) unsigned char work[dann::rust_order::kWorkBytes + 16];
     std::memset(work, 0xA5, sizeof work);
@@ -40,6 +54,8 @@ def host_lib(tmp_path_factory):
     lib = C.CDLL(str(so))
     lib.ro_sorted_neighbors.restype = C.c_int
     lib.ro_sorted_neighbors.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    lib.ro_sorted_neighbors_lds.restype = C.c_int
+    lib.ro_sorted_neighbors_lds.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
     return lib
 
 
@@ -87,3 +103,22 @@ def test_specials_compare_like_partial_cmp(host_lib):
             ids = np.arange(n, dtype=np.uint32)
             want, _ = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, ids, d, n)
             assert np.array_equal(_product(host_lib, d, n), want)
+
+
+def test_the_walk_stays_inside_the_lds_region_the_kernels_give_it(host_lib):
+    """prune_sorted_pool / sort_pool_wave pass the region of the sort keys as the work area: 8 bytes per pool slot.  For
+    every pool length the walk's merge buffer and stacks stay inside it (the arrays behind it in LDS are the pool's ids
+    and distances)"""
+    rng = np.random.default_rng(41)
+    for n in list(range(1, 140)) + [255, 256, 257, 511, 512, 1000, 2048, 4096]:
+        for levels in (1, 2, 4, 10 ** 6):
+            for rep in range(3):
+                d = np.ascontiguousarray(rng.integers(0, levels, n), np.float32)
+                if rep == 1:
+                    d = np.sort(d)[::-1].copy()
+                out = np.zeros(n, np.uint16)
+                for mx in (n, max(n // 2, 1), 750):
+                    rc = host_lib.ro_sorted_neighbors_lds(d.ctypes.data, n, mx, out.ctypes.data)
+                    assert rc >= 0, (n, levels, rep, mx)
+                    want, _ = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, np.arange(n, dtype=np.uint32), d, mx)
+                    assert np.array_equal(out[:min(mx, n)].astype(np.uint32), want)
