@@ -122,3 +122,18 @@ def test_the_walk_stays_inside_the_lds_region_the_kernels_give_it(host_lib):
                     assert rc >= 0, (n, levels, rep, mx)
                     want, _ = oracle.rust_sort(oracle.RUST_SORTED_NEIGHBORS, np.arange(n, dtype=np.uint32), d, mx)
                     assert np.array_equal(out[:min(mx, n)].astype(np.uint32), want)
+
+
+def test_both_restatements_under_address_and_ub_sanitizers(tmp_path):
+    """tests/src/rust_order_sanitize.cpp: 24 000 tied pools (lengths 0 .. 4096) through the product's walk on exact-size
+    heap blocks and through the checker's restatement, compiled with -fsanitize=address,undefined: clean, and equal"""
+    exe = tmp_path / "sanitize"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", os.path.join(ROOT, "diskann_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"),
+           os.path.join(ROOT, "tests", "src", "rust_order_sanitize.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr.lower():
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.startswith("ok 24000 cases"), run.stdout + run.stderr
