@@ -12,11 +12,13 @@
 //     multi_insert_bootstrap_leaf              index.rs:597-645
 //     set_neighbors_bulk                       index.rs:948-962
 //     add_edge_and_prune / robust_prune_list   index.rs:2264-2341, 2397-2454
-// with the adjacency lists it produces identical to the CPU restatement (oracle tie rule:
-// equal pool distances keep their original pool order).
+// with the adjacency lists it produces identical to the CPU restatement -- and, by default, to the
+// reference itself on pools with EQUAL distances as well: such a pool is put in the order the reference's
+// own select_nth_unstable_by + sort_unstable_by leave it in (rust_order.h, dann_set_prune_tie_order).
 //
 // One wavefront owns one point.  The candidate pool is sorted in LDS (bitonic, 64-bit
-// keys = order-preserving distance bits : pool position).  The alpha sweep keeps 64/G
+// keys = order-preserving distance bits : pool position; a pool whose sorted keys show equal
+// distances is then walked by one lane, rust_order_by_lane0).  The alpha sweep keeps 64/G
 // candidates in flight, one per G-lane distance group (the same bit-exact groups as the
 // search path): each walks the selected list in the reference's order, is rejected at the
 // first entry that pushes its factor past alpha, and is selected only once it is the oldest
