@@ -158,6 +158,8 @@ def main():
         print(json.dumps(_strict({"cpu_distance_kernels": cpu_distance_microbench()})), flush=True)
         return
     maybe_spawn(args)
+    # (multi-process GPU work on this pool needs dmabuf IPC; exported on the boxes already -- kept in any launch)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import diskann_amd as da
