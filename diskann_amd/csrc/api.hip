@@ -539,14 +539,17 @@ int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* 
 // ---- packed search layout of PQ indexes ----------------------------------------------------------------------------
 int32_t dann_pq_pack_neighbors(dann_index* idx) try {
     CHECK_IDX(idx);
-    if (idx->cfg.dtype != DT_PQ || idx->cfg.pq_chunks > 16u || idx->cfg.inline_tags) {
-        set_error("dann_pq_pack_neighbors: a DANN_PQ index of at most 16 chunks without inline tags");
+    // (only pq_search_kernel reads the packed rows: an index it can never serve -- pq_lut_shape / plain_mode -- would pay
+    // 1.3 KB per node for nothing)
+    if (idx->cfg.dtype != DT_PQ || idx->cfg.pq_chunks > 16u || idx->cfg.inline_tags || idx->cfg.max_degree > 64u ||
+        idx->cfg.num_start_points > 64u) {
+        set_error("dann_pq_pack_neighbors: a DANN_PQ index of at most 16 chunks, degree <= 64, at most 64 start points, "
+                  "without inline tags");
         return DANN_EUNSUPPORTED;
     }
-    if (idx->srv_outstanding.sum() != 0) {
-        set_error("the index has search-server tickets outstanding");
-        return DANN_EBUSY;
-    }
+    // the rebuild rewrites (and may free) what a concurrent dann_search_submit's relaunch reads through idx->view():
+    // it is a mutation -- refused while tickets are outstanding, submits bounce while it runs, the resident kernel leaves
+    DANN_MUTATION(idx);
     const uint32_t R = idx->cfg.max_degree;
     const uint32_t codes_off = ((R + 1u) * 4u + 15u) & ~15u;
     const uint32_t stride = (codes_off + 16u * R + 63u) & ~63u;

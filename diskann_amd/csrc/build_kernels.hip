@@ -56,7 +56,8 @@ struct PruneCfg {
     // kStatStripes copies of the eight, one 64-byte line each, a workgroup adds to the copy of its index (stat_stripe):
     // every workgroup of a prune launch ends with a few of these adds, and atomics on ONE address are served one after
     // another -- 354 k of them per launch were 3 ms of backedge_scan_kernel's 4.4 ms at 10 M points
-    // (profiles/r05_scan_atomics.txt).  dann_build_counters sums the copies.
+    // (profiles/r05_scan_atomics.txt).  dann_build_counters sums the copies.  One more word behind the stripes
+    // (counters[kStatStripes * 8]): tied pools whose DANN_TIE_RUST walk reached the selection's fallback (rust_order.h).
     unsigned long long* counters;
 };
 constexpr uint32_t kStatStripes = 256;
@@ -156,7 +157,11 @@ __device__ __forceinline__ void rust_order_by_lane0(const PruneCfg& cfg, uint32_
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < P; i += kWave) ord[i] = (uint16_t)i;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) rust_order::sorted_neighbors(ord, pd, P, cfg.max_occlusion, smem + L.keys_off);
+    // (the selection's median-of-medians fallback -- sixteen unlucky partitions in a row -- is restated as a sort of the
+    // range, which may leave equal keys in another arrangement than core's: counted, so that builds and tests can assert
+    // it never happened: dann_build_counters()[10])
+    if (lane == 0 && rust_order::sorted_neighbors(ord, pd, P, cfg.max_occlusion, smem + L.keys_off) && cfg.counters)
+        atomicAdd(cfg.counters + (size_t)kStatStripes * 8u, 1ull);
 }
 
 // Sort pid/pd[0..P) (already in LDS) by (distance, position), truncate to max_occlusion,
@@ -2096,8 +2101,8 @@ int32_t ensure_scratch(BuildScratch& s, uint32_t batch, uint32_t rec_stride, uin
     DANN_HIP(s.meta.alloc(128));  // 16 words of flags and counts + the insert searches' totals (stats_reduce_kernel)
     DANN_HIP(hipMemset(s.meta.p, 0, 64));  // the commit phase may run first on this handle (sharded build: empty slice)
     if (!s.counters.p) {
-        DANN_HIP(s.counters.alloc((size_t)kStatStripes * 64));
-        DANN_HIP(hipMemset(s.counters.p, 0, (size_t)kStatStripes * 64));
+        DANN_HIP(s.counters.alloc((size_t)kStatStripes * 64 + 64));
+        DANN_HIP(hipMemset(s.counters.p, 0, (size_t)kStatStripes * 64 + 64));
     }
     size_t tmp = 0;
     DANN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, s.keys_in.as<uint64_t>(), s.keys_out.as<uint64_t>(),
@@ -2837,21 +2842,22 @@ extern "C" {
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n) try {
     if (!idx || (n && !out)) return DANN_EINVAL;
     ::dann::ExclusiveGuard lock(idx);
-    uint64_t dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sort_fallbacks = 0;
     if (idx->build_scratch) {
         BuildScratch& s = *static_cast<BuildScratch*>(idx->build_scratch);
         if (s.counters.p) {
             DeviceGuard guard(idx->device);
             DANN_HIP(hipStreamSynchronize(idx->main.stream));
-            std::vector<uint64_t> stripes((size_t)kStatStripes * 8);
+            std::vector<uint64_t> stripes((size_t)kStatStripes * 8 + 8);
             DANN_HIP(hipMemcpy(stripes.data(), s.counters.p, stripes.size() * 8, hipMemcpyDeviceToHost));
             for (uint32_t t = 0; t < kStatStripes; ++t)
                 for (uint32_t c = 0; c < 8; ++c) dev[c] += stripes[(size_t)t * 8 + c];
+            sort_fallbacks = stripes[(size_t)kStatStripes * 8];
         }
     }
-    const uint64_t all[10] = {dev[6], dev[7], idx->build_counters[2], idx->build_counters[3],
-                              dev[0], dev[1], dev[2], dev[3], dev[4], dev[5]};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? all[i] : 0u;
+    const uint64_t all[11] = {dev[6], dev[7], idx->build_counters[2], idx->build_counters[3],
+                              dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], sort_fallbacks};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 11 ? all[i] : 0u;
     return DANN_OK;
 } DANN_CATCH_ALL
 

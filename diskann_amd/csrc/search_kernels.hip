@@ -294,11 +294,12 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // instantiation exists).  Decided before the table is sized: teams carry more LDS.
     // DANN_DBG_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_DBG_TEAM_MAX_QUERIES: development switches
     // (dann_debug_set; read on every call).
+    // (dann_set_max_concurrency: the launch will be `max_concurrency` persistent waves over the batch -- search_with_retry
+    // sets a.grid after this function -- never teams, pairs or the PQ table kernel: those launch one block per query
+    // (pair) and never read `grid`; the persistent waves draw their queries from a counter in the spill pool's pad)
+    const bool will_grid = idx->max_concurrency && a.nq > idx->max_concurrency && plain_mode(a);
     {
         const uint32_t limit = idx->dbg_u32(DANN_DBG_TEAM_MAX_QUERIES, 4u * idx->num_cus);
-        // (dann_set_max_concurrency: the launch will be `max_concurrency` persistent waves over the batch -- search_with_retry
-        // sets a.grid after this function -- never teams; they draw their queries from a counter in the spill pool's pad)
-        const bool will_grid = idx->max_concurrency && a.nq > idx->max_concurrency && plain_mode(a);
         a.team = (inflight <= limit && !a.grid && !will_grid && !a.srv.ring && !a.range_ids && !a.qmap && plain_mode(a) &&
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !idx->tune_off(4) &&
                   team_shape(a)) ? 1u : 0u;
@@ -314,7 +315,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
         const uint32_t floor_q = idx->dbg_u32(DANN_DBG_PAIR_MIN_QUERIES, 20u * idx->num_cus);
         SearchArgs t = a;
         t.team = 0;
-        if (a.nq >= floor_q && inflight >= floor_q && idx->visited_format != 32u && pair_shape(t) && !idx->tune_off(16)) {
+        if (a.nq >= floor_q && inflight >= floor_q && !will_grid && idx->visited_format != 32u && pair_shape(t) && !idx->tune_off(16)) {
             a.pair = 1;
             a.team = 0;
         }
@@ -325,7 +326,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     if (!a.team) DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
     // PQ rows of at most 16 chunks, plain Knn search: the lookup table in registers (search_pq_impl.h).
     // DANN_DBG_TUNE_OFF bit 32: development switch.
-    a.pqlut = (pq_lut_shape(a) && idx->visited_format != 32u && !idx->tune_off(32)) ? 1u : 0u;
+    a.pqlut = (!will_grid && pq_lut_shape(a) && idx->visited_format != 32u && !idx->tune_off(32)) ? 1u : 0u;
     const bool autosize = a.ht_entries == 0;
     const uint64_t key = calib_key(a);
     // calibration state of this (L, beam, mode) -- shared by concurrent callers: read and written under stat_mu

@@ -172,8 +172,10 @@ namespace {
 // the group stays failed: its ranks are out of step for good).  The one exception: an error found by the checks of the
 // call's own arguments that every rank passes alike by contract (null output pointers, k = 0, a bad growth factor ...),
 // before anything rank-specific is looked at -- `past_args` still false -- is the same on every rank and nobody waits
-// for anybody: the communicator stays usable.  Everything later (a null or foreign index on ONE rank, a per-rank
-// capacity or dtype mismatch, an unsupported configuration of one device, an exception) releases the peers.
+// for anybody: the communicator stays usable.  The same holds for what depends only on the configuration the replicas
+// share by contract (a range beyond the capacity, an invalid build configuration, L = 0).  Everything later (a null or
+// foreign index on ONE rank, a per-rank dtype mismatch, an unsupported configuration of one device, an exception)
+// releases the peers.
 struct AbortOnError {
     dann_comm* c;
     int32_t rc = DANN_OK;
@@ -340,9 +342,17 @@ static int32_t build_sharded_impl(dann_index* idx, dann_comm* comm, const dann_b
                                   float growth, uint32_t max_batch, uint64_t* stats, bool* past_args) {
     if (!comm || !cfg) return DANN_EINVAL;
     if (!(growth > 0.0f) || max_batch == 0) return DANN_EINVAL;
+    // (the replicas of one sharded build share one dann_config by contract -- dann.h -- so a range beyond the capacity
+    // or an invalid build configuration is every rank's error alike: plain argument errors, the communicator stays usable)
+    if (idx && (uint64_t)first + n > idx->cfg.capacity) return DANN_EBOUNDS;
+    if (idx && (cfg->pruned_degree == 0 || cfg->l_build == 0 || cfg->max_degree < cfg->pruned_degree ||
+                cfg->max_degree > idx->cfg.max_degree || !(cfg->alpha >= 1.0f))) {
+        set_error("invalid build config (pruned_degree %u, max_degree %u (provider %u), l_build %u, alpha %g)",
+                  cfg->pruned_degree, cfg->max_degree, idx->cfg.max_degree, cfg->l_build, (double)cfg->alpha);
+        return DANN_EINVAL;
+    }
     *past_args = true;  // (from here on an error may be this rank's alone: AbortOnError releases the peers)
     if (!idx) return DANN_EINVAL;
-    if ((uint64_t)first + n > idx->cfg.capacity) return DANN_EBOUNDS;
     const uint32_t world = comm->world, rank = comm->rank;
     DeviceGuard guard(idx->device);
     const uint32_t width = cfg->pruned_degree + 1, rw = idx->cfg.max_degree + 2;
@@ -479,6 +489,10 @@ static int32_t search_sharded_impl(dann_index* idx, dann_comm* comm, const void*
     if (!comm) return DANN_EINVAL;
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists || k == 0) return DANN_EINVAL;
+    if (l_value == 0 || beam_width == 0) {  // (KnnSearchError, knn_search.rs:27-33: the same on every rank)
+        set_error("l_value and beam_width must be non-zero (KnnSearchError, knn_search.rs:27-33)");
+        return DANN_EINVAL;
+    }
     *past_args = true;  // (from here on an error may be this rank's alone: AbortOnError releases the peers)
     if (!idx) return DANN_EINVAL;
     const uint32_t world = comm->world, rank = comm->rank;

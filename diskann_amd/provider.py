@@ -389,8 +389,8 @@ class Provider:
         check(_ffi.lib().dann_set_build_options(self._h, int(flags)), "dann_set_build_options")
 
     def build_counters(self):
-        out = np.zeros(10, np.uint64)
-        check(_ffi.lib().dann_build_counters(self._h, _p(out), 10), "dann_build_counters")
+        out = np.zeros(11, np.uint64)  # ([10]: tied pools whose Rust-order walk reached the selection's fallback, dann.h)
+        check(_ffi.lib().dann_build_counters(self._h, _p(out), 11), "dann_build_counters")
         return out
 
     def build(self, cfg, first, n, growth=0.02, max_batch=16384):

@@ -434,7 +434,12 @@ int32_t dann_set_build_options(dann_index* idx, uint32_t flags);
  * insert-time searches, [4] pair distances d(c_i, c_j) evaluated by the row kernel in the prune sweeps, [5] list /
  * extra distances d(location, c), [6] candidate rows that went through an MFMA Gram, [7] Gram entries computed
  * (x dim x 2 = MFMA flop), [8] pair distances the lazy scans of the MFMA sweeps asked for, [9] those of [8] that needed
- * an exact re-evaluation by the row kernel (the rest were answered from a Gram).  n <= 10 entries are written. */
+ * an exact re-evaluation by the row kernel (the rest were answered from a Gram), [10] tied candidate pools whose
+ * DANN_TIE_RUST walk ran into the selection's last resort: after sixteen unlucky partitions core's select_nth_unstable_by
+ * calls median_of_medians, which csrc/rust_order.h replaces by a sort of the range -- the index-th element is in place
+ * either way, equal keys may be arranged differently, so such a pool is not guaranteed to match the reference's order
+ * (never reached by the reference's goldens or by any build measured so far; 0 = the promise of
+ * dann_set_prune_tie_order holds for every pool of this index's builds).  n <= 11 entries are written. */
 int32_t dann_build_counters(const dann_index* idx, uint64_t* out, uint32_t n);
 
 /* ABI revision of this header; bumped on any incompatible change of a signature or struct layout */

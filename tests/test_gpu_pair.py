@@ -155,3 +155,20 @@ def test_default_threshold_pairs_exactly_from_twenty_queries_per_compute_unit():
         _check(gix, oix, queries[:nq], 26, 10, nq, family=family)
     _check(gix, oix, queries, 63, 10, "L = 63", family="pair")   # two queue entries per lane at the default threshold
     _check(gix, oix, queries, 64, 10, "L = 64", family="pair")   # three (SURVEY 8(a)'s C-int8 sizing: L = 64 + the start point)
+
+
+def test_max_concurrency_cap_takes_pair_launches_to_persistent_waves():
+    """dann_set_max_concurrency: a capped call is `cap` persistent wavefronts over the batch; pair_search_kernel launches
+    nq / 2 blocks and never reads the cap, so the capped call is served by the persistent family -- same results"""
+    rng = np.random.default_rng(78)
+    n, dim, R = 5000, 128, 32
+    data = rand_vectors(rng, oracle.U8, n, dim)
+    adj = random_graph(rng, n, R)
+    oix, gix = make_pair(oracle.U8, oracle.L2, data, adj, data[:1], R)
+    q = rand_vectors(rng, oracle.U8, 301, dim)
+    _check(gix, oix, q, 26, 10, "no cap")
+    gix.set_max_concurrency(32)
+    _check(gix, oix, q, 26, 10, "capped: 301 queries over 32 persistent waves", family="persistent")
+    _check(gix, oix, q[:32], 26, 10, "at the cap")
+    gix.set_max_concurrency(0)
+    _check(gix, oix, q, 26, 10, "cap lifted")

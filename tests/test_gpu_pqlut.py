@@ -133,3 +133,18 @@ def test_packed_layout_is_dropped_by_mutations_and_rebuilt_on_request():
     _check(gix, oix, q, 50, 10, "after the mutation (plain layout)")
     gix.pq_pack_neighbors()
     _check(gix, oix, q, 50, 10, "packed again")
+
+
+def test_max_concurrency_cap_takes_pq_launches_to_persistent_waves():
+    """dann_set_max_concurrency: a call with more queries than the cap runs as `cap` persistent wavefronts -- pq_search_kernel
+    launches one block per query and never reads the cap, so a capped call must not be served by it (the families counter
+    names the kernel that ran); results do not move"""
+    rng = np.random.default_rng(77)
+    oix, gix = _pq_index(rng, 4000, 64, 16, 32, 1, oracle.L2)
+    q = rng.standard_normal((300, 64)).astype(np.float32)
+    _check(gix, oix, q, 40, 10, "no cap")
+    gix.set_max_concurrency(64)
+    _check(gix, oix, q, 40, 10, "capped: 300 queries over 64 persistent waves", family="persistent")
+    _check(gix, oix, q[:64], 40, 10, "at the cap: one block per query again")
+    gix.set_max_concurrency(0)
+    _check(gix, oix, q, 40, 10, "cap lifted")

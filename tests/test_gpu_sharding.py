@@ -192,8 +192,13 @@ def test_one_process_several_replicas_through_the_c_abi():
     start = data.mean(0, keepdims=True).astype(np.float32)
     growth, max_batch = 0.1, 400
     o, nb_o = _oracle_build(oracle.F32, oracle.L2, data, start, Rp, maxdeg, lb, growth, max_batch)
-    for ndev in (2, 3):
-        m = da.MultiProvider(da.F32, da.L2, dim, n, maxdeg, start, [0] * ndev)
+    # one GPU: the replicas share device 0; a box with more devices spreads them (and adds a run over all of them, at
+    # most 8): the first multi-GPU box that runs `-m gpu` exercises hipMemcpyPeerAsync between real devices
+    import torch
+    visible = min(torch.cuda.device_count(), 8)
+    worlds = [2, 3] + ([visible] if visible > 3 else [])
+    for ndev in worlds:
+        m = da.MultiProvider(da.F32, da.L2, dim, n, maxdeg, start, [r % visible for r in range(ndev)])
         m.set_elements(0, data)
         nb, st = m.build(da.build_config(Rp, maxdeg, lb, intra_batch_candidates=da.IBC_NONE), 0, n, growth, max_batch)
         assert nb == nb_o
@@ -244,3 +249,72 @@ def test_rccl_communicator_preflight_on_one_gpu():
     assert b.build(cfg, 0, n, 0.1, 256) == nb
     assert np.array_equal(a.download_graph(), b.download_graph())
     comm.close()
+
+
+def test_rccl_world_n_over_the_visible_gpus():
+    """RCCL at world > 1, as soon as the box has more than one GPU (skipped on one): one host thread per device creates
+    its rank of a dann_comm_create_rccl communicator, all-gathers a device buffer (ncclAllGather over xGMI), builds its
+    replica with dann_build_sharded over it and searches the shared block with dann_search_sharded -- every replica's
+    graph == a single-GPU dann_build, every rank's gathered results == one rank searching alone."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import torch
+    import oracle
+    import diskann_amd as da
+    from diskann_amd import _ffi
+    from diskann_amd.sharding import Comm, build_sharded_native, search_sharded_native
+    from helpers import bits, rand_vectors
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("one visible GPU: RCCL at world > 1 needs at least two")
+    lib = _ffi.lib()
+    uid = (C.c_char * 128)()
+    _ffi.check(lib.dann_comm_rccl_unique_id(uid), "dann_comm_rccl_unique_id")
+    rng = np.random.default_rng(18)
+    n, dim, Rp, maxdeg, lb = 4000, 32, 10, 12, 32
+    data = rand_vectors(rng, oracle.F32, n, dim)
+    start = data.mean(0, keepdims=True).astype(np.float32)
+    q = rand_vectors(rng, oracle.F32, 257, dim)
+    cfg = da.build_config(Rp, maxdeg, lb, intra_batch_candidates=da.IBC_NONE)
+    ref = da.Provider(da.F32, da.L2, dim, n, maxdeg, start, device=0)
+    ref.set_elements(0, data)
+    nb_ref = ref.build(cfg, 0, n, 0.1, 512)
+    g_ref = ref.download_graph()
+    i_ref, d_ref, _ = ref.search(da.Knn(40, 1), q, 10)
+    out, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            h = C.c_void_p()
+            _ffi.check(lib.dann_comm_create_rccl(uid, r, world, r, C.byref(h)), "dann_comm_create_rccl")
+            comm = Comm(h)
+            src = torch.full((1000,), r, dtype=torch.int32, device=f"cuda:{r}")
+            dst = torch.zeros(1000 * world, dtype=torch.int32, device=f"cuda:{r}")
+            torch.cuda.synchronize(r)
+            _ffi.check(lib.dann_comm_all_gather_device(h, r, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 4000),
+                       "dann_comm_all_gather_device")
+            gathered = dst.cpu().numpy().reshape(world, 1000)
+            p = da.Provider(da.F32, da.L2, dim, n, maxdeg, start, device=r)
+            p.set_elements(0, data)
+            st = {}
+            nb = build_sharded_native(p, cfg, 0, n, 0.1, 512, comm, stats=st)
+            ids, dd = search_sharded_native(p, comm, q, 40, 1, 10)
+            out[r] = (gathered, nb, st, p.download_graph(), ids, dd)
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            err[r] = repr(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a rank did not return within 300 s"
+    assert err == [None] * world, err
+    for r in range(world):
+        gathered, nb, st, g, ids, dd = out[r]
+        assert np.array_equal(gathered, np.repeat(np.arange(world, dtype=np.int32)[:, None], 1000, 1)), r
+        assert nb == nb_ref and st["rounds"] == nb and st["bytes_gathered"] > 0, (r, nb, nb_ref, st)
+        assert np.array_equal(g, g_ref), f"replica {r} of the RCCL build differs from dann_build"
+        assert np.array_equal(ids, i_ref) and np.array_equal(bits(dd), bits(d_ref)), r

@@ -75,6 +75,8 @@ def test_grid_insert_goldens_on_the_gpu_in_the_references_tie_order(golden_dir):
             assert [int(cnt[2]), int(cnt[3]), int(cnt[4])] == [m["set_neighbors"], m["append_neighbors"], m["get_neighbors"]], f["test"]
             # ... and the GPU built the same graph, list by list in the same order
             assert _same_graph(gix, oix), f["test"]
+            # no pool's walk ran into the selection's last resort (restated as a sort: dann_build_counters()[10])
+            assert int(gix.build_counters()[10]) == 0, f["test"]
             for sc in p["searches"]:
                 ids, dists, st = gix.search(da.Knn(10, sc["beam_width"]), np.array(sc["query"], np.float32), 10)
                 k = sc["num_results"]
@@ -179,6 +181,7 @@ def test_batched_build_on_integer_data_in_the_references_tie_order(dtype, dim, i
             assert _same_graph(gix, oix), (b, s0)
             s0 += b
         assert s0 == n
+        assert int(gix.build_counters()[10]) == 0
     finally:
         oracle.set_tie_rule()
 
