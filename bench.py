@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--only-large", action="store_true",
                     help="run only the roofline_large workload and print its object (used under rocprofv3)")
     ap.add_argument("--no-pq-pack", action="store_true", help="PQ leg: search the plain rows (no dann_pq_pack_neighbors)")
-    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "gather", "sq8", "u8", "pq",
+    ap.add_argument("--large-int-n", type=int, default=0, help="large_u8 / large_sq8 legs: number of rows (0 = 10 M)")
+    ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "large_u8", "large_sq8", "gather", "sq8", "u8", "pq",
                                                    "build768", "cpu-distance"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
                          "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
@@ -212,6 +213,13 @@ def main():
     if args.only in ("gather", "sq8", "u8", "pq"):
         print(json.dumps(_strict({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
+    if args.only in ("large_u8", "large_sq8"):
+        rd = C.c_double(0.0)
+        _ffi.lib().dann_debug_stream_read_gbps(local, 4 << 30, 10, C.byref(rd))
+        kind = args.only.split("_")[1]
+        print(json.dumps(_strict({"roofline_large_" + kind: large_int_variant(args, kind, torch, da, _ffi.lib(), _ffi, dev, local,
+                                                                             10, args.beam_width, rd.value or None)})), flush=True)
+        return
     if args.only in ("large", "large768", "large768f16"):
         args.only_large = True
         if args.only == "large768":
@@ -372,8 +380,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - tstart
     kernel_ms, launches = prov.kernel_time(0)
+    per_rank_qps = [args.nq * args.steps / elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], device=torch.device("cpu") if one_dev else dev, dtype=torch.float64)
+        cdev = torch.device("cpu") if one_dev else dev
+        mine_t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        all_t = torch.empty(world, device=cdev, dtype=torch.float64)
+        dist.all_gather_into_tensor(all_t, mine_t)  # every rank's own time over the same K steps (self-checking record)
+        per_rank_qps = [args.nq * args.steps / float(x) for x in all_t.cpu().tolist()]
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -454,6 +468,10 @@ def main():
                 "build_seconds": round(t_build, 2),
                 **({"build_exchange": build_stats} if build_stats is not None else {}),
                 "parallelism": f"replicated index x{world}, query streams sharded, no collective",
+                # multi-GPU records check themselves: the collective backend the ranks ran on, every rank's own rate over
+                # the timed steps (value = world * nq * steps / the slowest rank's time) and, above, the build's exchange
+                "rccl_world": 0 if (world == 1 or one_dev) else world,
+                "per_rank_qps": per_rank_qps,
             },
             "roofline": {
                 "kernel": "beam_search_kernel",
@@ -696,6 +714,15 @@ def main():
                 except Exception as e:
                     out[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
+        # north_star's int8 rows on the HBM side: the integer search kernel on 10 M x 128 u8 rows and SQ-8 codes
+        if args.large != "none" and not args.no_extras and not args.no_sq8 and world == 1:
+            for kind in ("u8", "sq8"):
+                try:
+                    out["roofline_large_" + kind] = large_int_variant(args, kind, torch, da, lib, _ffi, dev, local, k, W,
+                                                                      out["roofline"].get("measured_stream_read_GBps"))
+                except Exception as e:  # noqa: BLE001
+                    out["roofline_large_" + kind] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
         for key in ("roofline_large_d768", "roofline_large_d768_f16"):  # north_star: MFMA utilisation of the build
             b = out.get(key, {}).get("build") if isinstance(out.get(key), dict) else None
             if b and b.get("used"):
@@ -704,6 +731,7 @@ def main():
         if isinstance(out.get("roofline_large"), dict) and "frac" in out["roofline_large"]:
             # the HBM-side fraction of the same kernel: the 6.4 GB index, 25 x the Infinity Cache
             out["roofline"]["hbm_side_frac"] = out["roofline_large"]["frac"]
+            out["roofline"]["frac_hbm_side"] = out["roofline_large"]["frac"]  # (the same figure under the name the review asked for)
             out["roofline"]["hbm_side_workload"] = out["roofline_large"]["workload"]
             # what of that HBM provably served (first-touch bytes), and the distance kernel on rows read once per launch
             out["roofline"]["hbm_side"] = {
@@ -1231,6 +1259,175 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
             res["traffic_source"] = "profiles/pmc_large_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
+    prov.close()
+    return res
+
+
+def _first_touch(torch, dev, prov, queries_h, L, R, adj, st, row_bytes, adj_bytes, alg, avg_ms, achieved):
+    """What part of a launch's reads HBM must have served: the rows (and adjacency rows) a launch reads for the FIRST
+    time cannot come from the 256 MiB Infinity Cache when the index is many times its size (large_variant explains the
+    counters' blind spot).  Distinct rows = the union over all queries of the neighbours of the nodes they expanded."""
+    rid, _, rn, _ = prov.search_record_queries(queries_h, L)
+    rid_t = torch.from_numpy(rid.view(np.int32)).to(dev)
+    valid = torch.arange(rid.shape[1], device=dev)[None, :] < torch.from_numpy(rn.astype(np.int64)).to(dev)[:, None]
+    expanded = torch.unique(rid_t[valid])
+    del rid_t, valid
+    adj_t = torch.from_numpy(adj.view(np.int32)).to(dev)
+    rows_of = adj_t[expanded.long()]
+    lens = rows_of[:, 0].clamp(max=R)
+    nb = rows_of[:, 1:]
+    keep = torch.arange(R, device=dev)[None, :] < lens[:, None]
+    distinct_rows = int(torch.unique(nb[keep]).numel()) + 1  # (+ the start point)
+    distinct_adj = int(expanded.numel())
+    del adj_t, rows_of, nb, keep
+    compulsory = distinct_rows * row_bytes + distinct_adj * adj_bytes
+    reads_per_row = int(st[:, 0].sum()) / max(distinct_rows, 1)
+    turnover_us = (256 << 20) / (achieved * 1e9) * 1e6
+    interval_us = avg_ms * 1e3 / max(reads_per_row, 1e-9)
+    return {"distinct_rows_per_launch": distinct_rows, "distinct_adjacency_rows_per_launch": distinct_adj,
+            "first_touch_bytes_per_launch": compulsory, "share_of_algorithmic_bytes": compulsory / alg,
+            "dram_rate_at_least_GBps": compulsory / (avg_ms * 1e-3) / 1e9,
+            "mean_reads_per_distinct_row": reads_per_row, "infinity_cache_turnover_us": turnover_us,
+            "mean_interval_between_reads_of_a_row_us": interval_us,
+            "model_share_of_rereads_within_one_turnover": 1.0 - float(np.exp(-turnover_us / interval_us))}
+
+
+def large_int_variant(args, kind, torch, da, lib, _ffi, dev, local, k, W, stream_read_gbps):
+    """BASELINE config 3's integer rows on a working set far beyond the 256 MiB Infinity Cache: 10 M x 128 u8 rows
+    (1.28 GB + 1.32 GB adjacency) or SQ-8 codes (132-byte rows at a 256-byte stride: 2.56 GB), the headline generator at
+    2 560 blobs, index built on the GPU over those rows.  The search kernel (two queries per wavefront) is timed at the
+    first L whose recall@10 against the exact f32 neighbours reaches the target (no rerank) and at SURVEY 8(a)'s C-int8
+    sizing L = 64; algorithmic bytes over kernel time are stated against the 8 TB/s peak AND this box's stream-read probe;
+    the first rows of the timed launch's own output are checked against the CPU oracle; the distance kernel alone is run
+    over row ids drawn without repetition (every row read once per launch: nothing can be cached)."""
+    import oracle
+    n, dim, R, pruned, l_build = 10_000_000, 128, 32, 28, 100
+    if args.large_int_n:
+        n = args.large_int_n
+    dist = "sift_like:1:%d" % max(256, n // 3906)
+    nq, ngt = args.nq, min(args.nq, 10000)
+    base, queries = make_data(torch, dev, n, dim, nq, dist, 0xD15CA11, 0xD15CA12)
+    mean = base.double().mean(0).float()
+    medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
+    okw = {}
+    if kind == "sq8":
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        sample = base[torch.randperm(n, generator=g, device=dev)[:131072]].cpu().numpy()
+        shift, scale, _ = da.sq8_train(sample, 2.0, device=local)
+        snorm = float(np.float32((shift ** 2).sum(dtype=np.float32)))
+        rows = np.empty((n, dim + 4), np.uint8)
+        for s0 in range(0, n, 1 << 20):
+            rows[s0:s0 + (1 << 20)] = da.sq8_compress(base[s0:s0 + (1 << 20)].cpu().numpy(), shift, scale, device=local)
+        qrows = da.sq8_compress(queries.cpu().numpy(), shift, scale, device=local)
+        okw = dict(sq_scale=scale, sq_shift_norm_sq=snorm)
+        prov = da.Provider(da.SQ8, da.L2, dim, n, R, rows[medoid:medoid + 1], device=local, row_stride=args.sq8_stride, **okw)
+        row_bytes, odt, stride = dim + 4, oracle.SQ8, args.sq8_stride
+    else:
+        lo, hi = float(base.min()), float(base.max())
+        rows = np.empty((n, dim), np.uint8)
+        for s0 in range(0, n, 1 << 21):
+            rows[s0:s0 + (1 << 21)] = ((base[s0:s0 + (1 << 21)] - lo) * (255.0 / (hi - lo))).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        qrows = ((queries - lo) * (255.0 / (hi - lo))).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        prov = da.Provider(da.U8, da.L2, dim, n, R, rows[medoid:medoid + 1], device=local)
+        row_bytes, odt, stride = dim, oracle.U8, dim
+    for s0 in range(0, n, 1 << 21):
+        prov.set_elements(s0, rows[s0:s0 + (1 << 21)])
+    t0 = time.time()
+    prov.build(da.build_config(pruned, R, l_build, intra_batch_candidates=da.IBC_NONE), 0, n, args.growth, 65536)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    dq = torch.from_numpy(qrows).to(dev)
+    sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96]
+    if args.L:  # profiling passes: fixed L, no ground truth
+        Ls, rec_by_L = [args.L], {}
+        _, _, _, run, _ = _sweep(torch, lib, _ffi, prov, dq, nq, k, W, np.zeros((ngt, k), np.int64), ngt, [args.L], -1.0)
+    else:
+        gt = ground_truth(torch, base, queries[:ngt], k)
+        Lr, rec, _, run, hist = _sweep(torch, lib, _ffi, prov, dq, nq, k, W, gt, ngt, sweep, args.target_recall)
+        rec_by_L = dict(hist)
+        Ls = sorted({Lr or sweep[-1], 64})
+    del base
+    torch.cuda.empty_cache()
+    adj_bytes = (R + 1) * 4
+    res = {"workload": f"batched beam search over a {n}x{dim} {kind} index ({dist}; {n * stride / 1e9:.2f} GB of rows at a "
+                       f"{stride}-byte stride + {(n + 1) * adj_bytes / 1e9:.2f} GB adjacency resident in HBM), {nq} "
+                       f"queries/launch, k=10, beam_width={W}; Vamana R={R} (pruned {pruned}), l_build={l_build}, built "
+                       f"on the GPU over the {kind} rows in {t_build:.1f} s",
+           "rows": kind, "row_bytes": row_bytes, "row_stride": stride, "build_seconds": round(t_build, 2),
+           "working_set_bytes": n * stride + (n + 1) * adj_bytes, "recall_at_10_vs_exact_f32_no_rerank_by_L": rec_by_L,
+           "recall_measured_on": f"first {ngt} queries", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           **({"measured_stream_read_GBps": stream_read_gbps} if stream_read_gbps else {})}
+    t_ids, t_d, t_st = run.bufs
+    adj = None
+    for L in Ls:
+        for _ in range(2):
+            run(L)
+        prov.kernel_time_reset()
+        fam0 = prov.search_families()
+        for _ in range(5):
+            run(L)
+        torch.cuda.synchronize()
+        family = family_of(fam0, prov.search_families())
+        ms, nl = prov.kernel_time(0)
+        avg_ms = ms / max(nl, 1)
+        st = t_st.cpu().numpy().view(np.uint32)
+        alg = int(st[:, 0].sum()) * row_bytes + int(st[:, 1].sum()) * adj_bytes
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        leg = {"L": L, "kernel": "pair_search_kernel" if family == "pair" else "beam_search_kernel", "kernel_family": family,
+               "recall_at_10_vs_exact_f32_no_rerank": rec_by_L.get(L), "mean_cmps": float(st[:, 0].mean()),
+               "mean_hops": float(st[:, 1].mean()), "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": avg_ms,
+               "qps": nq / (avg_ms * 1e-3), "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+               "bound": "hbm"}
+        if stream_read_gbps:
+            leg["frac_of_measured_stream_read"] = achieved / stream_read_gbps
+            if achieved > stream_read_gbps:
+                leg["bound"] = "fabric (HBM + Infinity Cache): above this box's stream-read probe"
+        if not args.L:
+            try:
+                leg["oracle_sample"] = oracle_sample(prov, odt, oracle.L2, dim, n, R, rows[medoid:medoid + 1], rows, qrows, L,
+                                                     W, k, t_ids[:256].cpu().numpy(), t_d[:256].cpu().numpy(), st[:256],
+                                                     family, **okw)
+            except Exception as e:  # noqa: BLE001
+                leg["oracle_sample"] = {"error": str(e)[:200]}
+            try:
+                if adj is None:
+                    adj = prov.download_graph()
+                leg["hbm_side"] = _first_touch(torch, dev, prov, qrows, L, R, adj, st, row_bytes, adj_bytes, alg, avg_ms,
+                                               achieved)
+            except Exception as e:  # noqa: BLE001
+                leg["hbm_side"] = {"error": str(e)[:200]}
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"pmc_large_{kind}_latest.json")))
+            if pm.get("n") == n and pm.get("L") == L and pm.get("nq") == nq:
+                leg["traffic"] = pm["hbm_bytes_per_launch_corrected"]
+                leg["traffic_over_algorithmic"] = pm["hbm_bytes_per_launch_corrected"] / alg
+                leg["traffic_source"] = f"profiles/pmc_large_{kind}_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
+        res["L%d" % L] = leg
+    if not args.L:
+        # the distance kernel where nothing CAN be cached: row ids drawn WITHOUT repetition, every row read once per launch
+        try:
+            gq = 20000
+            gl = max(1, min(256, n // gq))
+            gids = np.random.default_rng(7).permutation(n)[:gq * gl].astype(np.uint32)
+            goff = np.arange(gq + 1, dtype=np.uint64) * gl
+            prov.expand_beam_batch(qrows[:gq], gids, goff)
+            prov.kernel_time_reset()
+            for _ in range(3):
+                prov.expand_beam_batch(qrows[:gq], gids, goff)
+            gms, gn = prov.kernel_time(1)
+            gbytes = gq * gl * row_bytes
+            grate = gbytes / (gms / max(gn, 1) * 1e-3) / 1e9
+            res["hbm_side_distance_kernel"] = {
+                "kernel": "expand_beam_kernel", "rows_per_launch": gq * gl, "every_row_read_once": True,
+                "bytes_per_launch": gbytes, "avg_kernel_ms": gms / max(gn, 1), "achieved_GBps": grate,
+                "frac_of_hbm_peak": grate / HBM_PEAK_GBS,
+                # (128-byte rows at a 128- or 256-byte stride: HBM moves whole 128-byte lines, the SQ-8 row straddles two)
+                **({"frac_of_measured_stream_read": grate / stream_read_gbps} if stream_read_gbps else {})}
+        except Exception as e:  # noqa: BLE001
+            res["hbm_side_distance_kernel"] = {"error": str(e)[:200]}
     prov.close()
     return res
 

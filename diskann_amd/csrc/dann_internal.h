@@ -134,6 +134,8 @@ struct SearchArgs {
     uint32_t ht_shift = 0;       // 32 - m, m = bits of the index's slot count
     uint32_t ht_tb = 0;          // tag bits: 2^tb >= ceil(2^m / slots)
     uint32_t ht_kmax = 0;        // probes per id
+    uint32_t ht_ov = 0;          // pair / PQ-table kernels: words of the overflow table behind the 16-bit table (a power
+                                 // of two; 0 = none): it takes the ids whose ht_kmax probes are all taken (ov_insert)
     uint32_t ht_open = 0;        // ids the open table takes before it is frozen (set with ht_prime: 75 % of the 32-bit
                                  // table's prime, 75 % -- DANN_DBG_HT16_OPEN_EIGHTHS -- of the 16-bit table's entries)
     uint32_t* out_ids = nullptr; // nq x k (may be null in record mode)

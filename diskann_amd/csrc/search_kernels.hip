@@ -52,8 +52,8 @@ __global__ void collect_failed_kernel(const dann_search_stats* stats, const uint
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a) {
-    if (a.pair) return 2u * (size_t)pair_lds_layout(pair_qe(a), pair_re(a), a.ht_entries).half_bytes;
-    if (a.pqlut) return pq_lds_layout(pq_lut_qs(a), a.ht_entries).total;
+    if (a.pair) return 2u * (size_t)pair_lds_layout(pair_qe(a), pair_re(a), a.ht_entries, a.ht_ov).half_bytes;
+    if (a.pqlut) return pq_lds_layout(pq_lut_qs(a), a.ht_entries, a.ht_ov).total;
     return search_lds_layout(a.ht_entries, cmax_of(a), lds_queue_entries(a), query_lds_bytes(a.ix), a.team != 0).total;
 }
 
@@ -90,7 +90,7 @@ struct Ht16Geom {
     bool ok = false;
     uint32_t shift = 0, tb = 0, kmax = 0, slots = 0;  // slots = 2 * words: the entries the table holds
 };
-Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
+Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots, uint32_t kcap = 64u) {
     Ht16Geom g;
     if (words < 32u || words > 65536u) return g;
     uint32_t m = 1;
@@ -102,20 +102,26 @@ Ht16Geom ht16_geometry(uint32_t words, uint32_t nslots) {
     if (tb > 14u) return g;  // fewer than 2 bits for the probe number: too few probes per id
     g.tb = tb;
     g.shift = 32u - m;
-    g.kmax = std::min<uint32_t>((1u << (16u - tb)) - 1u, 64u);
+    g.kmax = std::min<uint32_t>((1u << (16u - tb)) - 1u, std::max<uint32_t>(kcap, 1u));  // (kcap: DANN_DBG_HT16_MAX_PROBES)
     g.slots = words * 2u;
     g.ok = true;
     return g;
 }
+// Overflow table of the pair / PQ-table kernels (SearchArgs::ht_ov, ov_insert): where a 16-bit entry leaves fewer than
+// eight probes per id (indexes of 2^18 slots and more at these table sizes) some percent of a search's ids find all of
+// them taken (simulated at 75 % load: 75 of 2 064 ids with three probes, 5 with seven); a small table of 32-bit ids
+// takes those instead of freezing the whole table at the first of them.  Words per query (a power of two).
+uint32_t ht16_overflow_words(const Ht16Geom& g, bool pair) { return !g.ok || g.kmax >= 8u ? 0u : pair ? 128u : 256u; }
 // may this launch use 16-bit entries at all?  (plain-mode kernels, one wave per query)
 bool ht16_eligible(const SearchArgs& a) { return plain_mode(a) && !a.team; }
 
+uint32_t ht16_kcap(const dann_index* idx) { return std::min(64u, std::max(1u, idx->dbg_u32(DANN_DBG_HT16_MAX_PROBES, 64u))); }
 uint32_t ht16_open_eighths(const dann_index* idx) { return std::min(7u, std::max(4u, idx->dbg_u32(DANN_DBG_HT16_OPEN_EIGHTHS, 6u))); }
 
 // probing modulus / slot count, the 16-bit geometry and the open-table limit of the table `a` has been given
-int32_t finish_visited_table(SearchArgs& a, uint32_t open_eighths) {
+int32_t finish_visited_table(SearchArgs& a, uint32_t open_eighths, uint32_t kcap) {
     if (a.ht16) {
-        const Ht16Geom g = ht16_geometry(a.ht_entries, a.ix.nslots);
+        const Ht16Geom g = ht16_geometry(a.ht_entries, a.ix.nslots, kcap);
         if (!g.ok || !ht16_eligible(a)) {
             set_error("internal: no 16-bit visited table of %u words for %u slots", a.ht_entries, a.ix.nslots);
             return DANN_EINTERNAL;
@@ -311,6 +317,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // 16 384: 497 / 585, 65 536: 1 423 / 1 801.  DANN_DBG_TUNE_OFF bit 16 / DANN_DBG_PAIR_MIN_QUERIES: development
     // switches (dann_debug_set; read on every call).
     a.pair = 0;
+    a.ht_ov = 0;
     {
         const uint32_t floor_q = idx->dbg_u32(DANN_DBG_PAIR_MIN_QUERIES, 20u * idx->num_cus);
         SearchArgs t = a;
@@ -360,17 +367,25 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             // tenth to spare: the step decides how many wavefronts share a CU, and the pair kernel lives on that
             // (profiles/r04m: 16 / 8 / 4 wavefronts per CU -> 2.09 / 2.94 / 5.27 ms)
             const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
-            const uint32_t fixed = pair_lds_layout(pair_qe(a), pair_re(a), 0).half_bytes;
-            uint32_t words = 0;
+            const uint32_t fixed = pair_lds_layout(pair_qe(a), pair_re(a), 0, 0).half_bytes;
+            uint32_t words = 0, ovw = 0;
             for (uint32_t g = 2; g <= kLdsGranules && !words; ++g) {
                 const uint32_t half = g * kLdsGranule / 2u;
                 if (half <= fixed) continue;
-                const uint32_t w = std::min<uint32_t>((half - fixed) / 4u / 4u * 4u, 16384u);
-                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+                uint32_t w = std::min<uint32_t>((half - fixed) / 4u / 4u * 4u, 16384u);
+                const uint32_t o = ht16_overflow_words(ht16_geometry(w, a.ix.nslots, ht16_kcap(idx)), true);
+                if (w <= o + 32u) continue;
+                w -= o;
+                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok &&
+                    ht16_overflow_words(ht16_geometry(w, a.ix.nslots, ht16_kcap(idx)), true) <= o) {
+                    words = w;
+                    ovw = o;
+                }
             }
             if (words) {
                 a.ht16 = 1;
                 a.ht_entries = words;
+                a.ht_ov = ovw;
             } else {
                 a.pair = 0;
             }
@@ -380,16 +395,24 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             // them (a sparse table costs nothing but its wipe), or -- a larger 90th percentile of comparisons -- the
             // first step whose open capacity holds it with a tenth to spare
             const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
-            const uint32_t fixed = pq_lds_layout(pq_lut_qs(a), 0).total;
-            uint32_t words = 0;
+            const uint32_t fixed = pq_lds_layout(pq_lut_qs(a), 0, 0).total;
+            uint32_t words = 0, ovw = 0;
             for (uint32_t g = kLdsGranules / 16u; g <= kLdsGranules && !words; ++g) {
                 if (g * kLdsGranule <= fixed) continue;
-                const uint32_t w = std::min<uint32_t>((g * kLdsGranule - fixed) / 4u / 64u * 64u, 32768u);
-                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok) words = w;
+                uint32_t w = std::min<uint32_t>((g * kLdsGranule - fixed) / 4u / 64u * 64u, 32768u);
+                const uint32_t o = ht16_overflow_words(ht16_geometry(w, a.ix.nslots, ht16_kcap(idx)), false);
+                if (w <= o + 64u) continue;
+                w -= o;
+                if ((uint64_t)w * 2u * ht16_open_eighths(idx) / 8u >= (uint64_t)cap + cap / 10u && ht16_geometry(w, a.ix.nslots).ok &&
+                    ht16_overflow_words(ht16_geometry(w, a.ix.nslots, ht16_kcap(idx)), false) <= o) {
+                    words = w;
+                    ovw = o;
+                }
             }
             if (words) {
                 a.ht16 = 1;
                 a.ht_entries = words;
+                a.ht_ov = ovw;
             } else {
                 a.pqlut = 0;
             }
@@ -411,12 +434,14 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             if (ht16_geometry(words, a.ix.nslots).ok) {
                 a.ht16 = 1;
                 a.ht_entries = words;
+                if (a.pair || a.pqlut) a.ht_ov = ht16_overflow_words(ht16_geometry(words, a.ix.nslots, ht16_kcap(idx)), a.pair != 0);
             }
         }
         if (a.pair && !a.ht16) a.pair = 0;
         if (a.pqlut && !a.ht16) a.pqlut = 0;
         // (the two special kernels carry their own LDS layout: a table they cannot hold goes to beam_search_kernel)
         if ((a.pair || a.pqlut) && search_lds_bytes(a) > 160 * 1024) a.pair = a.pqlut = 0;
+        if (!a.pair && !a.pqlut) a.ht_ov = 0;
     }
     // the start points are inserted unconditionally and the first hop needs room before the freeze test can
     // trigger: the open table must hold nstart + W * R ids below its 75 % load limit, or ht_visit could probe a
@@ -451,7 +476,7 @@ int32_t launch_search_server(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     int32_t rc = prepare_launch(idx, ctx, a, a.srv.workers);
     if (rc != DANN_OK) return rc;
     a.fail_flag = nullptr;
-    if (int32_t frc = finish_visited_table(a, ht16_open_eighths(idx))) return frc;
+    if (int32_t frc = finish_visited_table(a, ht16_open_eighths(idx), ht16_kcap(idx))) return frc;
     rc = launch_search(a, ctx.stream);
     if (rc == DANN_OK) {
         std::lock_guard<std::mutex> lk(idx->stat_mu);
@@ -491,7 +516,7 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
     // HIP events bracket exactly the beam-search launches, on the stream they run on
     float last_ms = 0.f;
     auto timed_launch = [&](SearchArgs& args) -> int32_t {
-        if (int32_t frc = finish_visited_table(args, ht16_open_eighths(idx))) return frc;
+        if (int32_t frc = finish_visited_table(args, ht16_open_eighths(idx), ht16_kcap(idx))) return frc;
 #ifdef DANN_PHASE_CYCLES
         args.phase_cycles = dann_phase_buffer();
 #endif
@@ -560,6 +585,7 @@ int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a) {
             a.team = 0;  // a team never spills its visited table: the same table, one wave per query (which does)
         } else if (a.pair || a.pqlut) {
             a.pair = a.pqlut = 0;  // re-runs go through beam_search_kernel: the table of one query doubled
+            a.ht_ov = 0;
             a.ht_entries = std::min<uint32_t>(a.ht_entries * 2, 32768);
         } else {
             if (a.ht_entries >= 32768) return DANN_OK;  // callers see the per-query status

@@ -38,11 +38,11 @@ constexpr uint32_t kPairHalf = 32;
 // stores of lanes that have nothing to store, the visited table.  QE = queue entries per lane (1: L + start points <=
 // 32, 2: <= 64), RE = adjacency ids per lane (1: degree <= 32, 2: <= 64).
 struct PairLds {
-    uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, sd_off, sink_off, ht_off, half_bytes;
+    uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, sd_off, sink_off, ht_off, ov_off, half_bytes;
 };
 // keys of the queue image: a power of two beyond the queue's entries (the lower-bound search needs no bound check)
 __host__ __device__ inline uint32_t pair_qimg_keys(uint32_t qe) { return qe == 1u ? 64u : 128u; }
-__host__ __device__ inline PairLds pair_lds_layout(uint32_t qe, uint32_t re, uint32_t ht_words) {
+__host__ __device__ inline PairLds pair_lds_layout(uint32_t qe, uint32_t re, uint32_t ht_words, uint32_t ov_words) {
     PairLds l;
     l.cand_id_off = 0;
     l.cand_d_off = 128u * re;
@@ -63,7 +63,8 @@ __host__ __device__ inline PairLds pair_lds_layout(uint32_t qe, uint32_t re, uin
     l.sink_off = off;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
     off += 128u;       // 8-byte stores of the merge's scatter sink into [sd, sink + 128): the survivors' keys are dead by then
     l.ht_off = off;
-    l.half_bytes = l.ht_off + ht_words * 4u;
+    l.ov_off = l.ht_off + ht_words * 4u;  // the overflow table of the 16-bit table (ov_insert; 0 words: none)
+    l.half_bytes = l.ov_off + ov_words * 4u;
     return l;
 }
 // the instantiation a launch takes: queue entries per lane = ceil((L + start points) / 32) (1 .. 3), two adjacency ids per
@@ -112,6 +113,32 @@ __device__ __forceinline__ uint32_t ht16_insert_flat(uint32_t* htw, const Ht16& 
     return res;
 }
 
+// The overflow table of a 16-bit visited table (SearchArgs::ht_ov words, a power of two, 32-bit ids, linear probing):
+// it takes the ids whose kmax probes of the 16-bit table are all taken.  With 2^21 index slots and more a 16-bit entry
+// has 14 tag bits and room for three probes (six places per id): at the tables' load some 4 % of a search's ids find all
+// six taken -- freezing the table at the first of them (rounds 4-5) sent nearly every search of a 10 M-point index
+// through the spill tables in global memory (57 ms per 100 000 u8 queries at L = 64, profiles/r06b_*).  A full bucket
+// stays full, so "all probes taken" is permanent for an id: insert and every later lookup of it end here alike.  The
+// caller keeps one slot free (the probing ends).
+__device__ __forceinline__ bool ov_insert(uint32_t* ov, uint32_t mask, uint32_t id) {
+    uint32_t h = ((id * 0x9E3779B1u) >> 16) & mask;
+    for (;;) {
+        const uint32_t old = atomicCAS(&ov[h], kEmpty, id);
+        if (old == kEmpty) return true;
+        if (old == id) return false;
+        h = (h + 1u) & mask;
+    }
+}
+__device__ __forceinline__ bool ov_contains(const uint32_t* ov, uint32_t mask, uint32_t id) {
+    uint32_t h = ((id * 0x9E3779B1u) >> 16) & mask;
+    for (;;) {
+        const uint32_t old = ov[h];
+        if (old == kEmpty) return false;
+        if (old == id) return true;
+        h = (h + 1u) & mask;
+    }
+}
+
 template <int DT, int OP, bool NORM, int QE, int RE>
 __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     static_assert(DT == DT_U8 || DT == DT_I8 || DT == DT_SQ8, "integer rows");
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     const uint32_t slot_c = exists ? slot : a.nq - 1u;
     const uint32_t qi = a.qmap ? a.qmap[slot_c] : slot_c;
 
-    const PairLds L = pair_lds_layout(QE, RE, a.ht_entries);
+    const PairLds L = pair_lds_layout(QE, RE, a.ht_entries, a.ht_ov);
     uint8_t* const hbase = smem + (up ? L.half_bytes : 0u);
     uint32_t* const cand_id = reinterpret_cast<uint32_t*>(hbase + L.cand_id_off);
     float* const cand_d = reinterpret_cast<float*>(hbase + L.cand_d_off);
@@ -147,11 +174,15 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     uint32_t* const sink = reinterpret_cast<uint32_t*>(hbase + L.sink_off) + li;  // this lane's own sink
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
     uint32_t* const ht = reinterpret_cast<uint32_t*>(hbase + L.ht_off);
+    uint32_t* const ov = reinterpret_cast<uint32_t*>(hbase + L.ov_off);  // (behind the table: wiped with it)
     const Ht16 h16 = ht16_of(a);
     const uint32_t ht_limit = a.ht_open;  // ids the open table takes (75 % of its entries by default)
+    // the overflow table takes the ids that find their few probes taken (indexes of 2^21 slots and more: 14 tag bits
+    // leave three probes); it always keeps a slot free (linear probing ends), so it is open while ovcv + a hop's ids fit
+    const uint32_t ov_mask = a.ht_ov - 1u, ov_limit = a.ht_ov ? a.ht_ov - 1u : 0u;
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
-        for (uint32_t i = li * 4u; i < a.ht_entries; i += kPairHalf * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
+        for (uint32_t i = li * 4u; i < a.ht_entries + a.ht_ov; i += kPairHalf * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
 #pragma unroll
         for (int e = 0; e < RE; ++e) cand_id[e * kPairHalf + li] = 0u;
 #pragma unroll
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
         qid[e] = kEmpty;
         qd[e] = 0.0f;
     }
-    uint32_t sizev = 0, cmpsv = 0, hopsv = 0, htcv = ns, spcv = 0, stv = 0, ncv = 0;
+    uint32_t sizev = 0, cmpsv = 0, hopsv = 0, htcv = ns, ovcv = 0, spcv = 0, stv = 0, ncv = 0;
     bool alivev = exists, openv = true;
     uint32_t* spv = nullptr;  // the half's spill table once its LDS table is frozen
     const uint32_t spill_size = 1u << a.spill_bits, spill_mask = spill_size - 1u, spill_shift = 32u - a.spill_bits;
@@ -414,8 +445,9 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
             const uint32_t len = lenl < R ? lenl : R;  // Neighbors::get clamps (neighbors.rs:146-148)
             // the open table takes ids up to 75 % of its entries; then it is frozen and new ids go to a spill table
             const bool live = alivev & (stv == 0u);
-            if (ballot64(live & (openv ? (htcv + len > ht_limit) : (spcv + len > spill_limit)))) {
-                freeze(live & openv & (htcv + len > ht_limit));
+            const bool tofreeze = (htcv + len > ht_limit) | ((a.ht_ov != 0u) & (ovcv + len > ov_limit));
+            if (ballot64(live & (openv ? tofreeze : (spcv + len > spill_limit)))) {
+                freeze(live & openv & tofreeze);
                 if (alivev & !openv & (!spv | (spcv + len > spill_limit))) stv = kOverflow;
             }
             uint32_t total_new = 0;
@@ -432,11 +464,18 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                 const bool exh = r == 2u;
                 if (ballot64(exh | (act & !openv))) {  // (rare) no room among an id's probes, or a frozen table
                     if (ballot64(exh)) {
-                        freeze(exh);  // that half's table is frozen; the id goes to its spill table
-                        if (exh && spv) isnew = spill_insert(spv, spill_mask, spill_shift, id);
+                        if (a.ht_ov) {  // the id goes to the half's overflow table (room for this hop: checked above)
+                            if (exh) isnew = ov_insert(ov, ov_mask, id);
+                            const uint64_t om = ballot64(exh & isnew);
+                            ovcv += (uint32_t)__popc(up ? (uint32_t)(om >> 32) : (uint32_t)om);
+                        } else {
+                            freeze(exh);  // that half's table is frozen; the id goes to its spill table
+                            if (exh && spv) isnew = spill_insert(spv, spill_mask, spill_shift, id);
+                        }
                     }
                     if (act && !openv && !exh && spv && !stv && !isnew)
-                        isnew = !ht16_contains(ht, h16, id) && spill_insert(spv, spill_mask, spill_shift, id);
+                        isnew = !ht16_contains(ht, h16, id) && !(a.ht_ov && ov_contains(ov, ov_mask, id)) &&
+                                spill_insert(spv, spill_mask, spill_shift, id);
                 }
                 const uint64_t km = ballot64(isnew);
                 const uint32_t k0 = (uint32_t)km, k1 = (uint32_t)(km >> 32);

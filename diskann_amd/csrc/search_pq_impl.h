@@ -36,13 +36,14 @@ constexpr uint32_t kPqLutChunks = 16;  // chunks the register-resident table cov
 struct PqLds {
     uint32_t stage_off, cbi_off, cbd_off, ht_off, total;
 };
-__host__ __device__ inline PqLds pq_lds_layout(uint32_t qs, uint32_t ht_words) {
+// (ov_words: the overflow table of the 16-bit table directly behind it -- ov_insert, search_pair_impl.h)
+__host__ __device__ inline PqLds pq_lds_layout(uint32_t qs, uint32_t ht_words, uint32_t ov_words) {
     PqLds l;
     l.stage_off = 0;
     l.cbi_off = qs * 64u * 8u;
     l.cbd_off = l.cbi_off + 256u;
     l.ht_off = l.cbd_off + 256u;
-    l.total = l.ht_off + ht_words * 4u;
+    l.total = l.ht_off + (ht_words + ov_words) * 4u;
     return l;
 }
 
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     constexpr uint32_t kOverflow = (uint32_t)(-DANN_EOVERFLOW);
     constexpr uint32_t QCAPP = QS * kWave;
 
-    const PqLds L = pq_lds_layout(QS, a.ht_entries);
+    const PqLds L = pq_lds_layout(QS, a.ht_entries, a.ht_ov);
     uint2* const stage = reinterpret_cast<uint2*>(smem + L.stage_off);
     uint32_t* const cbi = reinterpret_cast<uint32_t*>(smem + L.cbi_off);
     float* const cbd = reinterpret_cast<float*>(smem + L.cbd_off);
@@ -183,9 +184,12 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     auto stage_dist = [&](uint32_t p) -> float { return __builtin_bit_cast(float, stage[p].y); };
     const Ht16 h16 = ht16_of(a);
     const uint32_t ht_limit = a.ht_open;  // ids the open table takes (75 % of its entries by default)
+    uint32_t* const ov = ht + a.ht_entries;  // overflow table (ids whose probes are all taken), wiped with the table
+    const uint32_t ov_mask = a.ht_ov - 1u, ov_limit = a.ht_ov ? a.ht_ov - 1u : 0u;
+    uint32_t ovc = 0;
     {
         const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
-        for (uint32_t i = lane * 4u; i < a.ht_entries; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
+        for (uint32_t i = lane * 4u; i < a.ht_entries + a.ht_ov; i += kWave * 4u) *reinterpret_cast<u32x4*>(ht + i) = e4;
     }
 
     // ---- the query's lookup table, into registers: lut[4 c + j] of lane l = entry (chunk c, centroid 64 j + l).  One
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
 
         // ---- visited filter.  The open table takes ids up to 75 % of its slots; then it is frozen and new ids go to a
         // spill table in global memory
-        if (open && htc + len > ht_limit) {
+        if (open && (htc + len > ht_limit || (a.ht_ov && ovc + len > ov_limit))) {
             open = false;
             claim_spill();
         }
@@ -482,17 +486,23 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
         if (open) {
             const uint32_t r = ht16_insert_flat(ht, h16, id, act, cbi + lane);  // (cbi: idle outside the merge)
             isnew = r == 1u;
-            if (ballot64(r == 2u)) {  // (rare) no slot among an id's probes: the table is frozen, the id goes to the spill table
-                open = false;
-                claim_spill();
-                if (!spill) {
-                    status = kOverflow;
-                    break;
+            if (ballot64(r == 2u)) {  // (rare) no slot among an id's probes
+                if (a.ht_ov) {  // the overflow table takes it (room for this hop's ids: checked above)
+                    if (r == 2u) isnew = ov_insert(ov, ov_mask, id);
+                    ovc += (uint32_t)__popcll(ballot64(r == 2u && isnew));
+                } else {  // the table is frozen, the id goes to the spill table
+                    open = false;
+                    claim_spill();
+                    if (!spill) {
+                        status = kOverflow;
+                        break;
+                    }
+                    if (r == 2u) isnew = spill_insert(spill, spill_mask, spill_shift, id);
                 }
-                if (r == 2u) isnew = spill_insert(spill, spill_mask, spill_shift, id);
             }
         } else if (act) {
-            isnew = !ht16_contains(ht, h16, id) && spill_insert(spill, spill_mask, spill_shift, id);
+            isnew = !ht16_contains(ht, h16, id) && !(a.ht_ov && ov_contains(ov, ov_mask, id)) &&
+                    spill_insert(spill, spill_mask, spill_shift, id);
         }
         const uint32_t nnew = (uint32_t)__popcll(ballot64(isnew));
         if (open) htc += nnew;

@@ -53,7 +53,9 @@ enum {
     DANN_DBG_BACKEDGE_SINGLE_POOL = 13,  /* small rows: the back-edge phase runs as ONE kernel (list build + prune per target, LDS
                                             pool sized by the batch's longest list) while that pool has at most this many
                                             entries; beyond it, scan + short / long worklists (default 128) */
-    DANN_DBG_COUNT = 14
+    DANN_DBG_HT16_MAX_PROBES = 14,       /* test hook: cap on the probes per id of a 16-bit visited table (default 64; a large
+                                            index leaves three): small test indexes reach the overflow table with it */
+    DANN_DBG_COUNT = 15
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
 int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);

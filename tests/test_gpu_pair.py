@@ -172,3 +172,34 @@ def test_max_concurrency_cap_takes_pair_launches_to_persistent_waves():
     _check(gix, oix, q[:32], 26, 10, "at the cap")
     gix.set_max_concurrency(0)
     _check(gix, oix, q, 26, 10, "cap lifted")
+
+
+@pytest.mark.parametrize("probes,R,L", [(1, 32, 30), (2, 64, 60), (3, 32, 90)])
+def test_pair_kernel_overflow_table_of_few_probes(probes, R, L):
+    """An index of 2^21 slots and more leaves a 16-bit table entry three probes per id; ids that find them all taken
+    go to the query's overflow table (ov_insert) instead of freezing the table.  Small indexes reach that path through
+    the probe cap (DANN_DBG_HT16_MAX_PROBES): automatic and explicit table sizes -- overflow while the table is open,
+    lookups of overflowed ids once it is frozen, spill tables, re-runs -- all equal to one wave per query."""
+    rng = np.random.default_rng(210 + probes)
+    n, dim, nq = 20000, 128, 6000
+    data = rand_vectors(rng, oracle.U8, n, dim)
+    adj = random_graph(rng, n, R, nstart=2)
+    oix, gix = make_pair(oracle.U8, oracle.L2, data, adj, data[:2], R)
+    queries = rand_vectors(rng, oracle.U8, nq, dim)
+    gix.debug_set(tune_off=20)      # one wave per query, no teams
+    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(L), queries, 10))
+    assert fam == {"one_wave"}, fam
+    gix.debug_set(tune_off=None, ht16_max_probes=probes)
+    gix.set_visited_format(16)
+    for words in (0, 128, 512, 2048):
+        gix.set_visited_bits(words)
+        for eighths in (6, 7):
+            gix.debug_set(ht16_open_eighths=eighths)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(L), queries, 10))
+            assert "pair" in fam and fam <= {"pair", "one_wave"}, (fam, words)
+            assert not gst["status"].any(), words
+            assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd)), (words, eighths)
+            assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), (words, eighths)
+    oi, od, oc, ost = oix.search_batch(queries[:200], L, 1, 10)
+    assert np.array_equal(ri[:200], oi) and np.array_equal(ost[:, 0], rst["cmps"][:200])
+    assert rst["cmps"].mean() > 300

@@ -148,3 +148,30 @@ def test_max_concurrency_cap_takes_pq_launches_to_persistent_waves():
     _check(gix, oix, q[:64], 40, 10, "at the cap: one block per query again")
     gix.set_max_concurrency(0)
     _check(gix, oix, q, 40, 10, "cap lifted")
+
+
+@pytest.mark.parametrize("probes", [1, 3])
+def test_pq_lut_kernel_overflow_table_of_few_probes(probes):
+    """large indexes leave a 16-bit visited-table entry three probes per id; ids that find them taken go to the overflow
+    table (ov_insert, search_pair_impl.h).  Reached here through the probe cap; equal to beam_search_kernel throughout"""
+    rng = np.random.default_rng(79 + probes)
+    n, dim, R, nq = 20000, 64, 32, 6000
+    oix, gix = _pq_index(rng, n, dim, 16, R, 1, oracle.L2)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    gix.debug_set(tune_off=32)
+    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(60), q, 10))
+    assert fam == {"one_wave"}, fam
+    gix.debug_set(tune_off=None, ht16_max_probes=probes)
+    for packed in (False, True):
+        if packed:
+            gix.pq_pack_neighbors()
+        for words in (0, 128, 1024):
+            gix.set_visited_bits(words)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(60), q, 10))
+            assert "pq_lut" in fam and fam <= {"pq_lut", "one_wave"}, (fam, words)
+            assert not gst["status"].any(), words
+            assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd)), words
+            assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), words
+        gix.set_visited_bits(0)
+    oi, od, oc, ost = oix.search_batch(q[:200], 60, 1, 10)
+    assert np.array_equal(ri[:200], oi) and np.array_equal(ost[:, 0], rst["cmps"][:200])
