@@ -179,6 +179,7 @@ SYMBOLS = {
     "dann_debug_get": (_i32, [_vp, _i32, _P(C.c_double)]),
     "dann_debug_search_families": (_i32, [_vp, _P(_u64), _P(C.c_double)]),
     "dann_debug_family_name": (C.c_char_p, [_i32]),
+    "dann_debug_pq_rolling_sum_stats": (_i32, [_i32, _P(_u64), _i32]),
 }
 
 # dann_debug.h: development switches (dann_debug_set) and kernel families (dann_debug_search_families)

@@ -634,6 +634,14 @@ def pq_train(data, chunk_offsets, ncenters, lloyds_reps, uniform_index, uniform_
     return piv
 
 
+def pq_rolling_sum_stats(reset=False, device=-1):
+    """dann_debug_pq_rolling_sum_stats: {wave_ranges, thread_ranges, walked_ranges, walked_elements} of the trainer's
+    rolling f64 sums since the last reset"""
+    out = (C.c_uint64 * 4)()
+    check(_ffi.lib().dann_debug_pq_rolling_sum_stats(device, out, 1 if reset else 0), "dann_debug_pq_rolling_sum_stats")
+    return dict(zip(("wave_ranges", "thread_ranges", "walked_ranges", "walked_elements"), (int(v) for v in out)))
+
+
 def sq8_train(data, standard_deviations=2.0, device=-1):
     """ScalarQuantizationParameters::train on the GPU: (shift[dim] f32, scale, mean_norm)."""
     x = np.ascontiguousarray(data, dtype=np.float32)

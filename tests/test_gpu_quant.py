@@ -310,6 +310,57 @@ def test_pq_kmeanspp_and_train_vs_oracle(n, dim, off, k):
     assert np.array_equal(bits(piv), bits(want))
 
 
+def test_pq_lloyds_chunk_beyond_the_mfma_slab_takes_the_row_kernel():
+    """a chunk whose transposed centres do not fit 64 KiB of LDS keeps the row kernel; same bits as the oracle either way"""
+    rng = np.random.default_rng(41)
+    n, dim, k = 900, 200, 64
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    init = x[rng.choice(n, k, replace=False)].copy()
+    wc, wa, wr = oracle.pq_lloyds(x, [0, dim], init, 2)
+    gc, ga, gr = da.pq_lloyds(x, [0, dim], init, 2)
+    assert np.array_equal(ga, wa) and np.array_equal(bits(gc), bits(wc)) and np.array_equal(bits(gr), bits(wr))
+
+
+@pytest.mark.parametrize("kind", ["scales", "duplicates", "tiny", "large"])
+def test_pq_kmeanspp_rolling_sums_on_hard_inputs(kind):
+    """The D^2 draw and its totals are rolling f64 sums in row order; the kernels evaluate them in parallel only over
+    ranges where no addition can round (seq_exact) and walk the rest element by element.  Inputs that force the walk --
+    rows on scales 12 orders of magnitude apart, thousands of copies of the centres picked (distances of rounding-noise
+    size, some negative), distances below the running sum's last place -- and a set large enough for full ranges:
+    seeds and selected counts bit-identical to the oracle's sequential loops."""
+    rng = np.random.default_rng(len(kind))
+    dim, off, k = 12, [0, 4, 12], 24
+    if kind == "scales":
+        n = 5000
+        x = rng.standard_normal((n, dim)).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 6, (n, 1)).astype(np.float32)
+    elif kind == "duplicates":
+        n = 6000
+        base = (rng.standard_normal((40, dim)) * 100).astype(np.float32) + np.float32(1000.0)
+        x = base[rng.integers(0, 40, n)].copy()
+        x[::7] += (rng.standard_normal((len(x[::7]), dim)) * 1e-3).astype(np.float32)
+    elif kind == "tiny":
+        n = 4000
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        x[rng.integers(0, n, 300)] *= np.float32(1e-12)
+        x[rng.integers(0, n, 300)] *= np.float32(1e-30)
+    else:
+        n, k = 70001, 40
+        x = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 2.0, (1, dim))).astype(np.float32)
+    d1, d2 = _Draws(11, len(off) - 1), _Draws(11, len(off) - 1)
+    rc, ocen, osel = oracle.pq_kmeanspp(x, off, k, d1.index, d1.f64)
+    da.pq_rolling_sum_stats(reset=True)
+    gcen, gsel = da.pq_kmeanspp(x, off, k, d2.index, d2.f64)
+    st = da.pq_rolling_sum_stats()
+    assert rc == 0 and np.array_equal(osel, gsel), (osel, gsel)
+    assert np.array_equal(bits(ocen), bits(gcen))
+    # which paths the rolling sums took: the hard inputs reach the element walk, the large plain one sums in parallel
+    assert st["wave_ranges"] + st["thread_ranges"] > 0, st
+    if kind in ("scales", "tiny"):
+        assert st["walked_ranges"] > 0, st
+    if kind == "large":
+        assert st["walked_elements"] < 0.01 * 2 * (k - 1) * 2 * n, st
+
+
 def test_pq_kmeanspp_degenerate_inputs():
     rng = np.random.default_rng(3)
     few = np.repeat(rng.integers(-3, 4, (4, 6)).astype(np.float32), 30, axis=0)   # 4 distinct rows (exact arithmetic), 10 centres wanted
