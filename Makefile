@@ -7,7 +7,7 @@ ARCH    ?= gfx950
 FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero
 CSRC    := diskann_amd/csrc
 OBJDIR  := diskann_amd/build
-SOURCES := api search_kernels search_f32 search_f16 search_u8 search_i8 search_sq8 search_pq search_pqlut search_pair server sharded paged_kernels \
+SOURCES := api search_kernels search_f32 search_f16 search_u8 search_i8 search_sq8 search_pq search_pqlut search_pqlut2 search_pqlut3 search_pqlut4 search_pair server sharded paged_kernels \
            distance_kernels build_kernels pq_kernels
 OBJS    := $(SOURCES:%=$(OBJDIR)/%.o)
 HEADERS := $(wildcard $(CSRC)/*.h) include/dann.h

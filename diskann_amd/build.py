@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdann_hip.so")
 SOURCES = ["api.hip", "search_kernels.hip", "search_f32.hip", "search_f16.hip", "search_u8.hip", "search_i8.hip",
-           "search_sq8.hip", "search_pq.hip", "search_pqlut.hip", "search_pair.hip", "server.hip", "sharded.hip", "paged_kernels.hip", "distance_kernels.hip", "build_kernels.hip", "pq_kernels.hip"]
+           "search_sq8.hip", "search_pq.hip", "search_pqlut.hip", "search_pqlut2.hip", "search_pqlut3.hip", "search_pqlut4.hip", "search_pair.hip", "server.hip", "sharded.hip", "paged_kernels.hip", "distance_kernels.hip", "build_kernels.hip", "pq_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-flush-denormals-to-zero=0" if False else "-fno-gpu-flush-denormals-to-zero", "-Wall",
          "-Wno-unused-function"]

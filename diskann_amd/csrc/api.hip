@@ -541,10 +541,11 @@ int32_t dann_pq_pack_neighbors(dann_index* idx) try {
     CHECK_IDX(idx);
     // (only pq_search_kernel reads the packed rows: an index it can never serve -- pq_lut_shape / plain_mode -- would pay
     // 1.3 KB per node for nothing)
-    if (idx->cfg.dtype != DT_PQ || idx->cfg.pq_chunks > 16u || idx->cfg.inline_tags || idx->cfg.max_degree > 64u ||
-        idx->cfg.num_start_points > 64u) {
-        set_error("dann_pq_pack_neighbors: a DANN_PQ index of at most 16 chunks, degree <= 64, at most 64 start points, "
-                  "without inline tags");
+    const uint32_t code_words = (idx->cfg.pq_chunks + 15u) / 16u;  // 16-byte words of a code row
+    if (idx->cfg.dtype != DT_PQ || idx->cfg.pq_chunks > 64u || idx->cfg.inline_tags || idx->cfg.max_degree > 64u ||
+        idx->cfg.num_start_points > 64u || idx->cfg.row_stride < 16u * code_words || idx->cfg.row_stride % 16u) {
+        set_error("dann_pq_pack_neighbors: a DANN_PQ index of at most 64 chunks, degree <= 64, at most 64 start points, "
+                  "without inline tags, rows at a 16-byte stride");
         return DANN_EUNSUPPORTED;
     }
     // the rebuild rewrites (and may free) what a concurrent dann_search_submit's relaunch reads through idx->view():
@@ -552,7 +553,7 @@ int32_t dann_pq_pack_neighbors(dann_index* idx) try {
     DANN_MUTATION(idx);
     const uint32_t R = idx->cfg.max_degree;
     const uint32_t codes_off = ((R + 1u) * 4u + 15u) & ~15u;
-    const uint32_t stride = (codes_off + 16u * R + 63u) & ~63u;
+    const uint32_t stride = (codes_off + 16u * code_words * R + 63u) & ~63u;
     const size_t bytes = (size_t)idx->nslots * stride;
     if (idx->pq_pack_bytes < bytes) {
         if (idx->d_pq_pack) (void)hipFree(idx->d_pq_pack);

@@ -224,6 +224,10 @@ DANN_DECL_LAUNCH(sq8);
 DANN_DECL_LAUNCH(pq);
 #undef DANN_DECL_LAUNCH
 int32_t launch_search_pqlut(const SearchArgs& a, size_t lds, hipStream_t stream);  // search_pqlut.hip (SearchArgs::pqlut)
+int32_t launch_search_pqlut_g1(const SearchArgs& a, size_t lds, hipStream_t stream);
+int32_t launch_search_pqlut_g2(const SearchArgs& a, size_t lds, hipStream_t stream);  // search_pqlut2.hip .. 4: 17 .. 64 chunks
+int32_t launch_search_pqlut_g3(const SearchArgs& a, size_t lds, hipStream_t stream);
+int32_t launch_search_pqlut_g4(const SearchArgs& a, size_t lds, hipStream_t stream);
 int32_t launch_search_pair(const SearchArgs& a, size_t lds, hipStream_t stream);   // search_pair.hip (SearchArgs::pair)
 // launch + re-run queries whose visited table overflowed with a table twice as large (up to 2^15)
 int32_t search_with_retry(dann_index* idx, SearchCtx& ctx, SearchArgs a);

@@ -699,26 +699,28 @@ struct Buf {
     }
 };
 
-// dann_pq_pack_neighbors: one wavefront per node.  Row = [len][ids x R][pad to 16][16-byte code row of neighbour 0 .. R-1]
+// dann_pq_pack_neighbors: one wavefront per node.  Row = [len][ids x R][pad to 16][code row (16 bytes per 16 chunks) of neighbour 0 .. R-1]
 // (neighbours beyond the length, and ids beyond the index, get zero code rows: they are never candidates).
 __global__ __launch_bounds__(256) void pq_pack_kernel(IndexView ix, uint8_t* pack, uint32_t stride, uint32_t codes_off) {
     const uint32_t node = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (node >= ix.nslots) return;
     const uint32_t R = ix.max_degree;
+    const uint32_t cw = (ix.pq_chunks + 15u) / 16u;  // 16-byte words of a code row (1 .. 4)
     const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
     uint8_t* prow = pack + (uint64_t)node * stride;
     const uint32_t len = arow[0] < R ? arow[0] : R;
     for (uint32_t w = lane; w < codes_off / 4u; w += 64u)
         reinterpret_cast<uint32_t*>(prow)[w] = w <= R ? arow[w] : 0u;  // (the stored length word, unclamped, as the adjacency row has it)
-    for (uint32_t j = lane; j < R; j += 64u) {
+    for (uint32_t t = lane; t < R * cw; t += 64u) {
+        const uint32_t j = t / cw, g = t % cw;
         uint4 code = make_uint4(0u, 0u, 0u, 0u);
         if (j < len) {
             const uint32_t id = arow[1u + j];
-            if (id < ix.nslots) code = *reinterpret_cast<const uint4*>(ix.rows + (uint64_t)id * ix.row_stride);
+            if (id < ix.nslots) code = *reinterpret_cast<const uint4*>(ix.rows + (uint64_t)id * ix.row_stride + 16u * g);
         }
-        *reinterpret_cast<uint4*>(prow + codes_off + 16u * j) = code;
+        *reinterpret_cast<uint4*>(prow + codes_off + 16u * t) = code;
     }
-    for (uint32_t o = codes_off + 16u * R + 4u * lane; o < stride; o += 256u) *reinterpret_cast<uint32_t*>(prow + o) = 0u;
+    for (uint32_t o = codes_off + 16u * cw * R + 4u * lane; o < stride; o += 256u) *reinterpret_cast<uint32_t*>(prow + o) = 0u;
 }
 
 }  // namespace

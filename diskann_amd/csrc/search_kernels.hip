@@ -343,7 +343,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             std::lock_guard<std::mutex> lk(idx->stat_mu);
             cal = idx->calib[key];
         }
-        if (a.pqlut) cal.waves = 16u;  // (pq_search_kernel is compiled for four wavefronts per SIMD)
+        if (a.pqlut) cal.waves = pq_lut_waves_per_cu(a.ix.pq_chunks);  // (what pq_search_kernel's table size is compiled for)
         if (!cal.waves) {  // queries per CU the registers of this instantiation allow (512 VGPRs per SIMD lane)
             int regs = 0;
             a.ht_entries = 256;
@@ -391,13 +391,13 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
             }
         }
         if (a.pqlut) {
-            // one 16-bit table: registers cap the CU at 16 queries = 8 LDS granules each; the table takes what is left of
-            // them (a sparse table costs nothing but its wipe), or -- a larger 90th percentile of comparisons -- the
-            // first step whose open capacity holds it with a tenth to spare
+            // one 16-bit table: registers cap the CU at 16 queries = 8 LDS granules each (8 / 4 queries beyond 16 / 48
+            // chunks); the table takes what is left of them (a sparse table costs nothing but its wipe), or -- a larger
+            // 90th percentile of comparisons -- the first step whose open capacity holds it with a tenth to spare
             const uint32_t cap = cal.cap_ids ? cal.cap_ids : prior_visited_cap(a);
             const uint32_t fixed = pq_lds_layout(pq_lut_qs(a), 0, 0).total;
             uint32_t words = 0, ovw = 0;
-            for (uint32_t g = kLdsGranules / 16u; g <= kLdsGranules && !words; ++g) {
+            for (uint32_t g = kLdsGranules / pq_lut_waves_per_cu(a.ix.pq_chunks); g <= kLdsGranules && !words; ++g) {
                 if (g * kLdsGranule <= fixed) continue;
                 uint32_t w = std::min<uint32_t>((g * kLdsGranule - fixed) / 4u / 64u * 64u, 32768u);
                 const uint32_t o = ht16_overflow_words(ht16_geometry(w, a.ix.nslots, ht16_kcap(idx)), false);

@@ -5,7 +5,8 @@
 // (adjacency row, then 16-byte code rows of which whole 64-byte sectors are fetched).  Measured at 1 M x 16 chunks,
 // L = 96 (profiles/r04_final_pq_summary.json): 0.02 of the HBM peak, 4.7 x its algorithmic bytes.
 //
-// What this kernel does instead (one wavefront per query, plain Knn search, at most 16 chunks, degree <= 64):
+// What this kernel does instead (one wavefront per query, plain Knn search, degree <= 64; at most 16 chunks in round 5,
+// at most 64 since round 6 -- NG = 1 .. 4 groups of 16 chunks, 64 table registers each: 4 / 2 / 2 / 1 wavefronts per SIMD):
 //   * the table lives in 64 vector registers per lane: entry (chunk c, centroid b) in register 4 c + (b >> 6) of lane
 //     b & 63.  A lookup is four ds_bpermute_b32 (every lane pulls from lane b & 63 of the chunk's four registers) and a
 //     select on b >> 6 -- the LDS crossbar, but no LDS footprint: ~10 KB of LDS per query, and the register budget of
@@ -29,7 +30,9 @@
 namespace dann {
 namespace {
 
-constexpr uint32_t kPqLutChunks = 16;  // chunks the register-resident table covers (4 registers each)
+constexpr uint32_t kPqLutChunks = 64;  // chunks the register-resident table covers at most (4 registers each)
+// groups of 16 chunks = code-row dwordx4 loads = 64 table registers: the instantiation a chunk count takes
+__host__ __device__ inline uint32_t pq_lut_groups(uint32_t chunks) { return (chunks + 15u) / 16u; }
 
 // LDS of one query: the queue image ((id, distance) pairs: the merge scatters the register-resident queue here and
 // reloads it), two 64-word buffers of the merge's slow path, the visited table
@@ -148,26 +151,29 @@ __device__ __forceinline__ void pq_lut_word(float& accum, uint32_t w, float t0, 
           [t13] "v"(t13), [t14] "v"(t14), [t15] "v"(t15));
 }
 
-// sum over the 16 chunk tables of one 16-byte code row (chunk order, f32, from 0.0).  Every lane must be active: a
-// permute delivers zero from a source lane that is switched off.
-__device__ __forceinline__ float pq_lut_sum(const float (&lut)[4 * kPqLutChunks], const uint4& w) {
+// sum over the 16 NG chunk tables of one code row of 16 NG bytes (chunk order, f32, from 0.0).  Every lane must be active:
+// a permute delivers zero from a source lane that is switched off.
+template <int NG>
+__device__ __forceinline__ float pq_lut_sum(const float (&lut)[64 * NG], const uint4 (&code)[NG]) {
     float accum = 0.0f;
-    pq_lut_word(accum, w.x, lut[0], lut[1], lut[2], lut[3], lut[4], lut[5], lut[6], lut[7], lut[8], lut[9], lut[10],
-                lut[11], lut[12], lut[13], lut[14], lut[15]);
-    pq_lut_word(accum, w.y, lut[16], lut[17], lut[18], lut[19], lut[20], lut[21], lut[22], lut[23], lut[24], lut[25],
-                lut[26], lut[27], lut[28], lut[29], lut[30], lut[31]);
-    pq_lut_word(accum, w.z, lut[32], lut[33], lut[34], lut[35], lut[36], lut[37], lut[38], lut[39], lut[40], lut[41],
-                lut[42], lut[43], lut[44], lut[45], lut[46], lut[47]);
-    pq_lut_word(accum, w.w, lut[48], lut[49], lut[50], lut[51], lut[52], lut[53], lut[54], lut[55], lut[56], lut[57],
-                lut[58], lut[59], lut[60], lut[61], lut[62], lut[63]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float* t = lut + 64 * g;
+        const uint4 w = code[g];
+        pq_lut_word(accum, w.x, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14],
+                    t[15]);
+        pq_lut_word(accum, w.y, t[16], t[17], t[18], t[19], t[20], t[21], t[22], t[23], t[24], t[25], t[26], t[27], t[28],
+                    t[29], t[30], t[31]);
+        pq_lut_word(accum, w.z, t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39], t[40], t[41], t[42], t[43], t[44],
+                    t[45], t[46], t[47]);
+        pq_lut_word(accum, w.w, t[48], t[49], t[50], t[51], t[52], t[53], t[54], t[55], t[56], t[57], t[58], t[59], t[60],
+                    t[61], t[62], t[63]);
+    }
     return accum;
 }
 
-#ifndef DANN_PQ_KERNEL_ATTR
-#define DANN_PQ_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-template <int OP, int QS, bool PACK>
-__global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(SearchArgs a) {
+template <int OP, int QS, bool PACK, int NG>
+__device__ __forceinline__ void pq_search_body(const SearchArgs& a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const IndexView& ix = a.ix;
     const uint32_t lane = threadIdx.x;
@@ -195,13 +201,14 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     // ---- the query's lookup table, into registers: lut[4 c + j] of lane l = entry (chunk c, centroid 64 j + l).  One
     // chunk per trip of a rolled loop (four entries per lane), the array rotated by four registers per trip: register
     // indices stay compile-time constants, the entry arithmetic is instantiated four times, not 64.
-    float lut[4 * kPqLutChunks];
+    constexpr int NLUT = 64 * NG;
+    float lut[NLUT];
 #pragma unroll
-    for (int k = 0; k < 4 * (int)kPqLutChunks; ++k) lut[k] = 0.0f;
+    for (int k = 0; k < NLUT; ++k) lut[k] = 0.0f;
     {
         const float* q = reinterpret_cast<const float*>(a.queries) + (uint64_t)qi * ix.dim;
 #pragma nounroll
-        for (uint32_t c = 0; c < kPqLutChunks; ++c) {
+        for (uint32_t c = 0; c < 16u * NG; ++c) {
             float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (c < ix.pq_chunks) {
                 const uint32_t s0 = ix.pq_offsets[c], e0 = ix.pq_offsets[c + 1];
@@ -210,9 +217,9 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
                     v[j] = pq_lut_entry<OP>(q + s0, ix.pq_pivots + (uint64_t)(64u * j + lane) * ix.dim + s0, e0 - s0);
             }
 #pragma unroll
-            for (int k = 0; k < 4 * (int)kPqLutChunks - 4; ++k) lut[k] = lut[k + 4];
+            for (int k = 0; k < NLUT - 4; ++k) lut[k] = lut[k + 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lut[4 * (int)kPqLutChunks - 4 + j] = v[j];
+            for (int j = 0; j < 4; ++j) lut[NLUT - 4 + j] = v[j];
         }
     }
     __syncthreads();  // the table is wiped
@@ -401,17 +408,23 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
 
     // the row of `node`: length (every lane), neighbour `lane`, and -- packed layout -- that neighbour's code row
     const uint32_t jn = lane < R ? lane : R - 1u;
-    auto fetch = [&](uint32_t node, uint32_t& lenv, uint32_t& idv, uint4& codev) {
+    auto fetch = [&](uint32_t node, uint32_t& lenv, uint32_t& idv, uint4 (&codev)[NG]) {
         if constexpr (PACK) {
             const uint8_t* prow = ix.pq_pack + (uint64_t)node * ix.pq_pack_stride;
             lenv = *reinterpret_cast<const uint32_t*>(prow);
             idv = reinterpret_cast<const uint32_t*>(prow)[1u + jn];
-            codev = *reinterpret_cast<const uint4*>(prow + ix.pq_pack_codes + 16u * jn);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                codev[g] = *reinterpret_cast<const uint4*>(prow + ix.pq_pack_codes + 16u * NG * jn + 16u * g);
         } else {
             const uint32_t* arow = ix.adj + (uint64_t)node * ix.adj_stride;
             lenv = arow[0];
             idv = arow[1u + jn];
         }
+    };
+    auto code_row = [&](uint32_t id, uint4 (&codev)[NG]) {  // (PQ rows: 16 NG bytes at a stride of at least that)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) codev[g] = *reinterpret_cast<const uint4*>(ix.rows + (uint64_t)id * ix.row_stride + 16u * g);
     };
 
     // ---- start points: frozen slots [capacity, capacity + nstart) (index.rs:1950-1958), the candidates of "hop 0" ----
@@ -420,14 +433,17 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
         const uint32_t id = ix.capacity + (on ? lane : 0u);
         if (ballot64(ht16_insert_flat(ht, h16, id, on, cbi + lane) == 2u)) status = kOverflow;  // (a table of >= 128 slots: never)
         htc = ns;
-        const uint4 w = *reinterpret_cast<const uint4*>(ix.rows + (uint64_t)id * ix.row_stride);
-        const float d = pq_lut_sum(lut, w);
+        uint4 w[NG];
+        code_row(id, w);
+        const float d = pq_lut_sum<NG>(lut, w);
         cmps = ns;
         merge(on, d, id);
     }
 
     uint32_t pfn = kEmpty, pf_len = 0, pf_id = kEmpty;  // the row requested ahead: its node (kEmpty: none)
-    uint4 pf_code = {0u, 0u, 0u, 0u};
+    uint4 pf_code[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) pf_code[g] = make_uint4(0u, 0u, 0u, 0u);
     while (!status) {
         // ---- pop: the closest unexpanded entry (queue.rs:297-313) and the one after it, the node the next hop expands
         // unless a new candidate gets in front of it
@@ -456,13 +472,16 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
 
         // ---- the node's row: requested a hop ahead when the prediction held; then the request for the predicted next one
         uint32_t lenv, idv;
-        uint4 codev = {0u, 0u, 0u, 0u};
+        uint4 codev[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) codev[g] = make_uint4(0u, 0u, 0u, 0u);
         if (node != pfn) {
             fetch(node, lenv, idv, codev);
         } else {
             lenv = pf_len;
             idv = pf_id;
-            codev = pf_code;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) codev[g] = pf_code[g];
         }
         pfn = next;
         fetch(next != kEmpty ? next : 0u, pf_len, pf_id, pf_code);
@@ -510,8 +529,8 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
         cmps += nnew;
 
         // ---- distances: the new neighbours' code rows (already here in the packed layout), sixteen table lookups each
-        if constexpr (!PACK) codev = *reinterpret_cast<const uint4*>(ix.rows + (uint64_t)(isnew ? id : 0u) * ix.row_stride);
-        const float d = pq_lut_sum(lut, codev);
+        if constexpr (!PACK) code_row(isnew ? id : 0u, codev);
+        const float d = pq_lut_sum<NG>(lut, codev);
         merge(isnew, d, id);
     }
 
@@ -562,10 +581,34 @@ __global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR void pq_search_kernel(Se
     }
 }
 
+// The kernels: one per table size, compiled for the wavefronts per SIMD its registers allow (512 per SIMD lane): 64
+// table registers + ~64 of state at four wavefronts, 128 / 192 + state at two, 256 + state at one (the table's upper half
+// in accumulation registers, moved through v_accvgpr_read in front of its permutes).
+#ifndef DANN_PQ_KERNEL_ATTR
+#define DANN_PQ_KERNEL_ATTR(W) __attribute__((amdgpu_waves_per_eu(W, W)))
+#endif
+template <int OP, int QS, bool PACK>
+__global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR(4) void pq_search_kernel(SearchArgs a) {
+    pq_search_body<OP, QS, PACK, 1>(a);
+}
+template <int OP, int QS, bool PACK>
+__global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR(2) void pq_search_kernel_g2(SearchArgs a) {
+    pq_search_body<OP, QS, PACK, 2>(a);
+}
+template <int OP, int QS, bool PACK>
+__global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR(2) void pq_search_kernel_g3(SearchArgs a) {
+    pq_search_body<OP, QS, PACK, 3>(a);
+}
+template <int OP, int QS, bool PACK>
+__global__ __launch_bounds__(kWave) DANN_PQ_KERNEL_ATTR(1) void pq_search_kernel_g4(SearchArgs a) {
+    pq_search_body<OP, QS, PACK, 4>(a);
+}
+
 // what the kernel serves (host side; the table geometry is checked by the caller)
 inline bool pq_lut_shape(const SearchArgs& a) {
     return a.ix.dtype == DT_PQ && plain_mode(a) && !a.team && !a.grid && !a.srv.ring && !a.rec_ids && !a.range_ids &&
            !a.qslots && a.out_ids && a.ix.pq_chunks <= kPqLutChunks && a.ix.row_stride % 16u == 0u &&
+           a.ix.row_stride >= 16u * pq_lut_groups(a.ix.pq_chunks) &&
            std::max(a.l_value + a.ix.nstart, a.qcap_max) <= 4u * (uint32_t)kWave && a.ix.nstart >= 1u &&
            (a.ix.metric == M_L2 || a.ix.metric == M_IP);
 }
@@ -573,8 +616,14 @@ inline uint32_t pq_lut_qs(const SearchArgs& a) {
     const uint32_t q = a.l_value + a.ix.nstart;
     return q <= 64u ? 1u : q <= 128u ? 2u : 4u;
 }
+// queries per CU the registers of a table size allow
+inline uint32_t pq_lut_waves_per_cu(uint32_t chunks) {
+    const uint32_t g = pq_lut_groups(chunks);
+    return g <= 1u ? 16u : g <= 3u ? 8u : 4u;
+}
 
-inline int32_t launch_pq_lut(const SearchArgs& a, size_t lds, hipStream_t stream) {
+template <int NG>
+inline int32_t launch_pq_lut_g(const SearchArgs& a, size_t lds, hipStream_t stream) {
     auto go = [&](auto kern) -> int32_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -588,8 +637,14 @@ inline int32_t launch_pq_lut(const SearchArgs& a, size_t lds, hipStream_t stream
     };
     const bool l2 = a.ix.metric == M_L2, pack = a.ix.pq_pack != nullptr;
     const uint32_t qs = pq_lut_qs(a);
-#define DANN_PQ_GO(OP, QS)                                          \
-    return pack ? go(pq_search_kernel<OP, QS, true>) : go(pq_search_kernel<OP, QS, false>)
+#define DANN_PQ_K(OP, QS, PK)                                          \
+    [&]() -> int32_t {                                                 \
+        if constexpr (NG == 1) return go(pq_search_kernel<OP, QS, PK>); \
+        else if constexpr (NG == 2) return go(pq_search_kernel_g2<OP, QS, PK>); \
+        else if constexpr (NG == 3) return go(pq_search_kernel_g3<OP, QS, PK>); \
+        else return go(pq_search_kernel_g4<OP, QS, PK>);               \
+    }()
+#define DANN_PQ_GO(OP, QS) return pack ? DANN_PQ_K(OP, QS, true) : DANN_PQ_K(OP, QS, false)
     if (l2) {
         if (qs == 1) DANN_PQ_GO(OP_L2, 1);
         if (qs == 2) DANN_PQ_GO(OP_L2, 2);
@@ -599,6 +654,7 @@ inline int32_t launch_pq_lut(const SearchArgs& a, size_t lds, hipStream_t stream
     if (qs == 2) DANN_PQ_GO(OP_IP, 2);
     DANN_PQ_GO(OP_IP, 4);
 #undef DANN_PQ_GO
+#undef DANN_PQ_K
 }
 
 }  // namespace

@@ -392,12 +392,12 @@ int32_t dann_load_vectors_bin(dann_index* idx, const char* path, uint32_t first_
 /* attach the PQ schema of a DANN_PQ index: pivots 256 x dim f32 row-major, chunk_offsets pq_chunks + 1
  * (FixedChunkPQTable::new, fixed_chunk_pq_table.rs:105-140) */
 int32_t dann_set_pq_table(dann_index* idx, const float* pivots, const uint32_t* chunk_offsets);
-/* Optional GPU-private search layout of a DANN_PQ index (at most 16 chunks, no inline tags): for every slot one
+/* Optional GPU-private search layout of a DANN_PQ index (at most 64 chunks, no inline tags): for every slot one
  * 64-byte-aligned row holding its adjacency list AND the code rows of its neighbours, so that a hop of the beam search
  * (expand_beam over PQ rows: diskann-providers/src/model/pq/fixed_chunk_pq_table.rs:82-100 per neighbour) is one
- * contiguous read instead of one adjacency row plus one 16-byte gather per neighbour.  Built from the index's current
- * rows and adjacency; costs (capacity + start points) x round_up(16-rounded 4 (R + 1) + 16 R, 64) bytes of device
- * memory.  Search results never depend on it.  Any later mutation of the index (rows, adjacency, build, load) drops
+ * contiguous read instead of one adjacency row plus one code-row gather per neighbour.  Built from the index's current
+ * rows and adjacency; costs (capacity + start points) x round_up(16-rounded 4 (R + 1) + C R, 64) bytes of device
+ * memory, C = the chunk count rounded up to 16.  Search results never depend on it.  Any later mutation of the index (rows, adjacency, build, load) drops
  * the layout -- searches fall back to the plain rows -- until this is called again.  DANN_EUNSUPPORTED for other
  * indexes. */
 int32_t dann_pq_pack_neighbors(dann_index* idx);

@@ -46,6 +46,13 @@ CASES = [
     (oracle.L2, 100, 10, 64, 3),        # uneven chunks, fewer than 16 of them (zero tables beyond), the full 64 lanes
     (oracle.INNER_PRODUCT, 96, 1, 7, 2),  # one chunk, short lists
     (oracle.L2, 64, 16, 33, 64),        # 64 start points: the first merge takes the slow path
+    # round 6: 17 .. 64 chunks -- two, three and four groups of 64 table registers, code rows of 32 / 48 / 64 bytes
+    (oracle.L2, 128, 32, 32, 1),
+    (oracle.INNER_PRODUCT, 111, 17, 40, 2),   # one chunk into the second group, uneven chunk lengths
+    (oracle.L2, 192, 48, 64, 1),
+    (oracle.INNER_PRODUCT, 160, 37, 20, 3),
+    (oracle.L2, 256, 64, 64, 2),
+    (oracle.INNER_PRODUCT, 130, 64, 33, 1),   # chunks of two and three elements
 ]
 
 
@@ -53,13 +60,15 @@ CASES = [
 def test_pq_lut_kernel_equals_the_oracle(metric, dim, nchunks, R, nstart):
     rng = np.random.default_rng(900 + nchunks + R)
     oix, gix = _pq_index(rng, 5000, dim, nchunks, R, nstart, metric, min_len=0 if R == 7 else None)
+    wide = nchunks > 16
     for packed in (False, True):
         if packed:
             gix.pq_pack_neighbors()
-        for nq in (1, 33, 400):
+        for nq in ((1, 130) if wide else (1, 33, 400)):
             q = rng.standard_normal((nq, dim)).astype(np.float32)
-            for L, k in ((1, 1), (10, 10), (64 - nstart, 10), (65, 65), (100, 7), (128 - nstart, 300), (129, 10),
-                         (256 - nstart, 20)):
+            for L, k in (((1, 1), (10, 10), (64 - nstart, 10), (100, 7), (129, 10), (256 - nstart, 20)) if wide else
+                         ((1, 1), (10, 10), (64 - nstart, 10), (65, 65), (100, 7), (128 - nstart, 300), (129, 10),
+                          (256 - nstart, 20))):
                 if L < 1:
                     continue
                 _check(gix, oix, q, L, k, (packed, nq, L, k))
@@ -75,13 +84,40 @@ def test_pq_lut_kernel_equals_the_oracle(metric, dim, nchunks, R, nstart):
     assert fam == {"one_wave"} and np.array_equal(oi, gi) and np.array_equal(bits(od), bits(gd))
 
 
-def test_pq_lut_kernel_more_than_16_chunks_stays_on_the_lds_table():
+def test_pq_lut_kernel_more_than_64_chunks_stays_on_the_lds_table():
     rng = np.random.default_rng(37)
-    oix, gix = _pq_index(rng, 3000, 111, 37, 16, 1, oracle.L2)
+    oix, gix = _pq_index(rng, 3000, 140, 70, 16, 1, oracle.L2)
     with pytest.raises(da.DannError) as e:
         gix.pq_pack_neighbors()
     assert e.value.status == da._ffi.EUNSUPPORTED
-    _check(gix, oix, rng.standard_normal((40, 111)).astype(np.float32), 48, 10, "37 chunks", family="one_wave")
+    _check(gix, oix, rng.standard_normal((40, 140)).astype(np.float32), 48, 10, "70 chunks", family="one_wave")
+
+
+@pytest.mark.parametrize("nchunks", [32, 48, 64])
+def test_wide_pq_lut_kernel_freezes_and_spills(nchunks):
+    """the wide tables (2 .. 4 register groups) with explicit visited tables that freeze after a few hops: spill tables,
+    the re-run of queries that outgrow them, plain and packed rows -- all equal to one wave per query"""
+    rng = np.random.default_rng(nchunks)
+    n, dim, R, nq = 12000, 2 * nchunks, 32, 3000
+    oix, gix = _pq_index(rng, n, dim, nchunks, R, 1, oracle.L2)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    gix.debug_set(tune_off=32)
+    (ri, rd, rst), fam = gix.last_family(lambda: gix.search(da.Knn(40), q, 10))
+    assert fam == {"one_wave"}, fam
+    gix.debug_set(tune_off=None)
+    for packed in (False, True):
+        if packed:
+            gix.pq_pack_neighbors()
+        for words in (0, 64, 256):
+            gix.set_visited_bits(words)
+            (gi, gd, gst), fam = gix.last_family(lambda: gix.search(da.Knn(40), q, 10))
+            assert "pq_lut" in fam and fam <= {"pq_lut", "one_wave"}, (fam, words)
+            assert not gst["status"].any(), words
+            assert np.array_equal(gi, ri) and np.array_equal(bits(gd), bits(rd)), words
+            assert np.array_equal(gst["cmps"], rst["cmps"]) and np.array_equal(gst["hops"], rst["hops"]), words
+        gix.set_visited_bits(0)
+    oi, od, oc, ost = oix.search_batch(q[:200], 40, 1, 10)
+    assert np.array_equal(ri[:200], oi) and np.array_equal(bits(rd[:200]), bits(od))
 
 
 def test_pq_lut_kernel_freezes_spills_and_gives_up_like_one_wave_per_query():
