@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-pq-pack", action="store_true", help="PQ leg: search the plain rows (no dann_pq_pack_neighbors)")
     ap.add_argument("--large-int-n", type=int, default=0, help="large_u8 / large_sq8 legs: number of rows (0 = 10 M)")
     ap.add_argument("--only", default="", choices=["", "large", "large768", "large768f16", "large_u8", "large_sq8", "gather", "sq8", "u8", "pq",
-                                                   "build768", "cpu-distance"],
+                                                   "pq768", "build768", "cpu-distance"],
                     help="run ONE secondary workload and print its object (profiles/run_profiles_r02.sh): the large "
                          "index (first / second --large spec), the gather-distance kernel on a 5 GB store, the SQ-8 or "
                          "u8 search kernel")
@@ -209,6 +209,16 @@ def main():
 
     if args.only == "build768":
         print(json.dumps(_strict({"build_large": build_large_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
+        return
+    if args.only == "pq768":
+        # config 5's row shape: 1 M x 768, R = 64 / 56, l_build 128; codes of --pq-chunks bytes (default 48 here), searched
+        # with the register-resident table, reranked on the f32 rows -- beside the f16 rows searched at full precision
+        args.dim, args.max_degree, args.pruned_degree, args.l_build = 768, 64, 56, 128
+        if args.pq_chunks == 16:
+            args.pq_chunks = 48
+        args.pq768 = True
+        args.only = "pq"
+        print(json.dumps(_strict({"pq768": only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
         return
     if args.only in ("gather", "sq8", "u8", "pq"):
         print(json.dumps(_strict({args.only: only_variant(args, torch, da, _ffi.lib(), _ffi, dev, local)})), flush=True)
@@ -609,7 +619,30 @@ def main():
             out["other_configs"]["host_pointer_search_batch"] = {
                 "queries_per_call": args.nq, "qps_pcie_inclusive": args.nq / th, "ms_per_call": th * 1e3,
                 "ids_identical_to_device_path": bool(np.array_equal(h_ids, evaluate.last_ids)),
-                "note": "host (pageable) buffers in and out; never the reported `value`"}
+                "fraction_of_device_resident_rate": (args.nq / th) / (qps / world),
+                "note": "host (pageable) buffers in and out: three lanes (threads, each with its own stream and pinned ring "
+                        "slot) take 16 384-query chunks round robin -- copy in, kernel, copy out; never the reported `value`"}
+            try:  # the same call on buffers the caller page-locked (hipHostMalloc): ONE launch, the kernel reads the queries
+                  # from and writes the results to the caller's memory itself -- no copy, no chunks
+                pq_ = torch.empty(qh_host.shape, dtype=torch.float32, pin_memory=True)
+                pq_.numpy()[...] = qh_host
+                pi_ = torch.empty((args.nq, k), dtype=torch.int32, pin_memory=True)
+                pd_ = torch.empty((args.nq, k), dtype=torch.float32, pin_memory=True)
+
+                def pinned_call():
+                    _ffi.check(lib.dann_search_batch(prov._h, pq_.data_ptr(), args.nq, chosen, W, k, pi_.data_ptr(),
+                                                     pd_.data_ptr(), None), "dann_search_batch")
+                pinned_call()
+                t_0 = time.perf_counter()
+                for _ in range(5):
+                    pinned_call()
+                tp = (time.perf_counter() - t_0) / 5
+                out["other_configs"]["host_pointer_search_batch"]["pinned_caller_buffers"] = {
+                    "qps_pcie_inclusive": args.nq / tp, "ms_per_call": tp * 1e3,
+                    "ids_identical_to_device_path": bool(np.array_equal(pi_.numpy().view(np.uint32), evaluate.last_ids)),
+                    "fraction_of_device_resident_rate": (args.nq / tp) / (qps / world)}
+            except Exception as e:  # noqa: BLE001
+                out["other_configs"]["host_pointer_search_batch"]["pinned_caller_buffers"] = {"error": str(e)[:200]}
             # the reference's serving model on one shared index: 16 host threads, one query per call
             try:
                 out["other_configs"]["concurrent_callers"] = callers_variant(prov, qh_host, chosen, k, same_as_oracle)
@@ -963,6 +996,30 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                                 d_st[:256].cpu().numpy(), family, pq_pivots=pivots_h, pq_offsets=bounds)
     except Exception as e:  # noqa: BLE001
         osample = {"error": str(e)[:200]}
+    f16_cmp = None
+    if getattr(args, "pq768", False):
+        # the same graph over the rows stored as f16 (Full<f16>, config 5's replica), searched at full precision: first L
+        # of the sweep that reaches the recall the PQ + Rerank search reached
+        p16 = da.Provider(da.F16, da.L2, dim, args.n, args.max_degree, base[medoid:medoid + 1].half().cpu().numpy(), device=local)
+        for s0 in range(0, args.n, 1 << 18):
+            p16.set_elements(s0, base[s0:s0 + (1 << 18)].half().cpu().numpy())
+        p16.upload_graph(full_prov.download_graph())
+        q16 = queries.half().contiguous()
+        L16, rec16, st16, run16, _ = _sweep(torch, lib, _ffi, p16, q16, args.nq, k, W, gt, len(gt),
+                                            [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 32, 36, 40, 48, 56, 64, 80, 96, 128],
+                                            min(rec, args.target_recall) if args.target_recall > 0 else 0.95)
+        if L16:
+            run16(L16)
+            p16.kernel_time_reset()
+            for _ in range(5):
+                run16(L16)
+            torch.cuda.synchronize()
+            ms16, n16 = p16.kernel_time(0)
+            f16_cmp = {"rows": "f16, 1536 B", "L": L16, "recall_at_10_vs_exact_f32": round(rec16, 4),
+                       "mean_cmps": float(st16[:, 0].mean()), "avg_kernel_ms": ms16 / max(n16, 1),
+                       "qps": args.nq / (ms16 / max(n16, 1) * 1e-3),
+                       "bytes_per_point": dim * 2, "pq_bytes_per_point": nch}
+        p16.close() if hasattr(p16, "close") else None
     traffic = None
     try:  # fabric traffic of the search kernel from the committed PMC pass (rocprofv3 cannot run inside bench.py)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pq_latest.json")))
@@ -975,7 +1032,7 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
         pass
     return {"oracle_sample": osample, "chunks": nch, "row_bytes": nch, "L": chosen, "recall_at_10_vs_exact_f32": round(rec, 4),
             "qps": args.nq / dt, "mean_cmps": float(st[:, 0].mean()), "mean_hops": float(st[:, 1].mean()),
-            "search_kernel_traffic": traffic,
+            "search_kernel_traffic": traffic, "full_precision_f16_same_graph": f16_cmp,
             "algorithmic_bytes_per_query": alg / args.nq, "graph": "the f32 index's graph (full-precision build)",
             "search_kernel": {"kernel": "pq_search_kernel" if family == "pq_lut" else "beam_search_kernel<DT_PQ>",
                               "kernel_family": family, "avg_kernel_ms": search_ms,
@@ -983,20 +1040,22 @@ def pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid
                               "algorithmic_bytes_per_launch": alg_search,
                               "algorithmic_GBps": alg_search / (search_ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": alg_search / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "bound": ("vector-instruction issue (profiles/r05_pq_*): the query's 16 x 256 f32 table lives in "
-                                        "64 VGPRs per lane and is looked up with ds_bpermute_b32 (4 permutes + a bit-field "
-                                        "select per chunk and candidate); ~10 KB of LDS and 128 VGPRs per query -> 16 queries "
-                                        "per CU; one contiguous read per hop with the packed layout") if family == "pq_lut" else
+                              "bound": (f"vector-instruction issue / LDS crossbar (profiles/r05_pq_*): the query's {nch} x 256 f32 table "
+                                        f"lives in {64 * ((nch + 15) // 16)} VGPRs per lane and is looked up with ds_bpermute_b32 (4 "
+                                        "permutes + a bit-field select per chunk and candidate); "
+                                        f"{16 if nch <= 16 else 8 if nch <= 48 else 4} queries per CU; one contiguous read "
+                                        "per hop with the packed layout") if family == "pq_lut" else
                                        ("LDS / latency, not HBM: 16-byte code rows (a 64-byte sector each), a 16 KB lookup "
                                         "table per query in LDS, one dependent LDS lookup per chunk and candidate"),
-                              "queries_per_cu": 16 if family == "pq_lut" else 6,
+                              "queries_per_cu": (16 if nch <= 16 else 8 if nch <= 48 else 4) if family == "pq_lut" else
+                                                max(1, 160 // (10 + nch)),
                               "table_lookups_per_launch": lds_lookups,
                               "table_lookups_per_s": lds_lookups / (search_ms * 1e-3),
                               "lut_build_flop_per_launch": lut_flop},
             "rerank_share_of_time": max(0.0, 1.0 - search_ms * 1e-3 / dt),
             "packed_neighbor_codes": None if t_pack is None else {
                 "seconds": round(t_pack, 4), "bytes": (args.n + 1) * ((((args.max_degree + 1) * 4 + 15) // 16 * 16 +
-                                                                       16 * args.max_degree + 63) // 64 * 64)},
+                                                                       (nch + 15) // 16 * 16 * args.max_degree + 63) // 64 * 64)},
             "train_seconds_kmeanspp_plus_10_lloyds_131072_rows": round(t_train, 3),
             "compress_seconds_incl_pcie": round(t_comp, 3)}
 
@@ -1647,7 +1706,7 @@ def only_variant(args, torch, da, lib, _ffi, dev, local):
         full.set_elements(0, base.cpu().numpy())
         full.build(da.build_config(args.pruned_degree, args.max_degree, args.l_build, intra_batch_candidates=da.IBC_NONE),
                    0, args.n, args.growth, args.max_batch)
-        gt = ground_truth(torch, base, queries, k)
+        gt = ground_truth(torch, base, queries[:10000] if getattr(args, "pq768", False) else queries, k)
         if args.L:  # profiling pass: fixed L
             args.target_recall = -1.0
         return pq_variant(args, torch, da, lib, _ffi, dev, local, base, queries, gt, medoid, k, W, full)

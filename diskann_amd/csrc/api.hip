@@ -10,6 +10,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "dann_device.h"
@@ -123,7 +126,7 @@ void SearchCtx::destroy() {
     *this = SearchCtx();
 }
 
-CtxLease::CtxLease(dann_index* i) : idx(i) {
+CtxLease::CtxLease(dann_index* i, bool try_only) : idx(i) {
     std::unique_lock<std::mutex> lk(idx->ctx_mu);
     for (;;) {
         if (!idx->ctx_free.empty()) {
@@ -147,6 +150,10 @@ CtxLease::CtxLease(dann_index* i) : idx(i) {
                 return;
             }
             ctx = c;
+            return;
+        }
+        if (try_only) {  // (a caller that can do without: no context is free and none may be created)
+            status = DANN_EBUSY;
             return;
         }
         idx->ctx_cv.wait(lk);
@@ -976,7 +983,24 @@ static int32_t first_failed_query(const dann_search_stats* stats, uint32_t nq, u
 }
 
 // queries per chunk of the host-pointer pipeline, and the batch size from which it is used
-constexpr uint32_t kHostChunk = 32768;
+constexpr uint32_t kHostChunk = 16384;
+
+namespace {
+// is [p, p + bytes) page-locked host memory the device can reach by DMA (hipHostMalloc / hipHostRegister)?  Then the
+// pipeline copies straight from / to it; pageable buffers travel through the context's pinned ring.
+bool host_pinned(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t at;
+    for (const void* q : {p, (const void*)(reinterpret_cast<const uint8_t*>(p) + bytes - 1)}) {
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();  // (a pageable pointer is an "invalid value" to the runtime: not an error of this call)
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+}  // namespace
 
 int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
                           uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
@@ -984,20 +1008,22 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     if (nq == 0) return DANN_OK;
     if (!queries || !out_ids || !out_dists) return DANN_EINVAL;
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
-    const bool pipeline_off = idx->dbg_u32(DANN_DBG_HOST_PIPELINE, 1u) == 0u;
-    const bool chunked = nq >= 2 * kHostChunk && !pipeline_off;
-    const uint32_t cq = chunked ? kHostChunk : nq;  // queries per device pass
-    // device staging owned by the context (grow-only): [0] queries, [1] ids | dists | stats in one block; the
-    // chunked form keeps two of each ([0]/[3] hold the two query buffers, [1] both output blocks)
+    const uint32_t pipeline_dbg = idx->dbg_u32(DANN_DBG_HOST_PIPELINE, 1u);  // 0 off, 1 default, 2 .. 8 lanes
+    const bool pipeline_off = pipeline_dbg == 0u;
+    const uint32_t host_chunk = std::max<uint32_t>(idx->dbg_u32(DANN_DBG_HOST_CHUNK, kHostChunk), 256u);
+    const bool chunked = nq >= 2 * host_chunk && !pipeline_off;
+    const uint32_t cq = chunked ? host_chunk : nq;  // queries per device pass
+    // device staging owned by the context (grow-only): [0] queries, [1] ids | dists | stats in one block (the chunked form:
+    // one of each per lane, in the lane's own context)
     const size_t ids_b = ((size_t)cq * k * 4 + 15) & ~(size_t)15, st_b = ((size_t)cq * sizeof(dann_search_stats) + 15) & ~(size_t)15;
     const size_t in_b = (size_t)cq * qb, out_b = 2 * ids_b + st_b;
-    if (int32_t rc = grow_stage(ctx, 0, in_b + 16)) return rc;
-    if (int32_t rc = grow_stage(ctx, 1, (chunked ? 2 : 1) * out_b + 16)) return rc;
-    if (chunked)
-        if (int32_t rc = grow_stage(ctx, 3, in_b + 16)) return rc;
+    if (!chunked) {
+        if (int32_t rc = grow_stage(ctx, 0, in_b + 16)) return rc;
+        if (int32_t rc = grow_stage(ctx, 1, out_b + 16)) return rc;
+    }
     // pinned host staging: copies from / to pageable memory are neither asynchronous nor fast on ROCm 7.2
-    const bool pinned = chunked || in_b + out_b <= (1u << 20);
-    const size_t h_need = chunked ? 2 * (in_b + out_b) : (size_t)1 << 20;
+    const bool pinned = !chunked && in_b + out_b <= (1u << 20);
+    const size_t h_need = (size_t)1 << 20;
     if (pinned && ctx.h_stage_bytes < h_need) {
         if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
         ctx.h_stage = nullptr;
@@ -1035,63 +1061,168 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
         if (out_stats) memcpy(out_stats, stats.data(), (size_t)nq * sizeof(dann_search_stats));
         return first_failed_query(stats.data(), nq, 0);
     }
-    // ---- chunked pipeline: while the kernel of chunk i runs on the context's stream, the copy stream carries chunk
-    // i + 1's queries up and chunk i - 1's results down, and the host moves them between the caller's (pageable)
-    // buffers and the pinned ring.  The kernel call itself blocks (it waits on its own HIP events), so everything
-    // that should overlap with it is enqueued before it.
-    if (!ctx.copy_stream) DANN_HIP(hipStreamCreateWithFlags(&ctx.copy_stream, hipStreamNonBlocking));
-    for (hipEvent_t& e : ctx.chunk_ev)
-        if (!e) DANN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    uint8_t* hs = reinterpret_cast<uint8_t*>(ctx.h_stage);
-    uint8_t* h_in[2] = {hs, hs + in_b};
-    uint8_t* h_out[2] = {hs + 2 * in_b, hs + 2 * in_b + out_b};
-    void* d_in[2] = {ctx.stage[0], ctx.stage[3]};
-    uint8_t* d_out[2] = {reinterpret_cast<uint8_t*>(ctx.stage[1]), reinterpret_cast<uint8_t*>(ctx.stage[1]) + out_b};
-    hipEvent_t up_done[2] = {ctx.chunk_ev[0], ctx.chunk_ev[1]}, down_done[2] = {ctx.chunk_ev[2], ctx.chunk_ev[3]};
+    // ---- chunked pipeline: up to three lanes -- the calling thread and two helpers, each with a search context (stream,
+    // device staging, pinned ring slot) of its own -- take the chunks round robin; a lane runs copy in, kernel, copy out
+    // of its chunk back to back on its stream, and the lanes overlap one another: while one lane's kernel drains (the
+    // last queries of a batch leave most of the chip idle) or its host thread copies between the caller's pageable
+    // buffers and the ring, another lane's kernel has the chip.  Rounds 3-5 ran the chunks' kernels one after the other
+    // with the calling thread's copies between them (11.7 M QPS on 100 000 queries where the device-resident call does
+    // 18.6 M).  Buffers the caller page-locked (hipHostMalloc / hipHostRegister) need no ring: the DMA reads and writes
+    // them directly.
+    const bool q_direct = host_pinned(queries, (size_t)nq * qb);
+    const bool o_direct = host_pinned(out_ids, (size_t)nq * k * 4) && host_pinned(out_dists, (size_t)nq * k * 4);
+    int dev = 0;
+    DANN_HIP(hipGetDevice(&dev));
+    // ---- no copies at all: page-locked, device-mapped caller buffers are read and written by the search kernel itself
+    // (a query is read once, when its wavefront stages it; 51 MB in and 8 MB out over the 5 ms of a 100 000-query launch
+    // are a fifth of what the link carries).  One launch for the whole batch -- the chunked lanes below pay for their
+    // smaller launches (the last queries of every chunk leave the chip half idle).  Row types whose kernels read the
+    // query more than once (PQ: the table build; SQ-8: the compensation) keep the lanes.
+    const int dt = idx->cfg.dtype;
+    if (q_direct && o_direct && (dt == DT_F32 || dt == DT_F16 || dt == DT_U8 || dt == DT_I8) &&
+        (!out_stats || host_pinned(out_stats, (size_t)nq * sizeof(dann_search_stats)))) {
+        void *dq = nullptr, *di = nullptr, *dd = nullptr, *ds = nullptr;
+        bool mapped = hipHostGetDevicePointer(&dq, const_cast<void*>(queries), 0) == hipSuccess &&
+                      hipHostGetDevicePointer(&di, out_ids, 0) == hipSuccess &&
+                      hipHostGetDevicePointer(&dd, out_dists, 0) == hipSuccess &&
+                      (!out_stats || hipHostGetDevicePointer(&ds, out_stats, 0) == hipSuccess);
+        if (!mapped) (void)hipGetLastError();  // (registered without hipHostRegisterMapped: the lanes copy instead)
+        if (mapped) {
+            std::vector<dann_search_stats> hstats;
+            if (!ds) {  // statistics the caller did not ask for: the call's status is still read from them
+                if (int32_t rc = grow_stage(ctx, 1, (size_t)nq * sizeof(dann_search_stats) + 16)) return rc;
+                ds = ctx.stage[1];
+            }
+            int32_t rc = search_device(idx, ctx, dq, nullptr, nq, l_value, beam_width, k, static_cast<uint32_t*>(di),
+                                       static_cast<float*>(dd), static_cast<dann_search_stats*>(ds), nullptr, nullptr, 0, nullptr);
+            if (rc != DANN_OK) return rc;
+            DANN_HIP(hipStreamSynchronize(ctx.stream));
+            if (!out_stats) {
+                hstats.resize(nq);
+                DANN_HIP(hipMemcpy(hstats.data(), ds, (size_t)nq * sizeof(dann_search_stats), hipMemcpyDeviceToHost));
+                return first_failed_query(hstats.data(), nq, 0);
+            }
+            return first_failed_query(out_stats, nq, 0);
+        }
+    }
     const uint32_t nchunks = (nq + cq - 1) / cq;
     auto chunk_len = [&](uint32_t c) { return std::min(cq, nq - c * cq); };
-    auto upload = [&](uint32_t c) -> int32_t {
-        const uint32_t n = chunk_len(c);
-        memcpy(h_in[c & 1], reinterpret_cast<const uint8_t*>(queries) + (size_t)c * cq * qb, (size_t)n * qb);
-        DANN_HIP(hipMemcpyAsync(d_in[c & 1], h_in[c & 1], (size_t)n * qb, hipMemcpyHostToDevice, ctx.copy_stream));
-        DANN_HIP(hipEventRecord(up_done[c & 1], ctx.copy_stream));
-        return DANN_OK;
+    struct Lane {
+        int32_t rc = DANN_OK;          // a call-level failure (HIP, arguments)
+        int32_t failed = DANN_OK;      // the first failed query of this lane's chunks
+        uint32_t failed_chunk = ~0u;
+        std::string text;              // error text of whichever comes first (set_error is thread-local)
     };
-    int32_t failed = DANN_OK;
-    auto drain = [&](uint32_t c) -> int32_t {  // results of chunk c: pinned ring -> the caller's buffers
-        const uint32_t n = chunk_len(c);
-        DANN_HIP(hipEventSynchronize(down_done[c & 1]));
-        const uint8_t* o = h_out[c & 1];
-        memcpy(out_ids + (size_t)c * cq * k, o, (size_t)n * k * 4);
-        memcpy(out_dists + (size_t)c * cq * k, o + ids_b, (size_t)n * k * 4);
-        const dann_search_stats* st = reinterpret_cast<const dann_search_stats*>(o + 2 * ids_b);
-        if (out_stats) memcpy(out_stats + (size_t)c * cq, st, (size_t)n * sizeof(dann_search_stats));
-        if (failed == DANN_OK) failed = first_failed_query(st, n, c * cq);
-        return DANN_OK;
+    auto grab_text = [](std::string& t) {
+        char buf[512];
+        buf[0] = 0;
+        dann_last_error(buf, sizeof buf);
+        t = buf;
     };
-    if (int32_t rc = upload(0)) return rc;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const uint32_t n = chunk_len(c);
-        if (c + 1 < nchunks)
-            if (int32_t rc = upload(c + 1)) return rc;  // chunk c - 1's kernel finished before: its query buffer is free
-        DANN_HIP(hipStreamWaitEvent(ctx.stream, up_done[c & 1], 0));
-        uint8_t* ob = d_out[c & 1];
-        int32_t rc = search_device(idx, ctx, d_in[c & 1], nullptr, n, l_value, beam_width, k, reinterpret_cast<uint32_t*>(ob),
-                                   reinterpret_cast<float*>(ob + ids_b), reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b),
-                                   nullptr, nullptr, 0, nullptr);
-        if (rc != DANN_OK) {
-            (void)hipStreamSynchronize(ctx.copy_stream);
-            return rc;
+    // everything one lane does, on context `lc`; `first` / `step`: its chunks
+    auto run_lane = [&](SearchCtx& lc, uint32_t first, uint32_t step, Lane& ln) -> int32_t {
+#define DANN_HIP_RC(call)                                  \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+    } while (0)
+        if (int32_t rc = grow_stage(lc, 0, in_b + 16)) return rc;
+        if (int32_t rc = grow_stage(lc, 1, out_b + 16)) return rc;
+        if (lc.h_stage_bytes < in_b + out_b) {
+            if (lc.h_stage) (void)hipHostFree(lc.h_stage);
+            lc.h_stage = nullptr;
+            lc.h_stage_bytes = 0;
+            DANN_HIP_RC(hipHostMalloc(&lc.h_stage, in_b + out_b, hipHostMallocDefault));
+            lc.h_stage_bytes = in_b + out_b;
         }
-        // (the search call returned: the kernel is complete, its output block can travel)
-        if (c >= 2) DANN_HIP(hipEventSynchronize(down_done[c & 1]));  // ring slot of chunk c - 2 (drained below, in order)
-        DANN_HIP(hipMemcpyAsync(h_out[c & 1], ob, out_b, hipMemcpyDeviceToHost, ctx.copy_stream));
-        DANN_HIP(hipEventRecord(down_done[c & 1], ctx.copy_stream));
-        if (c >= 1)
-            if (int32_t drc = drain(c - 1)) return drc;
+        uint8_t* const h_in = reinterpret_cast<uint8_t*>(lc.h_stage);
+        uint8_t* const h_out = h_in + in_b;
+        void* const d_in = lc.stage[0];
+        uint8_t* const ob = reinterpret_cast<uint8_t*>(lc.stage[1]);
+        for (uint32_t c = first; c < nchunks; c += step) {
+            const uint32_t n = chunk_len(c);
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(queries) + (size_t)c * cq * qb;
+            if (!q_direct) {
+                memcpy(h_in, src, (size_t)n * qb);
+                src = h_in;
+            }
+            DANN_HIP_RC(hipMemcpyAsync(d_in, src, (size_t)n * qb, hipMemcpyHostToDevice, lc.stream));
+            int32_t rc = search_device(idx, lc, d_in, nullptr, n, l_value, beam_width, k, reinterpret_cast<uint32_t*>(ob),
+                                       reinterpret_cast<float*>(ob + ids_b), reinterpret_cast<dann_search_stats*>(ob + 2 * ids_b),
+                                       nullptr, nullptr, 0, nullptr);
+            if (rc != DANN_OK) return rc;
+            if (o_direct) {
+                DANN_HIP_RC(hipMemcpyAsync(out_ids + (size_t)c * cq * k, ob, (size_t)n * k * 4, hipMemcpyDeviceToHost, lc.stream));
+                DANN_HIP_RC(hipMemcpyAsync(out_dists + (size_t)c * cq * k, ob + ids_b, (size_t)n * k * 4, hipMemcpyDeviceToHost,
+                                           lc.stream));
+                // the statuses always pass through the ring: the call's return value is read from them
+                DANN_HIP_RC(hipMemcpyAsync(h_out + 2 * ids_b, ob + 2 * ids_b, (size_t)n * sizeof(dann_search_stats),
+                                           hipMemcpyDeviceToHost, lc.stream));
+            } else {
+                DANN_HIP_RC(hipMemcpyAsync(h_out, ob, out_b, hipMemcpyDeviceToHost, lc.stream));
+            }
+            DANN_HIP_RC(hipStreamSynchronize(lc.stream));
+            const dann_search_stats* st = reinterpret_cast<const dann_search_stats*>(h_out + 2 * ids_b);
+            if (!o_direct) {
+                memcpy(out_ids + (size_t)c * cq * k, h_out, (size_t)n * k * 4);
+                memcpy(out_dists + (size_t)c * cq * k, h_out + ids_b, (size_t)n * k * 4);
+            }
+            if (out_stats) memcpy(out_stats + (size_t)c * cq, st, (size_t)n * sizeof(dann_search_stats));
+            if (ln.failed == DANN_OK) {
+                ln.failed = first_failed_query(st, n, c * cq);
+                if (ln.failed != DANN_OK) {
+                    ln.failed_chunk = c;
+                    grab_text(ln.text);
+                }
+            }
+        }
+        return DANN_OK;
+#undef DANN_HIP_RC
+    };
+    constexpr uint32_t kMaxLanes = 8, kDefaultLanes = 3;
+    const uint32_t want = std::min<uint32_t>(nchunks, pipeline_dbg >= 2u ? std::min(pipeline_dbg, kMaxLanes) : kDefaultLanes);
+    // helper lanes take a context only if one is free or may still be created: sixteen callers all waiting for a second
+    // context would wait for one another
+    std::unique_ptr<CtxLease> extra[kMaxLanes - 1];
+    uint32_t lanes = 1;
+    for (uint32_t t = 1; t < want; ++t) {
+        extra[lanes - 1].reset(new CtxLease(idx, /*try_only=*/true));
+        if (extra[lanes - 1]->status != DANN_OK || !extra[lanes - 1]->ctx) {
+            extra[lanes - 1].reset();
+            break;
+        }
+        ++lanes;
     }
-    if (int32_t drc = drain(nchunks - 1)) return drc;
-    return failed;
+    Lane ln[kMaxLanes];
+    std::thread th[kMaxLanes - 1];
+    for (uint32_t t = 1; t < lanes; ++t) {
+        th[t - 1] = std::thread([&, t]() {
+            try {
+                (void)hipSetDevice(dev);
+                ln[t].rc = run_lane(*extra[t - 1]->ctx, t, lanes, ln[t]);
+                if (ln[t].rc != DANN_OK) grab_text(ln[t].text);
+            } catch (...) {
+                ln[t].rc = DANN_EINTERNAL;
+                ln[t].text = "exception in a lane of the host-pointer pipeline";
+            }
+        });
+    }
+    ln[0].rc = run_lane(ctx, 0, lanes, ln[0]);
+    if (ln[0].rc != DANN_OK) grab_text(ln[0].text);
+    for (uint32_t t = 1; t < lanes; ++t) th[t - 1].join();
+    for (uint32_t t = 0; t < lanes; ++t)
+        if (ln[t].rc != DANN_OK) {
+            set_error("%s", ln[t].text.c_str());
+            return ln[t].rc;
+        }
+    const Lane* worst = nullptr;  // the failed query with the smallest index, whichever lane saw it
+    for (uint32_t t = 0; t < lanes; ++t)
+        if (ln[t].failed != DANN_OK && (!worst || ln[t].failed_chunk < worst->failed_chunk)) worst = &ln[t];
+    if (worst) {
+        set_error("%s", worst->text.c_str());
+        return worst->failed;
+    }
+    return DANN_OK;
 } DANN_CATCH_ALL
 
 int32_t dann_range_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t starting_l,
@@ -1298,7 +1429,8 @@ static int32_t filtered_search(dann_index* idx, SearchCtx& ctx, const FilteredCa
         rcap = c.max_returned ? c.max_returned : (uint64_t)4 * c.k + 1024;
         rcap = std::max<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(rcap, m_cap), nslots), 1);
     }
-    const uint64_t per_query = (uint64_t)m_cap * 8 + (uint64_t)key_cap * 8 + rcap * 8 + 64;
+    const bool tie_rust = idx->prune_tie_order == DANN_TIE_RUST;  // equal distances in the reference's own order
+    const uint64_t per_query = (uint64_t)m_cap * 8 + (uint64_t)key_cap * 8 + rcap * 8 + 64 + (tie_rust ? kTieWorkBytes : 0);
     const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c.nq, (1ull << 30) / per_query));
     // scratch of this call: one block of the context's grow-only arena (see dann_range_search_batch)
     const size_t fwords = f->stride_words ? (size_t)f->stride_words * c.nq : (size_t)words;
@@ -1307,18 +1439,19 @@ static int32_t filtered_search(dann_index* idx, SearchCtx& ctx, const FilteredCa
                  o_d = cv.take((size_t)chunk * c.k * 4), o_s = cv.take((size_t)chunk * sizeof(dann_search_stats)),
                  o_f = cv.take(fwords * 4), o_tab = cv.take(tab.size() * 4),
                  o_mi = cv.take(inl ? (size_t)chunk * m_cap * 4 : 0), o_md = cv.take(inl ? (size_t)chunk * m_cap * 4 : 0),
-                 o_k = cv.take(inl ? (size_t)chunk * key_cap * 8 : 0),
+                 o_k = cv.take(inl ? (size_t)chunk * key_cap * 8 : 0), o_tw = cv.take(tie_rust ? (size_t)chunk * kTieWorkBytes : 0),
                  o_ri = cv.take(c.range ? (size_t)chunk * rcap * 4 : 0), o_rd = cv.take(c.range ? (size_t)chunk * rcap * 4 : 0),
                  o_sec = cv.take(c.range ? (size_t)chunk * 4 : 0);
     if (int32_t grc = grow_stage(ctx, 4, cv.off)) return grc;
     void* const ar = ctx.stage[4];
     const ArenaPtr bq{ar, o_q}, bi{ar, o_i}, bd{ar, o_d}, bs{ar, o_s}, bf{ar, o_f}, btab{ar, o_tab}, bmi{ar, o_mi}, bmd{ar, o_md},
-        bk{ar, o_k}, bri{ar, o_ri}, brd{ar, o_rd}, bsec{ar, o_sec};
+        bk{ar, o_k}, btw{ar, o_tw}, bri{ar, o_ri}, brd{ar, o_rd}, bsec{ar, o_sec};
     DANN_HIP(hipMemcpyAsync(bf.p, f->bits, fwords * 4, hipMemcpyHostToDevice, st));
     if (!tab.empty()) {
         DANN_HIP(hipMemcpyAsync(btab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
         a.ad_table = btab.as<uint32_t>();
     }
+    if (tie_rust) a.tie_work = btw.as<uint8_t>();
     if (inl) {
         a.m_ids = bmi.as<uint32_t>();
         a.m_d = bmd.as<float>();

@@ -170,6 +170,9 @@ struct SearchArgs {
     uint32_t m_cap = 0;
     unsigned long long* m_keys = nullptr;  // sort scratch, nq x key_cap (key_cap a power of two)
     uint32_t key_cap = 0;
+    // DANN_TIE_RUST: lists with equal distances are ordered as Rust's sort_unstable_by leaves them (rust_order.h); per
+    // query kTieWorkBytes of scratch: 64 keys of a multihop hop + the sorter's work area
+    uint8_t* tie_work = nullptr;
     uint32_t ad_samples = 0;         // AdaptiveL::sample_count (0 = none)
     const uint32_t* ad_table = nullptr;  // new L for (visited - ad_samples, matched): row stride ad_stride
     uint32_t ad_stride = 0;
@@ -410,13 +413,14 @@ void server_quiesce(dann_index* idx);  // server.hip: the resident kernel leaves
         return DANN_EBUSY;                                                                                            \
     }                                                                                                                 \
     ::dann::server_quiesce(const_cast<dann_index*>(static_cast<const dann_index*>(idx)))
+constexpr uint32_t kTieWorkBytes = 512 + 2048;
 constexpr uint32_t kMaxSearchCtx = 16;
 // a search context for one concurrent call: from the pool, created on demand (at most kMaxSearchCtx), else waits
 struct CtxLease {
     dann_index* idx;
     SearchCtx* ctx = nullptr;
     int32_t status = DANN_OK;
-    explicit CtxLease(dann_index* idx);
+    explicit CtxLease(dann_index* idx, bool try_only = false);
     ~CtxLease();
     CtxLease(const CtxLease&) = delete;
     CtxLease& operator=(const CtxLease&) = delete;

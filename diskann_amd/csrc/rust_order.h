@@ -34,24 +34,31 @@ namespace dann {
 namespace rust_order {
 
 constexpr uint32_t kMaxLen = 4096;   // pool positions are 16-bit, the pivot recursion is sized for this
-constexpr uint32_t kWorkBytes = 512; // merge buffer 64 + quicksort stack 26 x 8 + pivot stack 6 x 12 (rounded up)
+constexpr uint32_t kWorkBytes = 512; // (16-bit form) merge buffer 64 + ancestors 52 + quicksort stack 26 x 6 + pivot stack 6 x 12, rounded up
 
-struct Sorter {
-    uint16_t* v;     // pool positions, permuted in place
-    const float* d;  // distance of pool position p
-    uint16_t* tmp;   // 32 entries
-    uint16_t* qs;    // quicksort stack: 4 x 16-bit words per frame
-    uint16_t* ms;    // pivot stack: 6 x 16-bit words per frame
+// E: the element type that is permuted (16-bit pool positions, or whole 8-byte (distance, payload) keys); W: the word of
+// the explicit stacks (holds an index into the array); Less: is_less(a, b) on two elements; QD / MD: depth of the
+// quicksort / pivot stacks (2 log2(len) + 2 and log8(len) - 1 for the longest array).
+template <typename E, typename W, typename Less, int QD, int MD>
+struct SorterT {
+    E* v;        // the elements, permuted in place
+    Less lt;
+    E* tmp;      // 32 entries
+    E* anc_st;   // ancestor pivot of each quicksort frame
+    W* qs;       // quicksort stack: 3 words per frame
+    W* ms;       // pivot stack: 6 words per frame
     bool fallback;   // the selection's median-of-medians fallback was reached
 
-    DANN_RO_HD Sorter(uint16_t* positions, const float* dist, void* work)
-        : v(positions), d(dist), tmp(static_cast<uint16_t*>(work)), qs(static_cast<uint16_t*>(work) + 32),
-          ms(static_cast<uint16_t*>(work) + 32 + 26 * 4), fallback(false) {}
+    static constexpr uint32_t work_bytes() { return (uint32_t)((32 + QD) * sizeof(E) + (QD * 3 + MD * 6) * sizeof(W)); }
+    DANN_RO_HD SorterT(E* elements, Less l, void* work)
+        : v(elements), lt(l), tmp(static_cast<E*>(work)), anc_st(static_cast<E*>(work) + 32),
+          qs(reinterpret_cast<W*>(static_cast<E*>(work) + 32 + QD)), ms(reinterpret_cast<W*>(static_cast<E*>(work) + 32 + QD) + QD * 3),
+          fallback(false) {}
 
     // is_less = |a, b| fast_distance(a, b) == Less; partial_cmp: an unordered pair is Equal (neighbor/mod.rs:150-154)
-    DANN_RO_HD bool less(uint16_t a, uint16_t b) const { return d[a] < d[b]; }
+    DANN_RO_HD bool less(const E& a, const E& b) const { return lt(a, b); }
     DANN_RO_HD void swap(uint32_t i, uint32_t j) {
-        const uint16_t t = v[i];
+        const E t = v[i];
         v[i] = v[j];
         v[j] = t;
     }
@@ -59,7 +66,7 @@ struct Sorter {
     // insertion_sort_shift_left(v[s .. s + len), offset)
     DANN_RO_HD void insertion(uint32_t s, uint32_t len, uint32_t offset) {
         for (uint32_t i = offset; i < len; ++i) {
-            const uint16_t x = v[s + i];
+            const E x = v[s + i];
             if (!less(x, v[s + i - 1])) continue;
             uint32_t j = i;
             do {
@@ -138,21 +145,21 @@ struct Sorter {
         // median3_rec(a, b, c, n): while n * 8 >= 64 each of the three is replaced by the pseudo-median of its own
         // (p, p + 4 (n / 8), p + 7 (n / 8)); frame = [p0, p1, p2, n, k, -]
         uint32_t sp = 0;
-        ms[0] = (uint16_t)s, ms[1] = (uint16_t)(s + n8 * 4), ms[2] = (uint16_t)(s + n8 * 7), ms[3] = (uint16_t)n8, ms[4] = 0;
+        ms[0] = (W)s, ms[1] = (W)(s + n8 * 4), ms[2] = (W)(s + n8 * 7), ms[3] = (W)n8, ms[4] = 0;
         for (;;) {
-            uint16_t* f = ms + sp * 6;
+            W* f = ms + sp * 6;
             if ((uint32_t)f[3] * 8u < 64u || f[4] == 3) {
                 const uint32_t r = median3(f[0], f[1], f[2]);
                 if (sp == 0) return r - s;
                 --sp;
-                uint16_t* p = ms + sp * 6;
-                p[p[4]] = (uint16_t)r;
+                W* p = ms + sp * 6;
+                p[p[4]] = (W)r;
                 ++p[4];
                 continue;
             }
             const uint32_t m8 = f[3] / 8u, base = f[f[4]];
-            uint16_t* c = ms + (sp + 1) * 6;
-            c[0] = (uint16_t)base, c[1] = (uint16_t)(base + m8 * 4), c[2] = (uint16_t)(base + m8 * 7), c[3] = (uint16_t)m8, c[4] = 0;
+            W* c = ms + (sp + 1) * 6;
+            c[0] = (W)base, c[1] = (W)(base + m8 * 4), c[2] = (W)(base + m8 * 7), c[3] = (W)m8, c[4] = 0;
             ++sp;
         }
     }
@@ -161,14 +168,14 @@ struct Sorter {
     // place.  le: the predicate is "element <= pivot" (!less(pivot, element)).  Returns the pivot's final offset.
     DANN_RO_HD uint32_t partition(uint32_t s, uint32_t len, uint32_t pivot_off, bool le) {
         swap(s, s + pivot_off);
-        const uint16_t pivot = v[s];
+        const E pivot = v[s];
         const uint32_t b = s + 1, n = len - 1;
         uint32_t num_lt = 0;
         if (n != 0) {
-            const uint16_t gap_value = v[b];
+            const E gap_value = v[b];
             uint32_t gap = 0;
             for (uint32_t right = 1; right < n; ++right) {
-                const uint16_t e = v[b + right];
+                const E e = v[b + right];
                 const bool r = le ? !less(pivot, e) : less(e, pivot);
                 v[b + gap] = v[b + num_lt];
                 v[b + num_lt] = e;
@@ -208,11 +215,11 @@ struct Sorter {
     }
 
     // quicksort(v[s .. s + len), ancestor_pivot, limit): the left part is sorted first (recursion in the original), the
-    // right part is pushed with the pivot as its ancestor.  frame = [start, len, ancestor value, limit | has << 15]
+    // right part is pushed with the pivot as its ancestor.  frame = [start, len, limit | has << 15] + its ancestor value
     DANN_RO_HD void quicksort(uint32_t s, uint32_t len, uint32_t limit) {
         uint32_t sp = 0;
         bool has_anc = false;
-        uint16_t anc = 0;
+        E anc = E();
         for (;;) {
             bool done = false;
             if (len <= 32) {
@@ -225,8 +232,8 @@ struct Sorter {
             if (done) {
                 if (sp == 0) return;
                 --sp;
-                const uint16_t* f = qs + sp * 4;
-                s = f[0], len = f[1], anc = f[2], limit = f[3] & 0x7FFFu, has_anc = (f[3] >> 15) != 0;
+                const W* f = qs + sp * 3;
+                s = f[0], len = f[1], anc = anc_st[sp], limit = f[2] & 0x7FFFu, has_anc = ((f[2] >> 15) & 1u) != 0;
                 continue;
             }
             --limit;
@@ -239,9 +246,9 @@ struct Sorter {
                 continue;
             }
             const uint32_t num_lt = partition(s, len, pp, false);
-            uint16_t* f = qs + sp * 4;  // the right part, for later
-            f[0] = (uint16_t)(s + num_lt + 1), f[1] = (uint16_t)(len - num_lt - 1), f[2] = v[s + num_lt];
-            f[3] = (uint16_t)(limit | 0x8000u);
+            W* f = qs + sp * 3;  // the right part, for later
+            f[0] = (W)(s + num_lt + 1), f[1] = (W)(len - num_lt - 1), anc_st[sp] = v[s + num_lt];
+            f[2] = (W)(limit | 0x8000u);
             ++sp;
             len = num_lt;  // the left part now: same ancestor, same limit
         }
@@ -287,7 +294,7 @@ struct Sorter {
         }
         uint32_t s = 0, limit = 16;
         bool has_anc = false;
-        uint16_t anc = 0;
+        E anc = E();
         for (;;) {
             if (len <= 16) {
                 if (len >= 2) insertion(s, len, 1);
@@ -325,16 +332,52 @@ struct Sorter {
     }
 };
 
+// the prune's form: 16-bit pool positions compared through their distances
+struct DistLess {
+    const float* d;
+    DANN_RO_HD bool operator()(uint16_t a, uint16_t b) const { return d[a] < d[b]; }
+};
+using Sorter = SorterT<uint16_t, uint16_t, DistLess, 26, 6>;
+static_assert(Sorter::work_bytes() <= kWorkBytes, "work area of the 16-bit form");
+
 // positions[0 .. P) = 0 .. P-1 on entry; on return positions[0 .. min(P, max)) is the pool SortedNeighbors::new(pool, max)
 // holds.  P <= kMaxLen; `work`: kWorkBytes, 4-byte aligned.  Returns whether the selection's fallback was reached.
 DANN_RO_HD inline bool sorted_neighbors(uint16_t* positions, const float* dist, uint32_t P, uint32_t max, void* work) {
-    Sorter s(positions, dist, work);
+    Sorter s(positions, DistLess{dist}, work);
     const uint32_t keep = max < P ? max : P;
     if (keep >= 1) {
         s.select_nth(P, keep - 1);
         s.sort_unstable(0, keep - 1);
     }
     return s.fallback;
+}
+
+// `slice.sort_unstable_by(fast_distance)` over whole 8-byte elements -- Neighbor<u32> is (id, distance) -- as the
+// post-processing of the filtered searches does it (inline_filter_search.rs:274, multihop_filter_search.rs:207): the
+// elements are keys (order-preserving distance bits << 32 | payload), compared by their distance alone and in the
+// reference's sense (partial_cmp: -0.0 == +0.0, an unordered pair is Equal).  n < 2^31; `work`: kKeyWorkBytes, 8-byte
+// aligned.
+struct KeyLess {
+    // f32 `a < b` on the order-preserving bits o (ordered_bits: u | 0x80000000 for u >= 0, ~u below), in integer
+    // arithmetic: the two zeros (0x7FFFFFFF / 0x80000000) are one value, a NaN (beyond +-infinity) is less than nothing
+    // and nothing is less than it.  (The float form of this comparison -- bits back to f32, then `<` -- takes hipcc 7.2's
+    // instruction selection down inside the quicksort: scratch/ notes in DESIGN.md.)
+    DANN_RO_HD static uint32_t canon(unsigned long long k) {
+        const uint32_t o = (uint32_t)(k >> 32);
+        return o == 0x7FFFFFFFu ? 0x80000000u : o;
+    }
+    DANN_RO_HD static bool nan(uint32_t o) { return (o > 0xFF800000u) | (o < 0x007FFFFFu); }
+    DANN_RO_HD bool operator()(unsigned long long a, unsigned long long b) const {
+        const uint32_t x = canon(a), y = canon(b);
+        return !nan(x) & !nan(y) & (x < y);
+    }
+};
+using KeySorter = SorterT<unsigned long long, uint32_t, KeyLess, 66, 12>;
+constexpr uint32_t kKeyWorkBytes = 2048;
+static_assert(KeySorter::work_bytes() <= kKeyWorkBytes, "work area of the key form");
+DANN_RO_HD inline void sort_keys_unstable(unsigned long long* keys, uint32_t n, void* work) {
+    KeySorter s(keys, KeyLess{}, work);
+    s.sort_unstable(0, n);
 }
 
 }  // namespace rust_order

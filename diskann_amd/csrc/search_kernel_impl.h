@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "dann_device.h"
+#include "rust_order.h"
 #include "dann_internal.h"
 
 namespace dann {
@@ -260,6 +261,11 @@ __device__ __forceinline__ bool spill_insert(uint32_t* gt, uint32_t mask, uint32
     }
 }
 
+// rust_order::sort_keys_unstable as a real call: inlined into beam_search_kernel it takes hipcc 7.2 down ("SI Fix SGPR
+// copies" / instruction selection crash), and the filtered kernels would carry its code in every instantiation
+__device__ __attribute__((noinline)) void rust_sort_keys_call(unsigned long long* keys, uint32_t n, void* work) {
+    rust_order::sort_keys_unstable(keys, n, work);
+}
 // total order on non-NaN f32 as unsigned bits (NaN sorts last)
 __device__ __forceinline__ uint32_t ordered_bits(float d) {
     const uint32_t u = __builtin_bit_cast(uint32_t, d);
@@ -1028,6 +1034,17 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     unsigned long long* m_keys = a.m_keys ? a.m_keys + (uint64_t)qi * a.key_cap : nullptr;
     uint32_t nm = 0, sample_visited = 0, sample_matched = 0;
     bool l_adjusted = false;
+    // DANN_TIE_RUST: 64 keys (the rejected candidates of a multihop hop) + the sorter's work area, per query
+    unsigned long long* const tie_keys =
+        (FILT && a.tie_work) ? reinterpret_cast<unsigned long long*>(a.tie_work + (uint64_t)qi * kTieWorkBytes) : nullptr;
+    // `keys[0 .. n).sort_unstable_by(fast_distance)` as the Rust standard library does it (rust_order.h), by one lane; the
+    // keys are in global memory (written with agent-scope stores by the whole wave)
+    auto rust_sort_keys = [&](unsigned long long* keys, uint32_t n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) rust_sort_keys_call(keys, n, reinterpret_cast<uint8_t*>(tie_keys) + 512);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     // inline filter search: accepted candidates of cand[0..nc) go to matched_results in emission order
     auto append_matched = [&](uint32_t nc) -> uint32_t {
         uint32_t added = 0;
@@ -1676,15 +1693,28 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             const bool rej = hasc && !acc;
             const uint64_t am = ballot64(acc), rm = ballot64(rej);
             const uint32_t na = (uint32_t)__popcll(am);
-            // rejected nodes closest first (stable), at most max_degree / 2 of them expand a second hop
+            // rejected nodes closest first, at most max_degree / 2 of them expand a second hop.  Equal distances: by
+            // emission order (a stable sort), or -- DANN_TIE_RUST, when the hop has any -- where the reference's
+            // `sort_unstable_by(fast_distance)` leaves them (multihop_filter_search.rs:207; tie_sorted below)
             uint32_t rank = 0;
+            bool tied = rej && cd != cd;
             for (uint64_t mm = rm; mm; mm &= mm - 1) {
                 const int j = __builtin_ctzll(mm);
                 const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cd), j));
                 rank += ((dj < cd) | ((dj == cd) & ((uint32_t)j < lane))) ? 1u : 0u;
+                tied |= rej & (dj == cd) & ((uint32_t)j != lane);
             }
             const uint32_t nrej = (uint32_t)__popcll(rm);
             const uint32_t nsel = nrej < R / 2 ? nrej : R / 2;
+            const bool tie_sorted = tie_keys && ballot64(tied);
+            uint32_t tie_src = lane;  // position `lane` of the sorted rejected list holds the candidate of lane tie_src
+            if (tie_sorted) {
+                const uint32_t e = mbcnt(rm);  // emission order of the rejected candidates
+                if (rej) key_store(tie_keys + e, ((unsigned long long)ordered_bits(cd) << 32) | lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                rust_sort_keys(tie_keys, nrej);
+                if (lane < nrej) tie_src = (uint32_t)key_load(tie_keys + lane);
+            }
             WS();
             if (acc) {  // accepted one-hop neighbours, emission order kept
                 const uint32_t r = mbcnt(am);
@@ -1694,7 +1724,12 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             WS();
             if (na) merge(0, na);
             WS();
-            if (rej && rank < nsel) cand_id[rank] = cid;
+            if (tie_sorted) {
+                const uint32_t scid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tie_src << 2), (int)cid);
+                if (lane < nsel) cand_id[lane] = scid;
+            } else if (rej && rank < nsel) {
+                cand_id[rank] = cid;
+            }
             WS();
             const uint32_t sel = lane < nsel ? cand_id[lane] : kEmpty;
             WS();
@@ -1748,16 +1783,33 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     // ---- graph::search::Range second phase (range_search.rs:283-316, 424-470) -----------------------
     uint32_t range_written = 0, range_second = 0;
     // ---- inline filter search: matched_results sorted by distance (inline_filter_search.rs:279) ------------
-    // sort_unstable_by(distance) restated as a stable sort: key = ordered distance bits << 32 | push index
+    // sort_unstable_by(fast_distance): key = ordered distance bits << 32 | push index, sorted by a network -- the
+    // order of a stable sort.  A list without equal distances has one sorted order; one with ties is, under
+    // DANN_TIE_RUST, sorted again from its push order the way the reference's unstable sort does it (rust_sort_keys).
     uint32_t nkeys = 0;
     if (fmode == DANN_FILTER_INLINE && !status) {
         nkeys = 1;
         while (nkeys < nm) nkeys <<= 1;
         __threadfence_block();
-        for (uint32_t i = lane; i < nkeys; i += kWave)
-            key_store(m_keys + i, i < nm ? ((unsigned long long)ordered_bits(f32_load(m_d + i)) << 32) | i : ~0ull);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto fill = [&]() {
+            for (uint32_t i = lane; i < nkeys; i += kWave)
+                key_store(m_keys + i, i < nm ? ((unsigned long long)ordered_bits(f32_load(m_d + i)) << 32) | i : ~0ull);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        fill();
         if (nm > 1) wave_sort_keys(m_keys, nkeys, lane);
+        if (tie_keys && nm > 1) {
+            bool tied = false;
+            for (uint32_t i = lane; i + 1 < nm; i += kWave) {
+                const uint32_t o0 = (uint32_t)(key_load(m_keys + i) >> 32), o1 = (uint32_t)(key_load(m_keys + i + 1) >> 32);
+                const float f0 = from_ordered_bits(o0), f1 = from_ordered_bits(o1);
+                tied |= (f0 == f1) | (f1 != f1);  // (-0.0 == +0.0; a NaN is Equal to everything)
+            }
+            if (ballot64(tied)) {
+                fill();
+                rust_sort_keys(m_keys, nm);
+            }
+        }
     }
     if (a.range_ids && fmode == DANN_FILTER_INLINE && !status) {
         // ---- FilteredRange (filtered_range_search.rs:140-330) -------------------------------------------

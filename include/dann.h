@@ -485,6 +485,11 @@ int32_t dann_set_max_concurrency(dann_index* idx, uint32_t max_queries_in_flight
  *   DANN_TIE_POSITION: equal distances keep their pool order (a stable sort; one wavefront-wide sorting network per
  *     pool, no walk).  Identical to DANN_TIE_RUST wherever the distances of a pool are distinct; on tied pools one of the
  *     orders the reference's API permits, not the one its implementation produces.
+ * The same setting orders equal distances in the filtered searches' post-processing (dann_filtered_search_batch): the
+ * matched list of the inline-filter search (`sort_unstable_by`, inline_filter_search.rs:274) and the rejected candidates
+ * a multihop hop expands (multihop_filter_search.rs:207-210) -- Rust's order under DANN_TIE_RUST (lists with ties are
+ * sorted again by one lane, in global memory: a conformance mode, slow on integer data), push order under
+ * DANN_TIE_POSITION; tests/test_gpu_filtered.py::test_equal_distances_follow_the_references_unstable_sort.
  * Replicas of one sharded build (dann_build_sharded; dann_multi_build: dann_multi_replica) must use the same order. */
 enum { DANN_TIE_POSITION = 0, DANN_TIE_RUST = 1 };
 int32_t dann_set_prune_tie_order(dann_index* idx, uint32_t order);

@@ -40,7 +40,8 @@ enum {
     DANN_DBG_PAIR_MIN_QUERIES = 2,       /* launches of at least this many queries take two queries per wavefront
                                             (default 20 x compute units) */
     DANN_DBG_TEAM_MAX_QUERIES = 3,       /* launches of at most this many queries take a team per query (default 4 x CUs) */
-    DANN_DBG_HOST_PIPELINE = 4,          /* 0: dann_search_batch never chunks its host buffers (default 1) */
+    DANN_DBG_HOST_PIPELINE = 4,          /* 0: dann_search_batch never chunks its host buffers; 2 .. 8: that many lanes
+                                            (default 1 = three lanes) */
     DANN_DBG_SWEEP_ONE_BY_ONE = 5,       /* 1: the MFMA prune's sweep decides one candidate at a time (default 0) */
     DANN_DBG_POOL_GRAM = 6,              /* 0: the pool prune of rows >= 1 KiB stays on the row kernel (default 1) */
     DANN_DBG_GRAM_COLS = 7,              /* columns of the Gram block: 32 / 64 / 96 (default 96) */
@@ -55,7 +56,8 @@ enum {
                                             entries; beyond it, scan + short / long worklists (default 128) */
     DANN_DBG_HT16_MAX_PROBES = 14,       /* test hook: cap on the probes per id of a 16-bit visited table (default 64; a large
                                             index leaves three): small test indexes reach the overflow table with it */
-    DANN_DBG_COUNT = 15
+    DANN_DBG_HOST_CHUNK = 15,            /* queries per chunk of the host-pointer pipeline (default 16384) */
+    DANN_DBG_COUNT = 16
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
 int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);

@@ -1108,8 +1108,21 @@ struct Matched {
     uint32_t id;
     float d;
 };
-/* inline_filter_search_internal, inline_filter_search.rs:166-281.  matched is returned sorted by
- * distance; ORACLE TIE RULE: equal distances keep push order (sort_unstable_by leaves it open). */
+/* `v.sort_unstable_by(neighbor::ord::fast_distance)` of the filtered searches' post-processing
+ * (inline_filter_search.rs:274, multihop_filter_search.rs:207): under the default tie rule (6) Rust's own unstable sort
+ * as restated in rust_unstable_sort.h -- equal distances end up where ipnsort leaves them --, under the other rules a
+ * stable sort (equal distances keep push order: the product's DANN_TIE_POSITION). */
+static void sort_matched_by_distance(std::vector<Matched>& v) {
+    auto by_d = [](const Matched& a, const Matched& b) { return a.d < b.d; };
+    if (g_tie_rule == 6) {
+        rust_sort::Impl<Matched, decltype(by_d)> srt(by_d);
+        srt.sort_unstable(v.data(), v.size());
+    } else {
+        std::stable_sort(v.begin(), v.end(), by_d);
+    }
+}
+/* inline_filter_search_internal, inline_filter_search.rs:166-281.  matched is returned sorted by distance
+ * (sort_matched_by_distance). */
 void inline_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t beam_width,
                      size_t l_search, const uint32_t* filter, uint32_t adaptive_samples, double adaptive_scale,
                      SearchOut& out, std::vector<Matched>& matched) {
@@ -1165,7 +1178,7 @@ void inline_internal(const QueryCtx& qc, Queue& best, IdSet& visited, uint32_t b
             }
         }
     }
-    std::stable_sort(matched.begin(), matched.end(), [](const Matched& a, const Matched& b) { return a.d < b.d; });
+    sort_matched_by_distance(matched);
 }
 }  // namespace
 
@@ -1244,8 +1257,8 @@ int32_t orc_multihop_search(const orc_index* ix, const void* query, uint32_t l_v
         }
         cmps += (uint32_t)one_hop.size();
         hops += (uint32_t)beam.size();
-        /* closest rejected nodes first (ORACLE TIE RULE: stable), at most max_degree / 2 of them */
-        std::stable_sort(cand.begin(), cand.end(), [](const Matched& a, const Matched& b) { return a.d < b.d; });
+        /* closest rejected nodes first (sort_unstable_by: sort_matched_by_distance), at most max_degree / 2 of them */
+        sort_matched_by_distance(cand);
         if (cand.size() > ix->max_degree / 2) cand.resize(ix->max_degree / 2);
         /* expand_beam_accept_only: pred.eval_mut = is_match(id) && visited.insert(id) (labeled.rs:284-291) */
         for (auto& c : cand) {

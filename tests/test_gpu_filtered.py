@@ -206,3 +206,48 @@ def test_inline_many_queries_cross_chunks():
         wn, wi, wd, ws = ox.inline_filter_search(queries[qi], 16, 5, match[qi])
         assert np.array_equal(ids[qi], wi) and np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), qi
         assert (int(st["cmps"][qi]), int(st["hops"][qi])) == (int(ws[0]), int(ws[1]))
+
+
+@pytest.mark.parametrize("mode", ["inline", "multihop"])
+def test_equal_distances_follow_the_references_unstable_sort(mode):
+    """`matched_results.sort_unstable_by(fast_distance)` (inline_filter_search.rs:274) and the multihop search's
+    `candidates_two_hop_expansion.sort_unstable_by(..)` + truncate (multihop_filter_search.rs:207-210): byte rows with
+    few distinct values give every query dozens of matched entries / rejected candidates at EQUAL distance (far beyond
+    the 20 entries Rust's sort handles by insertion), and which of them come first decides the returned ids and -- in the
+    multihop search -- which nodes are expanded.  Under the default order (DANN_TIE_RUST) the GPU follows the checker's
+    restatement of Rust's sort exactly; under DANN_TIE_POSITION both sides keep push order."""
+    import diskann_amd as da
+    rng = np.random.default_rng(99)
+    n, dim, R, nq = 4000, 6, 32, 64
+    data = rng.integers(0, 3, (n, dim)).astype(np.uint8)  # 3^6 distinct rows: distances are small integers
+    adj = random_graph(rng, n, R)
+    ox, px = make_pair(oracle.U8, oracle.L2, data, adj, data[:1].copy(), R)
+    queries = rng.integers(0, 3, (nq, dim)).astype(np.uint8)
+    match = rng.random(n + 1) < (0.5 if mode == "inline" else 0.3)
+    L, k = 40, 30
+    results = {}
+    try:
+        for order, rule in ((da.TIE_RUST, 6), (da.TIE_POSITION, 0)):
+            px.set_prune_tie_order(order)
+            oracle.set_tie_rule(rule)
+            if mode == "inline":
+                ids, dists, st = px.filtered_search(da.Knn(L), queries, k, match, matched_cap=n)
+            else:
+                ids, dists, st = px.filtered_search(da.Knn(L, 2), queries, k, match, mode=da.FILTER_MULTIHOP)
+            tied_lists = 0
+            for qi in range(nq):
+                if mode == "inline":
+                    wn, wi, wd, ws = ox.inline_filter_search(queries[qi], L, k, match)
+                else:
+                    wn, wi, wd, ws = ox.multihop_search(queries[qi], L, k, match, beam_width=2)
+                assert np.array_equal(ids[qi], wi), (order, qi)
+                assert np.array_equal(dists[qi].view(np.uint32), wd.view(np.uint32)), (order, qi)
+                assert (int(st["cmps"][qi]), int(st["hops"][qi]), int(st["written"][qi])) == (int(ws[0]), int(ws[1]), wn)
+                tied_lists += int(len(set(wd[:wn].tolist())) < wn)
+            assert tied_lists == nq  # every result list has equal distances in it
+            results[order] = ids.copy()
+    finally:
+        oracle.set_tie_rule()
+        px.set_prune_tie_order(da.TIE_RUST)
+    # the two orders really are different orders on these lists
+    assert not np.array_equal(results[da.TIE_RUST], results[da.TIE_POSITION])

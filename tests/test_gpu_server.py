@@ -133,18 +133,43 @@ def test_server_overflowing_query_falls_back_to_the_launch_path():
 
 
 def test_host_pointer_search_pipeline_equals_one_pass():
-    """dann_search_batch with a batch large enough for the chunked H2D / kernel / D2H pipeline returns exactly what the
-    same queries return in small calls."""
+    """dann_search_batch with a batch large enough for the chunked H2D / kernel / D2H pipeline (16 384 queries per chunk,
+    a helper thread staging chunk i + 1 and draining chunk i - 1 beside kernel i) returns exactly what the same queries
+    return in small calls -- from pageable buffers (through the pinned ring) and from buffers the caller page-locked
+    (read and written by the DMA directly), statistics included, ragged last chunk."""
+    import ctypes as C
+    import torch
     rng, oix, gix = _index(oracle.F32, oracle.L2, 5000, 64, 16, 3)
-    q = rand_vectors(rng, oracle.F32, 70000, 64)
+    nq = 70001
+    q = rand_vectors(rng, oracle.F32, nq, 64)
     L, k = 20, 10
     ids, d, st = gix.search(da.Knn(L), q, k)
-    for s0 in (0, 32768 - 100, 65536 - 50):
+    for s0 in (0, 16384 - 100, 32768 - 100, 65536 - 50, nq - 300):
         si, sd, sst = gix.search(da.Knn(L), q[s0:s0 + 300], k)
         assert np.array_equal(ids[s0:s0 + 300], si) and np.array_equal(bits(d[s0:s0 + 300]), bits(sd))
         assert np.array_equal(st["cmps"][s0:s0 + 300], sst["cmps"])
     oi, od, _, _ = oix.search_batch(q[:500], L, 1, k)
     assert np.array_equal(ids[:500], oi)
+    # page-locked caller buffers: queries, ids, distances and statistics
+    lib = da._ffi.lib()
+    pq = torch.empty((nq, 64), dtype=torch.float32, pin_memory=True)
+    pq.numpy()[...] = q
+    pi = torch.zeros((nq, k), dtype=torch.int32, pin_memory=True)
+    pd = torch.zeros((nq, k), dtype=torch.float32, pin_memory=True)
+    pst = torch.zeros((nq, da.STATS_DTYPE.itemsize // 4), dtype=torch.int32, pin_memory=True)
+    for stats in (pst, None):
+        pi.zero_()
+        da._ffi.check(lib.dann_search_batch(gix._h, C.c_void_p(pq.data_ptr()), nq, L, 1, k, C.c_void_p(pi.data_ptr()),
+                                            C.c_void_p(pd.data_ptr()), C.c_void_p(stats.data_ptr()) if stats is not None else None),
+                      "dann_search_batch")
+        assert np.array_equal(pi.numpy().view(np.uint32), ids) and np.array_equal(bits(pd.numpy()), bits(d))
+    assert np.array_equal(pst.numpy().view(da.STATS_DTYPE).reshape(-1)["cmps"], st["cmps"])
+    # mixed: pinned queries, pageable outputs
+    hi = np.zeros((nq, k), np.uint32)
+    hd = np.zeros((nq, k), np.float32)
+    da._ffi.check(lib.dann_search_batch(gix._h, C.c_void_p(pq.data_ptr()), nq, L, 1, k, hi.ctypes.data_as(C.c_void_p),
+                                        hd.ctypes.data_as(C.c_void_p), None), "dann_search_batch")
+    assert np.array_equal(hi, ids) and np.array_equal(bits(hd), bits(d))
 
 
 def test_mutations_are_refused_while_tickets_are_outstanding():
