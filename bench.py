@@ -1089,7 +1089,10 @@ def _index_on_gpu(args, torch, da, dev, local, n, dim, dist, R, pruned, l_build,
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (= the f32 vector rate)
 
 
-def build_mfma_info(prov, n, dim, row_bytes, t_build):
+F16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 / fp16 peak (v_mfma_f32_32x32x16_f16 = 16 x the f32 core)
+
+
+def build_mfma_info(prov, n, dim, row_bytes, t_build, f16=False):
     """The matrix-core share of an index build just finished on `prov` (north_star: "MFMA only for the dense ... case at
     index-build time ... MFMA utilisation against gfx950 peak"): flop from the library's work counter (Gram entries
     computed x dim x 2), time from HIP events around every gram_tiles_kernel launch on the build stream
@@ -1101,8 +1104,16 @@ def build_mfma_info(prov, n, dim, row_bytes, t_build):
                 "note": "rows below 1 KiB keep the row kernels (measured faster there, DESIGN 3.4)"}
     flop = 2.0 * c[7] * dim
     tf = flop / (ms * 1e-3) / 1e12
-    return {"kernel": "gram_tiles_kernel (v_mfma_f32_32x32x2_f32)", "used": True, "launches": int(launches),
-            "total_ms": ms, "flop": flop, "TFLOP_s": tf, "peak": F32_MFMA_PEAK_TFLOPS, "frac": tf / F32_MFMA_PEAK_TFLOPS,
+    # f16 rows (round 6): v_mfma_f32_32x32x16_f16.  Its own peak is 16 x the f32 core's: at that rate the Gram of a list is
+    # no longer matrix-pipe work at all -- the kernel is bound by filling its LDS slabs (rows x dim x 2 bytes once per list
+    # from L2 / HBM) -- so the line carries both fractions: of the f16 peak (what the instruction could do) and of the f32
+    # peak (what the same tiles cost until round 5)
+    peak = F16_MFMA_PEAK_TFLOPS if f16 else F32_MFMA_PEAK_TFLOPS
+    return {"kernel": "gram_tiles_f16_kernel (v_mfma_f32_32x32x16_f16)" if f16 else "gram_tiles_kernel (v_mfma_f32_32x32x2_f32)",
+            "used": True, "launches": int(launches),
+            "total_ms": ms, "flop": flop, "TFLOP_s": tf, "peak": peak, "frac": tf / peak,
+            **({"frac_of_f32_matrix_peak": tf / F32_MFMA_PEAK_TFLOPS,
+                "slab_fill_bytes": c[6] * dim * 2, "slab_fill_GBps": c[6] * dim * 2 / (ms * 1e-3) / 1e9} if f16 else {}),
             "share_of_prune_pairs": (c[8] - c[9]) / max(1, c[8] - c[9] + c[4]),
             "pairs_asked_by_the_sweeps": c[8], "of_those_re_evaluated_exactly": c[9], "row_kernel_pairs": c[4],
             "gram_rows": c[6], "gram_entries": c[7], "build_seconds": t_build, "points_per_s": n / t_build,
@@ -1181,7 +1192,7 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
     else:
         queries32 = queries
     esz, tname, odt = (2, "f16", oracle.F16) if f16 else (4, "f32", oracle.F32)
-    mfma = build_mfma_info(prov, n, dim, dim * esz, t_build)
+    mfma = build_mfma_info(prov, n, dim, dim * esz, t_build, f16=f16)
     sweep = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256]
     if args.L:  # profiling passes: fixed L, no ground truth
         gt = np.zeros((ngt, k), np.int64)

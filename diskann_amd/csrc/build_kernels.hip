@@ -1630,6 +1630,187 @@ __global__ __launch_bounds__(512, MAXNT == 1 ? 6 : 4) void gram_tiles_kernel(Til
     }
 }
 
+// ---- f16 rows on the f16 matrix core (round 6) ---------------------------------------------------------------------------
+// gram_tiles_kernel<__half> widens f16 rows and runs v_mfma_f32_32x32x2_f32 -- the f32 matrix core, 1/16 of the f16 rate,
+// and 32 LDS operand reads per tile and 32-column slab.  Here the slabs hold the rows' halfs as they are (80-byte row
+// stride: the 16-byte operand reads of 16 consecutive rows cover all 64 banks) and a tile advances 16 columns per
+// v_mfma_f32_32x32x16_f16: lane l supplies row l & 31, halfs 8 (l >> 5) .. + 7 of the 16-column step, for BOTH operands, so
+// whatever order the hardware walks those sixteen k in, row i's k meets row j's k (scratch/probe_mfma_f16.hip: exact on
+// integer data, 1 - 9 u sum|x y| off the exact product on random rows of 16 .. 1536 columns -- a third of the f32 chain's
+// error).  Products of two halfs are exact in f32; the sum is not the reference's FMA chain, and does not have to be: every
+// decision of the sweep goes through the error interval E = c1 (|x|^2 + |y|^2) + c2 |d'| (c1 = the chain's bound, which
+// covers any summation order of exactly rounded or truncated f32 additions with room to spare) and falls back to the
+// bit-exact pair kernel where E does not decide.  Same tiling, same dealing of tiles to waves, same
+// output as gram_tiles_kernel.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr uint32_t kF16SlabRowBytes = 80;  // 32 halfs + 16 bytes: conflict-free 16-byte operand reads
+template <int NT>
+__device__ __forceinline__ void tile_slab_f16(const uint8_t* lane_base, const uint32_t (&sa)[3], const uint32_t (&sb)[3],
+                                              f32x16 (&acc)[NT]) {
+    f16x8_t av[NT][2], bv[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            av[t][m] = *reinterpret_cast<const f16x8_t*>(lane_base + sa[t] + 32u * m);
+            bv[t][m] = *reinterpret_cast<const f16x8_t*>(lane_base + sb[t] + 32u * m);
+        }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[t][m], bv[t][m], acc[t], 0, 0, 0);
+}
+
+template <int MAXNT>
+__global__ __launch_bounds__(512, MAXNT == 1 ? 6 : 4) void gram_tiles_f16_kernel(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t slab_bytes = tile_slab_rows(a.ng) * kF16SlabRowBytes;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, item = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t wv = (blockIdx.x & 1u) ? (uint32_t)(kTileRowBlocks - 1) - wave : wave;
+    const uint32_t N = a.sn[item];
+    const uint32_t nrows = N < a.ng ? N : a.ng, ncols = N < a.mg ? N : a.mg;
+    if (nrows == 0) return;
+    const uint32_t TR = (nrows + 31u) >> 5, TC = (ncols + 31u) >> 5;
+    const uint32_t* ids = a.sid + (uint64_t)item * a.pcap;
+    const uint32_t dim = a.ix.dim;
+    // slab fill: 8 threads x 4 halfs per row, 64 rows per pass; unconditional requests (see gram_tiles_kernel)
+    const uint32_t lr = tid >> 3, c4 = (tid & 7u) << 2;
+    uint32_t rowid[kTilePasses];
+    double nsq[kTilePasses];
+#pragma unroll
+    for (int p = 0; p < kTilePasses; ++p) {
+        const uint32_t r = ((uint32_t)p << 6) + lr;
+        const uint32_t id = r < nrows ? ids[r] : kEmpty;
+        rowid[p] = id < a.ix.nslots ? id : kEmpty;
+        nsq[p] = 0.0;
+    }
+    const uint8_t* const rows_c4 = a.ix.rows + (size_t)c4 * 2u;
+    auto row_ptr = [&](int p) -> const uint8_t* {
+        return rows_c4 + (uint64_t)(rowid[p] != kEmpty ? rowid[p] : 0u) * a.ix.row_stride;
+    };
+    uint2 nxt[kTilePasses];
+    const uint32_t dim_full = dim & ~31u;
+    const uint32_t l31 = lane & 31u, hi = lane >> 5;
+    uint32_t T = 0;
+    for (uint32_t b = 0; b < TR; ++b) T += (b < TC ? b : TC - 1u) + 1u;
+    const uint32_t nt = T > wv ? (T - wv + 7u) >> 3 : 0u;
+    uint32_t trb[3] = {0, 0, 0}, tcb[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        uint32_t q = wv + 8u * (uint32_t)t, b = 0;
+        if ((uint32_t)t < nt) {
+            for (;;) {
+                const uint32_t c = (b < TC ? b : TC - 1u) + 1u;
+                if (q < c) break;
+                q -= c;
+                ++b;
+            }
+            trb[t] = b;
+            tcb[t] = q;
+        }
+    }
+    const uint8_t* const lane_base = smem + l31 * kF16SlabRowBytes + hi * 16u;
+    const uint32_t fill_passes = (TR + 1u) >> 1;
+    auto write_slab = [&](uint8_t* slab) {
+#pragma unroll
+        for (int p = 0; p < kTilePasses; ++p) {
+            if ((uint32_t)p < fill_passes) {
+                uint2 q = nxt[p];
+                if (rowid[p] == kEmpty) q = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(slab + (((uint32_t)p << 6) + lr) * kF16SlabRowBytes + c4 * 2u) = q;
+                const float2 x = __half22float2(__builtin_bit_cast(__half2, q.x)), y = __half22float2(__builtin_bit_cast(__half2, q.y));
+                nsq[p] += (double)x.x * x.x + (double)x.y * x.y + (double)y.x * y.x + (double)y.y * y.y;
+            }
+        }
+    };
+    auto fetch_tail = [&](int p) -> uint2 {  // the partial slab: elements beyond the row's end read as zero
+        const __half* r = reinterpret_cast<const __half*>(row_ptr(p) - (size_t)c4 * 2u);
+        const uint32_t k = dim_full + c4;
+        __half h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (k + (uint32_t)e < dim) ? r[k + (uint32_t)e] : __float2half(0.0f);
+        uint2 q;
+        q.x = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+        q.y = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+        return q;
+    };
+    float* const g = a.gram + (uint64_t)item * a.ng * a.mg;
+    auto run = [&](auto ntc) {
+        constexpr int NT = decltype(ntc)::value;
+        f32x16 acc[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int t = 0; t < (NT > 0 ? NT : 1); ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        uint32_t cur = 0;
+        constexpr uint32_t kBlock = 32u * kF16SlabRowBytes;  // bytes of one 32-row block of a slab
+        if (dim_full) {
+#pragma unroll
+            for (int p = 0; p < kTilePasses; ++p) nxt[p] = *reinterpret_cast<const uint2*>(row_ptr(p));
+            write_slab(smem);
+            __syncthreads();
+            for (uint32_t k0 = 0; k0 < dim_full; k0 += 32u) {
+                const bool more = k0 + 32u < dim_full;
+                const uint32_t kn = more ? k0 + 32u : k0;
+#pragma unroll
+                for (int p = 0; p < kTilePasses; ++p) nxt[p] = *reinterpret_cast<const uint2*>(row_ptr(p) + (size_t)kn * 2u);
+                __builtin_amdgcn_sched_barrier(0);  // the requests go out before the MFMAs, not behind them
+                if constexpr (NT > 0) {
+                    const uint32_t so = cur * slab_bytes;
+                    const uint32_t sa[3] = {so + trb[0] * kBlock, so + trb[1] * kBlock, so + trb[2] * kBlock};
+                    const uint32_t sb[3] = {so + tcb[0] * kBlock, so + tcb[1] * kBlock, so + tcb[2] * kBlock};
+                    tile_slab_f16<NT>(lane_base, sa, sb, acc);
+                }
+                cur ^= 1u;
+                if (more) write_slab(smem + cur * slab_bytes);
+                __syncthreads();
+            }
+        }
+        if (dim_full < dim) {
+#pragma unroll
+            for (int p = 0; p < kTilePasses; ++p) nxt[p] = fetch_tail(p);
+            write_slab(smem + cur * slab_bytes);
+            __syncthreads();
+            if constexpr (NT > 0) {
+                const uint32_t so = cur * slab_bytes;
+                const uint32_t sa[3] = {so + trb[0] * kBlock, so + trb[1] * kBlock, so + trb[2] * kBlock};
+                const uint32_t sb[3] = {so + tcb[0] * kBlock, so + tcb[1] * kBlock, so + tcb[2] * kBlock};
+                tile_slab_f16<NT>(lane_base, sa, sb, acc);
+            }
+        }
+        // C layout as v_mfma_f32_32x32x2_f32: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+        if constexpr (NT > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t i = (trb[t] << 5) + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * hi;
+                    g[(uint64_t)i * a.mg + (tcb[t] << 5) + l31] = acc[t][r];
+                }
+            }
+        }
+    };
+    if (MAXNT >= 3 && nt == 3u) run(std::integral_constant<int, 3>{});
+    else if (MAXNT >= 2 && nt == 2u) run(std::integral_constant<int, 2>{});
+    else if (nt >= 1u) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+    float* nr = a.nrm + (uint64_t)item * a.ng;
+#pragma unroll
+    for (int p = 0; p < kTilePasses; ++p) {
+        double v = nsq[p];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const uint32_t r = ((uint32_t)p << 6) + lr;
+        if ((tid & 7u) == 0 && r < nrows) nr[r] = (float)v;
+    }
+    if (tid == 0 && a.counters) {
+        atomicAdd(&stat_stripe(a.counters)[2], (unsigned long long)nrows);
+        atomicAdd(&stat_stripe(a.counters)[3], (unsigned long long)T * 1024ull);
+    }
+}
+
 // Longest lists first: a sweep is a serial walk over its list, and a launch in item order ends with a few long lists on an
 // otherwise idle chip (1 M x 768, 16 384 pools per launch: 6 of 13 wavefront slots per CU occupied on average).  The
 // workgroups of the Gram and sweep kernels take their items in descending order of list length instead -- a counting
@@ -1923,22 +2104,30 @@ DANN_LAUNCHER(SortLauncher, pool_sort_kernel, SortArgs)
 DANN_LAUNCHER(SweepLauncher, pool_sweep_kernel, SweepArgs)
 DANN_LAUNCHER(BackListLauncher, backedge_list_kernel, BackListArgs)
 
-int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream) {
-    const size_t lds = 2u * (size_t)tile_slab_rows(a.ng) * 33u * 4u;  // two slabs
+// f16_mfma: f16 rows through v_mfma_f32_32x32x16_f16 (gram_tiles_f16_kernel; the default) instead of widened through the
+// f32 matrix core (DANN_DBG_GRAM_F16_WIDEN: the round-3 form, whose entries are the reference's FMA chain bit for bit)
+int32_t launch_gram_tiles(const TileArgs& a, uint32_t grid, hipStream_t stream, bool f16_mfma) {
     if (a.ix.dtype != DT_F32 && a.ix.dtype != DT_F16) return DANN_EUNSUPPORTED;
+    const bool f32 = a.ix.dtype == DT_F32;
+    const bool h16 = !f32 && f16_mfma;
+    const size_t lds = h16 ? 2u * (size_t)tile_slab_rows(a.ng) * kF16SlabRowBytes
+                           : 2u * (size_t)tile_slab_rows(a.ng) * 33u * 4u;  // two slabs
     // the most tiles a wave of this launch can own: T tiles of a full item over eight waves
     const uint32_t tr = a.ng >> 5, tc = a.mg >> 5;
     uint32_t tmax = 0;
     for (uint32_t b2 = 0; b2 < tr; ++b2) tmax += (b2 < tc ? b2 : tc - 1u) + 1u;
     const bool narrow = tmax <= 8u;
-    const bool f32 = a.ix.dtype == DT_F32;
-    const void* fn = narrow ? (f32 ? (const void*)gram_tiles_kernel<float, 1> : (const void*)gram_tiles_kernel<__half, 1>)
+    const void* fn = h16 ? (narrow ? (const void*)gram_tiles_f16_kernel<1> : (const void*)gram_tiles_f16_kernel<3>)
+                   : narrow ? (f32 ? (const void*)gram_tiles_kernel<float, 1> : (const void*)gram_tiles_kernel<__half, 1>)
                             : (f32 ? (const void*)gram_tiles_kernel<float, 3> : (const void*)gram_tiles_kernel<__half, 3>);
     if (lds > 64u * 1024u) {  // beyond the default limit of dynamic LDS
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute");
     }
-    if (narrow) {
+    if (h16) {
+        if (narrow) hipLaunchKernelGGL((gram_tiles_f16_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((gram_tiles_f16_kernel<3>), dim3(grid), dim3(512), lds, stream, a);
+    } else if (narrow) {
         if (f32) hipLaunchKernelGGL((gram_tiles_kernel<float, 1>), dim3(grid), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((gram_tiles_kernel<__half, 1>), dim3(grid), dim3(512), lds, stream, a);
     } else {
@@ -2282,7 +2471,7 @@ static int32_t batch_candidates(dann_index* idx, const dann_build_config& cfg, B
         ta.counters = pc.counters;
         ta.order = longest_first(s, so.sn, m, st);
         if (int32_t trc = s.tile_begin(st)) return trc;
-        rc = launch_gram_tiles(ta, m, st);
+        rc = launch_gram_tiles(ta, m, st, idx->dbg_u32(DANN_DBG_GRAM_F16_WIDEN, 0u) == 0u);
         if (rc != DANN_OK) return rc;
         if (int32_t trc = s.tile_end(st)) return trc;
         SweepArgs sw;
@@ -2544,7 +2733,7 @@ static int32_t batch_commit(dann_index* idx, const dann_build_config& cfg, Build
                 ta.counters = pc.counters;
                 ta.order = longest_first(s, la.sn, nshort, st);
                 if (int32_t trc = s.tile_begin(st)) return trc;
-                rc = launch_gram_tiles(ta, nshort, st);
+                rc = launch_gram_tiles(ta, nshort, st, idx->dbg_u32(DANN_DBG_GRAM_F16_WIDEN, 0u) == 0u);
                 if (rc != DANN_OK) return rc;
                 if (int32_t trc = s.tile_end(st)) return trc;
                 SweepArgs sw;
@@ -2763,6 +2952,8 @@ int32_t dann_apply_neighbor_rows_device(dann_index* idx, const uint32_t* d_rows,
 
 int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
                               float* out_gram, float* out_nrm) try {
+    const bool widen = (dtype & 0x100) != 0;  // DANN_F16 | 0x100: f16 rows widened through the f32 matrix core
+    dtype &= 0xFF;
     if (!rows || !out_gram || !out_nrm || n == 0 || n > 32u * kTileRowBlocks || dim == 0 || (dtype != DT_F32 && dtype != DT_F16))
         return DANN_EINVAL;
     mg = std::min<uint32_t>(std::max<uint32_t>((mg + 31u) & ~31u, 32u), 32u * kTileColBlocks);
@@ -2798,7 +2989,7 @@ int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, u
     ta.gram = dg.as<float>();
     ta.nrm = dn.as<float>();
     ta.counters = nullptr;
-    int32_t rc = launch_gram_tiles(ta, 1, 0);
+    int32_t rc = launch_gram_tiles(ta, 1, 0, !widen);
     if (rc != DANN_OK) return rc;
     DANN_HIP(hipDeviceSynchronize());
     // out_gram: n x mg (row stride mg as passed, entries beyond the computed block are zero)

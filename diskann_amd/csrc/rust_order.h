@@ -369,7 +369,7 @@ struct KeyLess {
     DANN_RO_HD static bool nan(uint32_t o) { return (o > 0xFF800000u) | (o < 0x007FFFFFu); }
     DANN_RO_HD bool operator()(unsigned long long a, unsigned long long b) const {
         const uint32_t x = canon(a), y = canon(b);
-        return !nan(x) & !nan(y) & (x < y);
+        return (int)!nan(x) & (int)!nan(y) & (int)(x < y);
     }
 };
 using KeySorter = SorterT<unsigned long long, uint32_t, KeyLess, 66, 12>;

@@ -18,7 +18,10 @@ int32_t dann_debug_stream_read_gbps(int32_t device, uint64_t bytes, uint32_t rep
 
 /* diagnostic: the Gram block of the MFMA prunes (gram_tiles_kernel) for n <= 256 rows of dtype
  * DANN_F32 / DANN_F16: out_gram is n x mg (mg rounded up to 32, at most 96): entry (i, j), j <= i, is the f32 FMA chain
- * over k = 0 .. dim-1 of row_i[k] * row_j[k] (f16 rows widened exactly); out_nrm[i] = |row_i|^2 accumulated in f64 */
+ * over k = 0 .. dim-1 of row_i[k] * row_j[k] for DANN_F32 rows and for DANN_F16 | 0x100 (f16 rows widened exactly, the
+ * f32 matrix core); plain DANN_F16 is the builds' default for f16 rows, v_mfma_f32_32x32x16_f16: exact products, f32
+ * sums in the hardware's order -- within the sweep's error interval of the chain; out_nrm[i] = |row_i|^2 accumulated in
+ * f64 */
 int32_t dann_debug_gram_tiles(int32_t device, int32_t dtype, const void* rows, uint32_t n, uint32_t dim, uint32_t mg,
                               float* out_gram, float* out_nrm);
 
@@ -57,7 +60,9 @@ enum {
     DANN_DBG_HT16_MAX_PROBES = 14,       /* test hook: cap on the probes per id of a 16-bit visited table (default 64; a large
                                             index leaves three): small test indexes reach the overflow table with it */
     DANN_DBG_HOST_CHUNK = 15,            /* queries per chunk of the host-pointer pipeline (default 16384) */
-    DANN_DBG_COUNT = 16
+    DANN_DBG_GRAM_F16_WIDEN = 16,        /* 1: the MFMA prunes widen f16 rows and use the f32 matrix core (rounds 3-5; default
+                                            0: v_mfma_f32_32x32x16_f16) */
+    DANN_DBG_COUNT = 17
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
 int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);

@@ -395,7 +395,8 @@ def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
     """gram_tiles_kernel (the Gram of the three-kernel MFMA pool prune): v_mfma_f32_32x32x2_f32 with the accumulator
     running through the whole row is one k-ordered f32 FMA chain per entry -- bit-identical to orc_gram_chain on the
     lower triangle of the block (the sweep only asks for j < i), for sizes that exercise 1..8 row blocks, partial
-    blocks, the partial K slab and rows narrower than a slab; f16 rows are widened exactly.  Norms: f64 sums."""
+    blocks, the partial K slab and rows narrower than a slab; f16 rows widened exactly (DANN_F16 | 0x100: the round-3
+    form) likewise.  Norms: f64 sums."""
     import ctypes as C
     rng = np.random.default_rng(55)
     lib = da._ffi.lib()
@@ -405,8 +406,8 @@ def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
         rows = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 8.0, (n, 1))).astype(npdt)
         got = np.empty((n, mg), np.float32)
         nrm = np.empty(n, np.float32)
-        da._ffi.check(lib.dann_debug_gram_tiles(-1, dtype, rows.ctypes.data_as(C.c_void_p), n, dim, mg,
-                                                got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
+        da._ffi.check(lib.dann_debug_gram_tiles(-1, dtype | (0x100 if dtype == oracle.F16 else 0), rows.ctypes.data_as(C.c_void_p),
+                                                n, dim, mg, got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
                       "dann_debug_gram_tiles")
         wide = rows.astype(np.float32)
         want = oracle.gram_chain(wide)
@@ -415,6 +416,39 @@ def test_gram_tiles_equal_one_fmaf_chain_per_entry(dtype):
             assert np.array_equal(bits(got[i, :m]), bits(want[i, :m])), (n, dim, i)
         exact = (wide.astype(np.float64) ** 2).sum(1)
         assert np.all(np.abs(nrm.astype(np.float64) - exact) <= np.spacing(exact.astype(np.float32)).astype(np.float64)), (n, dim)
+
+
+def test_gram_tiles_of_f16_rows_on_the_f16_matrix_core_stay_inside_the_error_interval():
+    """gram_tiles_f16_kernel (round 6, the builds' default for f16 rows): v_mfma_f32_32x32x16_f16 -- exact products, f32
+    sums in the hardware's own order.  Not the reference's chain bit for bit, and it need not be: the sweep trusts a Gram
+    entry only through E = c1 (|x|^2 + |y|^2) + c2 |d'| with c1 = 1.05 (K + 4) 2^-24 (K = dim rounded up to 32).  Every
+    entry of the lower triangle lies within c1 / 2 (|x|^2 + |y|^2) of the exact product -- half the interval is left for
+    the chain's own error --, is exact on integer-valued rows, and the norms are the f64 sums."""
+    import ctypes as C
+    rng = np.random.default_rng(56)
+    lib = da._ffi.lib()
+    for n, dim, mg in ((1, 8, 32), (7, 33, 32), (33, 100, 64), (70, 768, 96), (96, 96, 96), (130, 260, 96), (200, 128, 96),
+                       (256, 64, 96), (160, 1536, 96)):
+        for ints in (False, True):
+            rows = (rng.integers(-4, 5, (n, dim)) if ints else
+                    rng.standard_normal((n, dim)) * rng.uniform(0.1, 8.0, (n, 1))).astype(np.float16)
+            got = np.empty((n, mg), np.float32)
+            nrm = np.empty(n, np.float32)
+            da._ffi.check(lib.dann_debug_gram_tiles(-1, oracle.F16, rows.ctypes.data_as(C.c_void_p), n, dim, mg,
+                                                    got.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)),
+                          "dann_debug_gram_tiles")
+            wide = rows.astype(np.float64)
+            exact = wide @ wide.T
+            sq = (wide ** 2).sum(1)
+            c1 = 1.05 * (((dim + 31) // 32 * 32) + 4) * 2.0 ** -24
+            for i in range(n):
+                m = min(i + 1, mg)
+                err = np.abs(got[i, :m].astype(np.float64) - exact[i, :m])
+                if ints:
+                    assert np.all(err == 0), (n, dim, i)
+                else:
+                    assert np.all(err <= 0.5 * c1 * (sq[i] + sq[:m])), (n, dim, i, err.max())
+            assert np.all(np.abs(nrm.astype(np.float64) - sq) <= np.spacing(sq.astype(np.float32)).astype(np.float64)), (n, dim)
 
 
 @pytest.mark.parametrize("dtype,metric,dim", [(oracle.F16, oracle.L2, 96), (oracle.F16, oracle.INNER_PRODUCT, 100),
