@@ -404,7 +404,8 @@ struct MutationScope {
     MutationScope(const MutationScope&) = delete;
     MutationScope& operator=(const MutationScope&) = delete;
 };
-void server_quiesce(dann_index* idx);  // server.hip: the resident kernel leaves and is waited for (relaunched by the next submit)
+bool server_quiesce(dann_index* idx);  // server.hip: the resident kernel leaves and is waited for (relaunched by the next
+                                       // submit); false: the server is poisoned and was not waited for
 #define DANN_MUTATION(idx)                                                                                            \
     ::dann::MutationScope _mut(idx);                                                                                  \
     if (!_mut.ok) {                                                                                                   \
@@ -412,7 +413,12 @@ void server_quiesce(dann_index* idx);  // server.hip: the resident kernel leaves
                           "the server before mutating the index");                                                   \
         return DANN_EBUSY;                                                                                            \
     }                                                                                                                 \
-    ::dann::server_quiesce(const_cast<dann_index*>(static_cast<const dann_index*>(idx)))
+    if (!::dann::server_quiesce(const_cast<dann_index*>(static_cast<const dann_index*>(idx)))) {                     \
+        ::dann::set_error("the index's search server stopped answering (a wait ran into its limit): dann_server_stop " \
+                          "before mutating the index");                                                              \
+        return DANN_EHIP;                                                                                             \
+    }                                                                                                                 \
+    (void)0
 constexpr uint32_t kTieWorkBytes = 512 + 2048;
 constexpr uint32_t kMaxSearchCtx = 16;
 // a search context for one concurrent call: from the pool, created on demand (at most kMaxSearchCtx), else waits

@@ -183,9 +183,12 @@ int32_t relaunch_if_exited(dann_index* idx, dann_server* s) {
 // a row another kernel or a copy has rewritten.  The next submit finds the exit word and relaunches -- the kernel
 // boundary gives the acquire / invalidate.
 namespace dann {
-void server_quiesce(dann_index* idx) {
+bool server_quiesce(dann_index* idx) {
     dann_server* s = idx->server.load(std::memory_order_seq_cst);
-    if (!s) return;
+    if (!s) return true;
+    // a poisoned server's kernel may be wedged: synchronising with it here -- under the exclusive index lock -- would turn
+    // a clean refusal into an unbounded hang.  The mutation is refused; dann_server_stop clears the way.
+    if (s->poisoned.load(std::memory_order_acquire)) return false;
     std::lock_guard<std::mutex> lk(s->launch_mu);
     if (!s->launched || __atomic_load_n(&s->hv.h_ctl[1], __ATOMIC_ACQUIRE) != 0u) {
         // never launched, or the dispatcher has already left: wait for the workers of that launch to drain
@@ -193,12 +196,13 @@ void server_quiesce(dann_index* idx) {
             DeviceGuard guard(idx->device);
             (void)hipStreamSynchronize(s->ctx.stream);
         }
-        return;
+        return true;
     }
     DeviceGuard guard(idx->device);
     __atomic_store_n(&s->hv.h_ctl[0], 1u, __ATOMIC_RELEASE);  // the dispatcher polls this word, sets the exit word, leaves
     (void)hipStreamSynchronize(s->ctx.stream);
     __atomic_store_n(&s->hv.h_ctl[0], 0u, __ATOMIC_RELEASE);  // (not a stop: relaunch_if_exited may start it again)
+    return true;
 }
 }  // namespace dann
 
@@ -523,7 +527,11 @@ int32_t dann_search_wait(dann_index* idx, uint64_t ticket, uint32_t* out_ids, fl
                 set_error("dann_search_wait: no answer for ticket %llu within %u s (or the server's ring is wedged): "
                           "dann_server_stop / dann_server_start", (unsigned long long)ticket, kWaitLimitSeconds);
                 // the ticket is given up: it no longer counts as outstanding (mutations of the index are not refused on
-                // its account).  Its result slot stays retired -- a late answer may still land in it.
+                // its account).  Its result slot stays retired -- a late answer may still land in it.  A wait that ran into
+                // the limit means the resident kernel is not answering: the server is poisoned (every later submit / wait /
+                // poll fails at once instead of after its own 30 s, and server_quiesce does not wait for a kernel that may
+                // never leave); dann_server_stop / dann_server_start recovers.
+                s->poisoned.store(true, std::memory_order_release);
                 s->slot_owner[slot].store(0, std::memory_order_release);
                 idx->srv_outstanding.add(-1);
                 return DANN_EHIP;

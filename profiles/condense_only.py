@@ -9,6 +9,8 @@ tag, wl, name = sys.argv[1], sys.argv[2], sys.argv[3]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = f"{R}/gpurun_out", f"{R}/profiles"
 flt = "expand_beam" if wl == "gather" else "search_kernel"  # beam_search_kernel and pair_search_kernel
+if wl in ("large_u8", "large_sq8"):  # (their 10 M index is built under the profiler too: the build's insert searches are
+    flt = "pair_search_kernel"       #  beam_search_kernel launches, longer than the timed searches)
 
 
 def last_json(path):
@@ -17,6 +19,17 @@ def last_json(path):
 
 plain = list(last_json(f"{G}/{tag}_{wl}.json").values())[0]
 under = list(last_json(f"{G}/{tag}_{wl}_under_rocprof.json").values())[0]
+
+
+def timed_leg(obj):
+    """the 10 M integer legs (large_u8 / large_sq8, run with --L 64) nest their timed leg: {.., "L64": {..}}"""
+    for key, val in obj.items():
+        if key.startswith("L") and key[1:].isdigit() and isinstance(val, dict) and "avg_kernel_ms" in val:
+            return {**{k: v for k, v in obj.items() if not isinstance(v, dict)}, **val}
+    return obj
+
+
+plain, under = timed_leg(plain), timed_leg(under)
 shutil.copy(f"{G}/{tag}_{wl}_kernel_trace.csv", f"{P}/{name}_{wl}_kernel_trace.csv")
 trace = None
 for row in csv.DictReader(open(f"{G}/{tag}_{wl}_kernel_trace.csv")):
