@@ -172,6 +172,56 @@ def test_host_pointer_search_pipeline_equals_one_pass():
     assert np.array_equal(hi, ids) and np.array_equal(bits(hd), bits(d))
 
 
+def test_host_pointer_pipeline_under_concurrent_callers_and_other_row_types():
+    """Eight threads call dann_search_batch on 40 000-query host batches at once: every call wants three lanes, the index
+    has sixteen search contexts -- callers that find none free run with fewer lanes (CtxLease try_only) instead of waiting
+    for one another; results equal the single-threaded call.  Then the zero-copy launch on page-locked buffers for u8, f16
+    and i8 rows (the kernel reads its query from mapped host memory when it stages it), against the pageable call."""
+    import ctypes as C
+    import threading
+    import torch
+    rng, oix, gix = _index(oracle.F32, oracle.L2, 5000, 64, 16, 3)
+    nq, L, k = 40000, 16, 5
+    q = rand_vectors(rng, oracle.F32, nq, 64)
+    want_i, want_d, _ = gix.search(da.Knn(L), q, k)
+    lib = da._ffi.lib()
+    outs, errs = [None] * 8, []
+
+    def caller(t):
+        try:
+            hi = np.zeros((nq, k), np.uint32)
+            hd = np.zeros((nq, k), np.float32)
+            for _ in range(3):
+                da._ffi.check(lib.dann_search_batch(gix._h, q.ctypes.data_as(C.c_void_p), nq, L, 1, k,
+                                                    hi.ctypes.data_as(C.c_void_p), hd.ctypes.data_as(C.c_void_p), None), "batch")
+            outs[t] = (hi, hd)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for hi, hd in outs:
+        assert np.array_equal(hi, want_i) and np.array_equal(bits(hd), bits(want_d))
+    for odt in (oracle.U8, oracle.F16, oracle.I8):
+        rng2, oix2, gix2 = _index(odt, oracle.L2, 4000, 128, 32, 1)
+        qq = rand_vectors(rng2, odt, 33000, 128)
+        wi, wd, wst = gix2.search(da.Knn(20), qq, 10)
+        nb = qq.nbytes
+        pq = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+        pq.numpy()[...] = qq.reshape(-1).view(np.uint8)
+        pi = torch.zeros((33000, 10), dtype=torch.int32, pin_memory=True)
+        pd = torch.zeros((33000, 10), dtype=torch.float32, pin_memory=True)
+        da._ffi.check(lib.dann_search_batch(gix2._h, C.c_void_p(pq.data_ptr()), 33000, 20, 1, 10, C.c_void_p(pi.data_ptr()),
+                                            C.c_void_p(pd.data_ptr()), None), "batch")
+        assert np.array_equal(pi.numpy().view(np.uint32), wi) and np.array_equal(bits(pd.numpy()), bits(wd)), odt
+    oi, od, _, _ = oix2.search_batch(qq[:200], 20, 1, 10)
+    assert np.array_equal(wi[:200], oi)
+
+
 def test_mutations_are_refused_while_tickets_are_outstanding():
     """dann.h: mutations of the index are refused with DANN_EBUSY while tickets are outstanding; once every ticket has
     been collected they go through (the server stays up), and the results after the mutation follow the new rows."""
