@@ -9,8 +9,11 @@
 #include <time.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -985,6 +988,7 @@ static int32_t first_failed_query(const dann_search_stats* stats, uint32_t nq, u
 // queries per chunk of the host-pointer pipeline, and the batch size from which it is used
 constexpr uint32_t kHostChunk = 16384;
 
+extern "C++" {
 namespace {
 // is [p, p + bytes) page-locked host memory the device can reach by DMA (hipHostMalloc / hipHostRegister)?  Then the
 // pipeline copies straight from / to it; pageable buffers travel through the context's pinned ring.
@@ -1000,7 +1004,67 @@ bool host_pinned(const void* p, size_t bytes) {
     }
     return true;
 }
+
+// Page-locking a caller's pageable buffer for the duration of one call (hipHostRegister, mapped): on this runtime the
+// first registration of a range costs ~65 us per MB (3.3 ms for the 51 MB of 100 000 f32 queries), registering the same
+// range again ~1 us (scratch/probe_host_register.hip) -- a caller that reuses its buffers from call to call, as a
+// serving loop does, can be given the zero-copy launch of page-locked memory at no cost from its second call on.
+// Several threads may pass one buffer (a shared query block) at the same time: temporary registrations are counted in a
+// process-wide table, the last user unregisters.
+struct TempPins {
+    std::mutex mu;
+    std::map<const void*, std::pair<size_t, uint32_t>> live;  // base -> (bytes, users)
+    bool acquire(const void* p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it != live.end()) {
+            if (it->second.first < bytes) return false;  // (registered shorter by another caller: not worth untangling)
+            ++it->second.second;
+            return true;
+        }
+        if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        live.emplace(p, std::make_pair(bytes, 1u));
+        return true;
+    }
+    void release(const void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        if (--it->second.second == 0) {
+            (void)hipHostUnregister(const_cast<void*>(p));
+            live.erase(it);
+        }
+    }
+    // page-locked by the CALLER (stable for the call), not by another thread's temporary registration -- decided under the
+    // table's lock: a release on another thread unregisters and erases inside it, so the answer is never "pinned, not ours"
+    // for memory that is about to lose its pin
+    bool caller_pinned(const void* p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        return live.count(p) == 0 && host_pinned(p, bytes);
+    }
+};
+TempPins& temp_pins() {
+    static TempPins t;
+    return t;
+}
+// the set of temporary registrations of one call; everything acquired is released when it goes out of scope
+struct PinScope {
+    const void* held[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    bool add(const void* p, size_t bytes) {
+        if (!temp_pins().acquire(p, bytes)) return false;
+        held[n++] = p;
+        return true;
+    }
+    ~PinScope() {
+        for (int i = 0; i < n; ++i) temp_pins().release(held[i]);
+    }
+};
 }  // namespace
+}  // extern "C++"
 
 int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uint32_t l_value, uint32_t beam_width,
                           uint32_t k, uint32_t* out_ids, float* out_dists, dann_search_stats* out_stats) try {
@@ -1069,8 +1133,10 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     // with the calling thread's copies between them (11.7 M QPS on 100 000 queries where the device-resident call does
     // 18.6 M).  Buffers the caller page-locked (hipHostMalloc / hipHostRegister) need no ring: the DMA reads and writes
     // them directly.
-    const bool q_direct = host_pinned(queries, (size_t)nq * qb);
-    const bool o_direct = host_pinned(out_ids, (size_t)nq * k * 4) && host_pinned(out_dists, (size_t)nq * k * 4);
+    // (a buffer page-locked by another thread of this process for the length of ITS call -- temp_pins -- is pageable to us)
+    const bool q_direct = temp_pins().caller_pinned(queries, (size_t)nq * qb);
+    const bool o_direct = temp_pins().caller_pinned(out_ids, (size_t)nq * k * 4) &&
+                          temp_pins().caller_pinned(out_dists, (size_t)nq * k * 4);
     int dev = 0;
     DANN_HIP(hipGetDevice(&dev));
     // ---- no copies at all: page-locked, device-mapped caller buffers are read and written by the search kernel itself
@@ -1079,8 +1145,45 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     // smaller launches (the last queries of every chunk leave the chip half idle).  Row types whose kernels read the
     // query more than once (PQ: the table build; SQ-8: the compensation) keep the lanes.
     const int dt = idx->cfg.dtype;
-    if (q_direct && o_direct && (dt == DT_F32 || dt == DT_F16 || dt == DT_U8 || dt == DT_I8) &&
-        (!out_stats || host_pinned(out_stats, (size_t)nq * sizeof(dann_search_stats)))) {
+    const bool zc_rows = dt == DT_F32 || dt == DT_F16 || dt == DT_U8 || dt == DT_I8;
+    // Pageable buffers this index has been handed before (same pointers, same batch) are page-locked for the call and take
+    // the same launch -- unless registering them turned out to be expensive on this system (then never again).  A buffer
+    // another thread of this process has page-locked the same way counts as pageable here, not as the caller's.
+    const size_t q_bytes = (size_t)nq * qb, o_bytes = (size_t)nq * k * 4, s_bytes = (size_t)nq * sizeof(dann_search_stats);
+    bool q_zc = q_direct;
+    bool i_zc = temp_pins().caller_pinned(out_ids, o_bytes);
+    bool d_zc = temp_pins().caller_pinned(out_dists, o_bytes);
+    bool s_zc = !out_stats || temp_pins().caller_pinned(out_stats, s_bytes);
+    PinScope pins;
+    if (zc_rows && !(q_zc && i_zc && d_zc && s_zc) && pipeline_dbg == 1u /* (an explicit lane count: lanes only) */ &&
+        idx->host_register_pays.load(std::memory_order_relaxed)) {
+        uint32_t registered_before = 0;
+        bool seen = false;
+        {
+            std::lock_guard<std::mutex> lk(idx->stat_mu);
+            const dann_index::HostCall key{queries, out_ids, out_dists, nq, 0};
+            for (auto& h : idx->host_calls)
+                if (h == key) {
+                    seen = true;
+                    registered_before = h.registered++;
+                }
+            if (!seen) idx->host_calls[idx->host_calls_next++ % 8u] = key;
+        }
+        if (seen) {
+            const auto t0 = std::chrono::steady_clock::now();
+            bool ok = true;
+            if (ok && !q_zc) ok = pins.add(queries, q_bytes);
+            if (ok && !i_zc) ok = pins.add(out_ids, o_bytes);
+            if (ok && !d_zc) ok = pins.add(out_dists, o_bytes);
+            if (ok && !s_zc) ok = pins.add(out_stats, s_bytes);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // the first registration of a range is expensive everywhere; if the second one is too, this runtime does not keep
+            // ranges warm and the lanes are the better deal
+            if (registered_before >= 1 && ms > 1.0) idx->host_register_pays.store(false, std::memory_order_relaxed);
+            if (ok) q_zc = i_zc = d_zc = s_zc = true;
+        }
+    }
+    if (zc_rows && q_zc && i_zc && d_zc && s_zc) {
         void *dq = nullptr, *di = nullptr, *dd = nullptr, *ds = nullptr;
         bool mapped = hipHostGetDevicePointer(&dq, const_cast<void*>(queries), 0) == hipSuccess &&
                       hipHostGetDevicePointer(&di, out_ids, 0) == hipSuccess &&

@@ -309,6 +309,19 @@ struct dann_index {
     uint32_t visited_format = 0;   // dann_set_visited_format: 0 = automatic, 32 / 16 = entry width of the LDS visited table
     uint32_t max_concurrency = 0;  // dann_set_max_concurrency: queries in flight per search call (0 = all of them)
     uint32_t prune_tie_order = DANN_TIE_RUST;  // dann_set_prune_tie_order: DANN_TIE_RUST (default) / DANN_TIE_POSITION
+    // dann_search_batch on pageable host buffers: the last eight (queries, ids, distances, nq) it was called with (stat_mu)
+    // -- a call seen before page-locks its buffers for its duration -- and whether doing so is cheap on this system
+    struct HostCall {
+        const void* q = nullptr;
+        const void* i = nullptr;
+        const void* d = nullptr;
+        uint32_t nq = 0;
+        uint32_t registered = 0;  // calls that page-locked these buffers so far
+        bool operator==(const HostCall& o) const { return q == o.q && i == o.i && d == o.d && nq == o.nq; }
+    };
+    HostCall host_calls[8];
+    uint32_t host_calls_next = 0;
+    std::atomic<bool> host_register_pays{true};
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
     // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of

@@ -43,8 +43,9 @@ enum {
     DANN_DBG_PAIR_MIN_QUERIES = 2,       /* launches of at least this many queries take two queries per wavefront
                                             (default 20 x compute units) */
     DANN_DBG_TEAM_MAX_QUERIES = 3,       /* launches of at most this many queries take a team per query (default 4 x CUs) */
-    DANN_DBG_HOST_PIPELINE = 4,          /* 0: dann_search_batch never chunks its host buffers; 2 .. 8: that many lanes
-                                            (default 1 = three lanes) */
+    DANN_DBG_HOST_PIPELINE = 4,          /* 0: dann_search_batch never chunks its host buffers; 2 .. 8: that many lanes and
+                                            no temporary page-locking of buffers seen before (default 1 = three lanes,
+                                            page-locking on) */
     DANN_DBG_SWEEP_ONE_BY_ONE = 5,       /* 1: the MFMA prune's sweep decides one candidate at a time (default 0) */
     DANN_DBG_POOL_GRAM = 6,              /* 0: the pool prune of rows >= 1 KiB stays on the row kernel (default 1) */
     DANN_DBG_GRAM_COLS = 7,              /* columns of the Gram block: 32 / 64 / 96 (default 96) */
