@@ -38,7 +38,7 @@ constexpr uint32_t kPairHalf = 32;
 // stores of lanes that have nothing to store, the visited table.  QE = queue entries per lane (1: L + start points <=
 // 32, 2: <= 64), RE = adjacency ids per lane (1: degree <= 32, 2: <= 64).
 struct PairLds {
-    uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, sd_off, sink_off, ht_off, ov_off, half_bytes;
+    uint32_t cand_id_off, cand_d_off, stage_off, qimg_off, qpiv_off, sd_off, sink_off, ht_off, ov_off, half_bytes;
 };
 // keys of the queue image: a power of two beyond the queue's entries (the lower-bound search needs no bound check)
 __host__ __device__ inline uint32_t pair_qimg_keys(uint32_t qe) { return qe == 1u ? 64u : 128u; }
@@ -58,6 +58,8 @@ __host__ __device__ inline PairLds pair_lds_layout(uint32_t qe, uint32_t re, uin
     }
     l.qimg_off = off;  // the entries beyond the queue stay "empty" = larger than every distance
     off += 4u * pair_qimg_keys(qe);
+    l.qpiv_off = off;  // one queue entry per lane: the last key of each eighth of the queue image (first level of the
+    off += 32u;        // lower-bound search); 32 bytes
     l.sd_off = off;
     off += 128u;
     l.sink_off = off;  // one dword per lane (stores of many lanes to ONE address serialise like a bank conflict); the
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
     // distances in these two are order-preserving integer keys (ordered_bits): the rank arithmetic of the merge is
     // integer compares feeding add-with-carry, no lane-mask logic on the scalar unit
     uint32_t* const qimg = reinterpret_cast<uint32_t*>(hbase + L.qimg_off);
+    uint32_t* const qpiv = reinterpret_cast<uint32_t*>(hbase + L.qpiv_off);
     uint32_t* const sd = reinterpret_cast<uint32_t*>(hbase + L.sd_off);
     uint32_t* const sink = reinterpret_cast<uint32_t*>(hbase + L.sink_off) + li;  // this lane's own sink
     uint2* const sink2 = reinterpret_cast<uint2*>(hbase + L.sd_off) + li;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
         for (int e = 0; e < RE; ++e) cand_id[e * kPairHalf + li] = 0u;
 #pragma unroll
         for (uint32_t e = 0; e < QP / kPairHalf; ++e) qimg[e * kPairHalf + li] = kEmpty;
+        if (li < 8u) qpiv[li] = kEmpty;
     }
     // the lane's 16 query bytes and the query's squared norm stay in registers (as in the fixed-length integer path)
     const uint8_t* const qsrc = reinterpret_cast<const uint8_t*>(a.queries) + (uint64_t)qi * ix.layer_bytes;
@@ -336,16 +340,43 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                     uint32_t before = 0, shift[QE];
 #pragma unroll
                     for (int e = 0; e < QE; ++e) shift[e] = 0;
+                    // the survivors' keys, four per LDS round trip (the buffer is padded with keys larger than every distance)
 #pragma nounroll
-                    for (uint32_t t = 0; t < nvmax; ++t) {
-                        const uint32_t okj = sd[t];
-                        before += okj < oknd + (t > cj ? 1u : 0u) ? 1u : 0u;  // d_j < d, or equal and emitted later
+                    for (uint32_t t = 0; t < nvmax; t += 4u) {
+                        const u32x4 k4 = *reinterpret_cast<const u32x4*>(sd + t);
 #pragma unroll
-                        for (int e = 0; e < QE; ++e) shift[e] += okj <= okq[e] ? 1u : 0u;  // (entries at or beyond the size are never scattered)
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t okj = k4[i];
+                            before += okj < oknd + (t + (uint32_t)i > cj ? 1u : 0u) ? 1u : 0u;  // d_j < d, or equal and emitted later
+#pragma unroll
+                            for (int e = 0; e < QE; ++e) shift[e] += okj <= okq[e] ? 1u : 0u;  // (entries at or beyond the size are never scattered)
+                        }
                     }
-                    uint32_t lb = 0;  // #{old e: d_e < d}
+                    // #{old e: d_e < d}.  The hop of this kernel is a chain of LDS round trips (round 6: requesting the
+                    // gather's rows a hop ahead changes nothing, profiles/README.md), and a binary search in the queue
+                    // image is six or seven DEPENDENT ones.  One queue entry per lane (64 keys): the eighth of the image
+                    // the key falls into (eight pivots, one broadcast read), then that eighth's eight keys -- two round
+                    // trips, 33 vector instructions instead of 24: 1.82 -> 1.76 ms at L = 26 (u8; SQ-8 1.85 -> 1.77) on
+                    // the same box.  Longer queues keep the binary search: the 16-key eighths of a 128-key image cost more
+                    // vector work than the five round trips they save (L = 64: 4.88 -> 4.90 ms; scratch/r06_lib_ab2.sh).
+                    uint32_t lb = 0;
+                    if constexpr (QE == 1) {
+                        constexpr uint32_t B = QP / 8u;
+                        const u32x4 p0 = *reinterpret_cast<const u32x4*>(qpiv), p1 = *reinterpret_cast<const u32x4*>(qpiv + 4);
 #pragma unroll
-                    for (uint32_t step = QP / 2u; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
+                        for (int i = 0; i < 4; ++i) lb += (p0[i] < oknd ? 1u : 0u) + (p1[i] < oknd ? 1u : 0u);
+                        lb *= B;
+                        const uint32_t* blk = qimg + lb;
+#pragma unroll
+                        for (uint32_t q4 = 0; q4 < B / 4u; ++q4) {
+                            const u32x4 kk = *reinterpret_cast<const u32x4*>(blk + 4u * q4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lb += kk[i] < oknd ? 1u : 0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t step = QP / 2u; step > 0; step >>= 1) lb = qimg[lb + step - 1u] < oknd ? lb + step : lb;
+                    }
                     const uint32_t pos_new = lb + before;
 #pragma unroll
                     for (int e = 0; e < QE; ++e) {
@@ -363,7 +394,9 @@ __global__ __launch_bounds__(kWave) void pair_search_kernel(SearchArgs a) {
                         const bool in = p < sizev;
                         qid[e] = in ? en.x : qid[e];
                         qd[e] = in ? __builtin_bit_cast(float, en.y) : qd[e];
-                        qimg[p] = in ? ordered_bits(qd[e]) : kEmpty;
+                        const uint32_t key = in ? ordered_bits(qd[e]) : kEmpty;
+                        qimg[p] = key;
+                        if constexpr (QE == 1) *(((p & (QP / 8u - 1u)) == QP / 8u - 1u) ? qpiv + p / (QP / 8u) : sink) = key;
                     }
                 }
             }
