@@ -9,8 +9,8 @@ tag, wl, name = sys.argv[1], sys.argv[2], sys.argv[3]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = f"{R}/gpurun_out", f"{R}/profiles"
 flt = "expand_beam" if wl == "gather" else "search_kernel"  # beam_search_kernel and pair_search_kernel
-if wl in ("large_u8", "large_sq8"):  # (their 10 M index is built under the profiler too: the build's insert searches are
-    flt = "pair_search_kernel"       #  beam_search_kernel launches, longer than the timed searches)
+if wl in ("large_u8", "large_sq8", "u8", "sq8"):  # (their index is built under the profiler too: the build's insert searches
+    flt = "pair_search_kernel"                    #  are beam_search_kernel launches, as long as or longer than the timed searches)
 
 
 def last_json(path):
