@@ -3,7 +3,7 @@
 # usage: scratch/r06_final.sh <tag>
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r06z}
 cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -3 | tee gpurun_out/${T}_pytest.log
+timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" | tee gpurun_out/${T}_pytest.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee -a gpurun_out/${T}_pytest.log
 t0=$(date +%s)
 timeout 900 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; echo "bench rc=$? wall $(( $(date +%s) - t0 )) s"; tail -2 gpurun_out/${T}_bench.err
