@@ -1344,6 +1344,29 @@ def large_variant(args, spec, torch, da, lib, _ffi, dev, local, k, W, stream_rea
             res["traffic_source"] = "profiles/pmc_large_latest.json (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
+    if dim >= 512 and not f16 and not args.no_pq:
+        # config 5's row shape through the PQ path: the same rows as 64-byte codes (chunks of dim / 64 columns), the same
+        # graph, lookup-table search with the table in four register groups, Rerank on these f32 rows -- next to this leg's
+        # full-precision number and the f16 leg's (`bench.py --only pq768` runs it alone, with other code lengths)
+        try:
+            import copy
+            pa = copy.copy(args)
+            pa.n, pa.dim, pa.max_degree, pa.pq_chunks, pa.L, pa.pq768 = n, dim, R, 64, 0, False
+            mean = base.double().mean(0).float()
+            med = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
+            pq = pq_variant(pa, torch, da, lib, _ffi, dev, local, base, queries, gt, med, k, W, prov)
+            res["pq64_plus_rerank_same_graph"] = {
+                "chunks": 64, "bytes_per_point": 64, "L": pq["L"], "recall_at_10_vs_exact_f32": pq["recall_at_10_vs_exact_f32"],
+                "qps": pq["qps"], "search_kernel": {kk: pq["search_kernel"][kk] for kk in
+                                                    ("kernel", "kernel_family", "avg_kernel_ms", "qps_search_only", "queries_per_cu")},
+                "mean_cmps": pq["mean_cmps"], "mean_hops": pq["mean_hops"], "oracle_sample": pq["oracle_sample"],
+                "train_seconds": pq["train_seconds_kmeanspp_plus_10_lloyds_131072_rows"],
+                "compress_seconds_incl_pcie": pq["compress_seconds_incl_pcie"],
+                "full_precision_qps_this_leg": nq / dt,
+                "reading": "a capacity format on this hardware: 48 x fewer bytes per point than these f32 rows for a "
+                           "fraction of the queries per second at equal recall (DESIGN.md 3.8)"}
+        except Exception as e:  # noqa: BLE001 -- never lose the leg over its side measurement
+            res["pq64_plus_rerank_same_graph"] = {"error": str(e)[:300]}
     prov.close()
     return res
 

@@ -184,7 +184,7 @@ struct SearchArgs {
     ServerView srv;                  // srv.ring != 0: the launch is the persistent server (grid = workers + 1 waves)
     uint32_t team = 0;               // 1: several wavefronts per query (latency regime; plain fixed-length searches only)
     uint32_t pqlut = 0;              // 1: PQ rows through pq_search_kernel (search_pq_impl.h: lookup table in registers, 16-bit
-                                     //    visited table; plain Knn, <= 16 chunks, L + start points <= 256)
+                                     //    visited table; plain Knn, <= 64 chunks, L + start points <= 256)
     uint32_t pair = 0;               // 1: two queries per wavefront (search_pair_impl.h; 128-byte integer rows, L + start
                                      //    points <= 96, degree <= 64); ht_entries = table words of ONE query then
 };

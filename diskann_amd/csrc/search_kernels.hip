@@ -331,7 +331,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     // touches the pool (a team gives a query that outgrows its table back to the host): one device operation less on
     // the single-query path
     if (!a.team) DANN_HIP(hipMemsetAsync(a.spill_next, 0, (16 + (size_t)ctx.spill_slices) * 4, st));
-    // PQ rows of at most 16 chunks, plain Knn search: the lookup table in registers (search_pq_impl.h).
+    // PQ rows of at most 64 chunks, plain Knn search: the lookup table in registers (search_pq_impl.h).
     // DANN_DBG_TUNE_OFF bit 32: development switch.
     a.pqlut = (!will_grid && pq_lut_shape(a) && idx->visited_format != 32u && !idx->tune_off(32)) ? 1u : 0u;
     const bool autosize = a.ht_entries == 0;
