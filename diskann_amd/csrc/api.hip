@@ -1297,22 +1297,41 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
         ++lanes;
     }
     Lane ln[kMaxLanes];
-    std::thread th[kMaxLanes - 1];
+    // (the helpers are joined on every way out of this scope: a joinable std::thread must never be destroyed)
+    struct Helpers {
+        std::thread th[kMaxLanes - 1];
+        ~Helpers() {
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+        }
+    } helpers;
+    bool started[kMaxLanes] = {true};
     for (uint32_t t = 1; t < lanes; ++t) {
-        th[t - 1] = std::thread([&, t]() {
-            try {
-                (void)hipSetDevice(dev);
-                ln[t].rc = run_lane(*extra[t - 1]->ctx, t, lanes, ln[t]);
-                if (ln[t].rc != DANN_OK) grab_text(ln[t].text);
-            } catch (...) {
-                ln[t].rc = DANN_EINTERNAL;
-                ln[t].text = "exception in a lane of the host-pointer pipeline";
-            }
-        });
+        try {
+            helpers.th[t - 1] = std::thread([&, t]() {
+                try {
+                    (void)hipSetDevice(dev);
+                    ln[t].rc = run_lane(*extra[t - 1]->ctx, t, lanes, ln[t]);
+                    if (ln[t].rc != DANN_OK) grab_text(ln[t].text);
+                } catch (...) {
+                    ln[t].rc = DANN_EINTERNAL;
+                    ln[t].text = "exception in a lane of the host-pointer pipeline";
+                }
+            });
+            started[t] = true;
+        } catch (...) {  // no thread to be had: the calling thread takes that lane's chunks after its own
+            started[t] = false;
+        }
     }
     ln[0].rc = run_lane(ctx, 0, lanes, ln[0]);
     if (ln[0].rc != DANN_OK) grab_text(ln[0].text);
-    for (uint32_t t = 1; t < lanes; ++t) th[t - 1].join();
+    for (uint32_t t = 1; t < lanes; ++t)
+        if (!started[t] && ln[0].rc == DANN_OK) {
+            ln[t].rc = run_lane(ctx, t, lanes, ln[t]);
+            if (ln[t].rc != DANN_OK) grab_text(ln[t].text);
+        }
+    for (uint32_t t = 1; t < lanes; ++t)
+        if (helpers.th[t - 1].joinable()) helpers.th[t - 1].join();
     for (uint32_t t = 0; t < lanes; ++t)
         if (ln[t].rc != DANN_OK) {
             set_error("%s", ln[t].text.c_str());
