@@ -829,8 +829,12 @@ def callers_variant(prov, qh, L, k, same_as_oracle):
     for threads in (1, 16):
         nq = 1500 * threads
         prov.concurrent_callers(qh[:128 * threads], L, k, threads=threads, mode=0)
+        sc0 = prov.small_call_stats()
         ids, d, lat, secs = prov.concurrent_callers(qh[:nq], L, k, threads=threads, mode=0)
+        sc1 = prov.small_call_stats()
         res[f"launch_path_{threads}_threads"] = {"qps": nq / secs, "queries": nq, **pct(lat),
+                                                # calls that arrive side by side share a launch (api.hip: small_call)
+                                                "calls_per_launch": (sc1[1] - sc0[1]) / max(sc1[0] - sc0[0], 1),
                                                 "ids_identical_to_oracle": same_as_oracle(ids, d, L, nq)}
     prov.server_start(L, k, workers=1024, ring=8192)
     try:

@@ -178,6 +178,7 @@ SYMBOLS = {
     "dann_debug_set": (_i32, [_vp, _i32, C.c_double]),
     "dann_debug_get": (_i32, [_vp, _i32, _P(C.c_double)]),
     "dann_debug_search_families": (_i32, [_vp, _P(_u64), _P(C.c_double)]),
+    "dann_debug_small_call_stats": (_i32, [_vp, _P(_u64)]),
     "dann_debug_family_name": (C.c_char_p, [_i32]),
     "dann_debug_pq_rolling_sum_stats": (_i32, [_i32, _P(_u64), _i32]),
 }

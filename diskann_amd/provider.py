@@ -454,6 +454,13 @@ class Provider:
         check(_ffi.lib().dann_debug_search_families(self._h, cnt, ms), "dann_debug_search_families")
         return {f: (int(cnt[i]), float(ms[i])) for i, f in enumerate(_ffi.FAMILIES)}
 
+    def small_call_stats(self):
+        """(launches, calls served by them) of the small host-pointer search calls so far: calls of several threads that
+        arrive side by side share a launch"""
+        out = (C.c_uint64 * 2)()
+        check(_ffi.lib().dann_debug_small_call_stats(self._h, out), "dann_debug_small_call_stats")
+        return int(out[0]), int(out[1])
+
     def last_family(self, fn):
         """runs fn() and returns (its result, the set of kernel families that served searches meanwhile)"""
         before = self.search_families()

@@ -84,6 +84,10 @@ int32_t dann_debug_search_families(const dann_index* idx, uint64_t* out_launches
 /* family name for logs ("one_wave", "team", "pair", "persistent", "server", "pq_lut"); null for an unknown family */
 const char* dann_debug_family_name(int32_t family);
 
+/* small dann_search_batch calls (host pointers, at most 16 queries) of several threads share launches: out2 = {launches,
+ * calls served by them} since the index was created -- calls / launches is the mean number of calls per launch */
+int32_t dann_debug_small_call_stats(dann_index* idx, uint64_t* out2);
+
 /* how the PQ trainer's rolling f64 sums (the D^2 draw and its totals, plusplus.rs:446-462) were evaluated on `device`
  * since the last reset: out4 = {wavefront-level ranges and thread-level ranges summed in parallel because no addition
  * in them can round, ranges walked element by element, elements walked}.  Same bits either way; the tests assert that

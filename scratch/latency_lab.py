@@ -20,7 +20,7 @@ ap.add_argument("--points", default="", help="comma list nq:L[:reps] run instead
 args = ap.parse_args()
 import diskann_amd._ffi as ffi
 if args.prof:
-    ffi.LIB_PATH = os.path.join(ROOT, "diskann_amd", "libdann_prof.so")
+    ffi.LIB_PATH = os.environ.get("DANN_PROF_LIB") or os.path.join(ROOT, "diskann_amd", "libdann_prof.so")
 import torch
 import diskann_amd as da
 from benchdata import make_data
@@ -76,11 +76,14 @@ def timed(nq, L, reps):
                  f"slow merges {buf[9] / max(buf[10], 1):.3f} | team: control wave's decision with the visited wave's candidates {buf[12] / max(buf[5], 1):.0f} "
                  f"(x{buf[5] / max(buf[5] + buf[6], 1):.2f}) otherwise {buf[13] / max(buf[6], 1):.0f} (waited for the pop x{buf[7] / max(buf[5] + buf[6], 1):.2f}) "
                  f"its loads {v[1]:.0f} start {v[2]:.0f} barrier wait {v[15]:.0f} | queue wave's barrier wait {v[14]:.0f}")
+        if os.environ.get("DANN_PROF_FINE"):  # scratch build with the finer timers of the control wave's short path
+            fp = max(buf[5], 1)
+            line += f"\n      per hop: gather wave go -> distances written {buf[10] / max(hops, 1):.0f}, its barrier wait {buf[8] / max(hops, 1):.0f}, visited wave's barrier wait {buf[9] / max(hops, 1):.0f}"
     print(line, flush=True)
 
 
 for tune in [int(x) for x in args.tunes.split(",")]:
-    os.environ["DANN_TUNE_OFF"] = str(tune)
+    prov.debug_set(tune_off=tune)
     print(f"---- DANN_TUNE_OFF={tune} (1: no row prefetch, 2: no latency-mode table sizing)", flush=True)
     if args.points:
         for pt in args.points.split(","):

@@ -38,6 +38,72 @@ def test_single_query_calls_from_many_threads_overlap():
     assert t16 < 0.5 * t1, (t1, t16)
 
 
+@pytest.mark.parametrize("odt", [oracle.F32, oracle.U8, oracle.F16, oracle.I8])
+def test_small_host_calls_of_many_threads_share_launches(odt):
+    """dann_search_batch calls of at most 16 queries go through the combiner (api.hip: small_call): queries and results
+    in page-locked mapped staging, one launch per call -- and per *group* of calls when several threads call side by side.
+    Twelve Python threads with call sizes 1 .. 16 and three different (L, k) between them (only equal parameters may
+    share a launch): every call returns what the oracle returns for its queries, statistics included; the counters show
+    that launches were shared; with the combiner off (host_pipeline = 0) the same calls give the same rows."""
+    import ctypes as C
+    dim = 128 if odt != oracle.F32 else 100
+    rng, oix, gix = _index(odt, oracle.L2, 6000, dim, 24, 91)
+    nq = 1500
+    q = rand_vectors(rng, odt, nq, dim)
+    params = [(20, 5), (33, 10), (64, 10)]
+    want = {p: oix.search_batch(q, p[0], 1, p[1]) for p in params}
+    lib = da._ffi.lib()
+    before = gix.small_call_stats()
+    errs = []
+
+    def caller(t, rounds):
+        try:
+            L, k = params[t % 3]
+            oi, od, oc, ost = want[(L, k)]
+            r = np.random.default_rng(1000 + t)
+            for _ in range(rounds):
+                n = int(r.integers(1, 17))
+                s0 = int(r.integers(0, nq - n))
+                qs = np.ascontiguousarray(q[s0:s0 + n])
+                hi = np.zeros((n, k), np.uint32)
+                hd = np.zeros((n, k), np.float32)
+                hs = np.zeros(n, da.STATS_DTYPE)
+                with_stats = bool(r.integers(0, 2))
+                da._ffi.check(lib.dann_search_batch(gix._h, qs.ctypes.data_as(C.c_void_p), n, L, 1, k,
+                                                    hi.ctypes.data_as(C.c_void_p), hd.ctypes.data_as(C.c_void_p),
+                                                    hs.ctypes.data_as(C.c_void_p) if with_stats else None), "batch")
+                assert np.array_equal(hi, oi[s0:s0 + n]) and np.array_equal(bits(hd), bits(od[s0:s0 + n])), (t, s0, n)
+                if with_stats:
+                    assert np.array_equal(hs["cmps"], ost[s0:s0 + n, 0]) and np.array_equal(hs["hops"], ost[s0:s0 + n, 1])
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=caller, args=(t, 60)) for t in range(12)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs[:3]
+    launches, calls = (a - b for a, b in zip(gix.small_call_stats(), before))
+    assert calls == 12 * 60 and launches <= calls
+    if odt == oracle.F32:
+        # native threads in lockstep (no interpreter between the calls): launches are shared for certain
+        before = gix.small_call_stats()
+        oi, od, _, _ = want[(64, 10)]
+        ids, d, _, _ = gix.concurrent_callers(q, 64, 10, threads=8, mode=0)
+        assert np.array_equal(ids, oi) and np.array_equal(bits(d), bits(od))
+        launches, calls = (a - b for a, b in zip(gix.small_call_stats(), before))
+        assert calls == nq and launches < calls, (launches, calls)
+    # the same calls without the combiner
+    gix.debug_set(host_pipeline=0)
+    before = gix.small_call_stats()
+    caller(0, 20)
+    caller(1, 20)
+    assert not errs, errs[:3]
+    assert gix.small_call_stats() == before
+    gix.debug_set(host_pipeline=None)
+
+
 @pytest.mark.parametrize("dtype,metric,dim,R,L,k", [
     (oracle.F32, oracle.L2, 128, 32, 64, 10),
     (oracle.F32, oracle.INNER_PRODUCT, 100, 24, 40, 5),
