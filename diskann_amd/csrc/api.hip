@@ -1085,7 +1085,16 @@ int32_t small_batch_run(dann_index* idx, dann_index::SmallCall* const* calls, ui
         memcpy(h + off, calls[c]->queries, (size_t)calls[c]->nq * qb);
         off += (size_t)calls[c]->nq * qb;
     }
-    int32_t rc = search_device(idx, ctx, d, nullptr, total, calls[0]->l_value, calls[0]->beam, k,
+    // row types whose kernels read a query more than once (PQ: the table build; SQ-8: the compensation) get the queries
+    // in device memory: one copy for the whole group of calls; the results still land in the mapped block
+    const int dt = idx->cfg.dtype;
+    const void* dq = d;
+    if (!(dt == DT_F32 || dt == DT_F16 || dt == DT_U8 || dt == DT_I8)) {
+        if (int32_t grc = grow_stage(ctx, 0, in_b + 16)) return grc;
+        DANN_HIP(hipMemcpyAsync(ctx.stage[0], h, (size_t)total * qb, hipMemcpyHostToDevice, ctx.stream));
+        dq = ctx.stage[0];
+    }
+    int32_t rc = search_device(idx, ctx, dq, nullptr, total, calls[0]->l_value, calls[0]->beam, k,
                                reinterpret_cast<uint32_t*>(d + in_b), reinterpret_cast<float*>(d + in_b + ids_b),
                                reinterpret_cast<dann_search_stats*>(d + in_b + 2 * ids_b), nullptr, nullptr, 0, nullptr);
     if (rc != DANN_OK) return rc;
@@ -1299,9 +1308,7 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     const size_t qb = idx->cfg.dtype == DT_PQ ? (size_t)idx->cfg.dim * 4 : idx->layer_bytes;  // PQ: f32 queries
     const uint32_t pipeline_dbg = idx->dbg_u32(DANN_DBG_HOST_PIPELINE, 1u);  // 0 off, 1 default, 2 .. 8 lanes
     {   // a small call: one launch reading and writing mapped host memory, shared with the small calls of other threads
-        const int sdt = idx->cfg.dtype;
-        const bool once = sdt == DT_F32 || sdt == DT_F16 || sdt == DT_U8 || sdt == DT_I8;  // (kernels that read a query once)
-        if (once && pipeline_dbg == 1u && nq <= kSmallCall && small_call_bytes(nq, qb, k) <= kSmallStage / 4) {
+        if (pipeline_dbg == 1u && nq <= kSmallCall && small_call_bytes(nq, qb, k) <= kSmallStage / 4) {
             dann_index::SmallCall me;
             me.queries = queries;
             me.nq = nq;

@@ -49,3 +49,38 @@ def teams_on():
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def small_calls_from_threads(gix, q, L, W, k, want_ids, want_d, nthreads=4, rounds=12):
+    """dann_search_batch calls of 1 .. 8 queries from `nthreads` threads at once (they share launches: api.hip,
+    small_call); every call must return the rows of want_ids / want_d (the oracle's, for all of q) for its queries"""
+    import ctypes as C
+    import threading
+    import diskann_amd as da
+    lib = da._ffi.lib()
+    errs = []
+
+    def caller(t):
+        try:
+            r = np.random.default_rng(500 + t)
+            for _ in range(rounds):
+                n = int(r.integers(1, 9))
+                s0 = int(r.integers(0, len(q) - n + 1))
+                qs = np.ascontiguousarray(q[s0:s0 + n])
+                hi = np.zeros((n, k), np.uint32)
+                hd = np.zeros((n, k), np.float32)
+                da._ffi.check(lib.dann_search_batch(gix._h, qs.ctypes.data_as(C.c_void_p), n, L, W, k,
+                                                    hi.ctypes.data_as(C.c_void_p), hd.ctypes.data_as(C.c_void_p), None), "batch")
+                assert np.array_equal(hi, want_ids[s0:s0 + n]) and np.array_equal(bits(hd), bits(want_d[s0:s0 + n])), (t, s0, n)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    before = gix.small_call_stats()
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(nthreads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs[:3]
+    launches, calls = (a - b for a, b in zip(gix.small_call_stats(), before))
+    assert calls == nthreads * rounds and 0 < launches <= calls

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import bits, random_graph
+from helpers import bits, random_graph, small_calls_from_threads
 
 pytestmark = pytest.mark.gpu
 da = pytest.importorskip("diskann_amd")
@@ -59,6 +59,8 @@ def test_sq8_search_and_distances(metric, stride):
     gix.set_elements(0, codes)
     gix.upload_graph(adj)
     queries = da.sq8_compress(rng.normal(0.3, 0.5, (40, dim)).astype(np.float32), shift, scale)
+    oi, od_, _, _ = oix.search_batch(queries, 30, 1, 10)
+    small_calls_from_threads(gix, queries, 30, 1, 10, oi, od_)
     ids = rng.choice(n, 200, replace=False).astype(np.uint32)
     _, od = oix.expand_beam(queries[0], ids)
     _, gd = gix.expand_beam(queries[0], ids)
@@ -203,6 +205,10 @@ def test_pq_beam_search(metric, nchunks):
         assert np.array_equal(oi, gi), (L, W)
         assert np.array_equal(bits(od), bits(gd)), (L, W)
         assert np.array_equal(ost[:, 0], gst["cmps"]) and np.array_equal(ost[:, 1], gst["hops"])
+    # small calls of several threads (one launch for a group of them; the f32 queries staged in device memory: the table
+    # build reads a query 256 times)
+    oi, od, _, _ = oix.search_batch(q, 48, 3, 10)
+    small_calls_from_threads(gix, q, 48, 3, 10, oi, od)
     # the build path is not defined on PQ rows
     with pytest.raises(da.DannError) as e:
         gix.insert_batch(da.build_config(4, 8, 10), [0])
