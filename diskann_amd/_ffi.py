@@ -187,7 +187,7 @@ SYMBOLS = {
 DBG_KEYS = {"tune_off": 0, "tune_on": 1, "pair_min_queries": 2, "team_max_queries": 3, "host_pipeline": 4,
             "sweep_one_by_one": 5, "pool_gram": 6, "gram_cols": 7, "gram_escale": 8, "backedge_gram_rows": 9,
             "server_max_resident_us": 10, "verbose": 11, "ht16_open_eighths": 12, "backedge_single_pool": 13,
-            "ht16_max_probes": 14, "host_chunk": 15, "gram_f16_widen": 16}
+            "ht16_max_probes": 14, "host_chunk": 15, "gram_f16_widen": 16, "time_small_launches": 17}
 FAMILIES = ("one_wave", "team", "pair", "persistent", "server", "pq_lut")
 
 _lib = None

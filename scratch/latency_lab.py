@@ -35,6 +35,7 @@ medoid = int(torch.argmin(((base - mean[None, :]) ** 2).sum(1)).item())
 prov = da.Provider(da.F32, da.L2, dim, n, R, base[medoid:medoid + 1].cpu().numpy(), device=0)
 prov.set_elements(0, base.cpu().numpy())
 prov.build(da.build_config(28, R, 100, intra_batch_candidates=da.IBC_NONE), 0, n, 0.05, 16384)
+prov.debug_set(time_small_launches=1)  # (kernel microseconds of single-query launches are printed below)
 k = 10
 d_ids = torch.empty((100000, k), dtype=torch.int32, device=dev)
 d_d = torch.empty((100000, k), dtype=torch.float32, device=dev)
