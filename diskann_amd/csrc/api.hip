@@ -986,81 +986,18 @@ static int32_t first_failed_query(const dann_search_stats* stats, uint32_t nq, u
     return DANN_OK;
 }
 
-// ---- small host-pointer calls: one launch for all callers that are waiting -----------------------------------------
-// A call of a few queries used to cost four runtime calls (copy in, launch, copy out, wait) on its own stream, and
-// sixteen threads making such calls met in the runtime's launch path (42 k calls/s whatever the kernel does).  Now the
-// queries are copied into page-locked, device-mapped staging the kernel reads directly, the results are written the
-// same way, and calls of several threads that ask for the same (L, beam, k) travel in ONE launch: the first caller to
-// find no leader leads -- takes every waiting call that fits, launches, waits, hands out the rows -- the others wait
-// for their rows (or for the leadership, if the launch in flight left without them).  The results are those of the
-// calls made one by one: a query's search does not depend on what else is in its launch.
-constexpr uint32_t kSmallCall = 16;          // queries per call up to which calls are combined
-constexpr uint32_t kSmallBatch = 256;        // queries per combined launch
-constexpr size_t kSmallStage = (size_t)1 << 20;  // the staging block of a context (h_stage)
-constexpr int32_t kSmallCallDeclined = 1;    // (not a status: the caller takes the general path)
-static size_t small_call_bytes(uint32_t nq, size_t qb, uint32_t k) {
-    return (((size_t)nq * qb + 15) & ~(size_t)15) + 2 * (((size_t)nq * k * 4 + 15) & ~(size_t)15) +
-           (((size_t)nq * sizeof(dann_search_stats) + 15) & ~(size_t)15);
-}
-struct dann_index::SmallCall {
-    const void* queries = nullptr;
-    uint32_t nq = 0, l_value = 0, beam = 0, k = 0;
-    uint32_t* out_ids = nullptr;
-    float* out_dists = nullptr;
-    dann_search_stats* out_stats = nullptr;
-    SmallCall* next = nullptr;  // (queue link)
-    std::atomic<bool> done{false};
-    int32_t rc = DANN_OK;
-    std::string text;  // the error text that goes with rc (set_error is thread-local: the waiter repeats it)
-};
-
+// ---- small host-pointer calls: one launch for all callers that are waiting (the queue and the leadership: small_calls.h)
 extern "C++" {
 namespace {
-inline void small_relax() {
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-}
 void grab_error_text(std::string& t) {
     char buf[512];
     buf[0] = 0;
     dann_last_error(buf, sizeof buf);
     t = buf;
 }
-// Waiting callers poll (a launch takes ~100 us: a futex sleep would double a call's latency) -- but only as many of them as
-// this process has processors to spare: under a CPU quota (cgroup cpu.max; 16 of this box's 256 hardware threads) every
-// polling thread beyond it gets the whole process throttled for tens of milliseconds.  The rest nap between polls.
-uint32_t small_spin_budget() {
-    static const uint32_t budget = [] {
-        uint32_t cpus = std::thread::hardware_concurrency();
-        if (cpus == 0) cpus = 4;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min<uint32_t>(cpus, (uint32_t)std::max(1, CPU_COUNT(&set)));
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // "<quota> <period>" in microseconds, or "max <period>"
-            long long q = 0, p = 0;
-            if (fscanf(f, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) cpus = std::min<uint32_t>(cpus, (uint32_t)std::max<long long>(1, q / p));
-            fclose(f);
-        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // (cgroup v1)
-            long long q = 0, p = 100000;
-            if (fscanf(g, "%lld", &q) != 1) q = 0;
-            fclose(g);
-            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (fscanf(h, "%lld", &p) != 1) p = 100000;
-                fclose(h);
-            }
-            if (q > 0 && p > 0) cpus = std::min<uint32_t>(cpus, (uint32_t)std::max<long long>(1, q / p));
-        }
-        return std::min<uint32_t>(cpus > 1 ? cpus - 1 : 1, 32u);  // (one is the leader's)
-    }();
-    return budget;
-}
-std::atomic<uint32_t> g_small_spinners{0};
-
 // one launch for `n` calls (same L, beam, k; `total` queries).  Returns kSmallCallDeclined if the staging cannot be
 // mapped (the calls then take the general path one by one).
-int32_t small_batch_run(dann_index* idx, dann_index::SmallCall* const* calls, uint32_t n, uint32_t total, size_t qb) {
+int32_t small_batch_run(dann_index* idx, SmallCall* const* calls, uint32_t n, uint32_t total, size_t qb) {
     CtxLease lease(idx);
     if (lease.status != DANN_OK) return lease.status;
     SearchCtx& ctx = *lease.ctx;
@@ -1104,7 +1041,7 @@ int32_t small_batch_run(dann_index* idx, dann_index::SmallCall* const* calls, ui
     const dann_search_stats* rs = reinterpret_cast<const dann_search_stats*>(h + in_b + 2 * ids_b);
     uint32_t q0 = 0;
     for (uint32_t c = 0; c < n; ++c) {
-        dann_index::SmallCall& r = *calls[c];
+        SmallCall& r = *calls[c];
         memcpy(r.out_ids, ri + (size_t)q0 * k, (size_t)r.nq * k * 4);
         memcpy(r.out_dists, rd + (size_t)q0 * k, (size_t)r.nq * k * 4);
         if (r.out_stats) memcpy(r.out_stats, rs + q0, (size_t)r.nq * sizeof(dann_search_stats));
@@ -1113,103 +1050,6 @@ int32_t small_batch_run(dann_index* idx, dann_index::SmallCall* const* calls, ui
         q0 += r.nq;
     }
     return DANN_OK;
-}
-// the leader's turn: cut a batch off the waiting calls, run it, mark its calls
-void small_lead(dann_index* idx, size_t qb) {
-    using clk = std::chrono::steady_clock;
-    if (idx->comb_recent > 1 && idx->comb_npending.load(std::memory_order_acquire) < idx->comb_recent) {
-        // callers in lockstep: the threads whose results the last launch delivered are on their way back -- a launch that
-        // leaves without them makes them wait for the whole of it
-        const uint32_t want = idx->comb_recent;
-        const auto t0 = clk::now();
-        while (idx->comb_npending.load(std::memory_order_acquire) < want && clk::now() - t0 < std::chrono::microseconds(25))
-            small_relax();
-    }
-    {   // the new arrivals, oldest first, behind the calls earlier leaders left
-        dann_index::SmallCall* got = idx->comb_head.exchange(nullptr, std::memory_order_acq_rel);
-        dann_index::SmallCall* rev = nullptr;
-        while (got) {
-            dann_index::SmallCall* nx = got->next;
-            got->next = rev;
-            rev = got;
-            got = nx;
-        }
-        for (; rev; rev = rev->next) idx->comb_pending.push_back(rev);
-    }
-    if (idx->comb_pending.empty()) return;
-    dann_index::SmallCall* batch[kSmallBatch];
-    uint32_t n = 0, total = 0;
-    size_t bytes = 0;
-    const dann_index::SmallCall& first = *idx->comb_pending.front();
-    const uint32_t L = first.l_value, W = first.beam, K = first.k;
-    for (auto it = idx->comb_pending.begin(); it != idx->comb_pending.end();) {
-        dann_index::SmallCall* r = *it;
-        const size_t b = small_call_bytes(r->nq, qb, K);
-        if (r->l_value == L && r->beam == W && r->k == K && total + r->nq <= kSmallBatch && bytes + b <= kSmallStage) {
-            batch[n++] = r;
-            total += r->nq;
-            bytes += b;
-            it = idx->comb_pending.erase(it);
-        } else {
-            ++it;
-        }
-    }
-    idx->comb_npending.fetch_sub(n, std::memory_order_acq_rel);
-    idx->comb_recent = std::max<uint32_t>(n, idx->comb_recent > 1 ? idx->comb_recent - 1 : 1);
-    idx->comb_stats[0].fetch_add(1, std::memory_order_relaxed);
-    idx->comb_stats[1].fetch_add(n, std::memory_order_relaxed);
-    int32_t rc;
-    std::string text;
-    try {
-        rc = small_batch_run(idx, batch, n, total, qb);
-        if (rc != DANN_OK && rc != kSmallCallDeclined) grab_error_text(text);
-    } catch (...) {
-        rc = DANN_EINTERNAL;
-        text = "exception in a combined small search call";
-    }
-    for (uint32_t c = 0; c < n; ++c) {
-        if (rc != DANN_OK) {
-            batch[c]->rc = rc;
-            batch[c]->text = text;
-        }
-        batch[c]->done.store(true, std::memory_order_release);  // (the call's owner may be gone the moment this is seen)
-    }
-}
-int32_t small_call(dann_index* idx, dann_index::SmallCall& me, size_t qb) {
-    me.next = idx->comb_head.load(std::memory_order_relaxed);
-    while (!idx->comb_head.compare_exchange_weak(me.next, &me, std::memory_order_release, std::memory_order_relaxed)) {
-    }
-    idx->comb_npending.fetch_add(1, std::memory_order_acq_rel);
-    bool spinner = false;
-    for (uint32_t spins = 0; !me.done.load(std::memory_order_acquire); ++spins) {
-        bool free_ = false;
-        if (!idx->comb_leader.load(std::memory_order_relaxed) &&
-            idx->comb_leader.compare_exchange_strong(free_, true, std::memory_order_acquire, std::memory_order_relaxed)) {
-            // (a call that is not done is queued: in comb_head or in comb_pending -- only leaders take calls out)
-            if (!me.done.load(std::memory_order_acquire)) small_lead(idx, qb);
-            idx->comb_leader.store(false, std::memory_order_release);
-            continue;
-        }
-        // another thread leads: poll; a wait that goes on for long, or one processor too many polling, naps between polls
-        if (!spinner && spins < 20000u) {
-            if (g_small_spinners.fetch_add(1, std::memory_order_relaxed) < small_spin_budget()) spinner = true;
-            else g_small_spinners.fetch_sub(1, std::memory_order_relaxed);
-        }
-        if (spinner && spins < 4096u) {
-            small_relax();
-        } else if (spinner && spins < 20000u) {
-            std::this_thread::yield();
-        } else {
-            if (spinner) {
-                g_small_spinners.fetch_sub(1, std::memory_order_relaxed);
-                spinner = false;
-            }
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
-        }
-    }
-    if (spinner) g_small_spinners.fetch_sub(1, std::memory_order_relaxed);
-    if (me.rc != DANN_OK && me.rc != kSmallCallDeclined && !me.text.empty()) set_error("%s", me.text.c_str());
-    return me.rc;
 }
 }  // namespace
 }  // extern "C++"
@@ -1309,7 +1149,7 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
     const uint32_t pipeline_dbg = idx->dbg_u32(DANN_DBG_HOST_PIPELINE, 1u);  // 0 off, 1 default, 2 .. 8 lanes
     {   // a small call: one launch reading and writing mapped host memory, shared with the small calls of other threads
         if (pipeline_dbg == 1u && nq <= kSmallCall && small_call_bytes(nq, qb, k) <= kSmallStage / 4) {
-            dann_index::SmallCall me;
+            SmallCall me;
             me.queries = queries;
             me.nq = nq;
             me.l_value = l_value;
@@ -1318,7 +1158,12 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
             me.out_ids = out_ids;
             me.out_dists = out_dists;
             me.out_stats = out_stats;
-            const int32_t src = small_call(idx, me, qb);
+            const int32_t src = small_call(idx->comb, me, qb, [&](SmallCall* const* calls, uint32_t n, uint32_t total, std::string& text) {
+                const int32_t rrc = small_batch_run(idx, calls, n, total, qb);
+                if (rrc != DANN_OK && rrc != kSmallCallDeclined) grab_error_text(text);
+                return rrc;
+            });
+            if (src != DANN_OK && src != kSmallCallDeclined && !me.text.empty()) set_error("%s", me.text.c_str());
             if (src != kSmallCallDeclined) return src;
         }
     }
@@ -2221,8 +2066,8 @@ int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value) try {
 
 int32_t dann_debug_small_call_stats(dann_index* idx, uint64_t* out2) try {
     if (!idx || !out2) return DANN_EINVAL;
-    out2[0] = idx->comb_stats[0].load(std::memory_order_relaxed);
-    out2[1] = idx->comb_stats[1].load(std::memory_order_relaxed);
+    out2[0] = idx->comb.stats[0].load(std::memory_order_relaxed);
+    out2[1] = idx->comb.stats[1].load(std::memory_order_relaxed);
     return DANN_OK;
 } DANN_CATCH_ALL
 

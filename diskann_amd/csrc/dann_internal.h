@@ -18,6 +18,7 @@
 
 #include "../../include/dann.h"
 #include "../../include/dann_debug.h"
+#include "small_calls.h"
 
 struct dann_index;
 
@@ -323,19 +324,8 @@ struct dann_index {
     HostCall host_calls[8];
     uint32_t host_calls_next = 0;
     std::atomic<bool> host_register_pays{true};
-    // dann_search_batch, small calls: several threads calling side by side are served by ONE launch -- the first caller
-    // to find no leader becomes it, takes every waiting call with its (L, beam, k) into the launch and hands the results
-    // back (api.hip: small_call).  Calls queue by a compare-and-swap on comb_head (sixteen threads arriving together
-    // must not put one another to sleep on a mutex); the leadership is a flag taken by compare-and-swap, and everything
-    // else here belongs to whoever holds it.  comb_recent: calls seen side by side lately (a leader waits a few
-    // microseconds for that many before it launches: callers in lockstep come back a moment after their results).
-    struct SmallCall;
-    std::atomic<SmallCall*> comb_head{nullptr};  // calls not yet seen by a leader, last arrival first
-    std::atomic<uint32_t> comb_npending{0};      // calls queued and not yet in a launch
-    std::atomic<bool> comb_leader{false};
-    std::deque<SmallCall*> comb_pending;         // (leader) calls taken off comb_head, in arrival order
-    uint32_t comb_recent = 1;                    // (leader)
-    std::atomic<uint64_t> comb_stats[2] = {{0}, {0}};  // launches, calls served
+    // dann_search_batch, small calls: several threads calling side by side are served by one launch (small_calls.h)
+    dann::SmallCallQueue comb;
     uint32_t num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t build_flags = 0;    // DANN_BUILD_* (dann_set_build_options)
     // [0] back-edge prunes through the MFMA path, [1] ... on the lazy path inside it, [2] / [3] comparisons / hops of
