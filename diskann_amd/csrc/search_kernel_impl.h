@@ -789,20 +789,12 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                 len = len < R ? len : R;
                 if (table_ids + len <= a.ht_open) {  // (an expansion would not overflow the table)
                     const uint32_t id = lane < len ? val : kEmpty;
-                    uint32_t slot = 0;
-                    const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
-                    const bool keep = isnew && id < ix.nslots;
-                    const uint64_t nm = ballot64(isnew), km = ballot64(keep);
-                    uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + out_buf * cstride);
-                    if (keep) out[mbcnt(km)] = id;
-                    slots[lane] = isnew ? slot : kEmpty;
-                    ran = 1;
-                    kept = (uint32_t)__popcll(km);
-                    fresh = (uint32_t)__popcll(nm);
-                    // latency regime: request the rows of exactly these candidates now, a whole gather ahead of the hop
-                    // that evaluates them (one dword per 128-byte line; nothing ever reads pf_dummy), and their
-                    // adjacency rows, should a candidate be expanded straight away
-                    if (touch && keep) {
+                    // latency regime: request the rows of the node's neighbours the moment its adjacency row is here --
+                    // before the visited filter, whose few hundred cycles are what the requests otherwise lack to land
+                    // before the gather of the hop that evaluates them (one dword per 128-byte line; nothing ever reads
+                    // pf_dummy), and their adjacency rows, should one of them be expanded straight away.  Neighbours the
+                    // filter then drops were requested in vain: a latency-regime launch has the bandwidth to spare.
+                    if (touch && id < ix.nslots) {
                         const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
                         const uint32_t last = ix.layer_bytes >= 4u ? ix.layer_bytes - 4u : 0u;  // (PQ rows of fewer than four chunks)
                         const uint8_t* p1 = prow + (128u < last ? 128u : last);
@@ -822,6 +814,16 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                             : "+v"(pf_dummy)
                             : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
                     }
+                    uint32_t slot = 0;
+                    const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
+                    const bool keep = isnew && id < ix.nslots;
+                    const uint64_t nm = ballot64(isnew), km = ballot64(keep);
+                    uint32_t* const out = reinterpret_cast<uint32_t*>(smem + L.cand_id_off + out_buf * cstride);
+                    if (keep) out[mbcnt(km)] = id;
+                    slots[lane] = isnew ? slot : kEmpty;
+                    ran = 1;
+                    kept = (uint32_t)__popcll(km);
+                    fresh = (uint32_t)__popcll(nm);
                 }
             }
         }
@@ -836,7 +838,8 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
 // waves 1 .. 3 of a team
 template <int DT, int OP, bool NORM, int QS, int DIM, int TEAM>
 __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) {
-    static_assert(TEAM == 4, "a team is four wavefronts: queue, control, visited, gather");
+    static_assert(TEAM == 4 || TEAM == 5 || TEAM == 7, "a team: queue, control, visited and 1, 2 or 4 gather wavefronts");
+    constexpr int NW = TEAM - 3;  // gather wavefronts: they split the hop's candidates (team_gather_share)
     using S = Scheme<DT, OP, false>;
     constexpr int G = S::G;
     constexpr bool kInt = S::kInt;
@@ -879,8 +882,8 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
         seen = mb_wait_change(mail, mail + kMbGo, seen);
         if (seen == kTeamExit) break;
         const uint32_t nc = (seen >> 20) & 0x7Fu, buf = (seen >> 27) & 1u;
-        team_gather_share<DT, OP, NORM, DIM, 1, 4>(
-            ix, 0u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
+        team_gather_share<DT, OP, NORM, DIM, NW, 4 / NW>(
+            ix, wave - 3u, nc, reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride),
             reinterpret_cast<float*>(smem + L.cand_d_off + buf * cstride), xq, xqi, xx_pre, qs, sqp, g, v);
         __syncthreads();  // distances ready
     }
@@ -1591,12 +1594,20 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
             __syncthreads();  // "distances ready" of hop npop -- or the release
             PH_T(ph2);
             PH_ADD(14, ph1, ph2);
-            if (mb_load(mail + kMbGo) == kTeamExit) break;
-            const uint32_t word = uni(mail[kMbHop + 8u * (npop & 1u)]);
+            // (one batch of LDS loads, one wait: the release word, the hop's word and BOTH candidate buffers -- which of
+            // them the hop used is in the word; a buffer holds 64 entries whatever the hop's count)
+            const uint32_t go_v = __hip_atomic_load(mail + kMbGo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t word_v = mail[kMbHop + 8u * (npop & 1u)];
+            const float nd0 = reinterpret_cast<const float*>(smem + L.cand_d_off)[lane];
+            const float nd1 = reinterpret_cast<const float*>(smem + L.cand_d_off + cstride)[lane];
+            const uint32_t ni0 = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off)[lane];
+            const uint32_t ni1 = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + cstride)[lane];
+            if (uni(go_v) == kTeamExit) break;
+            const uint32_t word = uni(word_v);
             const uint32_t nc = word & 0xFFFFu, buf = (word >> 16) & 1u;
             const bool has = lane < nc;
-            const float nd = has ? reinterpret_cast<const float*>(smem + L.cand_d_off + buf * cstride)[lane] : 0.0f;
-            const uint32_t nid = has ? reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + buf * cstride)[lane] : kEmpty;
+            const float nd = has ? (buf ? nd1 : nd0) : 0.0f;
+            const uint32_t nid = has ? (buf ? ni1 : ni0) : kEmpty;
             WS();
             if (lane == 0) mb_store(mail + kMbLoaded, npop + 1u);  // the buffer may be refilled now
             merge_regs(has, nd, nid, nc, reinterpret_cast<uint32_t*>(smem + L.mscr_off),
@@ -2345,7 +2356,10 @@ inline bool plain_mode(const SearchArgs& a) {
            a.ix.nstart <= (uint32_t)kWave;
 }
 
-constexpr int kTeam = 4;  // wavefronts per query in the latency regime (SearchArgs::team)
+#ifndef DANN_TEAM_WAVES
+#define DANN_TEAM_WAVES 5
+#endif
+constexpr int kTeam = DANN_TEAM_WAVES;  // wavefronts per query in the latency regime (SearchArgs::team)
 
 template <int DT, int OP, bool NORM, int QS, int DIM, int MODE, int LOOP = 0, int TEAM = 1, bool HT16 = false>
 int32_t launch_one(const SearchArgs& a, size_t lds, hipStream_t stream, int* regs_out) {
