@@ -521,7 +521,6 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
 #ifdef DANN_PHASE_CYCLES
     unsigned long long ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    uint32_t loaded_seen = 0;  // the last value of kMbLoaded this wave has read
     // start hop `hop + 1` on `nc` candidates in buffer `buf`: the gather wave first (team_go) -- the hop's critical
     // path --, then the visited wave with the node to work on meanwhile, pf_node (team_spec)
     auto team_go = [&](uint32_t nc, uint32_t buf) {
@@ -532,8 +531,8 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     };
     auto team_spec = [&]() {
         PH_T(pts0);
-        // the visited wave refills the previous hop's buffer: the queue wave must hold those distances in registers
-        if (loaded_seen < hop) mb_wait_at_least(mail, mail + kMbLoaded, hop);
+        // (the visited wave refills the previous hop's buffer once the queue wave holds those distances in registers: it
+        // waits for kMbLoaded itself, beside its wait for the adjacency row)
         spec_sent = (pf_node != kEmpty && !(a.tune & kTuneNoSpeculation)) ? pf_node : kEmpty;
         if (lane == 0) {
             uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
@@ -623,7 +622,6 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
             const uint32_t* wp = mail + kMbPop + 8u * (hop & 1u);
             const uint4 plo = *reinterpret_cast<const uint4*>(wp), phi = *reinterpret_cast<const uint4*>(wp + 4);
             const uint32_t r_v = mail[kMbVReply];
-            loaded_seen = mail[kMbLoaded];
             const bool has = lane < nc_cur;
             const float nd = has ? buf_d(cur)[lane] : 0.0f;
             const uint32_t nid = has ? buf_ids(cur)[lane] : kEmpty;
@@ -634,7 +632,6 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
             pub.pf_next_d = __builtin_bit_cast(float, uni(phi.x));
             pub.pf_next2 = uni(phi.y);
             pub.pf_next2_d = __builtin_bit_cast(float, uni(phi.z));
-            loaded_seen = uni(loaded_seen);
             const uint32_t r = uni(r_v);
             spec_node = kEmpty;
             if (spec_sent != kEmpty && (r & 1u)) {
@@ -691,13 +688,15 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                     if (status) break;
                 }
                 early_node = next;
+                // the hop's critical path first: the gather waves ("go", as soon as the candidates are there), then what
+                // the visited wave needs -- the runner-up's adjacency row on its way, its words --, prefetches last
+                if (!started) team_go(nc, cur ^ 1u);
                 if (pf_node != runner) {  // (else its row is in landing buffer 0 already)
                     pf_node = runner;
                     if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
                 }
-                touch_found();
-                if (!started) team_go(nc, cur ^ 1u);
                 team_spec();
+                touch_found();
                 started = true;
             }
         }
@@ -710,13 +709,13 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
             const uint32_t nc = expand(pub.node, pf_node == pub.node ? 0 : -1, cur ^ 1u);
             if (status) break;
             early_node = pub.node;
+            team_go(nc, cur ^ 1u);
             if (pf_node != pub.pf_next) {
                 pf_node = pub.pf_next;
                 if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
             }
-            touch_found();
-            team_go(nc, cur ^ 1u);
             team_spec();
+            touch_found();
 #ifdef DANN_PHASE_CYCLES
             overtaken = true;
             ph_acc[7] += 1;
@@ -766,7 +765,11 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
         const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
         const uint32_t node = uni(w[1]), table_ids = uni(w[2]), out_buf = uni(w[3]);
         uint32_t ran = 0, kept = 0, fresh = 0;
+        uint32_t touch_id = kEmpty;  // (per lane) a candidate whose rows are requested once the hop's barrier is behind
         if (node != kEmpty) {
+            // this wave refills the previous hop's candidate buffer: the queue wave must hold those distances in registers
+            // (it has, long since: one poll, beside the wait for the adjacency row)
+            mb_wait_at_least(mail, mail + kMbLoaded, hop);
             // the control wave asked for the node's adjacency row (kAdjPending in every dword first): wait for the
             // length, then for every neighbour slot below it
             // (all 64 dwords of the request, also those beyond the length: a part still in flight would land on top
@@ -789,31 +792,6 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                 len = len < R ? len : R;
                 if (table_ids + len <= a.ht_open) {  // (an expansion would not overflow the table)
                     const uint32_t id = lane < len ? val : kEmpty;
-                    // latency regime: request the rows of the node's neighbours the moment its adjacency row is here --
-                    // before the visited filter, whose few hundred cycles are what the requests otherwise lack to land
-                    // before the gather of the hop that evaluates them (one dword per 128-byte line; nothing ever reads
-                    // pf_dummy), and their adjacency rows, should one of them be expanded straight away.  Neighbours the
-                    // filter then drops were requested in vain: a latency-regime launch has the bandwidth to spare.
-                    if (touch && id < ix.nslots) {
-                        const uint8_t* prow = ix.rows + (uint64_t)id * ix.row_stride;
-                        const uint32_t last = ix.layer_bytes >= 4u ? ix.layer_bytes - 4u : 0u;  // (PQ rows of fewer than four chunks)
-                        const uint8_t* p1 = prow + (128u < last ? 128u : last);
-                        const uint8_t* p2 = prow + (256u < last ? 256u : last);
-                        const uint8_t* p3 = prow + (384u < last ? 384u : last);
-                        const uint8_t* p4 = prow + last;
-                        const uint32_t* a0 = ix.adj + (uint64_t)id * ix.adj_stride;
-                        const uint32_t* a1 = a0 + R;
-                        asm volatile(
-                            "global_load_dword %0, %1, off\n\t"
-                            "global_load_dword %0, %2, off\n\t"
-                            "global_load_dword %0, %3, off\n\t"
-                            "global_load_dword %0, %4, off\n\t"
-                            "global_load_dword %0, %5, off\n\t"
-                            "global_load_dword %0, %6, off\n\t"
-                            "global_load_dword %0, %7, off"
-                            : "+v"(pf_dummy)
-                            : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
-                    }
                     uint32_t slot = 0;
                     const bool isnew = ht_insert_open_slot(ht, ht_mod, id, id != kEmpty, &slot);
                     const bool keep = isnew && id < ix.nslots;
@@ -824,11 +802,41 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                     ran = 1;
                     kept = (uint32_t)__popcll(km);
                     fresh = (uint32_t)__popcll(nm);
+                    if (touch && keep) touch_id = id;
                 }
             }
         }
         if (lane == 0) mail[kMbVReply] = ran | (kept << 8) | (fresh << 16);
+#ifndef DANN_TOUCH_BEFORE_BARRIER
         __syncthreads();  // distances ready
+#endif
+        // latency regime: request the rows of the candidates just prepared (one dword per 128-byte line; nothing ever reads
+        // pf_dummy) and their adjacency rows, should one of them be expanded straight away -- after the barrier: this wave's
+        // filter is the tail of the hop's longest chain (decision -> adjacency row -> filter), the requests are not, and the
+        // gather that wants the rows starts a decision later
+        if (touch_id != kEmpty) {
+            const uint8_t* prow = ix.rows + (uint64_t)touch_id * ix.row_stride;
+            const uint32_t last = ix.layer_bytes >= 4u ? ix.layer_bytes - 4u : 0u;  // (PQ rows of fewer than four chunks)
+            const uint8_t* p1 = prow + (128u < last ? 128u : last);
+            const uint8_t* p2 = prow + (256u < last ? 256u : last);
+            const uint8_t* p3 = prow + (384u < last ? 384u : last);
+            const uint8_t* p4 = prow + last;
+            const uint32_t* a0 = ix.adj + (uint64_t)touch_id * ix.adj_stride;
+            const uint32_t* a1 = a0 + R;
+            asm volatile(
+                "global_load_dword %0, %1, off\n\t"
+                "global_load_dword %0, %2, off\n\t"
+                "global_load_dword %0, %3, off\n\t"
+                "global_load_dword %0, %4, off\n\t"
+                "global_load_dword %0, %5, off\n\t"
+                "global_load_dword %0, %6, off\n\t"
+                "global_load_dword %0, %7, off"
+                : "+v"(pf_dummy)
+                : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
+        }
+#ifdef DANN_TOUCH_BEFORE_BARRIER
+        __syncthreads();  // distances ready
+#endif
     }
     __syncthreads();  // the release
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
