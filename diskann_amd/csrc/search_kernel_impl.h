@@ -449,7 +449,7 @@ __device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t 
 // workgroup: a counter drain instead of the workgroup barrier
 __device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// ---- a team of four wavefronts per query (latency regime) -----------------------------------------------------------
+// ---- a team of five wavefronts per query (latency regime) -----------------------------------------------------------
 // The dependent chain of a hop is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  A team
 // gives every link its own wave and overlaps them:
 //   wave 0, queue:    merge of hop h's distances, pop, publication of (node, best and second-best unexpanded entry left)
@@ -459,7 +459,8 @@ __device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmc
 //                     and which node will be best after that; expands where no speculation covers it; starts the hop;
 //   wave 2, visited:  while hop h + 1's rows are evaluated, runs the visited filter of the predicted hop h + 2 node into
 //                     the spare candidate buffer (taken back by the control wave if the prediction fails);
-//   wave 3, gather:   evaluates the candidate rows.
+//   waves 3 and 4, gather: evaluate the candidate rows, half of the hop's candidates each (one wave alone spent half of
+//                     its time issuing the vector instructions of ~17 distances from a single SIMD: round 6).
 // One workgroup barrier per hop ("distances ready"); everything else goes through the LDS mailbox (kMb*).  The queue, the
 // visited set and the order of expansions are exactly those of the one-wave search: the early decisions only predict
 // what the pop after the merge returns, and the control wave checks every one of them against the queue wave's

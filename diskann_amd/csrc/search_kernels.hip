@@ -294,8 +294,8 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
     a.spill_slices = ctx.spill_slices;
     a.spill_bits = ctx.spill_bits;
     a.spill_next = ctx.d_spill + ((size_t)ctx.spill_slices << ctx.spill_bits);
-    // latency regime with at most one query per SIMD: a team of four wavefronts per query -- queue, control, visited
-    // filter, row gather (search_kernel_impl.h, team_control_wave).  Knn searches and the build's insert-time searches (the
+    // latency regime with at most one query per SIMD: a team of five wavefronts per query -- queue, control, visited
+    // filter, two for the row gather (search_kernel_impl.h, team_control_wave).  Knn searches and the build's insert-time searches (the
     // queue wave's pop records the visited node) only (the launch falls back to one wave per query where no team
     // instantiation exists).  Decided before the table is sized: teams carry more LDS.
     // DANN_DBG_TUNE_OFF bit 4 (teams) / bit 8 (speculation) / DANN_DBG_TEAM_MAX_QUERIES: development switches

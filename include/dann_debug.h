@@ -76,7 +76,7 @@ int32_t dann_debug_get(const dann_index* idx, int32_t key, double* value);
  * names the family of every timed leg).  out_launches / out_ms: DANN_FAMILY_COUNT entries each (either may be null). */
 enum {
     DANN_FAMILY_ONE_WAVE = 0,    /* beam_search_kernel, one wavefront per query */
-    DANN_FAMILY_TEAM = 1,        /* beam_search_kernel, four wavefronts per query (latency regime) */
+    DANN_FAMILY_TEAM = 1,        /* beam_search_kernel, a team of five wavefronts per query (latency regime) */
     DANN_FAMILY_PAIR = 2,        /* pair_search_kernel, two queries per wavefront (128-byte integer rows) */
     DANN_FAMILY_PERSISTENT = 3,  /* beam_search_kernel, persistent wavefronts sharing a batch (dann_set_max_concurrency) */
     DANN_FAMILY_SERVER = 4,      /* the resident server kernel */

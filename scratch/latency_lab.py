@@ -79,7 +79,7 @@ def timed(nq, L, reps):
                  f"its loads {v[1]:.0f} start {v[2]:.0f} barrier wait {v[15]:.0f} | queue wave's barrier wait {v[14]:.0f}")
         if os.environ.get("DANN_PROF_FINE"):  # scratch build with the finer timers of the control wave's short path
             fp = max(buf[5], 1)
-            line += f"\n      visited wave: wait for the adjacency row {buf[8] / max(buf[10], 1):.0f} cycles (x{buf[10] / max(hops, 1):.2f} of hops), its barrier wait {buf[9] / max(hops, 1):.0f}"
+            line += f"\n      per hop: first gather wave go -> distances written {buf[10] / max(hops, 1):.0f}, its barrier wait {buf[8] / max(hops, 1):.0f}, visited wave's barrier wait {buf[9] / max(hops, 1):.0f}"
     print(line, flush=True)
 
 

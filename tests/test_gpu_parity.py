@@ -266,7 +266,7 @@ def test_spill_tables_recycled_under_load():
 @pytest.mark.parametrize("dtype,metric", [(oracle.F32, oracle.L2), (oracle.F16, oracle.L2), (oracle.U8, oracle.L2),
                                           (oracle.I8, oracle.INNER_PRODUCT), (oracle.U8, oracle.COSINE)])
 def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric):
-    """Latency regime: launches with few queries give every query a team of four wavefronts (queue / control / visited
+    """Latency regime: launches with few queries give every query a team of wavefronts (queue / control / visited
     filter / row gather, talking through an LDS mailbox; the control wave decides the next expansion before the merge,
     the visited wave filters the predicted one after that speculatively -- inserts that are taken back when the prediction
     fails).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query launch's (debug_set(tune_off=...): bit 4
