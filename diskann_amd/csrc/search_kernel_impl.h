@@ -25,6 +25,7 @@ constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merg
 constexpr uint32_t kSeqInsert = 2;  // survivors inserted one by one, the queue never leaving its registers
 constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
 constexpr uint32_t kTuneNoSpeculation = 2u;  // teams: no speculative expansion of the predicted next node
+constexpr uint32_t kTuneNoSelfStart = 4u;    // teams: the visited wave always waits for the control wave's words
 constexpr uint8_t kTagPublished = 254;  // Tag::can_read: tag >= PUBLISHED (diskann-inmem/src/tag.rs:86-133)
 
 // optional per-phase cycle accounting (compile with -DDANN_PHASE_CYCLES; debug only)
@@ -337,6 +338,12 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 }
 
 constexpr uint32_t kTeamExit = 0xFFFFFFFFu;  // release word of a team (kMbGo)
+// Which physical wavefront of a team's workgroup is the queue wave (the others take the jobs 1, 2, ... in order).  Five
+// wavefronts sit on four SIMDs: the first and the last share one.
+#ifndef DANN_TEAM_QUEUE_WAVE
+#define DANN_TEAM_QUEUE_WAVE 0
+#endif
+constexpr int kTeamQueueWave = DANN_TEAM_QUEUE_WAVE;
 // the team's mailbox (SearchLds mail_off, 64 words).  Hops are numbered from 0 (the start points); pops from 1 (pop n
 // returns the node hop n expands).  Words that one wave rewrites while another may still read the previous value are
 // double-buffered by the parity of the hop / pop they belong to.
@@ -449,6 +456,12 @@ __device__ __forceinline__ void team_gather_share(const IndexView& ix, uint32_t 
 // workgroup: a counter drain instead of the workgroup barrier
 __device__ __forceinline__ void team_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// argmin over the lanes of `on` by (distance ascending, lane descending); `on` must not be empty
+__device__ __forceinline__ int team_best_lane(bool on, float d) {
+    const float m = wave_min_f32(on ? d : __builtin_inff());
+    return 63 - __builtin_clzll(ballot64(on && d == m));
+}
+
 // ---- a team of five wavefronts per query (latency regime) -----------------------------------------------------------
 // The dependent chain of a hop is  pop -> adjacency row -> visited filter -> candidate rows -> merge -> pop.  A team
 // gives every link its own wave and overlaps them:
@@ -506,10 +519,7 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
         return reinterpret_cast<const uint32_t*>(smem + L.adj_off + which * kAdjLandBytes);
     };
     // argmin over the lanes of `on` by (distance ascending, lane descending); `on` must not be empty
-    auto best_lane = [&](bool on, float d) -> int {
-        const float m = wave_min_f32(on ? d : __builtin_inff());
-        return 63 - __builtin_clzll(ballot64(on && d == m));
-    };
+    auto best_lane = [&](bool on, float d) -> int { return team_best_lane(on, d); };
 
     uint32_t hop = 0;                // the hop in flight / last finished
     uint32_t cur = 0, nc_cur = 0;    // its candidate buffer and count
@@ -517,6 +527,10 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     uint32_t pf_node = kEmpty;       // node whose adjacency row is in (or on its way to) landing buffer 0
     uint32_t spec_sent = kEmpty, spec_node = kEmpty, spec_nc = 0, spec_new = 0;
     uint32_t early_node = kEmpty;    // the node the hop in flight expands (the queue wave's pop must agree)
+    // pf_node's row was requested by the visited wave (self-start): this wave's memory counter does not cover it, so it
+    // never reads landing buffer 0 for that node (the row comes from memory in the rare case this wave expands it)
+    bool pf_by_visited = false;
+    const bool self_start = !(a.tune & kTuneNoSelfStart);
 
     // start hop `hop + 1` on `nc` candidates in buffer `buf`; the visited wave works on pf_node meanwhile
 #ifdef DANN_PHASE_CYCLES
@@ -614,6 +628,7 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
     __syncthreads();  // hop 0 (the start points): distances ready -- the queue wave merges them and pops the first node
     for (;;) {
         bool started = false;
+        bool self_started = false;  // this hop's runner-up is requested by the visited wave, not here
         bool overtaken = false;  // (phase statistics only)
         (void)overtaken;
         PH_T(pd0);
@@ -662,10 +677,13 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                         spec_node = kEmpty;
                         team_go(nc, cur ^ 1u);
                         started = true;
+                        // the visited wave has taken this very decision (team_visited_wave, self-start): it names the
+                        // runner-up computed below and requests its adjacency row itself
+                        self_started = self_start && hop >= 2u;  // (hop: the one just started)
                     } else {
                         overtaken = true;  // (statistics: not the short path)
                         if (spec_node != kEmpty) spec_rollback();  // (a runner-up the pop contradicted)
-                        nc = expand(next, pf_node == next ? 0 : -1, cur ^ 1u);
+                        nc = expand(next, (pf_node == next && !pf_by_visited) ? 0 : -1, cur ^ 1u);
                         if (status) break;
                     }
                     runner = pf_next2;
@@ -692,8 +710,12 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
                 // the hop's critical path first: the gather waves ("go", as soon as the candidates are there), then what
                 // the visited wave needs -- the runner-up's adjacency row on its way, its words --, prefetches last
                 if (!started) team_go(nc, cur ^ 1u);
-                if (pf_node != runner) {  // (else its row is in landing buffer 0 already)
+                if (self_started) {
+                    pf_node = runner;  // (never the node just expanded: the visited wave requests its row)
+                    pf_by_visited = true;
+                } else if (pf_node != runner) {  // (else its row is in landing buffer 0 already)
                     pf_node = runner;
+                    pf_by_visited = false;
                     if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
                 }
                 team_spec();
@@ -707,12 +729,13 @@ __device__ __forceinline__ void team_control_wave(const SearchArgs& a, uint8_t* 
             const Pub pub = read_pub(hop + 1u);
             if (hop == 0) ht_count = mb_load(mail + kMbHtCount0);
             if (!pub.found) break;  // the search is over
-            const uint32_t nc = expand(pub.node, pf_node == pub.node ? 0 : -1, cur ^ 1u);
+            const uint32_t nc = expand(pub.node, (pf_node == pub.node && !pf_by_visited) ? 0 : -1, cur ^ 1u);
             if (status) break;
             early_node = pub.node;
             team_go(nc, cur ^ 1u);
             if (pf_node != pub.pf_next) {
                 pf_node = pub.pf_next;
+                pf_by_visited = false;
                 if (pf_node != kEmpty) adj_fetch_lds(pf_node, 0);
             }
             team_spec();
@@ -758,13 +781,88 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
     const bool touch = (a.tune & kTuneRowPrefetch) && ix.layer_bytes <= 512u;
     uint32_t pf_dummy = 0;
     __syncthreads();  // the query is staged, the table wiped, the mailbox cleared
-    uint32_t seen = 0;
+    // what this wave did in the hop before (the control wave's spec_sent and the reply it reads): node, ran, ids inserted
+    uint32_t prev_node = kEmpty, prev_ran = 0, prev_fresh = 0;
+    bool released = false;  // the barrier just passed was the release
+    const bool self_start = !(a.tune & kTuneNoSelfStart);
     for (uint32_t hop = 0;; ++hop) {
-        seen = mb_wait_change(mail, mail + kMbGo, seen);
-        if (seen == kTeamExit) break;
-        mb_wait_at_least(mail, mail + kMbSpecSeq, hop + 1u);  // (the gather wave is started first)
-        const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
-        const uint32_t node = uni(w[1]), table_ids = uni(w[2]), out_buf = uni(w[3]);
+        uint32_t node = kEmpty, table_ids = 0, out_buf = 0;
+        // ---- self-start.  On a prepared hop -- the control wave finds that the node to expand next is the one this wave
+        // has filtered already -- the longest chain of the hop used to be: control wave (decision, "go", runner-up,
+        // adjacency request, words) -> this wave (row lands, filter).  The decision is a function of what lies in LDS when
+        // the barrier opens (the pop's publication, the hop's distances) and of this wave's own last reply, so this wave
+        // takes the same decision at the same time and, on exactly those hops, names the runner-up and requests its
+        // adjacency row itself, 1 300 cycles before the words would have told it to.  The control wave, on those hops,
+        // records the same runner-up without requesting anything (team_control_wave: `self_started`).
+        bool self = false;
+        if (self_start && hop >= 2u && prev_ran) {
+            const uint32_t h = hop - 1u;  // the hop whose distances are ready
+            const uint32_t* wp = mail + kMbPop + 8u * (h & 1u);
+            const uint4 plo = *reinterpret_cast<const uint4*>(wp), phi = *reinterpret_cast<const uint4*>(wp + 4);
+            const uint4 hw = *reinterpret_cast<const uint4*>(mail + kMbHop + 8u * (h & 1u));
+            const float nd0 = reinterpret_cast<const float*>(smem + L.cand_d_off)[lane];
+            const float nd1 = reinterpret_cast<const float*>(smem + L.cand_d_off + cstride)[lane];
+            const uint32_t ni0 = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off)[lane];
+            const uint32_t ni1 = reinterpret_cast<const uint32_t*>(smem + L.cand_id_off + cstride)[lane];
+            const uint32_t word = uni(hw.x), nc_h = word & 0xFFFFu, buf_h = (word >> 16) & 1u;
+            const uint32_t pf_next = uni(plo.w), pf_next2 = uni(phi.y);
+            const float pf_next_d = __builtin_bit_cast(float, uni(phi.x)), pf_next2_d = __builtin_bit_cast(float, uni(phi.z));
+            const bool has = lane < nc_h;
+            const float nd = has ? (buf_h ? nd1 : nd0) : 0.0f;
+            const uint32_t nid = has ? (buf_h ? ni1 : ni0) : kEmpty;
+            if (pf_next != kEmpty && prev_node == pf_next && ballot64(has && nd <= pf_next_d) == 0) {
+                self = true;
+                uint32_t runner = pf_next2;
+                if (pf_next2 != kEmpty) {
+                    const bool ahead2 = has && nd <= pf_next2_d;
+                    if (ballot64(ahead2)) runner = (uint32_t)__builtin_amdgcn_readlane((int)nid, team_best_lane(ahead2, nd));
+                }
+                node = runner;
+                table_ids = uni(hw.z) + prev_fresh;  // the control wave's count after this hop's "go"
+                out_buf = buf_h;                     // the buffer of the hop just finished is the spare one now
+                if (node != kEmpty) {
+                    // (landing buffer 0 is free: the request before this one -- whoever made it -- has landed, this wave
+                    // polled for it before it replied `ran`)
+                    const uint32_t* p = ix.adj + (uint64_t)node * ix.adj_stride + (lane <= R ? lane : R);
+                    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(
+                        __attribute__((address_space(3))) uint8_t*)(smem + L.adj_off));
+                    reinterpret_cast<uint32_t*>(smem + L.adj_off)[lane] = kAdjPending;
+                    uint32_t m0_saved;
+                    asm volatile(
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "s_mov_b32 %0, m0\n\t"
+                        "s_mov_b32 m0, %2\n\t"
+                        "global_load_lds_dword %1, off\n\t"
+                        "s_mov_b32 m0, %0"
+                        : "=&s"(m0_saved)
+                        : "v"(p), "s"(lds)
+                        : "memory");
+                }
+            }
+        }
+        // this hop's "go" (or the release).  A self-started hop waits for it too, before its first write to anything the
+        // control wave's decision reads (the spare candidate buffer, the slots, the reply): the control wave's LDS loads
+        // precede its store of "go" in its own instruction order, which is the order LDS performs them in
+        uint32_t g, gspins = 0;
+        while ((g = mb_load(mail + kMbGo)) != kTeamExit && (g & 0xFFFFFu) != ((hop + 1u) & 0xFFFFFu)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++gspins > (1u << 24)) team_abort(mail);
+        }
+        asm volatile("" ::: "memory");
+        if (g == kTeamExit) {
+            if (!self) break;  // (the release is still ahead)
+            // self-started, and the control wave ended the search instead of starting the hop (an error status): the
+            // barrier ahead is the release; the request, if any, must not stay in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            node = kEmpty;
+        }
+        if (!self) {
+            mb_wait_at_least(mail, mail + kMbSpecSeq, hop + 1u);  // (the gather waves are started first)
+            const uint32_t* w = mail + kMbHop + 8u * (hop & 1u);
+            node = uni(w[1]);
+            table_ids = uni(w[2]);
+            out_buf = uni(w[3]);
+        }
         uint32_t ran = 0, kept = 0, fresh = 0;
         uint32_t touch_id = kEmpty;  // (per lane) a candidate whose rows are requested once the hop's barrier is behind
         if (node != kEmpty) {
@@ -785,6 +883,9 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                 }
                 if (++spins > (1u << 16)) {  // (never observed; a speculation skipped costs nothing but time)
                     len = kAdjPending;
+                    // (a request of this wave's own must not be left in flight: the next one into the buffer may be the
+                    // control wave's, whose counter does not see it)
+                    if (self) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -808,9 +909,14 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
             }
         }
         if (lane == 0) mail[kMbVReply] = ran | (kept << 8) | (fresh << 16);
-#ifndef DANN_TOUCH_BEFORE_BARRIER
-        __syncthreads();  // distances ready
-#endif
+        prev_node = node;
+        prev_ran = ran;
+        prev_fresh = fresh;
+        __syncthreads();  // distances ready -- or, after a self-started hop the control wave ended instead, the release
+        if (mb_load(mail + kMbGo) == kTeamExit) {
+            released = true;
+            break;
+        }
         // latency regime: request the rows of the candidates just prepared (one dword per 128-byte line; nothing ever reads
         // pf_dummy) and their adjacency rows, should one of them be expanded straight away -- after the barrier: this wave's
         // filter is the tail of the hop's longest chain (decision -> adjacency row -> filter), the requests are not, and the
@@ -835,11 +941,8 @@ __device__ __forceinline__ void team_visited_wave(const SearchArgs& a, uint8_t* 
                 : "+v"(pf_dummy)
                 : "v"(prow), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(a0), "v"(a1));
         }
-#ifdef DANN_TOUCH_BEFORE_BARRIER
-        __syncthreads();  // distances ready
-#endif
     }
-    __syncthreads();  // the release
+    if (!released) __syncthreads();  // the release
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(pf_dummy));
 }
@@ -854,7 +957,9 @@ __device__ __forceinline__ void team_helper(const SearchArgs& a, uint8_t* smem) 
     constexpr bool kInt = S::kInt;
     const IndexView& ix = a.ix;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (the job of a physical wavefront: see kTeamQueueWave)
+    const uint32_t pwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave = pwave < (uint32_t)kTeamQueueWave ? pwave + 1u : pwave;
     const uint32_t qbytes = kInt ? (uint32_t)DIM + (DT == DT_SQ8 ? 4u : 0u) : (uint32_t)DIM * 4u;
     const SearchLds L = search_lds_layout(a.ht_entries, (uint32_t)kWave, lds_queue_entries(a), qbytes, true);
     if (wave == 1u) {
@@ -921,7 +1026,7 @@ __device__ __forceinline__ void beam_search_one(const SearchArgs& a, const uint3
     using RT = typename RowType<DT>::type;
 
     const IndexView& ix = a.ix;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = TEAM > 1 ? (threadIdx.x & 63u) : threadIdx.x;
     const uint32_t qi = a.qmap ? a.qmap[slot] : slot;
     const uint32_t R = ix.max_degree;
     const uint32_t W = PLAIN ? 1u : a.beam_width;
@@ -2262,7 +2367,7 @@ __global__ __launch_bounds__(kWave * TEAM) DANN_SEARCH_KERNEL_ATTR void beam_sea
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if constexpr (TEAM > 1) {
         static_assert(LOOP == 0, "teams serve one-shot launches");
-        if (threadIdx.x >= (uint32_t)kWave) {
+        if ((threadIdx.x >> 6) != (uint32_t)kTeamQueueWave) {
             team_helper<DT, OP, NORM, QS, DIM, TEAM>(a, smem);
             return;
         }

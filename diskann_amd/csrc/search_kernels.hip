@@ -310,6 +310,7 @@ static int32_t prepare_launch(dann_index* idx, SearchCtx& ctx, SearchArgs& a, ui
                   a.ix.max_degree <= 63u /* an adjacency row fits one 64-lane request */ && !idx->tune_off(4) &&
                   team_shape(a)) ? 1u : 0u;
         if (idx->tune_off(8)) a.tune |= kTuneNoSpeculation;
+        if (idx->tune_off(64)) a.tune |= kTuneNoSelfStart;
     }
     // throughput regime of 128-byte integer rows: two queries per wavefront (search_pair_impl.h).  A pair-hop is longer
     // than a hop of one query, so the pairing pays once the chip is full: measured on 1 M u8 rows at L = 26

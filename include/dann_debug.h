@@ -38,7 +38,8 @@ int32_t dann_debug_concurrent_callers(dann_index* idx, const void* queries, uint
 enum {
     DANN_DBG_TUNE_OFF = 0,               /* bit mask: 1 row prefetch in latency mode, 2 latency-mode table sizing, 4 teams of
                                             wavefronts, 8 the teams' speculative expansion, 16 two queries per wavefront,
-                                            32 the lookup-table kernel of PQ rows (default 0) */
+                                            32 the lookup-table kernel of PQ rows, 64 the self-start of the teams' visited wave
+                                            (default 0) */
     DANN_DBG_TUNE_ON = 1,                /* bit mask: 1 row prefetch in the throughput regime too (default 0) */
     DANN_DBG_PAIR_MIN_QUERIES = 2,       /* launches of at least this many queries take two queries per wavefront
                                             (default 20 x compute units) */
