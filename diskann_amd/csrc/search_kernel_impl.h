@@ -21,8 +21,14 @@ constexpr int kGatherRows = 4;
 #define DANN_WIDE_ROWS 2
 #endif
 constexpr int kWideRows = DANN_WIDE_ROWS;  // rows per lane group and trip in the wide (f16) gather
-constexpr uint32_t kRegMerge = 16;  // survivors handled by the in-register merge
-constexpr uint32_t kSeqInsert = 2;  // survivors inserted one by one, the queue never leaving its registers
+#ifndef DANN_REG_MERGE
+#define DANN_REG_MERGE 16
+#endif
+constexpr uint32_t kRegMerge = DANN_REG_MERGE;  // survivors handled by the in-register merge
+#ifndef DANN_SEQ_INSERT
+#define DANN_SEQ_INSERT 2
+#endif
+constexpr uint32_t kSeqInsert = DANN_SEQ_INSERT;  // survivors inserted one by one, the queue never leaving its registers
 constexpr uint32_t kTuneRowPrefetch = 1u;  // SearchArgs::tune bits
 constexpr uint32_t kTuneNoSpeculation = 2u;  // teams: no speculative expansion of the predicted next node
 constexpr uint32_t kTuneNoSelfStart = 4u;    // teams: the visited wave always waits for the control wave's words
