@@ -1010,8 +1010,17 @@ int32_t small_batch_run(dann_index* idx, SmallCall* const* calls, uint32_t n, ui
     }
     void* dbase = nullptr;
     if (hipHostGetDevicePointer(&dbase, ctx.h_stage, 0) != hipSuccess) {
+        // (a block another path of this context allocated without the mapping: once more, mapped)
         (void)hipGetLastError();
-        return kSmallCallDeclined;
+        (void)hipHostFree(ctx.h_stage);
+        ctx.h_stage = nullptr;
+        ctx.h_stage_bytes = 0;
+        DANN_HIP(hipHostMalloc(&ctx.h_stage, kSmallStage, hipHostMallocMapped));
+        ctx.h_stage_bytes = kSmallStage;
+        if (hipHostGetDevicePointer(&dbase, ctx.h_stage, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return kSmallCallDeclined;
+        }
     }
     const uint32_t k = calls[0]->k;
     const size_t in_b = ((size_t)total * qb + 15) & ~(size_t)15, ids_b = ((size_t)total * k * 4 + 15) & ~(size_t)15;
@@ -1189,7 +1198,7 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
         if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
         ctx.h_stage = nullptr;
         ctx.h_stage_bytes = 0;
-        DANN_HIP(hipHostMalloc(&ctx.h_stage, h_need, hipHostMallocDefault));
+        DANN_HIP(hipHostMalloc(&ctx.h_stage, h_need, hipHostMallocMapped));
         ctx.h_stage_bytes = h_need;
     }
     if (!chunked) {
@@ -1332,7 +1341,7 @@ int32_t dann_search_batch(dann_index* idx, const void* queries, uint32_t nq, uin
             if (lc.h_stage) (void)hipHostFree(lc.h_stage);
             lc.h_stage = nullptr;
             lc.h_stage_bytes = 0;
-            DANN_HIP_RC(hipHostMalloc(&lc.h_stage, in_b + out_b, hipHostMallocDefault));
+            DANN_HIP_RC(hipHostMalloc(&lc.h_stage, in_b + out_b, hipHostMallocMapped));
             lc.h_stage_bytes = in_b + out_b;
         }
         uint8_t* const h_in = reinterpret_cast<uint8_t*>(lc.h_stage);

@@ -53,7 +53,12 @@ def test_small_host_calls_of_many_threads_share_launches(odt):
     params = [(20, 5), (33, 10), (64, 10)]
     want = {p: oix.search_batch(q, p[0], 1, p[1]) for p in params}
     lib = da._ffi.lib()
+    # a middle-sized call first: it takes the copy path and allocates the contexts' page-locked block; the small calls
+    # below must find that block mapped (or map a new one) rather than decline to the copy path for good
+    mi, md, _ = gix.search(da.Knn(20), q[:40], 5)
+    assert np.array_equal(mi, want[(20, 5)][0][:40])
     before = gix.small_call_stats()
+    fam_before = gix.search_families()
     errs = []
 
     def caller(t, rounds):
@@ -86,6 +91,9 @@ def test_small_host_calls_of_many_threads_share_launches(odt):
     assert not errs, errs[:3]
     launches, calls = (a - b for a, b in zip(gix.small_call_stats(), before))
     assert calls == 12 * 60 and launches <= calls
+    # every search launch of this phase was a combined one: no call was declined to the copy path
+    fam_after = gix.search_families()
+    assert sum(fam_after[f][0] - fam_before[f][0] for f in fam_after) == launches
     if odt == oracle.F32:
         # native threads in lockstep (no interpreter between the calls): launches are shared for certain
         before = gix.small_call_stats()
