@@ -270,7 +270,7 @@ def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric):
     filter / row gather, talking through an LDS mailbox; the control wave decides the next expansion before the merge,
     the visited wave filters the predicted one after that speculatively -- inserts that are taken back when the prediction
     fails).  ids, distances, cmps and hops equal the oracle's and the one-wave-per-query launch's (debug_set(tune_off=...): bit 4
-    switches the teams off, bit 8 the speculation), with several start points and for every queue size the team
+    switches the teams off, bit 8 the speculation, bit 64 the visited wave's self-start), with several start points and for every queue size the team
     instantiations cover (L + start points <= 256) and beyond; a small explicit visited table makes a team give the query
     back (a team never spills) and the host re-run it with one wave."""
     rng = np.random.default_rng(777)
@@ -291,11 +291,14 @@ def test_team_of_wavefronts_per_query_does_not_change_results(dtype, metric):
             gix.debug_set(tune_off=8)
             (ni, nd, nst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))  # teams, no speculation
             assert ("team" in fam) == teamed, (fam, nq, L)
+            gix.debug_set(tune_off=64)  # teams whose visited wave always waits for the control wave's words (no self-start)
+            (wi, wd, wst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))
+            assert ("team" in fam) == teamed, (fam, nq, L)
             gix.debug_set(tune_off=4)
             (si, sd, sst), fam = gix.last_family(lambda: gix.search(da.Knn(L, 1), queries, k))  # one wave per query
             assert fam == {"one_wave"}, (fam, nq, L)
             gix.debug_set(tune_off=None)
-            for ids, d, st in ((gi, gd, gst), (ni, nd, nst), (si, sd, sst)):
+            for ids, d, st in ((gi, gd, gst), (ni, nd, nst), (wi, wd, wst), (si, sd, sst)):
                 assert np.array_equal(oi, ids), (nq, L)
                 assert np.array_equal(bits(od), bits(d)), (nq, L)
                 assert np.array_equal(ost[:, 0], st["cmps"]) and np.array_equal(ost[:, 1], st["hops"]), (nq, L)
