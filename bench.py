@@ -155,6 +155,10 @@ def maybe_spawn(args):
 
 def main():
     args = parse()
+    if args.nq <= 2048:
+        # launches that small are not bracketed by HIP events by default (dann_debug.h: DANN_DBG_TIME_SMALL_LAUNCHES); the
+        # roofline legs divide by the kernel time, so an odd run with a tiny --nq asks for the events on every index
+        os.environ.setdefault("DANN_TIME_SMALL_LAUNCHES", "1")
     if args.only == "cpu-distance":  # host only
         print(json.dumps(_strict({"cpu_distance_kernels": cpu_distance_microbench()})), flush=True)
         return

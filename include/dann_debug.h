@@ -64,9 +64,9 @@ enum {
     DANN_DBG_HOST_CHUNK = 15,            /* queries per chunk of the host-pointer pipeline (default 16384) */
     DANN_DBG_GRAM_F16_WIDEN = 16,        /* 1: the MFMA prunes widen f16 rows and use the f32 matrix core (rounds 3-5; default
                                             0: v_mfma_f32_32x32x16_f16) */
-    DANN_DBG_TIME_SMALL_LAUNCHES = 17,   /* 1: HIP events also around search launches of at most 64 queries (they cost such a
-                                            call 4-5 us of its ~90; default 0: those launches count in dann_kernel_time and
-                                            dann_debug_search_families with 0 ms) */
+    DANN_DBG_TIME_SMALL_LAUNCHES = 17,   /* 1: HIP events also around Knn search launches of at most 2 048 queries (they
+                                            cost such a call 4-5 us of its 80 ... 300; default 0: those launches count in
+                                            dann_kernel_time and dann_debug_search_families with 0 ms) */
     DANN_DBG_COUNT = 18
 };
 int32_t dann_debug_set(dann_index* idx, int32_t key, double value);
